@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of one full wgancls iteration (critic step + kt, then generator step; reference
+models/wgancls/trainer.py:97-102) at 64x64, batch 64 per GPU, fp32, synthetic inputs, random-init weights.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--no-cpu-baseline] [--instrument inline|after|off]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU over RCCL); the batch is per GPU (weak scaling) and gradients are all-reduced (dp.py).
+Rank 0 prints ONE JSON line.  See DESIGN.md §6 for how `roofline` and `cpu_baseline` are obtained.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# SURVEY.md §8(d) / BASELINE.md: algorithmic work per image (conv + dense MACs incl. padded taps, 2 FLOP/MAC)
+G_FWD_MAC = 969478144
+D_FWD_MAC = 694304768
+NOMINAL_FLOP_PER_IMAGE = 2 * (4 * G_FWD_MAC + 17 * D_FWD_MAC)      # 31.362 GFLOP, the survey's nominal count
+FP32_MATRIX_PEAK_TFLOPS = 157.3                                    # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
+
+
+def make_cfg(batch):
+    from t2i_amd.utils.config import config_from_yaml
+    cfg = config_from_yaml(os.path.join(ROOT, 'text-to-image_amd', 'models', 'wgancls', 'cfg', 'flowers.yml'))
+    cfg.TRAIN.BATCH_SIZE = batch
+    return cfg
+
+
+def synthetic_feed(cfg, device, seed):
+    """BASELINE.md §2 inputs, generated on the device (resident in HBM before the timed region)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    B, m = cfg.TRAIN.BATCH_SIZE, cfg.MODEL
+    shape = (B, m.IMAGE_SHAPE.H, m.IMAGE_SHAPE.W, m.IMAGE_SHAPE.D)
+    tn = lambda: torch.nn.init.trunc_normal_(torch.empty(B, m.COMPRESSED_EMBED_DIM, device=device), 0.0, 1.0, -2.0, 2.0, generator=g)
+    return {'x': torch.rand(shape, generator=g, device=device) * 2 - 1,
+            'x_mismatch': torch.rand(shape, generator=g, device=device) * 2 - 1,
+            'cond': torch.randn((B, m.EMBED_DIM), generator=g, device=device),
+            'z': torch.randn((B, m.Z_DIM), generator=g, device=device),
+            'epsilon': torch.rand((B, 1, 1, 1), generator=g, device=device),
+            'ca_noise_d': tn(), 'ca_noise_g': tn(),
+            'learning_rate_d': cfg.TRAIN.D_LR, 'learning_rate_g': cfg.TRAIN.G_LR}
+
+
+class ConvTimer(object):
+    """HIP-event pairs around every implicit-GEMM launch (torch.cuda.Event on the stream the kernels are launched
+    on: kernels.py launches on torch's current stream).  Records (flops, start, end) per launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        self.records.append((flops, s, e))
+        return e
+
+    def summary(self):
+        tot_ms = sum(s.elapsed_time(e) for _, s, e in self.records)
+        tot_flop = sum(f for f, _, _ in self.records)
+        return dict(launches=len(self.records), ms=tot_ms, flop=tot_flop)
+
+
+def cpu_baseline(batch, threads):
+    """The oracle (torch-CPU fp32 restatement of the identical iteration) timed on the host cores: 1 warm-up + 2 timed
+    iterations of the same B=64 workload (a bounded sample, ~10-30 s)."""
+    from oracle import torch_step as T
+    torch.set_num_threads(threads)
+    cfg = T.Cfg(batch=batch)
+    P = T.init_variables(cfg, seed=0)
+    feed = T.synthetic_feed(cfg, seed=1)
+    tr = T.Trainer(cfg, P)
+    tr.iteration(1, feed)
+    n = 2
+    t0 = time.time()
+    for i in range(n):
+        tr.iteration(2 + i, feed)
+    dt = (time.time() - t0) / n
+    return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d timed iterations (after 1 warm-up) of the same B=%d fp32 D+G step, torch-CPU oracle' % (n, batch),
+            'ms_per_step': dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
+                    help='where the per-launch HIP events for the roofline block are recorded')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    import t2i_amd  # noqa: F401
+    from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        from t2i_amd.dp import DataParallel
+        dp = DataParallel()
+
+    cfg = make_cfg(args.batch)
+    model = WGanCls(cfg, device=device, seed=0, dp=dp)
+    if dp is not None:
+        dp.broadcast_variables(model.store)
+    trainer = WGanClsTrainer(None, model, None, cfg)
+    feed = synthetic_feed(cfg, device, seed=1 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.iteration(1 + i, feed)
+    timer = ConvTimer()
+    barrier()
+    if args.instrument == 'inline':
+        K.set_conv_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.iteration(1 + args.warmup + i, feed)
+    barrier()
+    dt = time.perf_counter() - t0
+    K.set_conv_timer(None)
+    inst_steps = args.steps
+    if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
+        inst_steps = min(args.steps, 3)
+        K.set_conv_timer(timer)
+        for i in range(inst_steps):
+            trainer.iteration(1 + args.warmup + args.steps + i, feed)
+        torch.cuda.synchronize()
+        K.set_conv_timer(None)
+
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    out = {'metric': 'images/sec (G+D step) at 64x64 batch=64', 'value': value, 'unit': 'images/sec', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'wgancls 64x64 batch=%d/GPU fp32, synthetic images + random 1024-d text embeddings, '
+                                  'D step (+kt) then G step, Adam(b1=0,b2=0.9)' % args.batch,
+                      'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+           'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
+    if rank == 0:
+        if args.instrument != 'off':
+            s = timer.summary()
+            info = K.device_info(local_rank)
+            achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
+                'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
+                'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
+                'device': info}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.batch, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,134 @@
+/*
+ * t2i_hip.h — C ABI of libt2i_hip.so: the MI355X (gfx950) kernels behind the reference's operator surface.
+ *
+ * The reference (crisbodnar/text-to-image) has no FFI/plugin layer: its operator API is the Python wrappers in
+ * utils/ops.py, which hand the arithmetic to TensorFlow-1.4 kernels (Eigen / cuDNN).  This library is what sits
+ * under those wrappers instead.  Each entry point cites the reference interface it serves.
+ *
+ * Conventions (all entry points):
+ *   - extern "C"; return 0 on success, a negative T2I_ERR_* otherwise; never throw.  t2i_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees tensors.
+ *     Scratch comes from the caller's workspace (size from the matching *_workspace_bytes query; 256-byte aligned).
+ *   - tensors are dense NHWC fp32 ("[B,H,W,C]", C fastest); conv filters are TF "HWIO" [KH,KW,Cin,Cout];
+ *     dense kernels are [in,out].  No tensor may exceed 2^31-1 elements.
+ *   - every call is asynchronous on the given hipStream_t (void* here so the header needs no HIP include) and is
+ *     safe to capture into a hipGraph: no allocation, no synchronisation, no host-visible state.
+ */
+#ifndef T2I_HIP_H
+#define T2I_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2I_OK 0
+#define T2I_ERR_INVALID (-1)   /* bad descriptor / null pointer / unsupported geometry */
+#define T2I_ERR_WORKSPACE (-2) /* workspace too small or misaligned */
+#define T2I_ERR_LAUNCH (-3)    /* HIP launch failure (message holds hipGetErrorString) */
+
+/* activation fused into an epilogue (reference utils/ops.py `act=` argument; model.py:110,131 lrelu 0.2) */
+#define T2I_ACT_NONE 0
+#define T2I_ACT_LRELU 1 /* max(x, alpha*x) */
+#define T2I_ACT_RELU 2
+#define T2I_ACT_TANH 3
+
+typedef void* t2i_stream_t; /* a hipStream_t */
+
+/* Geometry of one 2-D convolution, already resolved from the TF padding string (SAME/VALID -> pad_t/pad_l, Ho/Wo):
+ * y[b,oh,ow,co] = sum_{kh,kw,ci} x[b, oh*SH-pad_t+kh, ow*SW-pad_l+kw, ci] * w[kh,kw,ci,co]. */
+typedef struct t2i_conv_desc {
+  int32_t B, H, W, Cin;  /* input  [B,H,W,Cin]   */
+  int32_t Ho, Wo, Cout;  /* output [B,Ho,Wo,Cout] */
+  int32_t KH, KW, SH, SW;
+  int32_t pad_t, pad_l;  /* TF SAME puts the odd pixel bottom/right, so only top/left are needed */
+} t2i_conv_desc;
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int t2i_version(void);            /* ABI version, currently 1 */
+const char* t2i_last_error(void); /* thread-local, never NULL */
+/* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
+int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
+
+/* ---- convolution family: reference utils/ops.py:58-63 (conv2d) and :66-71 (conv2d_transpose) ------------------ */
+size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fwd / bwd_data / bwd_filter */
+
+/* y = act(conv(x, w) + bias).  bias may be NULL.  Serves ops.conv2d (utils/ops.py:58-63), ops.fc as a 1x1 conv on
+ * [B,1,1,in] (utils/ops.py:84-87), and the double-backward term adj_gy = conv(ggx, w) of the gradient penalty. */
+int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                   float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
+/* dx = conv^T(dy, w) (+ bias over Cin if non-NULL, then act).  This IS ops.conv2d_transpose (utils/ops.py:66-71):
+ * TF stores the deconv filter as [KH,KW,Cout_deconv,Cin_deconv], i.e. the HWIO filter of the adjoint conv, so the
+ * descriptor is that adjoint conv's (d->Cin = deconv output channels) and no re-layout is needed. */
+int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx,
+                        int act, float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
+/* dw = x (*) dy over all B*Ho*Wo positions.  (tf.gradients wrt `weights`, reference models/wgancls/model.py:94-106.) */
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
+                          size_t ws_bytes, t2i_stream_t stream);
+
+/* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
+size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);
+/* out0[c] = sum_r a[r,c];  out1[c] = sum_r a[r,c]*b[r,c]  (b == NULL -> a*a; out1 == NULL -> skipped).
+ * bias gradients (db = colsum(dy)), BN moments (sum, sum of squares) and BN backward (sum dy, sum dy*x). */
+int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, void* ws,
+                   size_t ws_bytes, t2i_stream_t stream);
+
+/* ---- batch norm, training mode: reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm fused, scale=True) --- */
+/* From sum/sumsq over n rows: mean, rstd = 1/sqrt(var_biased+eps); scale = gamma*rstd, shift = beta-mean*scale;
+ * and, if moving_mean != NULL, moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
+int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma,
+                    const float* beta, float eps, float decay, float* mean, float* rstd, float* scale, float* shift,
+                    float* moving_mean, float* moving_var, t2i_stream_t stream);
+/* y = act(x*scale[c] + shift[c])  (normalise + affine + activation in one pass; also eval-mode BN). */
+int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act,
+                 float alpha, float* y, t2i_stream_t stream);
+/* dx = gamma*rstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n), xhat = (x-mean)*rstd.  sum_dy_x = sum dy*x (raw x);
+ * the kernel converts to the centred form.  Also emits dgamma, dbeta. */
+int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma,
+               float* dbeta, void* ws /* >= 3*C floats */, size_t ws_bytes, t2i_stream_t stream);
+
+/* ---- elementwise ----------------------------------------------------------------------------------------------- */
+/* y = act(x) */
+int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
+/* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
+int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream);
+/* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
+int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
+/* y = alpha*a + beta*b (b may be NULL). */
+int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream);
+/* x_hat[b,:] = eps[b]*g[b,:] + (1-eps[b])*x[b,:]   (reference models/wgancls/model.py:53). */
+int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int64_t per_sample, float* xhat,
+               t2i_stream_t stream);
+/* out[b,p,:] = concat(feat[b,p,:Cf], emb[b,:Ce]) for p < P: tile the compressed text embedding over the 4x4 map
+ * and concatenate on channels (reference models/wgancls/model.py:153-155).  bwd splits the gradient back. */
+int t2i_concat_tile_fwd(const float* feat, const float* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce,
+                        float* out, t2i_stream_t stream);
+int t2i_concat_tile_bwd(const float* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* dfeat, float* demb,
+                        t2i_stream_t stream);
+/* NCHW <-> NHWC physical transposes: reference utils/ops.py:129-134 (to_nchw / to_nhwc) and the dense_2 reshape. */
+int t2i_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream);
+int t2i_nhwc_to_nchw(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream);
+
+/* ---- gradient penalty: reference models/wgancls/model.py:62-70 -------------------------------------------------- */
+/* slopes[b] = sqrt(sum_j g[b,j]^2); one wavefront-shuffle reduction per sample. */
+int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, t2i_stream_t stream);
+/* out[b,:] = coef[b] * g[b,:]  (per-sample scaling: backward of the slope norm, and its own double backward). */
+int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream);
+
+/* ---- optimizer: tf.train.AdamOptimizer as used at reference models/wgancls/model.py:94-106 ---------------------- */
+/* m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; w -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
+ * caller (epsilon outside the bias correction).  One launch over a flat parameter arena. grad_scale multiplies g
+ * first (1/world_size for summed data-parallel gradients). */
+int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                float eps, float grad_scale, t2i_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2I_HIP_H */

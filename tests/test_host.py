@@ -1,0 +1,142 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header declares, the reference's
+operator surface / variable naming / trainer schedule are reproduced, and CPU tensors are refused (no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def t2i():
+    lib = os.path.join(ROOT, 'text-to-image_amd', 'lib', 'libt2i_hip.so')
+    if not os.path.exists(lib):
+        import __graft_entry__ as ge
+        ge.build()
+    import t2i_amd
+    return t2i_amd
+
+
+def test_abi_exports_every_declared_symbol(t2i):
+    from t2i_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 't2i_hip.h')).read()
+    declared = set(re.findall(r'\b(t2i_[a-z0-9_]+)\s*\(', header))
+    declared -= {'t2i_stream_t'}
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    assert _lib.lib.t2i_version() == 1
+    assert _lib.lib.t2i_last_error() is not None
+
+
+def test_descriptor_validation_without_gpu(t2i):
+    from t2i_amd import _lib, kernels as K
+    import ctypes
+    bad = _lib.ConvDesc(1, 4, 4, 8, 0, 2, 8, 4, 4, 2, 2, 1, 1)      # Ho = 0
+    assert _lib.lib.t2i_conv2d_workspace_bytes(ctypes.byref(bad)) == 0
+    d, ws = K.conv_desc(64, 4, 4, 1152, 1024, 3, 3, 1, 1, 'same')
+    assert (d.Ho, d.Wo, d.pad_t, d.pad_l) == (4, 4, 1, 1) and ws >= 0
+    d, _ = K.conv_desc(1, 6, 6, 4, 4, 4, 4, 1, 1, 'SAME')
+    assert (d.Ho, d.pad_t) == (6, 1)                                # k4s1 -> pads (1,2)
+    d, _ = K.conv_desc(1, 5, 5, 4, 4, 2, 2, 1, 1, 'SAME')
+    assert (d.Ho, d.pad_t) == (5, 0)                                # k2s1 -> pads (0,1)
+    d, _ = K.deconv_desc(2, 4, 4, 1024, 512, 4, 4, 2, 2, 'SAME')
+    assert (d.H, d.W, d.Cin, d.Cout, d.Ho, d.Wo) == (8, 8, 512, 1024, 4, 4)
+    with pytest.raises(ValueError):
+        K.conv_desc(1, 4, 4, 4, 4, 3, 3, 1, 1, 'FULL')
+
+
+def test_no_cpu_fallback(t2i):
+    from t2i_amd import kernels as K
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        K.act_fwd(torch.zeros(4), K.ACT_RELU)
+    with K.dry_run():
+        assert K.act_fwd(torch.zeros(4), K.ACT_RELU).shape == (4,)
+
+
+def _cfg(B=4):
+    from t2i_amd.utils.config import config_from_yaml
+    cfg = config_from_yaml(os.path.join(ROOT, 'text-to-image_amd', 'models', 'wgancls', 'cfg', 'flowers.yml'))
+    cfg.TRAIN.BATCH_SIZE = B
+    return cfg
+
+
+def test_variable_registry_matches_tf_names(t2i):
+    """TF auto-names, shapes, totals; arenas alias the variables."""
+    from oracle import torch_step as T
+    from t2i_amd.models.wgancls.model import WGanCls
+    m = WGanCls(_cfg(), device='cpu')
+    mine = {n: tuple(v.shape) for n, v in m.store.vars.items()}
+    ref = {n: tuple(s) for n, (s, k, f) in T.variable_shapes(T.Cfg()).items()}
+    assert mine == ref
+    for sc in ('g_net/', 'd_net/'):                                 # creation order inside each scope too
+        assert [n for n in mine if n.startswith(sc)] == [n for n in ref if n.startswith(sc)]
+    assert sum(v.numel() for v in m.g_vars.values()) == 22643287
+    assert sum(v.numel() for v in m.d_vars.values()) == 28995329
+    assert all(not n.endswith('moving_mean') for n in m.g_vars)
+    w = m.d_vars['d_net/Conv_3/weights']
+    assert w.data_ptr() == m.d_arena.flat.data_ptr() + 4 * m.d_arena.offsets['d_net/Conv_3/weights'][0]
+    assert w.grad.data_ptr() == m.d_arena.grad.data_ptr() + 4 * m.d_arena.offsets['d_net/Conv_3/weights'][0]
+    assert all(off % 4 == 0 for off, _ in m.d_arena.offsets.values())
+    # He init: std = sqrt(2.6/fan_in), truncated at 2 std; biases zero; gamma one
+    std = float(w.std()); want = (2.6 / (4 * 4 * 512)) ** 0.5
+    assert abs(std / (want * 0.8796) - 1) < 0.02                    # std of a 2-sigma truncated normal = 0.8796 sigma
+    assert float(w.abs().max()) <= 2 * want * 1.0001
+    assert float(m.store.vars['d_net/Conv_3/biases'].abs().max()) == 0.0
+    assert float(m.store.vars['g_net/BatchNorm_4/gamma'].min()) == 1.0
+    # the deconv fan-in quirk: kh*kw*Cout
+    wt = m.g_vars['g_net/Conv2d_transpose/weights']
+    assert tuple(wt.shape) == (4, 4, 512, 1024)
+    assert abs(float(wt.std()) / ((2.6 / (16 * 512)) ** 0.5 * 0.8796) - 1) < 0.02
+
+
+def test_scope_reuse_semantics(t2i):
+    from t2i_amd import kernels as K, scope as S
+    from t2i_amd.utils import ops
+    st = S.set_default_store(S.VariableStore(device='cpu'))
+    x = torch.zeros(2, 8, 8, 4)
+    with K.dry_run():
+        with S.variable_scope('net'):
+            y = ops.conv2d(x, 8); ops.conv2d(y, 8, ks=(3, 3), s=(1, 1)); ops.fc(torch.zeros(2, 5), 3); ops.linear(torch.zeros(2, 5), 3)
+        assert list(st.vars) == ['net/Conv/weights', 'net/Conv/biases', 'net/Conv_1/weights', 'net/Conv_1/biases',
+                                 'net/dense/kernel', 'net/dense/bias', 'net/dense_1/kernel', 'net/dense_1/bias']
+        with S.variable_scope('net', reuse=True):
+            ops.conv2d(x, 8)                                     # counters restart: resolves to net/Conv again
+        assert len(st.vars) == 8
+        with pytest.raises(ValueError):
+            with S.variable_scope('net'):                       # exists and reuse=False -> TF raises too
+                ops.conv2d(x, 8)
+        with pytest.raises(ValueError):
+            with S.variable_scope('other', reuse=True):         # reuse of a variable that was never created
+                ops.conv2d(x, 8)
+        with pytest.raises(ValueError):
+            ops.conv2d(x, 8, df='NCWH')
+        # logical NCHW in == logical NCHW out, storage NHWC
+        with S.variable_scope('fmt'):
+            out = ops.conv2d(ops.to_nchw(x), 16, df=ops.NCHW)
+        assert tuple(out.shape) == (2, 16, 4, 4) and ops.to_nhwc(out).is_contiguous()
+    assert ops.deconv2d is ops.conv2d_transpose and ops.bn is ops.batch_norm
+
+
+def test_trainer_schedule(t2i):
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+
+    class M(object):
+        device = torch.device('cpu'); batch_size = 2; z_dim = 3
+    cfg = _cfg()
+    tr = WGanClsTrainer(None, M(), None, cfg)
+    assert tr.lr_scale(1) == 1.0 and tr.lr_scale(9999) == 1.0
+    assert abs(tr.lr_scale(10000) - 0.95) < 1e-12 and abs(tr.lr_scale(25000) - 0.95 ** 2) < 1e-12
+    cfg.TRAIN.N_CRITIC = 5
+    assert abs(tr.lr_scale(50000) - 0.95) < 1e-12                  # (idx // n_critic) // 10000
+
+
+def test_config_keys_match_reference_yaml(t2i):
+    cfg = _cfg()
+    assert (cfg.MODEL.Z_DIM, cfg.MODEL.EMBED_DIM, cfg.MODEL.COMPRESSED_EMBED_DIM, cfg.MODEL.GF_DIM, cfg.MODEL.DF_DIM) == \
+        (128, 1024, 128, 128, 128)
+    assert (cfg.TRAIN.D_LR, cfg.TRAIN.BETA1, cfg.TRAIN.BETA2, cfg.TRAIN.N_CRITIC, cfg.TRAIN.COEFF.KL) == (1e-4, 0.0, 0.9, 1, 1.0)

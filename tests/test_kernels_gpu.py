@@ -1,0 +1,209 @@
+"""GPU parity tests of every libt2i_hip.so kernel, called through the C ABI (via t2i_amd.kernels), against the float64
+oracle: committed golden vectors (tests/golden/ops_tiny.npz), seeded medium shapes that force the vector / multi-tile /
+split-K paths, and size-independent adjoint identities at BASELINE.json's full layer sizes.
+
+Tolerances (fp32 kernels vs float64 oracle): max|d| / max|ref| <= 1e-5 forward, <= 1e-4 for gradients
+that accumulate over up to ~2e5 terms."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+GRAD_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import t2i_amd  # noqa: F401
+    from t2i_amd import kernels
+    return kernels
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device='cuda').contiguous()
+
+
+def relerr(got, ref):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+CONV_CASES = {  # name -> (stride, padding); geometry comes from the arrays
+    'k4s2_same': (2, 'SAME'), 'k4s2_same_c3': (2, 'SAME'), 'k4s2_same_odd': (2, 'SAME'), 'k3s1_same': (1, 'SAME'),
+    'k3s1_same_c3': (1, 'SAME'), 'k1s1_valid': (1, 'VALID'), 'k4s4_valid': (4, 'VALID'), 'k4s1_same': (1, 'SAME'),
+    'k2s1_same': (1, 'SAME'),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CONV_CASES))
+def test_conv_golden(K, golden_ops, name):
+    s, pad = CONV_CASES[name]
+    g = lambda k: golden_ops['conv/%s/%s' % (name, k)]
+    x, w, b, dy = dev(g('x')), dev(g('w')), dev(g('b')), dev(g('dy'))
+    B, H, W, Ci = x.shape
+    KH, KW, _, Co = w.shape
+    d, ws = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad)
+    assert relerr(K.conv_fwd(x, w, b, d, ws), g('y')) <= FWD_TOL
+    assert relerr(K.conv_bwd_data(dy, w, None, d, ws), g('dx')) <= FWD_TOL
+    assert relerr(K.conv_bwd_filter(x, dy, d, ws), g('dw')) <= FWD_TOL
+    assert relerr(K.col_reduce(dy)[0], g('db')) <= FWD_TOL
+
+
+@pytest.mark.parametrize('name', ['dk4s2', 'dk4s2_c3'])
+def test_deconv_golden(K, golden_ops, name):
+    g = lambda k: golden_ops['deconv/%s/%s' % (name, k)]
+    x, w, b = dev(g('x')), dev(g('w')), dev(g('b'))
+    B, H, W, Ci = x.shape
+    Co = w.shape[2]
+    d, ws = K.deconv_desc(B, H, W, Ci, Co, 4, 4, 2, 2, 'SAME')
+    assert relerr(K.conv_bwd_data(x, w, b, d, ws), g('y')) <= FWD_TOL
+
+
+def test_dense_golden(K, golden_ops):
+    x, k, b = dev(golden_ops['dense/x']), dev(golden_ops['dense/k']), dev(golden_ops['dense/b'])
+    B, I = x.shape
+    O = k.shape[1]
+    d, ws = K.conv_desc(B, 1, 1, I, O, 1, 1, 1, 1, 'VALID')
+    y = K.conv_fwd(x.view(B, 1, 1, I), k.view(1, 1, I, O), b, d, ws).view(B, O)
+    assert relerr(y, golden_ops['dense/y']) <= FWD_TOL
+
+
+@pytest.mark.parametrize('tag', ['r4', 'r2'])
+def test_batch_norm_golden(K, golden_ops, tag):
+    g = lambda k: golden_ops['bn/%s/%s' % (tag, k)]
+    x, gamma, beta, dy = dev(g('x')), dev(g('gamma')), dev(g('beta')), dev(g('dy'))
+    C = x.shape[-1]
+    n = x.numel() // C
+    s, ss = K.col_reduce(x, None, True)
+    mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, 1e-5, 0.9, mm, mv)
+    y = K.bn_apply(x, scale, shift)
+    assert relerr(y, g('y')) <= FWD_TOL
+    assert relerr(mean, g('mean')) <= FWD_TOL
+    assert relerr(1.0 / rstd ** 2 - 1e-5, g('var')) <= 1e-4
+    assert relerr(mm, g('moving_mean')) <= FWD_TOL and relerr(mv, g('moving_var')) <= 1e-5
+    sdy, sdyx = K.col_reduce(dy, x, True)
+    dx, dgamma, dbeta = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx)
+    assert relerr(dx, g('dx')) <= GRAD_TOL
+    assert relerr(dgamma, g('dgamma')) <= GRAD_TOL and relerr(dbeta, g('dbeta')) <= GRAD_TOL
+
+
+def test_adam_golden(K, golden_ops):
+    import math
+    g = lambda k: golden_ops['adam/' + k]
+    w, m, v = dev(g('w')), torch.zeros(16, device='cuda'), torch.zeros(16, device='cuda')
+    for t, grad, wk, mk, vk in ((1, g('g'), 'w1', 'm1', 'v1'), (2, g('g') * 0.5, 'w2', 'm2', 'v2')):
+        lr_t = 1e-4 * math.sqrt(1 - 0.9 ** t) / (1 - 0.0 ** t)
+        K.adam_tf(w, dev(grad), m, v, lr_t, 0.0, 0.9, 1e-8, 1.0)
+        assert relerr(w, g(wk)) <= 1e-6 and relerr(m, g(mk)) <= 1e-6 and relerr(v, g(vk)) <= 1e-6
+
+
+def test_gp_golden(K, golden_ops):
+    gr = dev(golden_ops['gp/g'])
+    s = K.gp_slopes(gr)
+    assert relerr(s, golden_ops['gp/slopes']) <= FWD_TOL
+    B = gr.shape[0]
+    coef = torch.where(s > 1, 2 * (s - 1) / (B * s), torch.zeros_like(s))
+    assert relerr(K.row_scale(gr, coef), golden_ops['gp/dg']) <= FWD_TOL
+
+
+# ---- seeded medium shapes vs the NumPy loop oracle: vector path, 128x128 tiles, ragged N, split-K, stride phases --------
+MEDIUM = [  # B, H, W, Cin, Cout, KH, KW, s, pad
+    (4, 16, 16, 64, 96, 4, 4, 2, 'SAME'),      # vec, several K tiles, N = 3*32
+    (2, 8, 8, 128, 136, 3, 3, 1, 'SAME'),      # N not a multiple of 32 -> ragged last tile, 128-wide tiles
+    (2, 4, 4, 512, 256, 3, 3, 1, 'SAME'),      # M = 32, K = 4608 -> split-K
+    (3, 4, 4, 256, 64, 1, 1, 1, 'VALID'),      # 1x1
+    (5, 4, 4, 64, 1, 4, 4, 4, 'VALID'),        # the logit head: 16 stride phases in bwd_data, N = 1
+    (2, 16, 16, 3, 32, 4, 4, 2, 'SAME'),       # Cin = 3 -> scalar gather path
+    (2, 9, 7, 8, 12, 4, 4, 2, 'SAME'),         # odd extents: ragged phases
+    (2, 8, 8, 32, 32, 4, 4, 1, 'SAME'),        # asymmetric pad (1,2)
+    (6, 32, 32, 32, 128, 3, 3, 1, 'SAME'),     # M = 6144: 128x128 tiles, M-inner filter gradient with split over rows
+]
+
+
+@pytest.mark.parametrize('case', MEDIUM)
+def test_conv_medium_vs_oracle(K, case):
+    from oracle import np_ops as O
+    B, H, W, Ci, Co, KH, KW, s, pad = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+    w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    d, ws = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad)
+    y_ref = O.conv2d(x, w, b, (s, s), pad)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= FWD_TOL
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= FWD_TOL
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_TANH), np.tanh(y_ref)) <= FWD_TOL
+    assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (s, s), pad)) <= GRAD_TOL
+    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), O.conv2d_bwd_filter(x, dy, w.shape, (s, s), pad)) <= GRAD_TOL
+
+
+def test_elementwise_and_layout(K):
+    from oracle import np_ops as O
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((3, 4, 4, 10)).astype(np.float32); b = rng.standard_normal(a.shape).astype(np.float32)
+    assert relerr(K.act_fwd(dev(a), K.ACT_LRELU, 0.2), O.lrelu(a)) <= 1e-7
+    y = O.lrelu(a)
+    assert relerr(K.act_bwd(dev(b), dev(y), K.ACT_LRELU, 0.2), O.lrelu_bwd(b, y)) <= 1e-7
+    assert relerr(K.act_bwd(dev(b), dev(O.relu(a)), K.ACT_RELU), O.relu_bwd(b, O.relu(a))) <= 1e-7
+    assert relerr(K.act_bwd(dev(b), dev(np.tanh(a)), K.ACT_TANH), O.tanh_bwd(b, np.tanh(a))) <= 1e-6
+    assert relerr(K.add_act(dev(a), dev(b), K.ACT_RELU), O.relu(a + b)) <= 1e-7
+    assert relerr(K.axpby(dev(a), 0.5, dev(b), -2.0), 0.5 * a - 2.0 * b) <= 1e-7
+    # odd length + unaligned views take the scalar tail
+    flat = dev(rng.standard_normal(1031).astype(np.float32))
+    assert relerr(K.axpby(flat[1:1030].contiguous(), 2.0), 2.0 * flat[1:1030].cpu().numpy()) <= 1e-7
+    eps = rng.uniform(0, 1, (3, 1, 1, 1)).astype(np.float32)
+    assert relerr(K.interp(dev(eps), dev(a), dev(b)), O.interpolate(eps, a, b)) <= 1e-6
+    emb = rng.standard_normal((3, 6)).astype(np.float32)
+    cat = np.concatenate([a, np.broadcast_to(emb[:, None, None, :], (3, 4, 4, 6))], -1)
+    assert relerr(K.concat_tile_fwd(dev(a), dev(emb)), cat) == 0.0
+    dfeat, demb = K.concat_tile_bwd(dev(cat), 10, 6)
+    assert relerr(dfeat, a) == 0.0 and relerr(demb, emb * 16) <= 1e-6
+    nchw = rng.standard_normal((2, 5, 3, 7)).astype(np.float32)
+    assert relerr(K.nchw_to_nhwc(dev(nchw)), nchw.transpose(0, 2, 3, 1)) == 0.0
+    assert relerr(K.nhwc_to_nchw(dev(nchw.transpose(0, 2, 3, 1).copy())), nchw) == 0.0
+
+
+# ---- BASELINE.json full sizes: size-independent properties (adjointness of the three kernels) ----------------------------
+FULL = [  # the heaviest critic / generator layers at B = 64: name, B,H,W,Cin,Cout,k,s,pad
+    ('D2', 64, 32, 32, 128, 256, 4, 2, 'SAME'),
+    ('D4', 64, 8, 8, 512, 1024, 4, 2, 'SAME'),
+    ('D10', 64, 4, 4, 1152, 1024, 3, 1, 'SAME'),
+    ('G8conv', 64, 32, 32, 128, 128, 3, 1, 'SAME'),
+    ('D1', 64, 64, 64, 3, 128, 4, 2, 'SAME'),
+]
+
+
+@pytest.mark.parametrize('case', FULL, ids=[c[0] for c in FULL])
+def test_full_size_adjoint_identities(K, case):
+    """<conv(x,w), dy> == <x, conv^T(dy,w)> == <w, filter_grad(x,dy)> at the benchmark's layer sizes; also linearity in x."""
+    _, B, H, W, Ci, Co, k, s, pad = case
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn((B, H, W, Ci), generator=g, device='cuda')
+    w = torch.randn((k, k, Ci, Co), generator=g, device='cuda') / (k * k * Ci) ** 0.5
+    d, ws = K.conv_desc(B, H, W, Ci, Co, k, k, s, s, pad)
+    y = K.conv_fwd(x, w, None, d, ws)
+    dy = torch.randn(y.shape, generator=g, device='cuda')
+    lhs = (y.double() * dy.double()).sum()
+    via_x = (x.double() * K.conv_bwd_data(dy, w, None, d, ws).double()).sum()
+    via_w = (w.double() * K.conv_bwd_filter(x, dy, d, ws).double()).sum()
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(float(lhs - via_x)) <= 1e-5 * scale
+    assert abs(float(lhs - via_w)) <= 1e-5 * scale
+    x2 = torch.randn(x.shape, generator=g, device='cuda')
+    y2 = K.conv_fwd(x2, w, None, d, ws)
+    ysum = K.conv_fwd((x + 2 * x2).contiguous(), w, None, d, ws)
+    assert float((ysum - (y + 2 * y2)).abs().max()) <= 1e-4 * float(ysum.abs().max())
+
+
+def test_cpu_tensor_is_refused(K):
+    with pytest.raises(RuntimeError):
+        K.act_fwd(torch.zeros(8), K.ACT_RELU)

@@ -1,0 +1,157 @@
+"""GPU parity of the whole wgancls iteration (model + autograd composition + optimizers) against the oracle.
+
+  * tiny model (GF=DF=8, B=4): every loss scalar, every gradient of both steps, kt', first Adam step and BN moving
+    statistics against the committed float64 golden step (tests/golden/step_tiny.npz);
+  * full-width model at B=8: losses and gradients against the torch-CPU fp32 oracle run on the same seeded inputs.
+Tolerances (fp32 vs float64 / fp32 oracle): loss scalars rel <= 1e-4 (they sum O(1e5) fp32 products through 12 layers
+and a double backward); gradients max|d|/max|ref| <= 1e-3 per tensor; post-Adam weights within 2*lr (Adam with beta1=0
+is sign-like at t=1)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(z, e, c, gf, df, B):
+    from t2i_amd.utils.config import AttrDict
+    return AttrDict({'MODEL': {'Z_DIM': z, 'OUTPUT_SIZE': 64, 'EMBED_DIM': e, 'COMPRESSED_EMBED_DIM': c, 'GF_DIM': gf,
+                               'DF_DIM': df, 'IMAGE_SHAPE': {'W': 64, 'H': 64, 'D': 3}},
+                     'TRAIN': {'BATCH_SIZE': B, 'SAMPLE_NUM': 4, 'D_LR': 1e-4, 'G_LR': 1e-4, 'BETA1': 0.0, 'BETA2': 0.9,
+                               'N_CRITIC': 1, 'SUMMARY_PERIOD': 10, 'MAX_STEPS': 10, 'COEFF': {'KL': 1.0, 'LAMBDA': 100.0}}})
+
+
+def relerr(got, ref):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import t2i_amd  # noqa: F401
+    return torch.device('cuda')
+
+
+def _feed(gs, dev):
+    f = {k[len('feed/'):]: torch.tensor(gs[k], dtype=torch.float32, device=dev) for k in gs.files if k.startswith('feed/')}
+    f['epsilon'] = f.pop('eps')
+    f['learning_rate_d'] = 1e-4
+    f['learning_rate_g'] = 1e-4
+    return f
+
+
+def test_tiny_step_matches_golden(gpu, golden_step):
+    from t2i_amd.models.wgancls.model import WGanCls
+    gs = golden_step
+    m = WGanCls(_cfg(8, 32, 16, 8, 8, 4), device=gpu)
+    m.store.load({k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')})
+    feed = _feed(gs, gpu)
+    d = m.d_losses(feed)
+    torch.cuda.synchronize()
+    assert relerr(d['G'], gs['d/G']) <= 1e-4
+    assert relerr(d['Dx_hat_logit'], gs['d/Dx_hat']) <= 1e-4
+    assert relerr(d['grad_x_hat'], gs['d/grad_x_hat']) <= 1e-4
+    assert relerr(d['grad_cond'], gs['d/grad_cond']) <= 1e-4
+    for k in ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2',
+              'reg_loss', 'balance_loss', 'kt_grad'):
+        ref = float(gs['d/' + k])
+        assert abs(float(d[k]) - ref) <= 1e-4 * max(abs(ref), 1.0), (k, float(d[k]), ref)
+    worst = 0.0
+    for n in m.d_vars:
+        e = relerr(m.d_arena.grad_of(n), gs['d/grad/' + n]); worst = max(worst, e)
+        assert e <= 1e-3, (n, e)
+    g = m.g_losses(feed)
+    assert abs(float(g['G_loss']) - float(gs['g/G_loss'])) <= 1e-4 * max(abs(float(gs['g/G_loss'])), 1.0)
+    assert abs(float(g['G_kl_loss']) - float(gs['g/G_kl_loss'])) <= 1e-4 * max(abs(float(gs['g/G_kl_loss'])), 1.0)
+    assert relerr(g['G'], gs['g/G']) <= 1e-4
+    for n in m.g_vars:
+        e = relerr(m.g_arena.grad_of(n), gs['g/grad/' + n])
+        assert e <= 1e-3, (n, e)
+
+
+def test_tiny_full_iteration_state(gpu, golden_step):
+    """D step (+kt) then G step with Adam and BN moving averages: post-update state vs the oracle trainer."""
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    gs = golden_step
+    cfg = _cfg(8, 32, 16, 8, 8, 4)
+    m = WGanCls(cfg, device=gpu)
+    m.store.load({k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')})
+    tr = WGanClsTrainer(None, m, None, cfg)
+    tr.iteration(1, _feed(gs, gpu))
+    torch.cuda.synchronize()
+    assert abs(float(m.kt) - float(gs['after/kt'])) <= 1e-5
+    lr = 1e-4
+    for n, v in m.store.vars.items():
+        ref = gs['after/' + n]
+        if n.endswith('moving_mean') or n.endswith('moving_variance'):
+            assert relerr(v, ref) <= 1e-4, n
+        else:
+            # Adam(beta1=0) at t=1 moves each weight by ~lr*sign(g): near-zero gradients may flip sign in fp32
+            delta = np.abs(v.detach().double().cpu().numpy() - ref)
+            assert delta.max() <= 2.0 * lr * 1.001, (n, delta.max())
+            assert np.mean(delta <= 0.02 * lr) >= 0.98, (n, np.mean(delta <= 0.02 * lr))
+
+
+def test_double_backward_of_conv_chain(gpu):
+    """grad-of-grad through conv -> lrelu -> conv (+ residual add) against torch's own CPU double backward."""
+    import torch.nn.functional as F
+    from t2i_amd import autograd as A, kernels as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 8, 8, 8, generator=g); w1 = torch.randn(4, 4, 8, 16, generator=g) * 0.2
+    w2 = torch.randn(3, 3, 16, 16, generator=g) * 0.2; b1 = torch.randn(16, generator=g) * 0.1
+
+    def ref():
+        xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+        W1, W2, B1 = w1.double().requires_grad_(True), w2.double().requires_grad_(True), b1.double().requires_grad_(True)
+        h = F.leaky_relu(F.conv2d(xr, W1.permute(3, 2, 0, 1), B1, stride=2, padding=1), 0.2)
+        y = F.leaky_relu(h + F.conv2d(h, W2.permute(3, 2, 0, 1), None, padding=1), 0.2)
+        gx, = torch.autograd.grad(y.sum(), [xr], create_graph=True)
+        pen = ((gx.reshape(3, -1) ** 2).sum(1).sqrt() - 1).clamp(min=0).pow(2).mean()
+        return (float(pen),) + torch.autograd.grad(pen, [W1, W2, B1])
+
+    def ours():
+        xd = x.cuda().requires_grad_(True)
+        W1, W2, B1 = w1.cuda().requires_grad_(True), w2.cuda().requires_grad_(True), b1.cuda().requires_grad_(True)
+        g1 = K.conv_desc(3, 8, 8, 8, 16, 4, 4, 2, 2, 'SAME'); g2 = K.conv_desc(3, 4, 4, 16, 16, 3, 3, 1, 1, 'SAME')
+        h = A.Conv2dFn.apply(xd, W1, B1, g1, K.ACT_LRELU, 0.2)
+        y = A.AddActFn.apply(h, A.Conv2dFn.apply(h, W2, None, g2, K.ACT_NONE, 0.0), K.ACT_LRELU, 0.2)
+        with A.input_grads_only():
+            gx, = torch.autograd.grad(y.sum(), [xd], create_graph=True)
+        s = A.GpSlopesFn.apply(gx)
+        pen = (s - 1).clamp(min=0).pow(2).mean()
+        return (float(pen),) + torch.autograd.grad(pen, [W1, W2, B1])
+
+    r, o = ref(), ours()
+    assert abs(r[0] - o[0]) <= 1e-5 * max(abs(r[0]), 1.0)
+    for a, b in zip(r[1:], o[1:]):
+        assert relerr(b, a.numpy()) <= 1e-4
+
+
+def test_full_width_step_vs_cpu_oracle(gpu):
+    """The benchmark's architecture (GF=DF=128, 1024-d text) at B=8 against the torch-CPU fp32 oracle."""
+    from oracle import torch_step as T
+    from t2i_amd.models.wgancls.model import WGanCls
+    B = 8
+    ocfg = T.Cfg(batch=B)
+    P = T.init_variables(ocfg, seed=0)
+    feed = T.synthetic_feed(ocfg, seed=1)
+    m = WGanCls(_cfg(128, 1024, 128, 128, 128, B), device=gpu)
+    m.store.load({n: v.numpy() for n, v in P.items()})
+    f = {k: v.to(gpu) for k, v in feed.items()}
+    f['epsilon'] = f.pop('eps'); f['learning_rate_d'] = 1e-4; f['learning_rate_g'] = 1e-4
+    d = m.d_losses(f)
+    ref = T.d_step(P, ocfg, feed, 0.7)
+    for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
+        assert abs(float(d[k]) - ref[k]) <= 2e-4 * max(abs(ref[k]), 1.0), (k, float(d[k]), ref[k])
+    for n in m.d_vars:
+        assert relerr(m.d_arena.grad_of(n), ref['grads'][n].numpy()) <= 2e-3, n
+    g = m.g_losses(f)
+    gref = T.g_step(P, ocfg, feed)
+    assert abs(float(g['G_loss']) - gref['G_loss']) <= 2e-4 * max(abs(gref['G_loss']), 1.0)
+    for n in m.g_vars:
+        assert relerr(m.g_arena.grad_of(n), gref['grads'][n].numpy()) <= 2e-3, n

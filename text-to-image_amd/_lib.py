@@ -1,0 +1,65 @@
+"""ctypes binding of libt2i_hip.so (C ABI: include/t2i_hip.h).  There is NO fallback: if the shared library is
+missing or a symbol is absent, importing this module raises — the product path never silently computes elsewhere."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('T2I_HIP_LIB', os.path.join(_HERE, 'lib', 'libt2i_hip.so'))
+
+
+class ConvDesc(ctypes.Structure):
+    """t2i_conv_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('B', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'SH', 'SW', 'pad_t', 'pad_l')]
+
+
+_p = ctypes.c_void_p
+_i32, _i64, _f, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_dp = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol include/t2i_hip.h declares (tests/test_abi.py checks that)
+SIGNATURES = {
+    't2i_version': (ctypes.c_int, []),
+    't2i_last_error': (ctypes.c_char_p, []),
+    't2i_device_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _sz]),
+    't2i_conv2d_workspace_bytes': (_sz, [_dp]),
+    't2i_conv2d_fwd': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, _p]),
+    't2i_conv2d_bwd_data': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, _p]),
+    't2i_conv2d_bwd_filter': (ctypes.c_int, [_dp, _p, _p, _p, _p, _sz, _p]),
+    't2i_col_reduce_workspace_bytes': (_sz, [_i64, _i32]),
+    't2i_col_reduce': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _sz, _p]),
+    't2i_bn_finalize': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p]),
+    't2i_bn_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p]),
+    't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
+    't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
+    't2i_axpby': (ctypes.c_int, [_p, _f, _p, _f, _i64, _p, _p]),
+    't2i_interp': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
+    't2i_concat_tile_fwd': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    't2i_concat_tile_bwd': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    't2i_nchw_to_nhwc': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    't2i_nhwc_to_nchw': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    't2i_gp_slopes': (ctypes.c_int, [_p, _i32, _i64, _p, _p]),
+    't2i_row_scale': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _p]),
+    't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('libt2i_hip.so not found at %s — build it with text-to-image_amd/csrc/build.sh '
+                      '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback' % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == ABI mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class T2IError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise T2IError('%s failed (%d): %s' % (what, rc, lib.t2i_last_error().decode('utf-8', 'replace')))

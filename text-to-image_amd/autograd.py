@@ -1,0 +1,260 @@
+"""torch.autograd.Functions whose forward AND backward are libt2i_hip.so kernels.
+
+The critic's gradient penalty (reference models/wgancls/model.py:62-70) differentiates through a gradient, so every
+Function on the critic path has a backward that is itself composed of Functions (conv <-> conv^T <-> filter-gradient
+form a closed family: the double backward needs no new kernel type).  Generator-only ops (batch norm, tanh, slope
+norm) are first-order (``once_differentiable``), exactly what the reference's two optimizers need.
+
+``input_grads_only()`` marks the first-order pass of the gradient penalty (tf.gradients(y, [x]) at model.py:63,68):
+there only d/d(input) is wanted, so filter / bias gradients are not launched.
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import kernels as K
+
+_INPUTS_ONLY = [False]
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    prev = _INPUTS_ONLY[0]
+    _INPUTS_ONLY[0] = True
+    try:
+        yield
+    finally:
+        _INPUTS_ONLY[0] = prev
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ActBwdFn(Function):
+    """gy * act'(.) with the derivative read from the activation OUTPUT y.  Linear in gy; piecewise-constant in y for
+    lrelu/relu (zero second derivative — only the mask propagates into the double backward)."""
+
+    @staticmethod
+    def forward(ctx, gy, y, act, alpha):
+        ctx.save_for_backward(y)
+        ctx.act, ctx.alpha = act, alpha
+        return K.act_bwd(_c(gy), y, act, alpha)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(gg, y, ctx.act, ctx.alpha), None, None, None
+
+
+def _act_bwd(gy, y, act, alpha):
+    return ActBwdFn.apply(gy, y, act, alpha) if act != K.ACT_NONE else _c(gy)
+
+
+class ColSumFn(Function):
+    """[rows, C] -> [C]  (bias gradients)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        ctx.shape = a.shape
+        return K.col_reduce(_c(a))[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape)
+
+
+class Conv2dFn(Function):
+    """y = act(conv(x, w) + b): reference utils/ops.py:58-63.  geom = (ConvDesc, workspace_bytes)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geom, act, alpha):
+        d, ws = geom
+        x = _c(x)
+        y = K.conv_fwd(x, w, b, d, ws, act, alpha)
+        ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
+        ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gpre = _act_bwd(gy, y, ctx.act, ctx.alpha)
+        params = not _INPUTS_ONLY[0]
+        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        gw = ConvBwdFilterFn.apply(x, gpre, ctx.geom) if (ctx.needs_input_grad[1] and params) else None
+        gb = ColSumFn.apply(gpre) if (ctx.has_bias and ctx.needs_input_grad[2] and params) else None
+        return gx, gw, gb, None, None, None
+
+
+class ConvBwdDataFn(Function):
+    """dx = act(conv^T(dy, w) + b).  As a backward piece: b=None, act=NONE.  As a forward op this is
+    tf conv2d_transpose (reference utils/ops.py:66-71) — same kernel, TF deconv filters are already HWIO of the adjoint."""
+
+    @staticmethod
+    def forward(ctx, dy, w, b, geom, act, alpha):
+        d, ws = geom
+        dy = _c(dy)
+        out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha)
+        ctx.save_for_backward(dy, w, out if act != K.ACT_NONE else None)
+        ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        dy, w, out = ctx.saved_tensors
+        gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
+        params = not _INPUTS_ONLY[0]
+        g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        g_w = ConvBwdFilterFn.apply(gpre, dy, ctx.geom) if (ctx.needs_input_grad[1] and params) else None
+        g_b = ColSumFn.apply(gpre) if (ctx.has_bias and ctx.needs_input_grad[2] and params) else None
+        return g_dy, g_w, g_b, None, None, None
+
+
+class ConvBwdFilterFn(Function):
+    """dw = x (*) dy."""
+
+    @staticmethod
+    def forward(ctx, x, dy, geom):
+        d, ws = geom
+        x, dy = _c(x), _c(dy)
+        ctx.save_for_backward(x, dy)
+        ctx.geom = geom
+        return K.conv_bwd_filter(x, dy, d, ws)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, dy = ctx.saved_tensors
+        ggw = _c(ggw)
+        g_x = ConvBwdDataFn.apply(dy, ggw, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        g_dy = Conv2dFn.apply(x, ggw, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[1] else None
+        return g_x, g_dy, None
+
+
+class AddActFn(Function):
+    """y = act(a + b): the residual joins (reference models/wgancls/model.py:145-146,190-191,206-207)."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, alpha):
+        y = K.add_act(_c(a), _c(b), act, alpha)
+        ctx.save_for_backward(y if act != K.ACT_NONE else None)
+        ctx.act, ctx.alpha = act, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        g = _act_bwd(gy, y, ctx.act, ctx.alpha)
+        return g, g, None, None
+
+
+class ConcatTileFn(Function):
+    """[B,H,W,Cf] ++ tile([B,Ce]) -> [B,H,W,Cf+Ce]  (reference models/wgancls/model.py:153-155)."""
+
+    @staticmethod
+    def forward(ctx, feat, emb):
+        ctx.cf, ctx.ce = feat.shape[-1], emb.shape[-1]
+        return K.concat_tile_fwd(_c(feat), _c(emb))
+
+    @staticmethod
+    def backward(ctx, g):
+        return ConcatTileBwdFn.apply(g, ctx.cf, ctx.ce)
+
+
+class ConcatTileBwdFn(Function):
+    @staticmethod
+    def forward(ctx, g, cf, ce):
+        return K.concat_tile_bwd(_c(g), cf, ce)
+
+    @staticmethod
+    def backward(ctx, gg_feat, gg_emb):
+        return ConcatTileFn.apply(gg_feat, gg_emb), None, None
+
+
+class NchwToNhwcFn(Function):
+    """physical [B,C,H,W] -> physical [B,H,W,C] (reference utils/ops.py:132-134 to_nhwc)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return K.nchw_to_nhwc(_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return NhwcToNchwFn.apply(g)
+
+
+class NhwcToNchwFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K.nhwc_to_nchw(_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return NchwToNhwcFn.apply(g)
+
+
+class ActFn(Function):
+    """y = act(x) as a standalone op (first-order for tanh, any order for lrelu/relu)."""
+
+    @staticmethod
+    def forward(ctx, x, act, alpha):
+        y = K.act_fwd(_c(x), act, alpha)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.alpha = act, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(gy, y, ctx.act, ctx.alpha), None, None
+
+
+class BatchNormTrainFn(Function):
+    """Training-mode fused batch norm + activation: reference utils/ops.py:7-29.  Normalises with the biased batch
+    variance; if moving_mean/var are given they are updated in place with the unbiased one (TF UPDATE_OPS semantics are
+    decided by the caller).  Generator only => first order."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, decay, act, alpha):
+        x = _c(x)
+        C = x.shape[-1]
+        n = x.numel() // C
+        s, ss = K.col_reduce(x, None, True)
+        mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean, moving_var)
+        y = K.bn_apply(x, scale, shift, act, alpha)
+        ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
+        ctx.act, ctx.alpha = act, alpha
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gm, _gr):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act != K.ACT_NONE:
+            gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
+        sum_dy, sum_dy_x = K.col_reduce(gy, x, True)
+        dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class GpSlopesFn(Function):
+    """slopes[b] = ||g[b]||_2 (reference models/wgancls/model.py:64,69).  Its backward feeds the double backward of the
+    critic; it is itself only differentiated once."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        s = K.gp_slopes(g)
+        ctx.save_for_backward(g, s)
+        return s
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        g, s = ctx.saved_tensors
+        coef = torch.where(s > 0, ds / s.clamp_min(1e-30), torch.zeros_like(s))   # [B] scalars per sample
+        return K.row_scale(g, _c(coef))

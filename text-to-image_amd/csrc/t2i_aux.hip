@@ -1,0 +1,463 @@
+// t2i_aux.hip — the bandwidth-bound kernels around the implicit GEMMs (gfx950 only): column reductions (bias
+// gradients, BatchNorm moments), BatchNorm finalize/apply/backward, activations, residual joins, x_hat interpolation,
+// text-embedding tile+concat, NCHW<->NHWC transposes, the gradient-penalty slope norm and TF-flavoured Adam.
+// All are HBM-bound: 16-byte accesses where the shape allows, grid-stride loops capped at 2048 blocks (256 CUs x 8),
+// wave64 shuffle reductions, fixed summation order (deterministic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+static inline int ew_blocks(size_t n_items) {
+  size_t b = (n_items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column reduction, stage 1: grid (col tiles of 64, row chunks); block (64 cols, 4 row lanes)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t rows, int C, int64_t rows_per_chunk,
+                                                         float* __restrict__ part0, float* __restrict__ part1,
+                                                         bool want1) {
+  __shared__ float s0[4][64], s1[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t rend = rbeg + rows_per_chunk;
+  if (rend > rows) rend = rows;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (c < C) {
+    for (int64_t r = rbeg + ty; r < rend; r += 4) {
+      float va = a[r * C + c];
+      acc0 += va;
+      if (want1) acc1 += va * (b ? b[r * C + c] : va);
+    }
+  }
+  s0[ty][tx] = acc0;
+  s1[ty][tx] = acc1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    part0[(size_t)blockIdx.y * C + c] = (s0[0][tx] + s0[1][tx]) + (s0[2][tx] + s0[3][tx]);
+    if (want1) part1[(size_t)blockIdx.y * C + c] = (s1[0][tx] + s1[1][tx]) + (s1[2][tx] + s1[3][tx]);
+  }
+}
+
+__global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                         int nchunks, int C, float* __restrict__ out0,
+                                                         float* __restrict__ out1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    s0 += part0[(size_t)k * C + c];
+    if (out1) s1 += part1[(size_t)k * C + c];
+  }
+  out0[c] = s0;
+  if (out1) out1[c] = s1;
+}
+
+static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int64_t* rows_per_chunk) {
+  *ctiles = (C + 63) / 64;
+  int64_t want = 1024 / *ctiles;              // ~1024 blocks in flight
+  if (want < 1) want = 1;
+  int64_t maxchunks = (rows + 63) / 64;       // at least 64 rows per chunk
+  if (want > maxchunks) want = maxchunks;
+  if (want < 1) want = 1;
+  *rows_per_chunk = (rows + want - 1) / want;
+  *nchunks = (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
+  if (*nchunks < 1) *nchunks = 1;
+}
+
+size_t col_reduce_ws(int64_t rows, int C) {
+  int ct, nc; int64_t rpc;
+  col_reduce_plan(rows, C, &ct, &nc, &rpc);
+  return (size_t)nc * C * 2 * sizeof(float);
+}
+
+hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C, float* out0, float* out1, void* ws,
+                             hipStream_t stream) {
+  int ct, nc; int64_t rpc;
+  col_reduce_plan(rows, C, &ct, &nc, &rpc);
+  float* part0 = reinterpret_cast<float*>(ws);
+  float* part1 = part0 + (size_t)nc * C;
+  hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
+                     out1 != nullptr);
+  hipLaunchKernelGGL(col_reduce_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, part0, part1, nc, C, out0, out1);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batch norm
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float n, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float decay, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mmean,
+                                   float* __restrict__ mvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = sum[c] / n;
+  float var = sumsq[c] / n - mu * mu;   // biased batch variance
+  if (var < 0.f) var = 0.f;
+  const float rs = rsqrtf(var + eps);
+  mean[c] = mu;
+  rstd[c] = rs;
+  const float sc = gamma[c] * rs;
+  scale[c] = sc;
+  shift[c] = beta[c] - mu * sc;
+  if (mmean) {  // TF fused BN: the moving variance takes the UNBIASED estimate
+    const float unb = var * (n / fmaxf(n - 1.f, 1.f));
+    mmean[c] = decay * mmean[c] + (1.f - decay) * mu;
+    mvar[c] = decay * mvar[c] + (1.f - decay) * unb;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, size_t n, int C, int act,
+                                                       float alpha, float* __restrict__ y) {
+  if (VEC) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)((i * 4) % (size_t)C);
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      v.x = apply_act(v.x * sc.x + sh.x, act, alpha);
+      v.y = apply_act(v.y * sc.y + sh.y, act, alpha);
+      v.z = apply_act(v.z * sc.z + sh.z, act, alpha);
+      v.w = apply_act(v.w * sc.w + sh.w, act, alpha);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % (size_t)C);
+      y[i] = apply_act(x[i] * scale[c] + shift[c], act, alpha);
+    }
+  }
+}
+
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ sum_dy,
+                                   const float* __restrict__ sum_dy_x, float n, int C, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, float* __restrict__ k_dy, float* __restrict__ k_x,
+                                   float* __restrict__ k_0) {
+  // dx = g*rs*(dy - sdy/n - xhat*sdyxh/n), xhat = (x-mu)*rs  ==  k_dy*dy + k_x*x + k_0
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], rs = rstd[c], g = gamma[c], sdy = sum_dy[c];
+  const float sdyxh = rs * (sum_dy_x[c] - mu * sdy);
+  dgamma[c] = sdyxh;
+  dbeta[c] = sdy;
+  const float grs = g * rs;
+  k_dy[c] = grs;
+  k_x[c] = -grs * rs * sdyxh / n;
+  k_0[c] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ k_dy, const float* __restrict__ k_x,
+                                                           const float* __restrict__ k_0, size_t n, int C,
+                                                           float* __restrict__ dx) {
+  if (VEC) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)((i * 4) % (size_t)C);
+      const float4 d = reinterpret_cast<const float4*>(dy)[i];
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 a = *reinterpret_cast<const float4*>(k_dy + c);
+      const float4 b = *reinterpret_cast<const float4*>(k_x + c);
+      const float4 e = *reinterpret_cast<const float4*>(k_0 + c);
+      float4 o;
+      o.x = a.x * d.x + b.x * v.x + e.x;
+      o.y = a.y * d.y + b.y * v.y + e.y;
+      o.z = a.z * d.z + b.z * v.z + e.z;
+      o.w = a.w * d.w + b.w * v.w + e.w;
+      reinterpret_cast<float4*>(dx)[i] = o;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % (size_t)C);
+      dx[i] = k_dy[c] * dy[i] + k_x[c] * x[i] + k_0[c];
+    }
+  }
+}
+
+hipError_t bn_finalize_launch(const float* sum, const float* sumsq, int64_t n, int C, const float* gamma,
+                              const float* beta, float eps, float decay, float* mean, float* rstd, float* scale,
+                              float* shift, float* mm, float* mv, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, (float)n, C, gamma,
+                     beta, eps, decay, mean, rstd, scale, shift, mm, mv);
+  return hipGetLastError();
+}
+
+hipError_t bn_apply_launch(const float* x, const float* scale, const float* shift, int64_t rows, int C, int act,
+                           float alpha, float* y, hipStream_t stream) {
+  const bool al = C > 0;          // the C API passes -C when some pointer is not 16-byte aligned
+  if (C < 0) C = -C;
+  const size_t n = (size_t)rows * C;
+  if (al && (C & 3) == 0)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act,
+                       alpha, y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, scale, shift, n, C, act,
+                       alpha, y);
+  return hipGetLastError();
+}
+
+// dgamma/dbeta double as scratch-free outputs; k_* coefficients live in the caller-visible dgamma-sized buffers
+hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* sum_dy, const float* sum_dy_x, int64_t rows, int C, float* dx, float* dgamma,
+                         float* dbeta, float* coef /* 3*C floats */, hipStream_t stream) {
+  const bool al = C > 0;
+  if (C < 0) C = -C;
+  float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, mean, rstd, gamma, sum_dy,
+                     sum_dy_x, (float)rows, C, dgamma, dbeta, k_dy, k_x, k_0);
+  const size_t n = (size_t)rows * C;
+  if (al && (C & 3) == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0,
+                       n, C, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0, n,
+                       C, dx);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise (float4 body + scalar tail handled by the same kernel)
+// ---------------------------------------------------------------------------------------------------------------
+enum { EW_ACT_FWD = 0, EW_ACT_BWD = 1, EW_ADD_ACT = 2, EW_AXPBY = 3 };
+
+__device__ __forceinline__ float act_grad_from_output(float y, int act, float alpha) {
+  switch (act) {
+    case T2I_ACT_LRELU: return y > 0.f ? 1.f : alpha;
+    case T2I_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case T2I_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ float ew_op(float a, float b, int act, float alpha, float beta) {
+  if (OP == EW_ACT_FWD) return apply_act(a, act, alpha);
+  if (OP == EW_ACT_BWD) return a * act_grad_from_output(b, act, alpha);   // a = dy, b = y
+  if (OP == EW_ADD_ACT) return apply_act(a + b, act, alpha);
+  return alpha * a + beta * b;                                            // EW_AXPBY
+}
+
+template <int OP, bool HAS_B>
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                 size_t n4, int act, float alpha, float beta, float* __restrict__ y) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t; i < n4; i += stride) {
+    const float4 va = reinterpret_cast<const float4*>(a)[i];
+    float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_B) vb = reinterpret_cast<const float4*>(b)[i];
+    float4 o;
+    o.x = ew_op<OP>(va.x, vb.x, act, alpha, beta);
+    o.y = ew_op<OP>(va.y, vb.y, act, alpha, beta);
+    o.z = ew_op<OP>(va.z, vb.z, act, alpha, beta);
+    o.w = ew_op<OP>(va.w, vb.w, act, alpha, beta);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+  for (size_t i = (n4 << 2) + t; i < n; i += stride) y[i] = ew_op<OP>(a[i], HAS_B ? b[i] : 0.f, act, alpha, beta);
+}
+
+hipError_t ew_launch(int op, const float* a, const float* b, size_t n_flag, int act, float alpha, float beta, float* y,
+                     hipStream_t stream) {
+  // bit 63 of n_flag set => some pointer is not 16-byte aligned: no float4 body, everything through the scalar tail
+  const bool al = (n_flag >> 63) == 0;
+  const size_t n = n_flag & ~(1ull << 63);
+  const size_t n4 = al ? (n >> 2) : 0;
+  dim3 g(ew_blocks(al ? ((n + 3) >> 2) : n)), blk(256);
+  switch (op) {
+    case EW_ACT_FWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_FWD, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
+    case EW_ACT_BWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_BWD, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
+    case EW_ADD_ACT: hipLaunchKernelGGL((ew_kernel<EW_ADD_ACT, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
+    default:
+      if (b) hipLaunchKernelGGL((ew_kernel<EW_AXPBY, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y);
+      else hipLaunchKernelGGL((ew_kernel<EW_AXPBY, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y);
+  }
+  return hipGetLastError();
+}
+
+// x_hat[b,:] = eps[b]*g[b,:] + (1-eps[b])*x[b,:]
+__global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ eps, const float* __restrict__ g,
+                                                     const float* __restrict__ x, size_t n, size_t per,
+                                                     float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = eps[i / per];
+    out[i] = e * g[i] + (1.f - e) * x[i];
+  }
+}
+
+// out[b,p,:] = [feat[b,p,:Cf] | emb[b,:Ce]]
+__global__ __launch_bounds__(256) void concat_tile_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ emb,
+                                                              size_t n, int P, int Cf, int Ce, float* __restrict__ out) {
+  const int Ct = Cf + Ce;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / Ct;
+    const int c = (int)(i - pix * Ct);
+    out[i] = c < Cf ? feat[pix * Cf + c] : emb[(pix / P) * Ce + (c - Cf)];
+  }
+}
+
+// dfeat = dout[..., :Cf]; demb[b,:] = sum_p dout[b,p,Cf:]
+__global__ __launch_bounds__(256) void concat_tile_bwd_kernel(const float* __restrict__ dout, size_t nfeat, size_t nemb,
+                                                              int P, int Cf, int Ce, float* __restrict__ dfeat,
+                                                              float* __restrict__ demb) {
+  const int Ct = Cf + Ce;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfeat + nemb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nfeat) {
+      const size_t pix = i / Cf;
+      const int c = (int)(i - pix * Cf);
+      dfeat[i] = dout[pix * Ct + c];
+    } else {
+      const size_t j = i - nfeat;
+      const size_t b = j / Ce;
+      const int c = (int)(j - b * Ce);
+      float s = 0.f;
+      for (int p = 0; p < P; ++p) s += dout[(b * P + p) * Ct + Cf + c];
+      demb[j] = s;
+    }
+  }
+}
+
+// [B,C,HW] <-> [B,HW,C] through a 32x32 LDS tile (+1 pad) so both sides are coalesced
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+  // per batch: x is [R, Cc] row-major -> y is [Cc, R]
+  __shared__ float tile[32][33];
+  const size_t boff = (size_t)blockIdx.z * R * Cc;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Cc) ? x[boff + (size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) y[boff + (size_t)c * R + r] = tile[tx][j];
+  }
+}
+
+hipError_t interp_launch(const float* eps, const float* g, const float* x, int B, int64_t per, float* out,
+                         hipStream_t stream) {
+  const size_t n = (size_t)B * per;
+  hipLaunchKernelGGL(interp_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, eps, g, x, n, (size_t)per, out);
+  return hipGetLastError();
+}
+
+hipError_t concat_tile_fwd_launch(const float* feat, const float* emb, int B, int P, int Cf, int Ce, float* out,
+                                  hipStream_t stream) {
+  const size_t n = (size_t)B * P * (Cf + Ce);
+  hipLaunchKernelGGL(concat_tile_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, feat, emb, n, P, Cf, Ce, out);
+  return hipGetLastError();
+}
+
+hipError_t concat_tile_bwd_launch(const float* dout, int B, int P, int Cf, int Ce, float* dfeat, float* demb,
+                                  hipStream_t stream) {
+  const size_t nfeat = (size_t)B * P * Cf, nemb = (size_t)B * Ce;
+  hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(ew_blocks(nfeat + nemb)), dim3(256), 0, stream, dout, nfeat, nemb, P,
+                     Cf, Ce, dfeat, demb);
+  return hipGetLastError();
+}
+
+hipError_t transpose_launch(const float* x, int B, int R, int Cc, float* y, hipStream_t stream) {
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32, B);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, x, R, Cc, y);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gradient penalty: per-sample L2 norm (one block per sample, wave64 shuffle + LDS across the 4 waves)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_slopes_kernel(const float* __restrict__ g, size_t per, float* __restrict__ slopes) {
+  __shared__ float red[4];
+  const float* row = g + (size_t)blockIdx.x * per;
+  float acc = 0.f;
+  const size_t n4 = ((per & 3) == 0 && (((size_t)blockIdx.x * per) & 3) == 0) ? (per >> 2) : 0;
+  for (size_t i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (size_t i = (n4 << 2) + threadIdx.x; i < per; i += 256) acc += row[i] * row[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) slopes[blockIdx.x] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ g, const float* __restrict__ coef,
+                                                        size_t n, size_t per, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = coef[i / per] * g[i];
+}
+
+hipError_t gp_slopes_launch(const float* g, int B, int64_t per, float* slopes, hipStream_t stream) {
+  hipLaunchKernelGGL(gp_slopes_kernel, dim3(B), dim3(256), 0, stream, g, (size_t)per, slopes);
+  return hipGetLastError();
+}
+
+hipError_t row_scale_launch(const float* g, const float* coef, int B, int64_t per, float* out, hipStream_t stream) {
+  const size_t n = (size_t)B * per;
+  hipLaunchKernelGGL(row_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer over a flat arena
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, size_t n, float lr_t,
+                                                      float b1, float b2, float eps, float gscale) {
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t; i < n4; i += stride) {
+    float4 W = reinterpret_cast<float4*>(w)[i];
+    const float4 G0 = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+    float gx = G0.x * gscale, gy = G0.y * gscale, gz = G0.z * gscale, gw = G0.w * gscale;
+    M.x = b1 * M.x + (1.f - b1) * gx; M.y = b1 * M.y + (1.f - b1) * gy;
+    M.z = b1 * M.z + (1.f - b1) * gz; M.w = b1 * M.w + (1.f - b1) * gw;
+    V.x = b2 * V.x + (1.f - b2) * gx * gx; V.y = b2 * V.y + (1.f - b2) * gy * gy;
+    V.z = b2 * V.z + (1.f - b2) * gz * gz; V.w = b2 * V.w + (1.f - b2) * gw * gw;
+    W.x -= lr_t * M.x / (sqrtf(V.x) + eps); W.y -= lr_t * M.y / (sqrtf(V.y) + eps);
+    W.z -= lr_t * M.z / (sqrtf(V.z) + eps); W.w -= lr_t * M.w / (sqrtf(V.w) + eps);
+    reinterpret_cast<float4*>(w)[i] = W;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  for (size_t i = (n4 << 2) + t; i < n; i += stride) {
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    w[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                          float eps, float gscale, hipStream_t stream) {
+  hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_blocks(((size_t)n + 3) >> 2)), dim3(256), 0, stream, w, g, m, v, (size_t)n,
+                     lr_t, b1, b2, eps, gscale);
+  return hipGetLastError();
+}
+
+}  // namespace t2i

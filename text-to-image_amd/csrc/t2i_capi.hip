@@ -1,0 +1,367 @@
+// t2i_capi.hip — the extern "C" surface of libt2i_hip.so (declared in include/t2i_hip.h): argument validation, GEMM
+// planning (tile shape, split-K, stride phases, vector-path eligibility) and launches.  No allocation, no
+// synchronisation: every entry point only enqueues kernels on the caller's stream, so a whole training step can be
+// captured into a hipGraph.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// launchers implemented in t2i_aux.hip
+size_t col_reduce_ws(int64_t rows, int C);
+hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, void*, hipStream_t);
+hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
+                              float*, float*, float*, float*, float*, hipStream_t);
+hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t);
+hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                         int64_t, int, float*, float*, float*, float*, hipStream_t);
+hipError_t ew_launch(int, const float*, const float*, size_t, int, float, float, float*, hipStream_t);
+hipError_t interp_launch(const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
+hipError_t concat_tile_fwd_launch(const float*, const float*, int, int, int, int, float*, hipStream_t);
+hipError_t concat_tile_bwd_launch(const float*, int, int, int, int, float*, float*, hipStream_t);
+hipError_t transpose_launch(const float*, int, int, int, float*, hipStream_t);
+hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
+hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
+hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, float, float, float, float, hipStream_t);
+
+static int check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return T2I_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return T2I_ERR_LAUNCH;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int validate_desc(const t2i_conv_desc* d) {
+  if (!d) { set_error("null descriptor"); return T2I_ERR_INVALID; }
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->KH <= 0 ||
+      d->KW <= 0 || d->SH <= 0 || d->SW <= 0 || d->pad_t < 0 || d->pad_l < 0) {
+    set_error("non-positive extent in conv descriptor");
+    return T2I_ERR_INVALID;
+  }
+  if (d->SH > 4 || d->SW > 4) { set_error("stride > 4 unsupported (16 phases max)"); return T2I_ERR_INVALID; }
+  // the last output pixel must start inside the padded image (true for TF SAME / VALID geometries)
+  if ((d->Ho - 1) * d->SH - d->pad_t >= d->H || (d->Wo - 1) * d->SW - d->pad_l >= d->W) {
+    set_error("output extent inconsistent with input/stride/pad");
+    return T2I_ERR_INVALID;
+  }
+  const int64_t lim = 2147483647LL;
+  int64_t nx = (int64_t)d->B * d->H * d->W * d->Cin, ny = (int64_t)d->B * d->Ho * d->Wo * d->Cout,
+          nw = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
+  if (nx > lim || ny > lim || nw > lim) { set_error("tensor exceeds 2^31-1 elements"); return T2I_ERR_INVALID; }
+  return T2I_OK;
+}
+
+struct Plan {
+  int wmt, wnt, splitk, k_per_split, tiles_m, tiles_n;
+  size_t ws_bytes;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// Tile / split-K choice.  The fp32 matrix pipe is slow relative to L2 (a 64x64 tile still needs only ~10 TB/s of
+// the ~34 TB/s aggregate L2 at full MFMA rate), so filling all 256 CUs with >= 2 workgroups each matters more than
+// the largest tile: shrink the tile, then split K, until there are ~512 workgroups or K per split hits 256.
+static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems) {
+  Plan pl;
+  pl.wnt = N > 64 ? 2 : 1;
+  pl.wmt = M > 64 ? 2 : 1;
+  auto blocks = [&](int wmt, int wnt) {
+    return ((M + 64 * wmt - 1) / (64 * wmt)) * ((N + 64 * wnt - 1) / (64 * wnt)) * nphase;
+  };
+  const int64_t target = 512;
+  int64_t maxsplit = K / 256;
+  if (maxsplit < 1) maxsplit = 1;
+  if (maxsplit > 32) maxsplit = 32;
+  if (blocks(pl.wmt, pl.wnt) * maxsplit < target && pl.wmt == 2) pl.wmt = 1;
+  if (blocks(pl.wmt, pl.wnt) * maxsplit < target && pl.wnt == 2) pl.wnt = 1;
+  int ft = env_int("T2I_FORCE_TILE", 0);   // e.g. 22, 12, 21, 11 (tuning hook)
+  if (ft) { pl.wmt = ft / 10; pl.wnt = ft % 10; }
+  int64_t nb = blocks(pl.wmt, pl.wnt);
+  int64_t sk = (target + nb - 1) / nb;
+  if (sk > maxsplit) sk = maxsplit;
+  if (sk < 1) sk = 1;
+  int fs = env_int("T2I_FORCE_SPLITK", 0);
+  if (fs > 0) sk = fs;
+  int64_t ktiles = (K + 31) / 32;
+  int64_t tiles_per_split = (ktiles + sk - 1) / sk;
+  if (tiles_per_split < 1) tiles_per_split = 1;
+  pl.k_per_split = (int)(tiles_per_split * 32);
+  pl.splitk = (int)((ktiles + tiles_per_split - 1) / tiles_per_split);
+  if (pl.splitk < 1) pl.splitk = 1;
+  pl.tiles_m = (int)((M + 64 * pl.wmt - 1) / (64 * pl.wmt));
+  pl.tiles_n = (int)((N + 64 * pl.wnt - 1) / (64 * pl.wnt));
+  pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
+  return pl;
+}
+
+static void fill_common(IgemmParams& p, const t2i_conv_desc* d) {
+  memset(&p, 0, sizeof(p));
+  p.d = *d;
+  p.howo = d->Ho * d->Wo;
+  p.div_howo.set(p.howo);
+  p.div_wo.set(d->Wo);
+  p.div_kw.set(d->KW);
+  const int Hq = (d->H + d->SH - 1) / d->SH;
+  p.Wq = (d->W + d->SW - 1) / d->SW;
+  p.hqwq = Hq * p.Wq;
+  p.div_hqwq.set(p.hqwq);
+  p.div_wq.set(p.Wq);
+  p.nphase = 1;
+}
+
+// stride phases of the transposed conv: dx pixels with (ih % SH, iw % SW) == (ph, pw) see taps kh = kh0 + SH*jh
+static int fill_phases(IgemmParams& p) {
+  const t2i_conv_desc& d = p.d;
+  int np = 0, kmax = 0;
+  for (int ph = 0; ph < d.SH; ++ph)
+    for (int pw = 0; pw < d.SW; ++pw) {
+      PhaseInfo& pi = p.phase[np++];
+      pi.ph = ph; pi.pw = pw;
+      pi.kh0 = (ph + d.pad_t) % d.SH;
+      pi.kw0 = (pw + d.pad_l) % d.SW;
+      pi.nth = pi.kh0 < d.KH ? (d.KH - pi.kh0 + d.SH - 1) / d.SH : 0;
+      pi.ntw = pi.kw0 < d.KW ? (d.KW - pi.kw0 + d.SW - 1) / d.SW : 0;
+      pi.oh_off = (ph + d.pad_t - pi.kh0) / d.SH;
+      pi.ow_off = (pw + d.pad_l - pi.kw0) / d.SW;
+      pi.K = pi.nth * pi.ntw * d.Cout;
+      pi.div_ntw.set(pi.ntw > 0 ? pi.ntw : 1);
+      if (pi.K > kmax) kmax = pi.K;
+    }
+  p.nphase = np;
+  return kmax;
+}
+
+static int run_gemm(int mode, IgemmParams& p, size_t out_elems, bool vec, float* out, const float* bias, int act,
+                    float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
+  p.out_elems = out_elems;
+  if (pl.splitk > 1) {
+    if (!ws || ws_bytes < pl.ws_bytes || !aligned16(ws)) {
+      set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, pl.ws_bytes);
+      return T2I_ERR_WORKSPACE;
+    }
+    p.c = reinterpret_cast<float*>(ws);
+    p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f;
+  } else {
+    p.c = out; p.bias = bias; p.act = act; p.alpha = alpha;
+  }
+  int rc = check(igemm_launch(mode, p, pl.wmt, pl.wnt, vec, stream), what);
+  if (rc != T2I_OK) return rc;
+  if (pl.splitk > 1)
+    rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(ws), pl.splitk, out_elems, bias, p.N, act, alpha, out,
+                                    stream), what);
+  return rc;
+}
+
+}  // namespace t2i
+
+using namespace t2i;
+
+extern "C" {
+
+int t2i_version(void) { return 1; }
+
+const char* t2i_last_error(void) { return g_err; }
+
+int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return check(e, "t2i_device_info");
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (arch && arch_len) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+  return T2I_OK;
+}
+
+size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
+  if (validate_desc(d) != T2I_OK) return 0;
+  IgemmParams p;
+  fill_common(p, d);
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout,
+               nw = (size_t)d->KH * d->KW * d->Cin * d->Cout;
+  size_t need = make_plan((int64_t)d->B * d->Ho * d->Wo, d->Cout, (int64_t)d->KH * d->KW * d->Cin, 1, ny).ws_bytes;
+  int kmax = fill_phases(p);
+  size_t b = make_plan((int64_t)d->B * p.hqwq, d->Cin, kmax, p.nphase, nx).ws_bytes;
+  if (b > need) need = b;
+  b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw).ws_bytes;
+  if (b > need) need = b;
+  return need;
+}
+
+int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                   float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
+  IgemmParams p;
+  fill_common(p, d);
+  p.a = x; p.b = w;
+  p.M = d->B * d->Ho * d->Wo; p.N = d->Cout; p.K = d->KH * d->KW * d->Cin;
+  p.div_c.set(d->Cin);
+  const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
+  return run_gemm(MODE_FWD, p, (size_t)p.M * p.N, vec, y, bias, act, alpha, ws, ws_bytes, (hipStream_t)stream,
+                  "t2i_conv2d_fwd");
+}
+
+int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
+                        float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
+  IgemmParams p;
+  fill_common(p, d);
+  p.a = dy; p.b = w;
+  p.K = fill_phases(p);
+  p.M = d->B * p.hqwq; p.N = d->Cin;
+  p.div_c.set(d->Cout);
+  const bool vec = (d->Cout % 4 == 0) && aligned16(dy) && aligned16(w);
+  return run_gemm(MODE_BWD_DATA, p, (size_t)d->B * d->H * d->W * d->Cin, vec, dx, bias, act, alpha, ws, ws_bytes,
+                  (hipStream_t)stream, "t2i_conv2d_bwd_data");
+}
+
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                          t2i_stream_t stream) {
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
+  IgemmParams p;
+  fill_common(p, d);
+  p.a = x; p.b = dy;
+  p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
+  p.div_c.set(d->Cin);
+  const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
+  return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, vec, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
+                  (hipStream_t)stream, "t2i_conv2d_bwd_filter");
+}
+
+size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return col_reduce_ws(rows, C);
+}
+
+int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, void* ws,
+                   size_t ws_bytes, t2i_stream_t stream) {
+  if (!a || !out0 || rows <= 0 || C <= 0) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
+  if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_col_reduce: workspace too small"); return T2I_ERR_WORKSPACE; }
+  return check(col_reduce_launch(a, b, rows, C, out0, out1, ws, (hipStream_t)stream), "t2i_col_reduce");
+}
+
+int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma, const float* beta,
+                    float eps, float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean,
+                    float* moving_var, t2i_stream_t stream) {
+  if (!sum || !sumsq || !gamma || !beta || !mean || !rstd || !scale || !shift || n <= 0 || C <= 0 ||
+      ((moving_mean == nullptr) != (moving_var == nullptr))) {
+    set_error("t2i_bn_finalize: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  return check(bn_finalize_launch(sum, sumsq, n, C, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean,
+                                  moving_var, (hipStream_t)stream), "t2i_bn_finalize");
+}
+
+int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act, float alpha,
+                 float* y, t2i_stream_t stream) {
+  if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) { set_error("t2i_bn_apply: bad argument"); return T2I_ERR_INVALID; }
+  const bool al = aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift);
+  return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, y, (hipStream_t)stream), "t2i_bn_apply");
+}
+
+int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma, float* dbeta,
+               void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !sum_dy || !sum_dy_x || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) {
+    set_error("t2i_bn_bwd: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  if (!ws || ws_bytes < (size_t)3 * C * sizeof(float) || !aligned16(ws)) { set_error("t2i_bn_bwd: workspace too small"); return T2I_ERR_WORKSPACE; }
+  const bool al = aligned16(dy) && aligned16(x) && aligned16(dx);
+  return check(bn_bwd_launch(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x, rows, al ? C : -C, dx, dgamma, dbeta,
+                             reinterpret_cast<float*>(ws), (hipStream_t)stream), "t2i_bn_bwd");
+}
+
+static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y,
+                   t2i_stream_t stream, const char* what, bool need_b) {
+  if (!a || !y || n <= 0 || (need_b && !b)) { set_error("%s: bad argument", what); return T2I_ERR_INVALID; }
+  const bool al = aligned16(a) && aligned16(y) && (!b || aligned16(b));
+  // unaligned views take the scalar tail path: tell the kernel there is no float4 body
+  return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, y, (hipStream_t)stream), what);
+}
+
+int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
+  return ew_call(0, x, nullptr, n, act, alpha, 0.f, y, stream, "t2i_act_fwd", false);
+}
+int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream) {
+  return ew_call(1, dy, y, n, act, alpha, 0.f, dx, stream, "t2i_act_bwd", true);
+}
+int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
+  return ew_call(2, a, b, n, act, alpha, 0.f, y, stream, "t2i_add_act", true);
+}
+int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream) {
+  return ew_call(3, a, b, n, T2I_ACT_NONE, alpha, beta, y, stream, "t2i_axpby", false);
+}
+
+int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int64_t per_sample, float* xhat,
+               t2i_stream_t stream) {
+  if (!eps || !g || !x || !xhat || B <= 0 || per_sample <= 0) { set_error("t2i_interp: bad argument"); return T2I_ERR_INVALID; }
+  return check(interp_launch(eps, g, x, B, per_sample, xhat, (hipStream_t)stream), "t2i_interp");
+}
+
+int t2i_concat_tile_fwd(const float* feat, const float* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* out,
+                        t2i_stream_t stream) {
+  if (!feat || !emb || !out || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0) { set_error("t2i_concat_tile_fwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(concat_tile_fwd_launch(feat, emb, B, P, Cf, Ce, out, (hipStream_t)stream), "t2i_concat_tile_fwd");
+}
+
+int t2i_concat_tile_bwd(const float* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* dfeat, float* demb,
+                        t2i_stream_t stream) {
+  if (!dout || !dfeat || !demb || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0) { set_error("t2i_concat_tile_bwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(concat_tile_bwd_launch(dout, B, P, Cf, Ce, dfeat, demb, (hipStream_t)stream), "t2i_concat_tile_bwd");
+}
+
+int t2i_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) { set_error("t2i_nchw_to_nhwc: bad argument"); return T2I_ERR_INVALID; }
+  return check(transpose_launch(x, B, C, HW, y, (hipStream_t)stream), "t2i_nchw_to_nhwc");   // [C,HW] -> [HW,C]
+}
+
+int t2i_nhwc_to_nchw(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) { set_error("t2i_nhwc_to_nchw: bad argument"); return T2I_ERR_INVALID; }
+  return check(transpose_launch(x, B, HW, C, y, (hipStream_t)stream), "t2i_nhwc_to_nchw");   // [HW,C] -> [C,HW]
+}
+
+int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, t2i_stream_t stream) {
+  if (!g || !slopes || B <= 0 || per_sample <= 0) { set_error("t2i_gp_slopes: bad argument"); return T2I_ERR_INVALID; }
+  return check(gp_slopes_launch(g, B, per_sample, slopes, (hipStream_t)stream), "t2i_gp_slopes");
+}
+
+int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream) {
+  if (!g || !coef || !out || B <= 0 || per_sample <= 0) { set_error("t2i_row_scale: bad argument"); return T2I_ERR_INVALID; }
+  return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream), "t2i_row_scale");
+}
+
+int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                float grad_scale, t2i_stream_t stream) {
+  if (!w || !g || !m || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
+  if (!(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
+  return check(adam_tf_launch(w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// t2i_internal.h — shared between the kernel translation units of libt2i_hip.so (not part of the C ABI).
+#ifndef T2I_INTERNAL_H
+#define T2I_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/t2i_hip.h"
+
+namespace t2i {
+
+enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_FILTER = 2 };
+
+// Division by a launch-constant via multiply-high (valid for 0 <= n < 2^31): the im2col index decode must not cost a
+// 30-instruction integer division per gathered element.
+struct FastDiv {
+  uint32_t mul, shr, one;
+  __host__ void set(uint32_t d) {
+    one = (d == 1);
+    if (d == 1) { mul = 0; shr = 0; return; }
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;                       // ceil(log2 d)
+    uint64_t pw = 1ull << (31 + l);
+    mul = (uint32_t)((pw + d - 1) / d);
+    shr = l - 1;
+  }
+  __device__ __forceinline__ int div(int n) const {
+    return one ? n : (int)(__umulhi((uint32_t)n, mul) >> shr);
+  }
+};
+
+struct PhaseInfo {      // one stride phase of BWD_DATA: output pixels with (ih % SH, iw % SW) == (ph, pw)
+  int32_t ph, pw;       // phase
+  int32_t kh0, kw0;     // first filter tap that lands on this phase; taps are kh0 + SH*jh
+  int32_t oh_off, ow_off;  // oh = ihq + oh_off - jh
+  int32_t nth, ntw;     // taps per phase
+  int32_t K;            // nth*ntw*Cout
+  FastDiv div_ntw;
+};
+
+struct IgemmParams {
+  t2i_conv_desc d;
+  const float* a;
+  const float* b;
+  float* c;
+  const float* bias;
+  int32_t act;
+  float alpha;
+  int32_t M, N, K;            // GEMM extents (BWD_DATA: M per phase; K = max over phases, per-phase K in phase[])
+  int32_t tiles_m, tiles_n;
+  int32_t splitk, k_per_split;
+  size_t out_elems;           // slab stride for split-K
+  int32_t howo, hqwq, Wq;     // Ho*Wo; Hq*Wq; Wq  (Hq = ceil(H/SH))
+  FastDiv div_howo, div_wo, div_hqwq, div_wq, div_c, div_kw;
+  int32_t nphase;
+  PhaseInfo phase[16];
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+  switch (act) {
+    case T2I_ACT_LRELU: return v > 0.f ? v : alpha * v;
+    case T2I_ACT_RELU: return v > 0.f ? v : 0.f;
+    case T2I_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, bool vec, hipStream_t stream);
+hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
+                                float alpha, float* out, hipStream_t stream);
+
+void set_error(const char* fmt, ...);
+
+}  // namespace t2i
+#endif

@@ -1,0 +1,356 @@
+"""Tensor-level wrappers over the C ABI (include/t2i_hip.h).  Each function allocates its output with torch (device
+memory + caching allocator are PyTorch's job), passes raw device pointers and the current HIP stream to libt2i_hip.so
+and returns.  No arithmetic happens in Python or in torch here.
+
+CPU tensors are refused: the product path has no CPU implementation.  The only exception is ``dry_run()``, used by
+the host-logic tests and by variable creation, in which launches are skipped and outputs are uninitialised
+``torch.empty`` of the right shape (shape inference only — values are garbage by construction).
+"""
+import contextlib
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+_DRY = [False]
+
+
+@contextlib.contextmanager
+def dry_run():
+    """Shape-inference mode: no kernel is launched, outputs are uninitialised."""
+    prev = _DRY[0]
+    _DRY[0] = True
+    try:
+        yield
+    finally:
+        _DRY[0] = prev
+
+
+def is_dry():
+    return _DRY[0]
+
+
+def _live(t):
+    """True -> launch on the GPU.  False -> dry run.  CPU tensor outside dry_run -> error (no fallback)."""
+    if _DRY[0]:
+        return False
+    if t.is_cuda:
+        return True
+    raise RuntimeError('text-to-image_amd kernels need a ROCm device tensor (got %s); there is no CPU path' % t.device)
+
+
+def _chk(t, name='tensor'):
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous (shape %s, strides %s)' % (name, tuple(t.shape), t.stride()))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- workspace: one grow-only buffer per device; all users are ordered on the current stream ---------------------------
+_WS = {}
+_WS_MIN = 64 << 20
+
+
+def workspace(device, nbytes):
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('workspace would grow during graph capture; run warm-up iterations first')
+        buf = torch.empty(max(int(nbytes), _WS_MIN), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ---- convolution geometry (TF padding rules; reference utils/ops.py:58-71 passes the string through to TF) -------------
+def same_pad(in_size, k, s):
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2
+
+
+_DESC_CACHE = {}
+
+
+def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
+    """-> (ConvDesc, workspace_bytes) for y = conv(x[B,H,W,Cin], w[KH,KW,Cin,Cout]) with a TF padding string."""
+    key = (B, H, W, Cin, Cout, KH, KW, SH, SW, padding.upper())
+    hit = _DESC_CACHE.get(key)
+    if hit is not None:
+        return hit
+    p = padding.upper()
+    if p == 'SAME':
+        Ho, pt = same_pad(H, KH, SH)
+        Wo, pl = same_pad(W, KW, SW)
+    elif p == 'VALID':
+        Ho, Wo, pt, pl = (H - KH) // SH + 1, (W - KW) // SW + 1, 0, 0
+    else:
+        raise ValueError('Invalid padding %s' % padding)
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError('convolution output is empty for input %dx%d kernel %dx%d' % (H, W, KH, KW))
+    d = ConvDesc(B, H, W, Cin, Ho, Wo, Cout, KH, KW, SH, SW, pt, pl)
+    ws = int(lib.t2i_conv2d_workspace_bytes(ctypes.byref(d)))
+    _DESC_CACHE[key] = (d, ws)
+    return d, ws
+
+
+def deconv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
+    """Descriptor of the ADJOINT conv of a TF conv2d_transpose x[B,H,W,Cin] -> [B,Hout,Wout,Cout]: that conv maps
+    [B,Hout,Wout,Cout] -> [B,H,W,Cin] with HWIO filter [KH,KW,Cout,Cin] (the TF deconv layout)."""
+    p = padding.upper()
+    if p == 'SAME':
+        Hout, Wout = H * SH, W * SW
+    elif p == 'VALID':
+        Hout, Wout = (H - 1) * SH + KH, (W - 1) * SW + KW
+    else:
+        raise ValueError('Invalid padding %s' % padding)
+    d, ws = conv_desc(B, Hout, Wout, Cout, Cin, KH, KW, SH, SW, padding)
+    if (d.Ho, d.Wo) != (H, W):
+        raise ValueError('conv2d_transpose geometry mismatch: adjoint conv gives %dx%d, input is %dx%d' % (d.Ho, d.Wo, H, W))
+    return d, ws
+
+
+# Optional per-launch timing hook (bench.py): an object with begin(flops) -> end_event; the wrappers record the end
+# event right after the launch, on the same (current) stream.
+_TIMER = [None]
+
+
+def set_conv_timer(timer):
+    _TIMER[0] = timer
+
+
+def conv_flops(d):
+    """Algorithmic FLOPs of any of the three conv primitives for descriptor d (2 x MACs incl. padded taps)."""
+    return 2 * d.B * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin
+
+
+def _ws_args(t, nbytes):
+    if nbytes == 0:
+        return None, 0
+    buf = workspace(t.device, nbytes)
+    return _ptr(buf), buf.numel()
+
+
+def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
+    _chk(x, 'x'); _chk(w, 'w')
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, ws_bytes)
+        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
+                                 _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
+        if ev is not None:
+            ev.record()
+    return y
+
+
+def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
+    _chk(dy, 'dy'); _chk(w, 'w')
+    dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dy.device)
+    if _live(dy):
+        wsp, wsn = _ws_args(dy, ws_bytes)
+        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        check(lib.t2i_conv2d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w),
+                                      _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, wsp,
+                                      wsn, _stream()), 't2i_conv2d_bwd_data')
+        if ev is not None:
+            ev.record()
+    return dx
+
+
+def conv_bwd_filter(x, dy, d, ws_bytes):
+    _chk(x, 'x'); _chk(dy, 'dy')
+    dw = torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, ws_bytes)
+        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), wsp, wsn, _stream()),
+              't2i_conv2d_bwd_filter')
+        if ev is not None:
+            ev.record()
+    return dw
+
+
+def col_reduce(a, b=None, want_second=False):
+    """a viewed as [rows, C] (C = last dim).  -> (colsum(a), colsum(a*b or a*a) or None)."""
+    _chk(a, 'a')
+    C = a.shape[-1]
+    rows = a.numel() // C
+    out0 = torch.empty(C, dtype=torch.float32, device=a.device)
+    out1 = torch.empty(C, dtype=torch.float32, device=a.device) if want_second else None
+    if b is not None:
+        _chk(b, 'b')
+        assert b.shape == a.shape
+    if _live(a):
+        need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
+        wsp, wsn = _ws_args(a, need)
+        check(lib.t2i_col_reduce(_ptr(a), _ptr(b), rows, C, _ptr(out0), _ptr(out1), wsp, wsn, _stream()), 't2i_col_reduce')
+    return out0, out1
+
+
+def bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean=None, moving_var=None):
+    C = s.numel()
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=s.device) for _ in range(4))
+    if _live(s):
+        check(lib.t2i_bn_finalize(_ptr(s), _ptr(ss), n, C, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(mean),
+                                  _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(moving_mean), _ptr(moving_var), _stream()),
+              't2i_bn_finalize')
+    return mean, rstd, scale, shift
+
+
+def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
+    _chk(x, 'x')
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    if _live(x):
+        check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _stream()),
+              't2i_bn_apply')
+    return y
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x):
+    _chk(dy, 'dy'); _chk(x, 'x')
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, 3 * C * 4)
+        check(lib.t2i_bn_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)), _ptr(sum_dy), _ptr(sum_dy_x),
+                             x.numel() // C, C, _ptr(dx), _ptr(dgamma), _ptr(dbeta), wsp, wsn, _stream()), 't2i_bn_bwd')
+    return dx, dgamma, dbeta
+
+
+def act_fwd(x, act, alpha=0.2):
+    _chk(x, 'x')
+    y = torch.empty_like(x)
+    if _live(x):
+        check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _stream()), 't2i_act_fwd')
+    return y
+
+
+def act_bwd(dy, y, act, alpha=0.2):
+    _chk(dy, 'dy'); _chk(y, 'y')
+    dx = torch.empty_like(dy)
+    if _live(dy):
+        check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _stream()), 't2i_act_bwd')
+    return dx
+
+
+def add_act(a, b, act=ACT_NONE, alpha=0.2):
+    _chk(a, 'a'); _chk(b, 'b')
+    assert a.shape == b.shape
+    y = torch.empty_like(a)
+    if _live(a):
+        check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _stream()), 't2i_add_act')
+    return y
+
+
+def axpby(a, alpha, b=None, beta=0.0, out=None):
+    _chk(a, 'a')
+    y = torch.empty_like(a) if out is None else out
+    if _live(a):
+        check(lib.t2i_axpby(_ptr(a), alpha, _ptr(_chk(b, 'b') if b is not None else None), beta, a.numel(), _ptr(y),
+                            _stream()), 't2i_axpby')
+    return y
+
+
+def interp(eps, g, x):
+    _chk(g, 'g'); _chk(x, 'x')
+    eps = _chk(eps.reshape(-1), 'eps')
+    B = g.shape[0]
+    assert eps.numel() == B and g.shape == x.shape
+    out = torch.empty_like(g)
+    if _live(g):
+        check(lib.t2i_interp(_ptr(eps), _ptr(g), _ptr(x), B, g.numel() // B, _ptr(out), _stream()), 't2i_interp')
+    return out
+
+
+def concat_tile_fwd(feat, emb):
+    """feat [B,H,W,Cf], emb [B,Ce] -> [B,H,W,Cf+Ce]"""
+    _chk(feat, 'feat'); _chk(emb, 'emb')
+    B, H, W, Cf = feat.shape
+    Ce = emb.shape[1]
+    out = torch.empty((B, H, W, Cf + Ce), dtype=torch.float32, device=feat.device)
+    if _live(feat):
+        check(lib.t2i_concat_tile_fwd(_ptr(feat), _ptr(emb), B, H * W, Cf, Ce, _ptr(out), _stream()), 't2i_concat_tile_fwd')
+    return out
+
+
+def concat_tile_bwd(dout, Cf, Ce):
+    _chk(dout, 'dout')
+    B, H, W, Ct = dout.shape
+    assert Ct == Cf + Ce
+    dfeat = torch.empty((B, H, W, Cf), dtype=torch.float32, device=dout.device)
+    demb = torch.empty((B, Ce), dtype=torch.float32, device=dout.device)
+    if _live(dout):
+        check(lib.t2i_concat_tile_bwd(_ptr(dout), B, H * W, Cf, Ce, _ptr(dfeat), _ptr(demb), _stream()), 't2i_concat_tile_bwd')
+    return dfeat, demb
+
+
+def nchw_to_nhwc(x):
+    """x physically [B,C,H,W] contiguous -> physically [B,H,W,C] contiguous"""
+    _chk(x, 'x')
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    if _live(x):
+        check(lib.t2i_nchw_to_nhwc(_ptr(x), B, C, H * W, _ptr(y), _stream()), 't2i_nchw_to_nhwc')
+    return y
+
+
+def nhwc_to_nchw(x):
+    _chk(x, 'x')
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    if _live(x):
+        check(lib.t2i_nhwc_to_nchw(_ptr(x), B, C, H * W, _ptr(y), _stream()), 't2i_nhwc_to_nchw')
+    return y
+
+
+def gp_slopes(g):
+    _chk(g, 'g')
+    B = g.shape[0]
+    s = torch.empty(B, dtype=torch.float32, device=g.device)
+    if _live(g):
+        check(lib.t2i_gp_slopes(_ptr(g), B, g.numel() // B, _ptr(s), _stream()), 't2i_gp_slopes')
+    return s
+
+
+def row_scale(g, coef):
+    _chk(g, 'g'); _chk(coef, 'coef')
+    B = g.shape[0]
+    assert coef.numel() == B
+    out = torch.empty_like(g)
+    if _live(g):
+        check(lib.t2i_row_scale(_ptr(g), _ptr(coef), B, g.numel() // B, _ptr(out), _stream()), 't2i_row_scale')
+    return out
+
+
+def adam_tf(w, g, m, v, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    """In place on flat arenas."""
+    for t in (w, g, m, v):
+        _chk(t)
+    assert w.numel() == g.numel() == m.numel() == v.numel()
+    if _live(w):
+        check(lib.t2i_adam_tf(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), lr_t, beta1, beta2, eps, grad_scale, _stream()),
+              't2i_adam_tf')
+
+
+def device_info(device=0):
+    cu, clk = ctypes.c_int32(0), ctypes.c_int32(0)
+    arch = ctypes.create_string_buffer(64)
+    check(lib.t2i_device_info(device, ctypes.byref(cu), ctypes.byref(clk), arch, 64), 't2i_device_info')
+    return dict(cu_count=cu.value, clock_khz=clk.value, arch=arch.value.decode())

@@ -1,0 +1,244 @@
+"""WGanCls — the reference's conditional WGAN-GP (reference models/wgancls/model.py:1-225) on libt2i_hip.so kernels.
+
+Same class, constructor, method names and argument meaning as the reference.  The TF-1 graph/session split becomes:
+  build_model()    creates every variable (a launch-free dry run of G and D, so it also works without a GPU) and the
+                   two parameter arenas; the placeholders of model.py:36-46 become the keys of the ``feed`` dict
+  define_losses()  creates kt and the two Adam optimizers (model.py:72-106)
+  d_step(feed) / g_step(feed)
+                   what ``sess.run([D_optim, kt_optim, D_loss])`` / ``sess.run([G_optim, G_loss])`` evaluate
+                   (reference trainer.py:97,101): losses and gradients at pre-update values, then the updates.
+Scheduling differences that do not change the mathematics: the three gradient-free critic passes
+D(G), D(x), D(x_mismatch) run as ONE batched pass of 3B samples (the critic has no batch norm, samples are independent
+and weights shared, model.py:49-51), and the zero-valued branches of the double backward are never launched.
+"""
+import torch
+
+from ... import autograd as A
+from ... import kernels as K
+from ... import optim
+from ... import scope as S
+from ...utils.ops import (NCHW, NHWC, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
+                          reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
+
+
+class WGanCls(object):
+    def __init__(self, cfg, build_model=True, device=None, seed=0, dp=None):
+        """
+        Args:
+          cfg: Config specifying all the parameters of the model (reference cfg/flowers.yml keys).
+          device/seed/dp: where the variables live, the initializer seed, an optional dp.DataParallel (RCCL)
+        """
+        self.cfg = cfg
+        m, t = cfg.MODEL, cfg.TRAIN
+        self.batch_size, self.sample_num = t.BATCH_SIZE, t.SAMPLE_NUM
+        self.output_size = m.OUTPUT_SIZE
+        self.z_dim, self.embed_dim, self.compressed_embed_dim = m.Z_DIM, m.EMBED_DIM, m.COMPRESSED_EMBED_DIM
+        self.gf_dim, self.df_dim = m.GF_DIM, m.DF_DIM
+        self.image_dims = [m.IMAGE_SHAPE.H, m.IMAGE_SHAPE.W, m.IMAGE_SHAPE.D]
+        if self.output_size != 64:
+            raise ValueError('the reference tiles the text code over a fixed 4x4 map (model.py:154): OUTPUT_SIZE must be 64')
+        self.store = S.set_default_store(S.VariableStore(device=device, seed=seed))
+        self.device = self.store.device
+        self.dp = dp
+        self.global_step = 0
+
+        if build_model:
+            self.build_model()
+            self.define_losses()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def build_model(self):
+        """Variable creation = one dry (launch-free) pass of generator and discriminator on empty tensors."""
+        B, dev = self.batch_size, self.device
+        with K.dry_run(), torch.no_grad():
+            z = torch.empty(B, self.z_dim, device=dev)
+            cond = torch.empty(B, self.embed_dim, device=dev)
+            G, _, _ = self.generator(z, cond, reuse=False)
+            self.discriminator(G, cond, reuse=False)
+        self.d_vars = S.trainable_variables('d_net')
+        self.g_vars = S.trainable_variables('g_net')
+        self.d_arena = optim.Arena(self.d_vars)
+        self.g_arena = optim.Arena(self.g_vars)
+
+    def get_gradient_penalty(self, x, y):
+        """reference model.py:62-65: one-sided penalty on the per-sample gradient norm of y wrt x."""
+        with A.input_grads_only():
+            grad_y, = torch.autograd.grad(y.sum(), [x], create_graph=True)
+        return self._penalty(grad_y)
+
+    def get_gradient_penalty2(self, x, y):
+        """reference model.py:67-70 (same, for the rank-2 text embedding)."""
+        return self.get_gradient_penalty(x, y)
+
+    @staticmethod
+    def _penalty(grad_y):
+        slopes = A.GpSlopesFn.apply(grad_y)                       # wave-reduced per-sample L2 norm
+        return torch.mean(torch.clamp(slopes - 1.0, min=0.0) ** 2)  # [B] scalars
+
+    def define_losses(self):
+        self.kl_coeff = float(self.cfg.TRAIN.COEFF.KL)
+        self.lambda1 = float(self.cfg.TRAIN.COEFF.LAMBDA)   # read but unused by the reference too (model.py:75,91)
+        self.gp_coeff = 150.0                               # hard-coded in the reference (model.py:91)
+        self.kt = torch.tensor(0.7, dtype=torch.float32, device=self.device)
+        self.kt_lr = 0.001
+        b1, b2 = float(self.cfg.TRAIN.BETA1), float(self.cfg.TRAIN.BETA2)
+        self.D_optim = optim.AdamTF(self.d_arena, b1, b2)
+        self.G_optim = optim.AdamTF(self.g_arena, b1, b2)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _ca_noise(self, feed, key, like):
+        n = feed.get(key)
+        if n is None:    # tf.truncated_normal(tf.shape(mean)) resampled per run (model.py:119)
+            n = torch.empty_like(like)
+            torch.nn.init.trunc_normal_(n, mean=0.0, std=1.0, a=-2.0, b=2.0)
+        return n
+
+    def d_losses(self, feed):
+        """Everything `sess.run([D_optim, kt_optim, D_loss])` evaluates before the updates.  Returns a dict of scalar
+        tensors; leaves the critic gradients in the arena (self.d_arena.grad)."""
+        x, xm, cond, z, eps = feed['x'], feed['x_mismatch'], feed['cond'], feed['z'], feed['epsilon']
+        B = x.shape[0]
+        with torch.no_grad():
+            # G in training mode (batch statistics), moving averages NOT updated here (D_optim is outside UPDATE_OPS)
+            self._noise = self._ca_noise(feed, 'ca_noise_d', cond[:, :self.compressed_embed_dim])
+            G, _, _ = self.generator(z, cond, reuse=True)
+            x_hat = K.interp(eps, G, x)
+        # D(G), D(x), D(x_mismatch): one batched pass (shared weights, no batch coupling in the critic)
+        logits = self.discriminator(torch.cat([G, x, xm], 0), torch.cat([cond, cond, cond], 0), reuse=True).view(3, B)
+        Dg_logit, Dx_logit, Dxmi_logit = logits[0], logits[1], logits[2]
+        x_hat.requires_grad_(True)
+        cond_inp = (cond + 0.0).requires_grad_(True)
+        Dx_hat_logit = self.discriminator(x_hat, cond_inp, reuse=True)
+        with A.input_grads_only():
+            gx, gc = torch.autograd.grad(Dx_hat_logit.sum(), [x_hat, cond_inp], create_graph=True)
+        real_gp, real_gp2 = self._penalty(gx), self._penalty(gc)
+
+        D_loss_real, D_loss_fake, D_loss_mismatch = Dx_logit.mean(), Dg_logit.mean(), Dxmi_logit.mean()
+        wdist = D_loss_real - D_loss_fake
+        wdist2 = D_loss_real - D_loss_mismatch
+        D_loss = -wdist - self.kt * wdist2 + self.gp_coeff * (real_gp + real_gp2)
+
+        self.d_arena.zero_grad()
+        if self.dp is not None:
+            self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this backward
+        D_loss.backward(inputs=list(self.d_vars.values()))
+        with torch.no_grad():
+            wd, wd2 = wdist.detach(), wdist2.detach()
+            out = dict(D_loss=D_loss.detach(), D_loss_real=D_loss_real.detach(), D_loss_fake=D_loss_fake.detach(),
+                       D_loss_mismatch=D_loss_mismatch.detach(), wdist=wd, wdist2=wd2, real_gp=real_gp.detach(),
+                       real_gp2=real_gp2.detach(), reg_loss=(Dxmi_logit.detach() ** 2).mean(),
+                       balance_loss=(self.kt * wd2 - wd) ** 2, kt_grad=2.0 * (self.kt * wd2 - wd) * wd2, kt=self.kt.clone(),
+                       G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
+        return out
+
+    def d_step(self, feed):
+        out = self.d_losses(feed)
+        scale = 1.0
+        if self.dp is not None:
+            scale = self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
+            out['kt_grad'] = out['kt_grad'] * scale
+        self.D_optim.step(float(feed['learning_rate_d']), grad_scale=scale)
+        with torch.no_grad():
+            self.kt -= self.kt_lr * out['kt_grad']          # GradientDescentOptimizer(0.001) on balance_loss
+        self.global_step += 1
+        return out
+
+    def g_losses(self, feed):
+        cond, z = feed['cond'], feed['z']
+        self._noise = self._ca_noise(feed, 'ca_noise_g', cond[:, :self.compressed_embed_dim])
+        with update_ops():   # G_optim runs under control_dependencies(UPDATE_OPS) (model.py:102)
+            G, mean, log_sigma = self.generator(z, cond, reuse=True)
+        with self.store.frozen('d_net'):
+            Dg_logit = self.discriminator(G, cond, reuse=True)
+        D_loss_fake = Dg_logit.mean()
+        G_kl_loss = self.kl_std_normal_loss(mean, log_sigma)
+        G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
+        self.g_arena.zero_grad()
+        if self.dp is not None:
+            self.dp.arm(self.g_arena)
+        G_loss.backward(inputs=list(self.g_vars.values()))
+        return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), D_loss_fake=D_loss_fake.detach(), G=G.detach())
+
+    def g_step(self, feed):
+        out = self.g_losses(feed)
+        scale = 1.0
+        if self.dp is not None:
+            scale = self.dp.allreduce_arena(self.g_arena)
+        self.G_optim.step(float(feed['learning_rate_g']), grad_scale=scale)
+        return out
+
+    def sampler(self, z_sample, cond_sample):
+        """eval-mode generator on fixed samples (reference model.py:57)"""
+        with torch.no_grad():
+            img, _, _ = self.generator(z_sample, cond_sample, reuse=True, is_training=False)
+        return img
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def generate_conditionals(self, embeddings):
+        """Conditioning augmentation statistics (reference model.py:108-115): two lrelu-activated 1024->128 dense
+        layers, `g_net/dense` (mu) and `g_net/dense_1` (log sigma)."""
+        act = lrelu_act(0.2)
+        flat = embeddings.reshape(embeddings.shape[0], -1)
+        return fc(flat, self.compressed_embed_dim, act=act), fc(flat, self.compressed_embed_dim, act=act)
+
+    def sample_normal_conditional(self, mean, log_sigma, cond_noise=True):
+        """c = mu + exp(log sigma) * eps, eps ~ truncated N(0,1) (reference model.py:117-122).  The draw comes from the
+        feed (`ca_noise_d` / `ca_noise_g`) when given so that runs are reproducible; [B,128] scalar math stays in torch."""
+        if not cond_noise:
+            return mean
+        eps = getattr(self, '_noise', None)
+        if eps is None or eps.shape != mean.shape:
+            eps = torch.empty_like(mean)
+            torch.nn.init.trunc_normal_(eps, mean=0.0, std=1.0, a=-2.0, b=2.0)
+        return mean + torch.exp(log_sigma) * eps
+
+    def kl_std_normal_loss(self, mean, log_sigma):
+        """KL(N(mu, sigma) || N(0, 1)) averaged over batch and features (reference model.py:124-127)."""
+        return torch.mean(0.5 * (torch.exp(2.0 * log_sigma) + mean * mean - 1.0) - log_sigma)
+
+    # -- critic: 4 stride-2 convs, a bottleneck residual, text conditioning, 3 head convs (reference model.py:129-161) --
+    def discriminator(self, inputs, embed, reuse=False):
+        nf, act, fmt = self.df_dim, lrelu_act(0.2), NCHW
+        h = to_nchw(inputs)
+        with S.variable_scope('d_net', reuse=reuse):
+            for mult in (1, 2, 4):                                             # d_net/Conv, Conv_1, Conv_2
+                h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), act=act, df=fmt)
+            trunk = conv2d(h, nf * 8, ks=(4, 4), s=(2, 2), df=fmt)             # Conv_3, linear
+            r = conv2d(trunk, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_4
+            r = conv2d(r, nf * 4, ks=(3, 3), s=(1, 1), act=act, df=fmt)        # Conv_5
+            r = conv2d(r, nf * 8, ks=(3, 3), s=(1, 1), df=fmt)                 # Conv_6
+            joined = add(trunk, r, act=act, df=fmt)
+            text = fc(embed, self.compressed_embed_dim, act=act)               # d_net/dense
+            h = concat_tile(joined, text, df=fmt)                              # [B,4,4,8nf+128]
+            h = conv2d(h, nf * 8, ks=(3, 3), s=(1, 1), padding='same', act=act, df=fmt)    # Conv_7
+            h = conv2d(h, nf * 8, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_8
+            return conv2d(h, 1, ks=(4, 4), s=(4, 4), padding='valid', df=fmt)              # Conv_9 -> [B,1,1,1]
+
+    # -- generator (reference model.py:163-225) ---------------------------------------------------------------------------
+    def _g_bottleneck(self, x, mid, out, train, fmt):
+        """1x1 -> BN/ReLU -> 3x3 -> BN/ReLU -> 3x3 -> BN, added to x, ReLU (model.py:184-191 and :200-207)."""
+        r = batch_norm(conv2d(x, mid, ks=(1, 1), s=(1, 1), padding='valid', df=fmt), train=train, act=relu, df=fmt)
+        r = batch_norm(conv2d(r, mid, ks=(3, 3), s=(1, 1), df=fmt), train=train, act=relu, df=fmt)
+        r = batch_norm(conv2d(r, out, ks=(3, 3), s=(1, 1), df=fmt), train=train, act=None, df=fmt)
+        return add(x, r, act=relu, df=fmt)
+
+    def _g_upsample(self, x, nf, train, fmt, act):
+        """k4s2 transposed conv -> 3x3 conv -> BN(+act) (model.py:194-196, 210-216)."""
+        u = conv2d(conv2d_transpose(x, nf, ks=(4, 4), s=(2, 2), df=fmt), nf, ks=(3, 3), s=(1, 1), df=fmt)
+        return batch_norm(u, train=train, act=act, df=fmt)
+
+    def generator(self, z, embed, reuse=False, is_training=True, df=NCHW, cond_noise=True):
+        nf, grid = self.gf_dim, self.output_size // 16
+        with S.variable_scope('g_net', reuse=reuse):
+            mean, log_sigma = self.generate_conditionals(embed)
+            code = torch.cat([z, self.sample_normal_conditional(mean, log_sigma, cond_noise)], 1)
+            h = batch_norm(fc(code, nf * 8 * grid * grid), train=is_training, df=df)      # dense_2 + rank-2 BatchNorm
+            h = reshape_to_map(h, nf * 8, grid, grid, df)                                 # [B,4,4,8nf]
+            h = self._g_bottleneck(h, nf * 2, nf * 8, is_training, df)
+            h = self._g_upsample(h, nf * 4, is_training, df, act=None)                    # 8x8
+            h = self._g_bottleneck(h, nf, nf * 4, is_training, df)
+            h = self._g_upsample(h, nf * 2, is_training, df, act=relu)                    # 16x16
+            h = self._g_upsample(h, nf, is_training, df, act=relu)                        # 32x32
+            rgb = conv2d_transpose(h, self.image_dims[-1], ks=(4, 4), s=(2, 2), df=df)    # 64x64
+            img = conv2d(rgb, self.image_dims[-1], ks=(3, 3), s=(1, 1), act=tanh, df=df)  # tanh fused in the epilogue
+            return (to_nhwc(img) if df == NCHW else img), mean, log_sigma

@@ -1,0 +1,38 @@
+"""Entry point mirroring reference models/wgancls/run.py:13-74: `--cfg <yaml>` then train when cfg.TRAIN.FLAG.
+Evaluation / visualisation modes (Inception score, caption grids) are outside the hot path."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+
+import t2i_amd  # noqa: E402,F401
+from t2i_amd.data import SyntheticTextDataset  # noqa: E402
+from t2i_amd.models.wgancls.model import WGanCls  # noqa: E402
+from t2i_amd.models.wgancls.trainer import WGanClsTrainer  # noqa: E402
+from t2i_amd.utils.config import config_from_yaml  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cfg', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cfg', 'flowers.yml'),
+                    help='Relative path to the config of the model')
+    ap.add_argument('--steps', type=int, default=None, help='override TRAIN.MAX_STEPS')
+    ap.add_argument('--batch', type=int, default=None, help='override TRAIN.BATCH_SIZE')
+    args = ap.parse_args(argv)
+    print(args.cfg)
+    cfg = config_from_yaml(args.cfg)
+    if args.batch:
+        cfg.TRAIN.BATCH_SIZE = args.batch
+    for d in (cfg.CHECKPOINT_DIR, cfg.SAMPLE_DIR, cfg.LOGS_DIR):
+        os.makedirs(d, exist_ok=True)
+    if cfg.EVAL.FLAG:
+        raise NotImplementedError('EVAL mode (Inception score / FID) is outside the hot path; see DESIGN.md')
+    wgan = WGanCls(cfg)
+    dataset = SyntheticTextDataset(cfg, wgan.device)
+    trainer = WGanClsTrainer(sess=None, model=wgan, dataset=dataset, cfg=cfg)
+    trainer.train(max_steps=args.steps)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,57 @@
+"""Flat parameter arenas + tf.train.AdamOptimizer semantics (reference models/wgancls/model.py:94-106).
+
+All trainable variables of one optimizer live back-to-back in ONE device buffer (16-byte aligned slots), with
+gradients, first and second moments in three more buffers of the same shape.  A step is then a single kernel launch
+over ~29 M (critic) / ~23 M (generator) floats instead of one launch per tensor, and data-parallel gradient exchange
+works on contiguous slices of the gradient arena (dp.py)."""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+
+
+class Arena(object):
+    def __init__(self, variables):
+        """variables: OrderedDict name -> leaf tensor.  Re-points every variable's storage (and .grad) into the arena."""
+        self.names = list(variables.keys())
+        self.vars = variables
+        self.offsets = OrderedDict()
+        off = 0
+        for n, v in variables.items():
+            self.offsets[n] = (off, v.numel())
+            off += (v.numel() + 3) // 4 * 4          # 16-byte slots: the kernels' float4 paths need aligned bases
+        self.numel = off
+        dev = next(iter(variables.values())).device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for n, v in variables.items():
+                o, k = self.offsets[n]
+                self.flat[o:o + k].copy_(v.reshape(-1))
+                v.data = self.flat[o:o + k].view(v.shape)
+                v.grad = self.grad[o:o + k].view(v.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def grad_of(self, name):
+        o, k = self.offsets[name]
+        return self.grad[o:o + k].view(self.vars[name].shape)
+
+
+class AdamTF(object):
+    """lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updates; w -= lr_t*m/(sqrt(v)+eps) — epsilon OUTSIDE the bias correction
+    (SURVEY.md §8a M5).  With beta1=0, t=1 this is ~lr*sign(g)."""
+
+    def __init__(self, arena, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.arena, self.beta1, self.beta2, self.eps = arena, beta1, beta2, eps
+        self.m = torch.zeros_like(arena.flat)
+        self.v = torch.zeros_like(arena.flat)
+        self.t = 0
+
+    def step(self, lr, grad_scale=1.0):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        K.adam_tf(self.arena.flat, self.arena.grad, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps, grad_scale)

@@ -1,0 +1,232 @@
+"""The reference's operator surface (reference utils/ops.py:1-148), eager and MI355X-native.
+
+Same names, parameters, defaults and error behaviour as the reference wrappers; below them sit libt2i_hip.so kernels
+instead of tf.contrib.layers.  Differences that follow from "eager torch instead of a TF-1 graph":
+  * parameters are created/looked up in a TF-style variable scope (``scope.py``) with TF's automatic names
+    (``Conv``, ``Conv_1``, ``Conv2d_transpose``, ``dense``, ``BatchNorm``), so ``reuse=True`` and
+    ``trainable_variables('d_net')`` mean what they mean in the reference (models/wgancls/model.py:59-60,134,167);
+  * ``act`` is an ``Activation`` (``lrelu_act(0.2)``, ``relu``, ``tanh``) which the conv / BN epilogues fuse; any other
+    callable is applied after the op, unfused;
+  * data is physically NHWC always.  ``df=NCHW`` tensors are *logical* NCHW views (a permute of NHWC storage), so
+    ``to_nchw`` / ``to_nhwc`` cost nothing and the result is layout-independent (SURVEY.md §7 last bullet).
+north_star's ``deconv2d / linear / bn`` do not exist in the reference; they are exported as aliases.
+"""
+import torch
+
+from .. import autograd as A
+from .. import kernels as K
+from .. import scope as S
+
+NHWC = 'NHWC'
+NCHW = 'NCHW'
+
+
+class Activation(object):
+    """A fusable activation (what the reference passes as a python callable: tf.nn.relu, a leaky_relu lambda, tf.nn.tanh)."""
+
+    def __init__(self, kind, alpha=0.0):
+        self.kind, self.alpha = kind, float(alpha)
+
+    def __call__(self, x):
+        shape = x.shape
+        return A.ActFn.apply(x.contiguous(), self.kind, self.alpha).view(shape)
+
+    def __repr__(self):
+        return 'Activation(%s, %g)' % ({K.ACT_LRELU: 'lrelu', K.ACT_RELU: 'relu', K.ACT_TANH: 'tanh'}[self.kind], self.alpha)
+
+
+relu = Activation(K.ACT_RELU)
+tanh = Activation(K.ACT_TANH)
+
+
+def lrelu_act(alpha=0.2):
+    """reference utils/ops.py:90-91"""
+    return Activation(K.ACT_LRELU, alpha)
+
+
+def _split_act(act):
+    """-> (fused kind, alpha, post-callable)"""
+    if act is None:
+        return K.ACT_NONE, 0.0, None
+    if isinstance(act, Activation):
+        return act.kind, act.alpha, None
+    if callable(act):
+        return K.ACT_NONE, 0.0, act
+    raise TypeError('act must be None, an ops.Activation or a callable')
+
+
+def _check_df(df):
+    if df not in (NHWC, NCHW):
+        raise ValueError('Invalid data format %s' % df)
+
+
+def _phys(x, df):
+    """logical tensor -> physically-NHWC 4-D tensor"""
+    _check_df(df)
+    if x.dim() != 4:
+        raise ValueError('expected a rank-4 tensor, got shape %s' % (tuple(x.shape),))
+    return x.permute(0, 2, 3, 1) if df == NCHW else x
+
+
+def _logical(y, df):
+    return y.permute(0, 3, 1, 2) if df == NCHW else y
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=None, df=NHWC):
+    """reference utils/ops.py:58-63.  Variables: <scope>/Conv[_k]/{weights [kh,kw,Cin,f] (He), biases [f] (zeros)}."""
+    st = S.default_store()
+    xp = _phys(x, df)
+    B, H, W, Cin = xp.shape
+    (kh, kw), (sh, sw) = _pair(ks), _pair(s)
+    kind, alpha, post = _split_act(act)
+    with st.variable_scope(name or st.unique_op_name('Conv'), reuse=st.reuse()):
+        w = st.get_variable('weights', (kh, kw, Cin, f), init or S.he_init(kh * kw * Cin))
+        b = st.get_variable('biases', (f,), S.constant_init(0.0))
+    geom = K.conv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
+    y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha)
+    y = _logical(y, df)
+    return post(y) if post else y
+
+
+def conv2d_transpose(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=None, df=NHWC):
+    """reference utils/ops.py:66-71.  Variables: <scope>/Conv2d_transpose[_k]/{weights [kh,kw,f,Cin], biases [f]}.
+    He fan_in follows TF's variance_scaling on that layout: kh*kw*shape[-2] = kh*kw*f."""
+    st = S.default_store()
+    xp = _phys(x, df)
+    B, H, W, Cin = xp.shape
+    (kh, kw), (sh, sw) = _pair(ks), _pair(s)
+    kind, alpha, post = _split_act(act)
+    with st.variable_scope(name or st.unique_op_name('Conv2d_transpose'), reuse=st.reuse()):
+        w = st.get_variable('weights', (kh, kw, f, Cin), init or S.he_init(kh * kw * f))
+        b = st.get_variable('biases', (f,), S.constant_init(0.0))
+    geom = K.deconv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
+    y = A.ConvBwdDataFn.apply(xp, w, b, geom, kind, alpha)
+    y = _logical(y, df)
+    return post(y) if post else y
+
+
+def fc(x, units, act=None, init=None, bias=True, name=None):
+    """reference utils/ops.py:84-87 (tf.layers.dense).  Variables: <scope>/dense[_k]/{kernel [in,units], bias [units]}.
+    Runs as a 1x1 convolution on a [B,1,1,in] view (the same MFMA GEMM kernel)."""
+    st = S.default_store()
+    if x.dim() != 2:
+        raise ValueError('fc expects a rank-2 tensor, got shape %s' % (tuple(x.shape),))
+    B, I = x.shape
+    kind, alpha, post = _split_act(act)
+    with st.variable_scope(name or st.unique_op_name('dense'), reuse=st.reuse()):
+        w = st.get_variable('kernel', (I, units), init or S.he_init(I))
+        b = st.get_variable('bias', (units,), S.constant_init(0.0)) if bias else None
+    geom = K.conv_desc(B, 1, 1, I, units, 1, 1, 1, 1, 'VALID')
+    y = A.Conv2dFn.apply(x.reshape(B, 1, 1, I), w.view(1, 1, I, units), b, geom, kind, alpha).view(B, units)
+    return post(y) if post else y
+
+
+# TF collects the moving-average assignments of batch_norm in GraphKeys.UPDATE_OPS and runs them only under ops that
+# depend on them (reference models/wgancls/model.py:98,102: G_optim yes, D_optim no).  Eager equivalent: the moving
+# statistics are updated by the BN kernel itself iff the caller is inside `update_ops()`.
+_UPDATE_OPS = [False]
+
+
+class update_ops(object):
+    def __enter__(self):
+        self.prev = _UPDATE_OPS[0]
+        _UPDATE_OPS[0] = True
+
+    def __exit__(self, *a):
+        _UPDATE_OPS[0] = self.prev
+
+
+def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df=NHWC):
+    """reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm, fused, scale=True).  Rank-4 (per channel) or rank-2
+    (per feature).  Variables: <scope>/BatchNorm[_k]/{beta, gamma, moving_mean, moving_variance}."""
+    st = S.default_store()
+    _check_df(df)
+    if x.dim() == 4:
+        xp = _phys(x, df)
+    elif x.dim() == 2:
+        xp = x
+    else:
+        raise ValueError('batch_norm expects rank 2 or 4, got shape %s' % (tuple(x.shape),))
+    C = xp.shape[-1]
+    kind, alpha, post = _split_act(act)
+    init = init or {}
+    with st.variable_scope(name or st.unique_op_name('BatchNorm'), reuse=st.reuse()):
+        beta = st.get_variable('beta', (C,), init.get('beta', S.constant_init(0.0)))
+        gamma = st.get_variable('gamma', (C,), init.get('gamma', S.constant_init(1.0)))
+        mm = st.get_variable('moving_mean', (C,), S.constant_init(0.0), trainable=False)
+        mv = st.get_variable('moving_variance', (C,), S.constant_init(1.0), trainable=False)
+    if train:
+        upd = _UPDATE_OPS[0]
+        y, _, _ = A.BatchNormTrainFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha)
+    else:
+        # inference: y = act(x*scale + shift) with the moving statistics; [C]-sized host-side vector math
+        with torch.no_grad():
+            scale = gamma / torch.sqrt(mv + eps)
+            shift = beta - mm * scale
+        y = K.bn_apply(xp.contiguous(), scale.contiguous(), shift.contiguous(), kind, alpha)
+    if x.dim() == 4:
+        y = _logical(y, df)
+    return post(y) if post else y
+
+
+def to_nchw(x):
+    """reference utils/ops.py:129-130.  Logical transpose only: storage stays NHWC."""
+    return x.permute(0, 3, 1, 2)
+
+
+def to_nhwc(x):
+    """reference utils/ops.py:133-134"""
+    return x.permute(0, 2, 3, 1)
+
+
+def reshape_to_map(x, C, H, W, df=NHWC):
+    """tf.reshape of a rank-2 activation to a feature map (reference models/wgancls/model.py:178-181).  With df=NCHW
+    feature index = c*H*W + h*W + w, so the storage is re-tiled to NHWC by one transpose kernel and returned as a
+    logical-NCHW view; with df=NHWC the reshape is free."""
+    _check_df(df)
+    B = x.shape[0]
+    if df == NHWC:
+        return x.reshape(B, H, W, C)
+    return A.NchwToNhwcFn.apply(x.reshape(B, C, H, W)).permute(0, 3, 1, 2)
+
+
+def add(a, b, act=None, df=NHWC):
+    """tf.add followed by an activation (the residual joins, reference models/wgancls/model.py:145-146,190-191)."""
+    kind, alpha, post = _split_act(act)
+    if a.dim() == 4:
+        y = _logical(A.AddActFn.apply(_phys(a, df), _phys(b, df), kind, alpha), df)
+    else:
+        y = A.AddActFn.apply(a, b, kind, alpha)
+    return post(y) if post else y
+
+
+def concat_tile(feat, emb, df=NHWC):
+    """expand_dims x2 -> tile over the spatial map -> concat on channels (reference models/wgancls/model.py:153-155)."""
+    return _logical(A.ConcatTileFn.apply(_phys(feat, df), emb), df)
+
+
+def get_conv_shape(tensor):
+    return get_ints_from_shape(tensor)
+
+
+def get_ints_from_shape(tensor):
+    return [int(n) for n in tensor.shape]
+
+
+def df_to_channel(df):
+    """reference utils/ops.py:137-142"""
+    if df == NHWC:
+        return 'channels_last'
+    if df == NCHW:
+        return 'channels_first'
+    raise RuntimeError('Invalid data format %s' % df)
+
+
+# aliases named by BASELINE.json:north_star
+deconv2d = conv2d_transpose
+linear = fc
+bn = batch_norm
