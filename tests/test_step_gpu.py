@@ -21,11 +21,13 @@ def _cfg(z, e, c, gf, df, B):
                                'N_CRITIC': 1, 'SUMMARY_PERIOD': 10, 'MAX_STEPS': 10, 'COEFF': {'KL': 1.0, 'LAMBDA': 100.0}}})
 
 
-def relerr(got, ref):
+def relerr(got, ref, floor=1e-3):
+    """max|d| / max(max|ref|, floor): the floor keeps exactly-zero reference gradients (e.g. the logit bias, whose
+    +1/-1 contributions cancel) from turning fp32 rounding residue into an infinite relative error."""
     got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
-    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), floor))
 
 
 @pytest.fixture(scope='module')
@@ -60,17 +62,25 @@ def test_tiny_step_matches_golden(gpu, golden_step):
               'reg_loss', 'balance_loss', 'kt_grad'):
         ref = float(gs['d/' + k])
         assert abs(float(d[k]) - ref) <= 1e-4 * max(abs(ref), 1.0), (k, float(d[k]), ref)
-    worst = 0.0
     for n in m.d_vars:
-        e = relerr(m.d_arena.grad_of(n), gs['d/grad/' + n]); worst = max(worst, e)
-        assert e <= 1e-3, (n, e)
+        _check_grad(m.d_arena.grad_of(n), gs['d/grad/' + n], n)
     g = m.g_losses(feed)
     assert abs(float(g['G_loss']) - float(gs['g/G_loss'])) <= 1e-4 * max(abs(float(gs['g/G_loss'])), 1.0)
     assert abs(float(g['G_kl_loss']) - float(gs['g/G_kl_loss'])) <= 1e-4 * max(abs(float(gs['g/G_kl_loss'])), 1.0)
     assert relerr(g['G'], gs['g/G']) <= 1e-4
     for n in m.g_vars:
-        e = relerr(m.g_arena.grad_of(n), gs['g/grad/' + n])
-        assert e <= 1e-3, (n, e)
+        _check_grad(m.g_arena.grad_of(n), gs['g/grad/' + n], n)
+
+
+def _check_grad(got, ref, name, tol=1e-3):
+    """Per-tensor max-norm check.  Tensors whose exact gradient is zero (a bias in front of a batch norm; the logit
+    bias, whose +1/-1 terms cancel) only carry fp32 rounding residue: bound it absolutely instead."""
+    ref = np.asarray(ref, np.float64)
+    if np.abs(ref).max() < 1e-9:
+        assert float(got.abs().max()) <= 1e-4, (name, float(got.abs().max()))
+    else:
+        e = relerr(got, ref, floor=1e-30)
+        assert e <= tol, (name, e)
 
 
 def test_tiny_full_iteration_state(gpu, golden_step):
@@ -94,7 +104,9 @@ def test_tiny_full_iteration_state(gpu, golden_step):
             # Adam(beta1=0) at t=1 moves each weight by ~lr*sign(g): near-zero gradients may flip sign in fp32
             delta = np.abs(v.detach().double().cpu().numpy() - ref)
             assert delta.max() <= 2.0 * lr * 1.001, (n, delta.max())
-            assert np.mean(delta <= 0.02 * lr) >= 0.98, (n, np.mean(delta <= 0.02 * lr))
+            gkey = ('d/grad/' if n.startswith('d_net') else 'g/grad/') + n
+            if np.abs(gs[gkey]).max() > 1e-9:      # exact-zero gradients: fp32 residue decides the sign, skip
+                assert np.mean(delta <= 0.02 * lr) >= 0.98, (n, np.mean(delta <= 0.02 * lr))
 
 
 def test_double_backward_of_conv_chain(gpu):
@@ -115,6 +127,8 @@ def test_double_backward_of_conv_chain(gpu):
         return (float(pen),) + torch.autograd.grad(pen, [W1, W2, B1])
 
     def ours():
+        # the penalty does not depend on b1 except through lrelu masks: torch reports a zero gradient, our graph has
+        # no edge at all (allow_unused) — both mean dpen/db1 == 0
         xd = x.cuda().requires_grad_(True)
         W1, W2, B1 = w1.cuda().requires_grad_(True), w2.cuda().requires_grad_(True), b1.cuda().requires_grad_(True)
         g1 = K.conv_desc(3, 8, 8, 8, 16, 4, 4, 2, 2, 'SAME'); g2 = K.conv_desc(3, 4, 4, 16, 16, 3, 3, 1, 1, 'SAME')
@@ -124,34 +138,55 @@ def test_double_backward_of_conv_chain(gpu):
             gx, = torch.autograd.grad(y.sum(), [xd], create_graph=True)
         s = A.GpSlopesFn.apply(gx)
         pen = (s - 1).clamp(min=0).pow(2).mean()
-        return (float(pen),) + torch.autograd.grad(pen, [W1, W2, B1])
+        gs_ = torch.autograd.grad(pen, [W1, W2, B1], allow_unused=True)
+        return (float(pen),) + tuple(g_ if g_ is not None else torch.zeros_like(p_) for g_, p_ in zip(gs_, [W1, W2, B1]))
 
     r, o = ref(), ours()
     assert abs(r[0] - o[0]) <= 1e-5 * max(abs(r[0]), 1.0)
     for a, b in zip(r[1:], o[1:]):
-        assert relerr(b, a.numpy()) <= 1e-4
+        assert relerr(b, a.numpy(), floor=1e-6) <= 1e-4
 
 
 def test_full_width_step_vs_cpu_oracle(gpu):
-    """The benchmark's architecture (GF=DF=128, 1024-d text) at B=8 against the torch-CPU fp32 oracle."""
+    """The benchmark's architecture (GF=DF=128, 1024-d text) at B=8 against the torch-CPU oracle run in float64 on
+    the same (float32-representable) weights and inputs."""
     from oracle import torch_step as T
     from t2i_amd.models.wgancls.model import WGanCls
     B = 8
     ocfg = T.Cfg(batch=B)
-    P = T.init_variables(ocfg, seed=0)
-    feed = T.synthetic_feed(ocfg, seed=1)
+    P = {n: v.double() for n, v in T.init_variables(ocfg, seed=0).items()}
+    feed = {k: v.double() for k, v in T.synthetic_feed(ocfg, seed=1).items()}
     m = WGanCls(_cfg(128, 1024, 128, 128, 128, B), device=gpu)
     m.store.load({n: v.numpy() for n, v in P.items()})
-    f = {k: v.to(gpu) for k, v in feed.items()}
+    f = {k: v.float().to(gpu) for k, v in feed.items()}
     f['epsilon'] = f.pop('eps'); f['learning_rate_d'] = 1e-4; f['learning_rate_g'] = 1e-4
+    # the same step by the torch-CPU oracle in fp32: its distance from float64 is the yardstick for "fp32-exact".
+    # (At random init the 150x gradient-penalty term makes dD_loss/dw a sum of large cancelling parts: even torch-CPU fp32
+    # is only ~2e-3 from float64 on some tensors, so a fixed 1e-4 bound would test conditioning, not the kernels.)
+    P32 = {n: v.float() for n, v in P.items()}
+    feed32 = {k: v.float() for k, v in feed.items()}
     d = m.d_losses(f)
-    ref = T.d_step(P, ocfg, feed, 0.7)
+    ref, ref32 = T.d_step(P, ocfg, feed, 0.7), T.d_step(P32, ocfg, feed32, 0.7)
     for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
-        assert abs(float(d[k]) - ref[k]) <= 2e-4 * max(abs(ref[k]), 1.0), (k, float(d[k]), ref[k])
+        tol = max(3 * abs(ref32[k] - ref[k]), 1e-4 * max(abs(ref[k]), 1.0))
+        assert abs(float(d[k]) - ref[k]) <= tol, (k, float(d[k]), ref[k], ref32[k])
+    worst = (0.0, 0.0, '')
     for n in m.d_vars:
-        assert relerr(m.d_arena.grad_of(n), ref['grads'][n].numpy()) <= 2e-3, n
+        e_cpu = relerr(ref32['grads'][n], ref['grads'][n].numpy())
+        e = relerr(m.d_arena.grad_of(n), ref['grads'][n].numpy())
+        worst = max(worst, (e, e_cpu, n))
+        assert e <= max(3 * e_cpu, 1e-3), (n, e, e_cpu)
+    print('critic grads: worst max-norm error vs f64 %.2e (torch-CPU fp32: %.2e) at %s' % worst)
     g = m.g_losses(f)
-    gref = T.g_step(P, ocfg, feed)
-    assert abs(float(g['G_loss']) - gref['G_loss']) <= 2e-4 * max(abs(gref['G_loss']), 1.0)
+    gref, gref32 = T.g_step(P, ocfg, feed), T.g_step(P32, ocfg, feed32)
+    assert abs(float(g['G_loss']) - gref['G_loss']) <= max(3 * abs(gref32['G_loss'] - gref['G_loss']), 1e-4 * max(abs(gref['G_loss']), 1.0))
+    worst = (0.0, 0.0, '')
     for n in m.g_vars:
-        assert relerr(m.g_arena.grad_of(n), gref['grads'][n].numpy()) <= 2e-3, n
+        if float(gref['grads'][n].abs().max()) < 1e-9:      # bias in front of a batch norm: exact zero gradient
+            assert float(m.g_arena.grad_of(n).abs().max()) <= 1e-4, n
+            continue
+        e_cpu = relerr(gref32['grads'][n], gref['grads'][n].numpy())
+        e = relerr(m.g_arena.grad_of(n), gref['grads'][n].numpy())
+        worst = max(worst, (e, e_cpu, n))
+        assert e <= max(3 * e_cpu, 1e-3), (n, e, e_cpu)
+    print('generator grads: worst max-norm error vs f64 %.2e (torch-CPU fp32: %.2e) at %s' % worst)

@@ -41,10 +41,13 @@ class ActBwdFn(Function):
     def forward(ctx, gy, y, act, alpha):
         ctx.save_for_backward(y)
         ctx.act, ctx.alpha = act, alpha
+        ctx.set_materialize_grads(False)
         return K.act_bwd(_c(gy), y, act, alpha)
 
     @staticmethod
     def backward(ctx, gg):
+        if gg is None:
+            return None, None, None, None
         (y,) = ctx.saved_tensors
         return ActBwdFn.apply(gg, y, ctx.act, ctx.alpha), None, None, None
 
@@ -73,6 +76,7 @@ class Conv2dFn(Function):
     def forward(ctx, x, w, b, geom, act, alpha):
         d, ws = geom
         x = _c(x)
+        ctx.set_materialize_grads(False)   # an undefined upstream gradient must not become a zero-filled conv launch
         y = K.conv_fwd(x, w, b, d, ws, act, alpha)
         ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
@@ -80,6 +84,8 @@ class Conv2dFn(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         gpre = _act_bwd(gy, y, ctx.act, ctx.alpha)
         params = not _INPUTS_ONLY[0]
@@ -97,6 +103,7 @@ class ConvBwdDataFn(Function):
     def forward(ctx, dy, w, b, geom, act, alpha):
         d, ws = geom
         dy = _c(dy)
+        ctx.set_materialize_grads(False)
         out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha)
         ctx.save_for_backward(dy, w, out if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
@@ -104,6 +111,8 @@ class ConvBwdDataFn(Function):
 
     @staticmethod
     def backward(ctx, gg):
+        if gg is None:
+            return None, None, None, None, None, None
         dy, w, out = ctx.saved_tensors
         gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
         params = not _INPUTS_ONLY[0]
@@ -138,6 +147,7 @@ class AddActFn(Function):
 
     @staticmethod
     def forward(ctx, a, b, act, alpha):
+        ctx.set_materialize_grads(False)
         y = K.add_act(_c(a), _c(b), act, alpha)
         ctx.save_for_backward(y if act != K.ACT_NONE else None)
         ctx.act, ctx.alpha = act, alpha
@@ -145,6 +155,8 @@ class AddActFn(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return None, None, None, None
         (y,) = ctx.saved_tensors
         g = _act_bwd(gy, y, ctx.act, ctx.alpha)
         return g, g, None, None
@@ -156,10 +168,13 @@ class ConcatTileFn(Function):
     @staticmethod
     def forward(ctx, feat, emb):
         ctx.cf, ctx.ce = feat.shape[-1], emb.shape[-1]
+        ctx.set_materialize_grads(False)
         return K.concat_tile_fwd(_c(feat), _c(emb))
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         return ConcatTileBwdFn.apply(g, ctx.cf, ctx.ce)
 
 
