@@ -11,7 +11,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees tensors.
  *     Scratch comes from the caller's workspace (size from the matching *_workspace_bytes query; 256-byte aligned).
  *   - tensors are dense NHWC fp32 ("[B,H,W,C]", C fastest); conv filters are TF "HWIO" [KH,KW,Cin,Cout];
- *     dense kernels are [in,out].  No tensor may exceed 2^31-1 elements.
+ *     dense kernels are [in,out].  No tensor may exceed 2^30-16 elements (4 GiB: buffer addressing).
  *   - every call is asynchronous on the given hipStream_t (void* here so the header needs no HIP include) and is
  *     safe to capture into a hipGraph: no allocation, no synchronisation, no host-visible state.
  */

@@ -53,18 +53,27 @@ __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict
   }
 }
 
+// stage 2: one block per 64 columns; 4 row lanes walk the partials (fixed order), LDS joins them
 __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
                                                          int nchunks, int C, float* __restrict__ out0,
                                                          float* __restrict__ out1) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    s0 += part0[(size_t)k * C + c];
-    if (out1) s1 += part1[(size_t)k * C + c];
+  __shared__ float s0[4][64], s1[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    for (int k = ty; k < nchunks; k += 4) {
+      a0 += part0[(size_t)k * C + c];
+      if (out1) a1 += part1[(size_t)k * C + c];
+    }
   }
-  out0[c] = s0;
-  if (out1) out1[c] = s1;
+  s0[ty][tx] = a0;
+  s1[ty][tx] = a1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    out0[c] = (s0[0][tx] + s0[1][tx]) + (s0[2][tx] + s0[3][tx]);
+    if (out1) out1[c] = (s1[0][tx] + s1[1][tx]) + (s1[2][tx] + s1[3][tx]);
+  }
 }
 
 static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int64_t* rows_per_chunk) {
@@ -73,6 +82,7 @@ static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int6
   if (want < 1) want = 1;
   int64_t maxchunks = (rows + 63) / 64;       // at least 64 rows per chunk
   if (want > maxchunks) want = maxchunks;
+  if (want > 256) want = 256;                 // keeps the second stage short
   if (want < 1) want = 1;
   *rows_per_chunk = (rows + want - 1) / want;
   *nchunks = (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
@@ -93,7 +103,7 @@ hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C
   float* part1 = part0 + (size_t)nc * C;
   hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
                      out1 != nullptr);
-  hipLaunchKernelGGL(col_reduce_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, part0, part1, nc, C, out0, out1);
+  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1);
   return hipGetLastError();
 }
 

@@ -59,10 +59,10 @@ static int validate_desc(const t2i_conv_desc* d) {
     set_error("output extent inconsistent with input/stride/pad");
     return T2I_ERR_INVALID;
   }
-  const int64_t lim = 2147483647LL;
+  const int64_t lim = (1LL << 30) - 16;   // buffer loads address with 32-bit byte offsets
   int64_t nx = (int64_t)d->B * d->H * d->W * d->Cin, ny = (int64_t)d->B * d->Ho * d->Wo * d->Cout,
           nw = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
-  if (nx > lim || ny > lim || nw > lim) { set_error("tensor exceeds 2^31-1 elements"); return T2I_ERR_INVALID; }
+  if (nx > lim || ny > lim || nw > lim) { set_error("tensor exceeds 2^30-16 elements"); return T2I_ERR_INVALID; }
   return T2I_OK;
 }
 
@@ -76,40 +76,52 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-// Tile / split-K choice.  The fp32 matrix pipe is slow relative to L2 (a 64x64 tile still needs only ~10 TB/s of
-// the ~34 TB/s aggregate L2 at full MFMA rate), so filling all 256 CUs with >= 2 workgroups each matters more than
-// the largest tile: shrink the tile, then split K, until there are ~512 workgroups or K per split hits 256.
+// Tile / split-K choice by a makespan model.  Measured on MI355X: a balanced launch of this kernel sustains ~72% of
+// the fp32 matrix peak, but launches whose workgroup count is not a multiple of the 256 CUs lose up to 45% to the
+// last partial round (each CU works through its workgroups at a fixed MFMA rate; co-resident workgroups time-share).
+// So: for every tile shape and split factor estimate  rounds x (K-tiles per split + fixed overhead) x tile work
+// (+ the split-K reduction traffic) and take the cheapest.
 static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems) {
-  Plan pl;
-  pl.wnt = N > 64 ? 2 : 1;
-  pl.wmt = M > 64 ? 2 : 1;
-  auto blocks = [&](int wmt, int wnt) {
-    return ((M + 64 * wmt - 1) / (64 * wmt)) * ((N + 64 * wnt - 1) / (64 * wnt)) * nphase;
-  };
-  const int64_t target = 512;
-  int64_t maxsplit = K / 256;
+  static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  static const double rel_eff[4] = {1.0, 0.90, 0.90, 0.78};   // MFMA efficiency relative to the 128x128 tile
+  const double unit_us = 0.57;       // one 64x64x32 tile-step on one CU at the sustained rate
+  const double overhead_tiles = 3.0; // prologue + epilogue of a workgroup, in K-tile steps
+  const int64_t ktiles = (K + 31) / 32;
+  int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
   if (maxsplit > 32) maxsplit = 32;
-  if (blocks(pl.wmt, pl.wnt) * maxsplit < target && pl.wmt == 2) pl.wmt = 1;
-  if (blocks(pl.wmt, pl.wnt) * maxsplit < target && pl.wnt == 2) pl.wnt = 1;
-  int ft = env_int("T2I_FORCE_TILE", 0);   // e.g. 22, 12, 21, 11 (tuning hook)
-  if (ft) { pl.wmt = ft / 10; pl.wnt = ft % 10; }
-  int64_t nb = blocks(pl.wmt, pl.wnt);
-  int64_t sk = (target + nb - 1) / nb;
-  if (sk > maxsplit) sk = maxsplit;
-  if (sk < 1) sk = 1;
-  int fs = env_int("T2I_FORCE_SPLITK", 0);
-  if (fs > 0) sk = fs;
-  int64_t ktiles = (K + 31) / 32;
-  int64_t tiles_per_split = (ktiles + sk - 1) / sk;
-  if (tiles_per_split < 1) tiles_per_split = 1;
-  pl.k_per_split = (int)(tiles_per_split * 32);
-  pl.splitk = (int)((ktiles + tiles_per_split - 1) / tiles_per_split);
-  if (pl.splitk < 1) pl.splitk = 1;
-  pl.tiles_m = (int)((M + 64 * pl.wmt - 1) / (64 * pl.wmt));
-  pl.tiles_n = (int)((N + 64 * pl.wnt - 1) / (64 * pl.wnt));
-  pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * out_elems * sizeof(float) : 0;
-  return pl;
+  const int ft = env_int("T2I_FORCE_TILE", 0);   // e.g. 22, 12, 21, 11 (tuning hooks)
+  const int fs = env_int("T2I_FORCE_SPLITK", 0);
+  Plan best;
+  double best_t = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    const int wmt = cand[c][0], wnt = cand[c][1];
+    if (ft) { if (ft != wmt * 10 + wnt) continue; }
+    else {
+      if (wmt == 2 && M <= 64) continue;
+      if (wnt == 2 && N <= 64) continue;
+    }
+    const int64_t tm = (M + 64 * wmt - 1) / (64 * wmt), tn = (N + 64 * wnt - 1) / (64 * wnt);
+    const int64_t tiles = tm * tn * nphase;
+    for (int64_t sk = 1; sk <= maxsplit; ++sk) {
+      if (fs > 0 && sk != fs && !(fs > maxsplit && sk == maxsplit)) continue;
+      const int64_t per = (ktiles + sk - 1) / sk;
+      const int64_t sk_eff = (ktiles + per - 1) / per;
+      if (sk_eff != sk) continue;                       // same plan as a smaller sk
+      const int64_t blocks = tiles * sk_eff;
+      const int64_t rounds = (blocks + 255) / 256;
+      double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us / rel_eff[c];
+      if (sk_eff > 1) t += 4.0 + (double)out_elems * 4.0 * (double)(sk_eff + 1) / 4.0e6;   // slabs out + in at ~4 TB/s
+      if (t < best_t) {
+        best_t = t;
+        best.wmt = wmt; best.wnt = wnt;
+        best.splitk = (int)sk_eff; best.k_per_split = (int)(per * 32);
+        best.tiles_m = (int)tm; best.tiles_n = (int)tn;
+        best.ws_bytes = sk_eff > 1 ? (size_t)sk_eff * out_elems * sizeof(float) : 0;
+      }
+    }
+  }
+  return best;
 }
 
 static void fill_common(IgemmParams& p, const t2i_conv_desc* d) {
@@ -216,6 +228,8 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
+  p.a_bytes = (uint32_t)((size_t)d->B * d->H * d->W * d->Cin * 4);
+  p.b_bytes = (uint32_t)((size_t)d->KH * d->KW * d->Cin * d->Cout * 4);
   p.M = d->B * d->Ho * d->Wo; p.N = d->Cout; p.K = d->KH * d->KW * d->Cin;
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
@@ -231,6 +245,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
+  p.a_bytes = (uint32_t)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
+  p.b_bytes = (uint32_t)((size_t)d->KH * d->KW * d->Cin * d->Cout * 4);
   p.K = fill_phases(p);
   p.M = d->B * p.hqwq; p.N = d->Cin;
   p.div_c.set(d->Cout);
@@ -247,6 +263,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;
+  p.a_bytes = (uint32_t)((size_t)d->B * d->H * d->W * d->Cin * 4);
+  p.b_bytes = (uint32_t)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
   p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);

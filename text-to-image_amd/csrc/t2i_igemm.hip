@@ -2,17 +2,24 @@
 //
 // One templated kernel serves the three conv primitives (and dense layers as 1x1 convs):
 //   FWD         y [M=B*Ho*Wo, N=Cout]   = im2col(x)[M,K=KH*KW*Cin]      * w[K,N]
-//   BWD_DATA    dx[M=B*Hq*Wq, N=Cin]    = gather(dy)[M,K=taps*Cout]     * w^T[K,N]   (one GEMM per stride phase)
+//   BWD_DATA    dx[M=B*Hq*Wq, N=Cin]    = gather(dy)[M,K=taps*Cout]     * w^T[K,N]   (grid.z = stride phase)
 //   BWD_FILTER  dw[M=KH*KW*Cin, N=Cout] = im2col(x)^T[M,K=B*Ho*Wo]      * dy[K,N]
 // Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 (an fmaf chain), 64 FLOP/clk/SIMD = the chip's fp32 peak.
-// Structure: 256 threads = 4 waves (2x2), each wave owns WMT x WNT accumulator tiles of 32x32; BK = 32;
-// operands are gathered global->registers (16-byte loads where channels allow) one K-tile ahead of the MFMAs and
-// staged through double-buffered LDS (one barrier per K-tile).  Two LDS images, chosen per operand by which global
-// dimension is contiguous:
+// Structure: 256 threads = 4 waves (2x2), each wave owns WMT x WNT accumulator tiles of 32x32; BK = 32.
+//   * operands are gathered with BUFFER loads (16 bytes where channels allow): padding taps, ragged edges and split-K
+//     tails get an out-of-range offset and the hardware returns zeros — the K loop has no divergent branch at all
+//     (a first version predicated each load with `ok ? *p : 0`; hipcc wrapped every load in an exec-mask branch, which
+//     split the loop into ~40 basic blocks and serialised the address arithmetic in front of the MFMAs);
+//   * tile t+1 sits in registers while tile t is multiplied; it is written to the other LDS buffer between the two
+//     halves of tile t's MFMAs, then the loads of tile t+2 are issued: one barrier per K-tile, loads in flight for a
+//     whole tile of MFMAs;
+//   * MFMA operand fragments are double-buffered in registers (8-k chunk c+1 is read from LDS while chunk c is
+//     multiplied), so no ds_read latency sits between MFMAs.
+// Two LDS images, chosen per operand by which global dimension is contiguous:
 //   K-inner  [rows][BK+4]   read with ds_read_b128 (4 k's per lane; row stride 36 dwords = 4*odd -> conflict free)
 //   N-inner  [BK][cols]     read with ds_read_b32  (lane = column; consecutive lanes, conflict free)
 // Both feed the same k-permutation: MFMA j of 8-k chunk c consumes k = 8c+j (lanes 0-31) and 8c+4+j (lanes 32-63).
-// Split-K (grid.z) writes full-layout partial slabs that t2i_splitk_reduce sums in a fixed order (deterministic),
+// Split-K (grid.y) writes full-layout partial slabs that splitk_reduce sums in a fixed order (deterministic),
 // applying bias + activation there; without split-K the epilogue is fused here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,10 +29,12 @@
 namespace t2i {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;              // K-inner row stride = 36 dwords
 constexpr int KSTRIDE = BK + KPAD;
+constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every legal buffer: the load returns 0
 
 template <int MODE, int WMT, int WNT>
 struct Smem {
@@ -37,14 +46,16 @@ struct Smem {
   static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
 };
 
-__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int off, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)elem_off * 4u : OOB, 0, 0);
+  return __builtin_bit_cast(float4, v);
 }
-__device__ __forceinline__ float ld1(const float* __restrict__ p, int off, bool ok) { return ok ? p[off] : 0.f; }
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)elem_off * 4u : OOB, 0, 0));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
-// Operand address generators.  Each returns the element offset of GEMM element (row/col index `r`, reduction index
-// `k`) and whether it exists (padding taps, ragged edges and split-K tails read as zero).
+// Operand address generators.  Each yields the element offset of a GEMM element and whether it exists.
 // ------------------------------------------------------------------------------------------------------------------
 struct RowFwd {  // an output pixel of FWD (A rows) or an input pixel of BWD_DATA (A rows): fixed per thread
   int base;      // pixel index of (b, 0, 0) in the tensor being gathered
@@ -79,8 +90,8 @@ __device__ __forceinline__ RowFwd make_row(const IgemmParams& p, const PhaseInfo
   return r;
 }
 
-// A operand of FWD / BWD_DATA: `k` must be a multiple of 4 when VEC.
-template <int MODE, bool VEC>
+// A operand of FWD / BWD_DATA: (tap, c) = decode of reduction index k; `k` is a multiple of 4 on the vector path.
+template <int MODE>
 __device__ __forceinline__ void a_offset(const IgemmParams& p, const PhaseInfo& pi, const RowFwd& r, int k, int kend,
                                          int& off, bool& ok) {
   const int C = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;  // channels of the gathered tensor
@@ -90,13 +101,13 @@ __device__ __forceinline__ void a_offset(const IgemmParams& p, const PhaseInfo& 
     int kh = p.div_kw.div(tap);
     int kw = tap - kh * p.d.KW;
     int ih = r.h0 + kh, iw = r.w0 + kw;
-    ok = r.ok && k < kend && (unsigned)ih < (unsigned)p.d.H && (unsigned)iw < (unsigned)p.d.W;
+    ok = r.ok & (k < kend) & ((unsigned)ih < (unsigned)p.d.H) & ((unsigned)iw < (unsigned)p.d.W);
     off = (r.base + ih * p.d.W + iw) * C + c;
   } else {
     int jh = pi.div_ntw.div(tap);
     int jw = tap - jh * pi.ntw;
     int oh = r.h0 - jh, ow = r.w0 - jw;
-    ok = r.ok && k < kend && (unsigned)oh < (unsigned)p.d.Ho && (unsigned)ow < (unsigned)p.d.Wo;
+    ok = r.ok & (k < kend) & ((unsigned)oh < (unsigned)p.d.Ho) & ((unsigned)ow < (unsigned)p.d.Wo);
     off = (r.base + oh * p.d.Wo + ow) * C + c;
   }
 }
@@ -109,7 +120,7 @@ __device__ __forceinline__ void bT_offset(const IgemmParams& p, const PhaseInfo&
   int jh = pi.div_ntw.div(tap);
   int jw = tap - jh * pi.ntw;
   int kh = pi.kh0 + jh * p.d.SH, kw = pi.kw0 + jw * p.d.SW;
-  ok = n < p.N && k < kend;
+  ok = (n < p.N) & (k < kend);
   off = ((kh * p.d.KW + kw) * p.d.Cin + n) * p.d.Cout + co;
 }
 
@@ -128,18 +139,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- block -> (tile, phase, split).  blockIdx.x walks M tiles fastest so that consecutive blocks (which the
+  // ---- block -> (tile, split, phase).  blockIdx.x walks M tiles fastest so that consecutive workgroups (which the
   // dispatcher spreads over the 8 XCDs) share the same filter panel in every L2.
   const int tiles_m = p.tiles_m;
   const int bm = (blockIdx.x % tiles_m) * BM;
   const int bn = (blockIdx.x / tiles_m) * BN;
   const int split = blockIdx.y;
-  // BWD_DATA: blockIdx.z is the stride phase (its tap set and K extent were resolved on the host)
   const PhaseInfo& pi = p.phase[MODE == MODE_BWD_DATA ? blockIdx.z : 0];
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
   const int kbeg = split * p.k_per_split;
   const int kend = min(Kdim, kbeg + p.k_per_split);
   const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), (short)0, (int)p.b_bytes, 0x00020000);
 
   // ---- per-thread loader state ---------------------------------------------------------------------------------
   // K-inner image: thread -> (k quad kq = tid&7, rows r0 + 32*i).   N-inner image: thread -> (col quad, k rows).
@@ -151,8 +164,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) arow[i] = make_row<MODE>(p, pi, bm + r0 + 32 * i);
   }
-  // N-inner thread mapping
-  constexpr int A_C4 = BM / 4, B_C4 = BN / 4;          // float4 columns per k-row
+  constexpr int A_C4 = BM / 4, B_C4 = BN / 4;          // float4 columns per k-row (N-inner images)
   constexpr int A_KSTEP = 256 / A_C4, B_KSTEP = 256 / B_C4;
   const int a_c4 = tid % A_C4, a_kr0 = tid / A_C4;
   const int b_c4 = tid % B_C4, b_kr0 = tid / B_C4;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   float4 areg[A_LD], breg[B_LD];
 
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t) {   // tiles past the end read as zeros (k >= kend), so the loop needs no tail branch
     const int k0 = kbeg + t * BK;
     // ---------------- A ----------------
     if (A_KINNER) {
@@ -183,20 +195,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       for (int i = 0; i < A_LD; ++i) {
         if (VEC) {
           int off; bool ok;
-          a_offset<MODE, VEC>(p, pi, arow[i], k, kend, off, ok);
-          areg[i] = ld4(p.a, off, ok);
+          a_offset<MODE>(p, pi, arow[i], k, kend, off, ok);
+          areg[i] = bload4(ra, off, ok);
         } else {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int off; bool ok;
-            a_offset<MODE, VEC>(p, pi, arow[i], k + e, kend, off, ok);
-            v[e] = ld1(p.a, off, ok);
+            a_offset<MODE>(p, pi, arow[i], k + e, kend, off, ok);
+            v[e] = bload1(ra, off, ok);
           }
           areg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
-    } else {  // BWD_FILTER: A[i, r] = x gathered; k index is r = (b,oh,ow)
+    } else {  // BWD_FILTER: A[i, r] = x gathered; the reduction index is r = (b,oh,ow)
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         const int r = k0 + a_kr0 + A_KSTEP * i;
@@ -210,15 +222,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const int h0 = oh * p.d.SH - p.d.pad_t, w0 = ow * p.d.SW - p.d.pad_l;
         if (VEC) {
           int ih = h0 + fa_kh[0], iw = w0 + fa_kw[0];
-          bool ok = rok && fa_ok[0] && (unsigned)ih < (unsigned)p.d.H && (unsigned)iw < (unsigned)p.d.W;
-          areg[i] = ld4(p.a, (pix + ih * p.d.W + iw) * p.d.Cin + fa_ci[0], ok);
+          bool ok = rok & fa_ok[0] & ((unsigned)ih < (unsigned)p.d.H) & ((unsigned)iw < (unsigned)p.d.W);
+          areg[i] = bload4(ra, (pix + ih * p.d.W + iw) * p.d.Cin + fa_ci[0], ok);
         } else {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int ih = h0 + fa_kh[e], iw = w0 + fa_kw[e];
-            bool ok = rok && fa_ok[e] && (unsigned)ih < (unsigned)p.d.H && (unsigned)iw < (unsigned)p.d.W;
-            v[e] = ld1(p.a, (pix + ih * p.d.W + iw) * p.d.Cin + fa_ci[e], ok);
+            bool ok = rok & fa_ok[e] & ((unsigned)ih < (unsigned)p.d.H) & ((unsigned)iw < (unsigned)p.d.W);
+            v[e] = bload1(ra, (pix + ih * p.d.W + iw) * p.d.Cin + fa_ci[e], ok);
           }
           areg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -233,14 +245,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         if (VEC) {
           int off; bool ok;
           bT_offset(p, pi, n, k, kend, off, ok);
-          breg[i] = ld4(p.b, off, ok);
+          breg[i] = bload4(rb, off, ok);
         } else {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int off; bool ok;
             bT_offset(p, pi, n, k + e, kend, off, ok);
-            v[e] = ld1(p.b, off, ok);
+            v[e] = bload1(rb, off, ok);
           }
           breg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -251,11 +263,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const int k = k0 + b_kr0 + B_KSTEP * i;
         const int n = bn + b_c4 * 4;
         if (VEC) {
-          breg[i] = ld4(p.b, k * p.N + n, k < kend && n < p.N);
+          breg[i] = bload4(rb, k * p.N + n, (k < kend) & (n < p.N));
         } else {
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ld1(p.b, k * p.N + n + e, k < kend && n + e < p.N);
+          for (int e = 0; e < 4; ++e) v[e] = bload1(rb, k * p.N + n + e, (k < kend) & (n + e < p.N));
           breg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
@@ -289,55 +301,75 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute_tile = [&](int buf) {
-    const float* as = As + buf * S::A_ELEMS;
-    const float* bs = Bs + buf * S::B_ELEMS;
+  // fragments of one 8-k chunk: 4 MFMA steps x (WMT + WNT) operands
+  struct Frag { float a[WMT][4]; float b[WNT][4]; };
+
+  auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) {
 #pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      float a[WMT][4], b[WNT][4];
+    for (int i = 0; i < WMT; ++i) {
+      const int row = wm * 32 * WMT + i * 32 + l31;
+      if (A_KINNER) {
+        float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
+        f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+      } else {
 #pragma unroll
-      for (int i = 0; i < WMT; ++i) {
-        const int row = wm * 32 * WMT + i * 32 + l31;
-        if (A_KINNER) {
-          float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
-          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) a[i][j] = as[(c * 8 + j + 4 * lh) * BM + row];
-        }
+        for (int j = 0; j < 4; ++j) f.a[i][j] = as[(c * 8 + j + 4 * lh) * BM + row];
       }
+    }
 #pragma unroll
-      for (int i = 0; i < WNT; ++i) {
-        const int col = wn * 32 * WNT + i * 32 + l31;
-        if (B_KINNER) {
-          float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
-          b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
-        } else {
+    for (int i = 0; i < WNT; ++i) {
+      const int col = wn * 32 * WNT + i * 32 + l31;
+      if (B_KINNER) {
+        float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
+        f.b[i][0] = v.x; f.b[i][1] = v.y; f.b[i][2] = v.z; f.b[i][3] = v.w;
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[i][j] = bs[(c * 8 + j + 4 * lh) * BN + col];
-        }
+        for (int j = 0; j < 4; ++j) f.b[i][j] = bs[(c * 8 + j + 4 * lh) * BN + col];
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-          for (int n = 0; n < WNT; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
     }
   };
 
-  // ---- main loop: registers hold tile t+1 while the MFMAs consume tile t from LDS ---------------------------------
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
+  auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int n = 0; n < WNT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][j], f.b[n][j], acc[i][n], 0, 0, 0);
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------------------------------
+  // registers: tile t+1 | LDS buf[t&1]: tile t | LDS buf[(t+1)&1]: free (its last reader finished before the barrier)
+  load_tile(0);
+  store_tile(0);
+  load_tile(1);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const float* as = As + (t & 1) * S::A_ELEMS;
+    const float* bs = Bs + (t & 1) * S::B_ELEMS;
+    Frag f0, f1;
+    // sched_barrier(0) pins the software pipeline: without it hipcc sinks every ds_read to just before its MFMAs
+    // (fewer live registers) and the LDS latency lands between MFMA groups — ~20% of the matrix pipe idle.
+    read_frag(f0, as, bs, 0);
+    read_frag(f1, as, bs, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(f0, as, bs, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // tile t+1: registers -> the other LDS buffer, interleaved with chunk 1's MFMAs
+    mma_frag(f1);
+    store_tile((t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(f1, as, bs, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    // start fetching tile t+2 (zeros past the end): address arithmetic + buffer loads hide behind chunk 2's MFMAs
+    load_tile(t + 2);
+    mma_frag(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f1);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-      if (t + 1 < ntiles) load_tile(t + 1);
-      compute_tile(t & 1);
-      if (t + 1 < ntiles) store_tile((t + 1) & 1);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
@@ -400,7 +432,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     s.z = apply_act(s.z, act, alpha); s.w = apply_act(s.w, act, alpha);
     reinterpret_cast<float4*>(out)[i] = s;
   }
-  // tail (out_elems % 4) and the N % 4 != 0 case go through the scalar kernel below
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slabs, int splitk,

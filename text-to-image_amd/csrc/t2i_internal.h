@@ -15,18 +15,22 @@ enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_FILTER = 2 };
 // Division by a launch-constant via multiply-high (valid for 0 <= n < 2^31): the im2col index decode must not cost a
 // 30-instruction integer division per gathered element.
 struct FastDiv {
-  uint32_t mul, shr, one;
+  uint32_t mul, shr, add;   // q = (umulhi(n, mul) + (n & add)) >> shr;  d == 1 is {0, 0, ~0}: branch-free
   __host__ void set(uint32_t d) {
-    one = (d == 1);
-    if (d == 1) { mul = 0; shr = 0; return; }
+    if (d == 1) { mul = 0; shr = 0; add = 0xFFFFFFFFu; return; }
+    add = 0;
     uint32_t l = 0;
     while ((1u << l) < d) ++l;                       // ceil(log2 d)
     uint64_t pw = 1ull << (31 + l);
     mul = (uint32_t)((pw + d - 1) / d);
     shr = l - 1;
   }
-  __device__ __forceinline__ int div(int n) const {
-    return one ? n : (int)(__umulhi((uint32_t)n, mul) >> shr);
+  __host__ __device__ __forceinline__ int div(int n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)((__umulhi((uint32_t)n, mul) + ((uint32_t)n & add)) >> shr);
+#else
+    return (int)(((uint32_t)(((uint64_t)(uint32_t)n * mul) >> 32) + ((uint32_t)n & add)) >> shr);
+#endif
   }
 };
 
@@ -51,6 +55,7 @@ struct IgemmParams {
   int32_t tiles_m, tiles_n;
   int32_t splitk, k_per_split;
   size_t out_elems;           // slab stride for split-K
+  uint32_t a_bytes, b_bytes;  // extents of the two operand buffers (buffer-load range check: out of range reads 0)
   int32_t howo, hqwq, Wq;     // Ho*Wo; Hq*Wq; Wq  (Hq = ceil(H/SH))
   FastDiv div_howo, div_wo, div_hqwq, div_wq, div_c, div_kw;
   int32_t nphase;

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Per-layer micro-benchmark of the three conv primitives at the wgancls shapes (tuning tool, not a test).
+usage: python tools/bench_conv.py [--batch 64] [--filter D10] [--reps 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import t2i_amd  # noqa: E402,F401
+from t2i_amd import kernels as K  # noqa: E402
+
+# name, H, W, Cin, Cout, k, s, pad, batch multiplier (3 = the batched critic pass)
+LAYERS = [
+    ('D1', 64, 64, 3, 128, 4, 2, 'SAME'), ('D2', 32, 32, 128, 256, 4, 2, 'SAME'), ('D3', 16, 16, 256, 512, 4, 2, 'SAME'),
+    ('D4', 8, 8, 512, 1024, 4, 2, 'SAME'), ('D5', 4, 4, 1024, 256, 1, 1, 'VALID'), ('D6', 4, 4, 256, 512, 3, 1, 'SAME'),
+    ('D7', 4, 4, 512, 1024, 3, 1, 'SAME'), ('D8fc', 1, 1, 1024, 128, 1, 1, 'VALID'), ('D10', 4, 4, 1152, 1024, 3, 1, 'SAME'),
+    ('D11', 4, 4, 1024, 1024, 1, 1, 'VALID'), ('D12', 4, 4, 1024, 1, 4, 4, 'VALID'),
+    ('G3fc', 1, 1, 256, 16384, 1, 1, 'VALID'), ('G4a', 4, 4, 1024, 256, 1, 1, 'VALID'), ('G4b', 4, 4, 256, 256, 3, 1, 'SAME'),
+    ('G4c', 4, 4, 256, 1024, 3, 1, 'SAME'), ('G5dc', 8, 8, 512, 1024, 4, 2, 'SAME'), ('G5c', 8, 8, 512, 512, 3, 1, 'SAME'),
+    ('G6a', 8, 8, 512, 128, 1, 1, 'VALID'), ('G6b', 8, 8, 128, 128, 3, 1, 'SAME'), ('G6c', 8, 8, 128, 512, 3, 1, 'SAME'),
+    ('G7dc', 16, 16, 256, 512, 4, 2, 'SAME'), ('G7c', 16, 16, 256, 256, 3, 1, 'SAME'), ('G8dc', 32, 32, 128, 256, 4, 2, 'SAME'),
+    ('G8c', 32, 32, 128, 128, 3, 1, 'SAME'), ('G9dc', 64, 64, 3, 128, 4, 2, 'SAME'), ('G9c', 64, 64, 3, 3, 3, 1, 'SAME'),
+]
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--filter', default='')
+    ap.add_argument('--reps', type=int, default=20)
+    a = ap.parse_args()
+    tot = {'fwd': [0, 0], 'bwd_data': [0, 0], 'bwd_filter': [0, 0]}
+    print('%-6s %5s %22s %10s | %8s %6s | %8s %6s | %8s %6s' % ('layer', 'B', 'shape', 'GFLOP', 'fwd us', 'TF/s', 'bwdD us', 'TF/s', 'bwdF us', 'TF/s'))
+    for name, H, W, Ci, Co, k, s, pad in LAYERS:
+        if a.filter and a.filter not in name:
+            continue
+        B = a.batch
+        d, ws = K.conv_desc(B, H, W, Ci, Co, k, k, s, s, pad)
+        x = torch.randn(B, H, W, Ci, device='cuda'); w = torch.randn(k, k, Ci, Co, device='cuda') * 0.05
+        dy = torch.randn(B, d.Ho, d.Wo, Co, device='cuda')
+        fl = K.conv_flops(d)
+        t1 = timeit(lambda: K.conv_fwd(x, w, None, d, ws), a.reps)
+        t2 = timeit(lambda: K.conv_bwd_data(dy, w, None, d, ws), a.reps)
+        t3 = timeit(lambda: K.conv_bwd_filter(x, dy, d, ws), a.reps)
+        for key, t in (('fwd', t1), ('bwd_data', t2), ('bwd_filter', t3)):
+            tot[key][0] += fl; tot[key][1] += t
+        print('%-6s %5d %22s %10.2f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f' % (
+            name, B, '%dx%dx%d->%d k%ds%d' % (H, W, Ci, Co, k, s), fl / 1e9, t1 * 1e6, fl / t1 / 1e12, t2 * 1e6, fl / t2 / 1e12,
+            t3 * 1e6, fl / t3 / 1e12))
+    for key, (f, t) in tot.items():
+        if t:
+            print('TOTAL %-10s %8.2f GFLOP %8.1f us  %6.1f TF/s' % (key, f / 1e9, t * 1e6, f / t / 1e12))
+
+
+if __name__ == '__main__':
+    main()
