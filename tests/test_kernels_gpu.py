@@ -124,7 +124,24 @@ MEDIUM = [  # B, H, W, Cin, Cout, KH, KW, s, pad
     (2, 9, 7, 8, 12, 4, 4, 2, 'SAME'),         # odd extents: ragged phases
     (2, 8, 8, 32, 32, 4, 4, 1, 'SAME'),        # asymmetric pad (1,2)
     (6, 32, 32, 32, 128, 3, 3, 1, 'SAME'),     # M = 6144: 128x128 tiles, M-inner filter gradient with split over rows
+    (3, 32, 32, 3, 128, 4, 4, 2, 'SAME'),      # critic first layer: bwd_data takes the direct thin_deconv_k4s2 kernel
+    (2, 48, 32, 4, 64, 4, 4, 2, 'SAME'),       # thin kernel, Cin = 4, non-square
+    (3, 32, 32, 3, 3, 3, 3, 1, 'SAME'),        # generator output conv 3->3: tiny_conv fwd / bwd_data, deep split filter grad
+    (2, 16, 16, 2, 4, 3, 3, 2, 'SAME'),        # tiny_conv forward with stride 2 (bwd_data falls back to the GEMM)
 ]
+
+
+def test_thin_deconv_with_bias_and_tanh(K):
+    """generator out_deconv (128 -> 3, k4 s2) = conv^T + bias, then an activation, through the direct kernel."""
+    from oracle import np_ops as O
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 16, 16, 128)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, 3, 128)) / 30).astype(np.float32)
+    b = rng.standard_normal(3).astype(np.float32)
+    d, ws = K.deconv_desc(3, 16, 16, 128, 3, 4, 4, 2, 2, 'SAME')
+    ref = O.conv2d_transpose(x, w, b, (2, 2), 'SAME')
+    assert relerr(K.conv_bwd_data(dev(x), dev(w), dev(b), d, ws), ref) <= FWD_TOL
+    assert relerr(K.conv_bwd_data(dev(x), dev(w), dev(b), d, ws, K.ACT_TANH), np.tanh(ref)) <= FWD_TOL
 
 
 @pytest.mark.parametrize('case', MEDIUM)

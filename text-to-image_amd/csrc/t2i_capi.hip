@@ -37,6 +37,11 @@ hipError_t transpose_launch(const float*, int, int, int, float*, hipStream_t);
 hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, float, float, float, float, hipStream_t);
+// direct kernels for the 3-channel layers (t2i_thin.hip)
+bool thin_deconv_eligible(const t2i_conv_desc& d);
+hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
+hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
 
 static int check(hipError_t e, const char* what) {
   if (e == hipSuccess) return T2I_OK;
@@ -81,15 +86,19 @@ static int env_int(const char* name, int dflt) {
 // last partial round (each CU works through its workgroups at a fixed MFMA rate; co-resident workgroups time-share).
 // So: for every tile shape and split factor estimate  rounds x (K-tiles per split + fixed overhead) x tile work
 // (+ the split-K reduction traffic) and take the cheapest.
-static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32) {
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
-  static const double rel_eff[4] = {1.0, 0.90, 0.90, 0.78};   // MFMA efficiency relative to the 128x128 tile
-  const double unit_us = 0.57;       // one 64x64x32 tile-step on one CU at the sustained rate
+  static const double rel_eff[4] = {1.0, 0.97, 0.97, 0.93};   // MFMA efficiency relative to the 128x128 tile
+  static const int max_resident[4] = {2, 3, 3, 4};            // co-resident workgroups per CU (LDS / VGPR limited)
+  // sustained rate of a CU as a function of how many workgroups it time-shares: one workgroup alone leaves the matrix
+  // pipe idle during its barrier / LDS-fill phases (measured: 128x128 tiles, 256 vs 512 workgroups: 0.80 vs 0.95)
+  static const double share_eff[5] = {0.0, 0.80, 0.95, 1.0, 1.0};
+  const double unit_us = 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
   const double overhead_tiles = 3.0; // prologue + epilogue of a workgroup, in K-tile steps
   const int64_t ktiles = (K + 31) / 32;
   int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
-  if (maxsplit > 32) maxsplit = 32;
+  if (maxsplit > split_cap) maxsplit = split_cap;
   const int ft = env_int("T2I_FORCE_TILE", 0);   // e.g. 22, 12, 21, 11 (tuning hooks)
   const int fs = env_int("T2I_FORCE_SPLITK", 0);
   Plan best;
@@ -110,7 +119,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       if (sk_eff != sk) continue;                       // same plan as a smaller sk
       const int64_t blocks = tiles * sk_eff;
       const int64_t rounds = (blocks + 255) / 256;
-      double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us / rel_eff[c];
+      const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
+      double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us /
+                 (rel_eff[c] * share_eff[resident]);
       if (sk_eff > 1) t += 4.0 + (double)out_elems * 4.0 * (double)(sk_eff + 1) / 4.0e6;   // slabs out + in at ~4 TB/s
       if (t < best_t) {
         best_t = t;
@@ -161,9 +172,12 @@ static int fill_phases(IgemmParams& p) {
   return kmax;
 }
 
+// the filter gradient reduces over B*Ho*Wo (up to ~2e5 rows) into a small output: allow deep splits there
+static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256 : 32; }
+
 static int run_gemm(int mode, IgemmParams& p, size_t out_elems, bool vec, float* out, const float* bias, int act,
                     float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
-  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems);
+  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode));
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
   p.out_elems = out_elems;
@@ -215,7 +229,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   int kmax = fill_phases(p);
   size_t b = make_plan((int64_t)d->B * p.hqwq, d->Cin, kmax, p.nphase, nx).ws_bytes;
   if (b > need) need = b;
-  b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw).ws_bytes;
+  b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER)).ws_bytes;
   if (b > need) need = b;
   return need;
 }
@@ -225,6 +239,8 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
+  if (tiny_conv_eligible(*d, false) && !env_int("T2I_NO_THIN", 0))
+    return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -242,6 +258,12 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
+  if (!env_int("T2I_NO_THIN", 0)) {
+    if (tiny_conv_eligible(*d, true))
+      return check(tiny_conv_launch(*d, true, dy, w, bias, dx, act, alpha, (hipStream_t)stream), "t2i_conv2d_bwd_data(tiny)");
+    if (thin_deconv_eligible(*d) && aligned16(dy) && aligned16(w))
+      return check(thin_deconv_launch(*d, dy, w, bias, dx, act, alpha, (hipStream_t)stream), "t2i_conv2d_bwd_data(thin)");
+  }
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;

@@ -1,0 +1,164 @@
+// t2i_thin.hip — direct (non-GEMM) kernels for the 3-channel ends of the networks (gfx950 only).
+//
+// The image-side layers have 3 channels on one side (critic conv 3->128, generator deconv 128->3 and conv 3->3).  As
+// implicit GEMMs their N (or both M and N) is 3: a 64-wide MFMA tile would spend >95% of the matrix pipe on padding,
+// while the real cost is streaming the 128-channel tensor once (33.5 MB at B=64).  They are HBM/LDS-bound, so they
+// get VALU kernels (SURVEY.md §7 "thin layers"):
+//   thin_deconv_k4s2   dx[B,H,W,Ci<=4] = act(conv^T(dy[B,H/2,W/2,Co], w[4,4,Ci,Co]) + bias)   (k4 s2 SAME)
+//                      = generator out_deconv forward, and the critic's first-layer input gradient.
+//                      One workgroup = a 16x16 tile of dx of one image; its 10x10xCo patch of dy is staged in LDS once
+//                      (pixel stride Co+4 floats: conflict-free ds_read_b128 across pixels); wave w computes the 64
+//                      pixels of stride phase w, so its 2x2 filter taps are wave-uniform and come through scalar loads.
+//   tiny_conv          y = act(conv(x, w) + b) and its input gradient for Cin<=4, Cout<=4 (the 3->3 output conv):
+//                      one thread per pixel, filter through scalar loads, input through L1/L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ dx,
+                                                               int H, int W, int Co, int act, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [10][10][Co+4]
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int PS = Co + 4;                       // pixel stride in LDS
+  const int b = blockIdx.z;
+  const int ih0 = blockIdx.y * 16, iw0 = blockIdx.x * 16;
+  const int oh0 = (ih0 >> 1) - 1, ow0 = (iw0 >> 1) - 1;
+  const int c4n = Co >> 2;                     // float4 per pixel
+  // ---- stage the dy patch (zero outside the image) ----------------------------------------------------------------
+  for (int i = threadIdx.x; i < 100 * c4n; i += 256) {
+    const int pix = i / c4n, c4 = i - pix * c4n;
+    const int r = pix / 10, c = pix - r * 10;
+    const int oh = oh0 + r, ow = ow0 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo)
+      v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * Co + c4 * 4);
+    *reinterpret_cast<float4*>(&tile[pix * PS + c4 * 4]) = v;
+  }
+  __syncthreads();
+  // ---- wave = stride phase; lane = one of its 8x8 pixels --------------------------------------------------------------
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ph = wv >> 1, pw = wv & 1;
+  const int lane = threadIdx.x & 63;
+  const int py = lane >> 3, px = lane & 7;
+  const int kh0 = (ph + 1) & 1, kw0 = (pw + 1) & 1;   // first tap of this phase (pad 1): kh = kh0 + 2*jh
+  float acc[CI];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) acc[ci] = 0.f;
+#pragma unroll
+  for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+    for (int jw = 0; jw < 2; ++jw) {
+      const int r = py + 1 + ph - jh, c = px + 1 + pw - jw;           // patch coordinates of the contributing dy pixel
+      const float* src = &tile[(r * 10 + c) * PS];
+      const float* wt = w + (size_t)(((kh0 + 2 * jh) * 4 + (kw0 + 2 * jw)) * CI) * Co;   // wave-uniform
+      for (int c4 = 0; c4 < c4n; ++c4) {
+        const float4 d = *reinterpret_cast<const float4*>(src + c4 * 4);
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const float4 f = *reinterpret_cast<const float4*>(wt + ci * Co + c4 * 4);     // scalar load (uniform address)
+          acc[ci] = fmaf(d.x, f.x, fmaf(d.y, f.y, fmaf(d.z, f.z, fmaf(d.w, f.w, acc[ci]))));
+        }
+      }
+    }
+  }
+  const int ih = ih0 + 2 * py + ph, iw = iw0 + 2 * px + pw;
+  float* o = dx + ((size_t)(b * H + ih) * W + iw) * CI;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) o[ci] = apply_act(acc[ci] + (bias ? bias[ci] : 0.f), act, alpha);
+}
+
+bool thin_deconv_eligible(const t2i_conv_desc& d) {
+  return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin >= 1 && d.Cin <= 4 &&
+         (d.Cout % 4) == 0 && d.Cout >= 16 && d.Cout <= 512 && (d.H % 16) == 0 && (d.W % 16) == 0 && d.Ho * 2 == d.H &&
+         d.Wo * 2 == d.W;
+}
+
+hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx,
+                              int act, float alpha, hipStream_t stream) {
+  const size_t lds = (size_t)100 * (d.Cout + 4) * sizeof(float);
+  dim3 grid(d.W / 16, d.H / 16, d.B);
+#define T2I_THIN(CI)                                                                                              \
+  case CI: {                                                                                                      \
+    auto k = thin_deconv_k4s2_kernel<CI>;                                                                         \
+    if (lds > 48 * 1024) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                              \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, dy, w, bias, dx, d.H, d.W, d.Cout, act, alpha);           \
+    break;                                                                                                        \
+  }
+  switch (d.Cin) {
+    T2I_THIN(1) T2I_THIN(2) T2I_THIN(3) T2I_THIN(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef T2I_THIN
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tiny conv: Cin <= 4 and Cout <= 4.  BWD = false: y[b,oh,ow,:] = act(b + sum x[b,oh*s-p+kh,ow*s-p+kw,:] w[kh,kw,:,:])
+//                                     BWD = true (stride 1): dx[b,ih,iw,:] = sum dy[b,ih+p-kh,iw+p-kw,:] w[kh,kw,:,:]^T
+// ------------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void tiny_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        t2i_conv_desc d, int act, float alpha) {
+  // FWD: in = x [B,H,W,Cin], out = y [B,Ho,Wo,Cout].   BWD: in = dy [B,Ho,Wo,Cout], out = dx [B,H,W,Cin]
+  const int OH = BWD ? d.H : d.Ho, OW = BWD ? d.W : d.Wo, OC = BWD ? d.Cin : d.Cout;
+  const int IH = BWD ? d.Ho : d.H, IW = BWD ? d.Wo : d.W, IC = BWD ? d.Cout : d.Cin;
+  const size_t npix = (size_t)d.B * OH * OW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(p % OW);
+    const size_t t = p / OW;
+    const int oh = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < d.KH; ++kh) {
+      const int ih = BWD ? oh + d.pad_t - kh : oh * d.SH - d.pad_t + kh;
+      if ((unsigned)ih >= (unsigned)IH) continue;
+      for (int kw = 0; kw < d.KW; ++kw) {
+        const int iw = BWD ? ow + d.pad_l - kw : ow * d.SW - d.pad_l + kw;
+        if ((unsigned)iw >= (unsigned)IW) continue;
+        const float* src = in + ((size_t)(b * IH + ih) * IW + iw) * IC;
+        const float* wt = w + (size_t)(kh * d.KW + kw) * d.Cin * d.Cout;    // [Cin][Cout], uniform
+        for (int ic = 0; ic < IC; ++ic) {
+          const float v = src[ic];
+#pragma unroll
+          for (int oc = 0; oc < 4; ++oc)
+            if (oc < OC) acc[oc] = fmaf(v, BWD ? wt[oc * d.Cout + ic] : wt[ic * d.Cout + oc], acc[oc]);
+        }
+      }
+    }
+    float* o = out + p * OC;
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc)
+      if (oc < OC) o[oc] = apply_act(acc[oc] + (bias ? bias[oc] : 0.f), act, alpha);
+  }
+}
+
+bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd) {
+  if (d.Cin > 4 || d.Cout > 4) return false;
+  if (bwd && (d.SH != 1 || d.SW != 1)) return false;
+  return true;
+}
+
+hipError_t tiny_conv_launch(const t2i_conv_desc& d, bool bwd, const float* in, const float* w, const float* bias,
+                            float* out, int act, float alpha, hipStream_t stream) {
+  const size_t npix = (size_t)d.B * (bwd ? d.H * d.W : d.Ho * d.Wo);
+  size_t blocks = (npix + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (bwd)
+    hipLaunchKernelGGL(tiny_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, in, w, bias, out, d, act, alpha);
+  else
+    hipLaunchKernelGGL(tiny_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, in, w, bias, out, d, act, alpha);
+  return hipGetLastError();
+}
+
+}  // namespace t2i
