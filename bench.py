@@ -208,10 +208,17 @@ def main():
             s = timer.summary()
             info = K.device_info(local_rank)
             achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
+            traffic, traffic_src = None, None
+            try:   # HBM-side bytes per launch measured by rocprofv3 PMC passes over this same command (tools/pmc_summary.py)
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_igemm.json')))
+                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_pmc_igemm.json (FETCH_SIZE x2 + WRITE_SIZE)'
+            except Exception:
+                pass
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
                 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
                 'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
                 'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
                 'device': info}

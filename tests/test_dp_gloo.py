@@ -1,0 +1,94 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange step (text-to-image_amd/dp.py): bucket plan, overlap hooks,
+arena all-reduce and the mean scaling that the Adam kernel applies.  The compute kernels are not involved (no GPU here):
+the "model" is a toy whose parameters live in a real optim.Arena, and the gradients come from torch autograd on CPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        lib = os.path.join(ROOT, 'text-to-image_amd', 'lib', 'libt2i_hip.so')
+        if not os.path.exists(lib):
+            import __graft_entry__ as ge
+            ge.build()
+        import t2i_amd  # noqa: F401
+        from collections import OrderedDict
+        from t2i_amd import optim
+        from t2i_amd.dp import DataParallel
+        torch.manual_seed(0)                       # identical weights on every rank
+        shapes = [(5, 7), (3,), (4, 4, 2, 6), (9,), (1001,), (2, 3)]
+        params = OrderedDict(('p%d' % i, torch.randn(s).requires_grad_(True)) for i, s in enumerate(shapes))
+        arena = optim.Arena(params)
+        dp = DataParallel(bucket_bytes=400)        # tiny buckets -> several of them, exercised in reverse order
+        plan = dp._plan(arena)
+        # buckets tile the arena exactly once, last-created parameters first
+        covered = sorted((s, e) for s, e, _ in plan)
+        assert covered[0][0] == 0 and covered[-1][1] == arena.numel
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        assert plan[0][2][0] == 'p5' and len(plan) >= 3
+
+        torch.manual_seed(100 + rank)              # different data per rank
+        data = {n: torch.randn_like(p) for n, p in params.items()}
+
+        def loss_fn():
+            names = list(params)
+            use = names if mode != 'unused' else names[:-2]      # leave two parameters out of the graph
+            return sum((params[n] * data[n]).sum() * (i + 1) for i, n in enumerate(use))
+
+        arena.zero_grad()
+        if mode in ('hooks', 'unused'):
+            dp.arm(arena)                           # overlap path: hooks launch buckets as they complete
+        loss_fn().backward(inputs=list(params.values()))
+        extra = torch.tensor(float(rank + 1))
+        scale = dp.allreduce_arena(arena, extra=extra)
+        assert scale == 1.0 / world
+        assert float(extra) == sum(range(1, world + 1))
+        # expected: sum over ranks of each rank's local gradient
+        local = {n: (data[n] * (i + 1) if (mode != 'unused' or i < len(params) - 2) else torch.zeros_like(data[n]))
+                 for i, n in enumerate(params)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {n: v.clone() for n, v in local.items()})
+        for n in params:
+            want = sum(g[n] for g in gathered)
+            assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n
+            assert params[n].grad.data_ptr() == arena.grad_of(n).data_ptr()     # still views of the arena
+        dp.broadcast_variables(type('S', (), {'vars': params})())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, 'FAIL: %s\n%s' % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused'])
+def test_dp_allreduce_two_ranks(mode):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in results), results
