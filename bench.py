@@ -127,6 +127,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='keep the step eager (default: hipGraph replay on 1 GPU)')
     ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
                     help='where the per-launch HIP events for the roofline block are recorded')
     ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
@@ -168,8 +169,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    use_graphs = (world == 1) and not args.no_graphs and args.instrument != 'inline'
     for i in range(args.warmup):
+        if use_graphs and i == min(2, args.warmup - 1):
+            model.enable_graphs(feed)          # the remaining warm-up and all timed steps are graph replays
         trainer.iteration(1 + i, feed)
+    if use_graphs and model._graphs is None:
+        model.enable_graphs(feed)
     timer = ConvTimer()
     barrier()
     if args.instrument == 'inline':
@@ -183,11 +189,13 @@ def main():
     inst_steps = args.steps
     if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
         inst_steps = min(args.steps, 3)
+        saved_graphs, model._graphs = model._graphs, None      # per-launch events need eager launches
         K.set_conv_timer(timer)
         for i in range(inst_steps):
             trainer.iteration(1 + args.warmup + args.steps + i, feed)
         torch.cuda.synchronize()
         K.set_conv_timer(None)
+        model._graphs = saved_graphs
 
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -201,7 +209,8 @@ def main():
            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': 'wgancls 64x64 batch=%d/GPU fp32, synthetic images + random 1024-d text embeddings, '
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)' % args.batch,
-                      'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+                      'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                      'launch': 'hipGraph replay (2 graphs/iteration)' if use_graphs else 'eager'},
            'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
     if rank == 0:
         if args.instrument != 'off':

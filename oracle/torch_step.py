@@ -335,3 +335,33 @@ def synthetic_feed(cfg, seed=1, dtype=torch.float32, batch=None):
         eps=t(rng.uniform(0, 1, (B, 1, 1, 1))),
         ca_noise_d=t(np_ops.truncated_normal(rng, (B, cfg.compressed))),
         ca_noise_g=t(np_ops.truncated_normal(rng, (B, cfg.compressed))))
+
+
+def d_step_term_scales(P, cfg, feed, kt):
+    """Per-variable magnitude of the individual terms of dD_loss/dtheta before they cancel.
+
+    D_loss = -(1+kt)*mean D(x) + mean D(G) + kt*mean D(x_mis) + gp_coeff*(gp + gp2): at initialisation the three
+    critic-mean terms carry a large sample-independent component whose coefficients sum to ZERO (-(1+kt) + 1 + kt), so
+    some gradients (notably biases) are small differences of large numbers and amplify fp32 rounding by 1e2-1e4.  The
+    parity tests therefore bound the error of a gradient by eps * (this un-cancelled scale), not by eps * |gradient|.
+    -> {name: max_i |coef_i| * max|d term_i / d theta|}"""
+    names = trainable(P, 'd_net')
+    Q = dict(P)
+    for n in names:
+        Q[n] = P[n].detach().requires_grad_(True)
+    with torch.no_grad():
+        G, _, _ = generator(P, cfg, feed['z'], feed['cond'], feed['ca_noise_d'], train=True)
+    x, xm, cond = feed['x'], feed['x_mismatch'], feed['cond']
+    x_hat = (feed['eps'] * G + (1.0 - feed['eps']) * x).requires_grad_(True)
+    cond_inp = (cond + 0.0).requires_grad_(True)
+    Dxh = discriminator(Q, cfg, x_hat, cond_inp)
+    gx, gc = torch.autograd.grad(Dxh.sum(), [x_hat, cond_inp], create_graph=True)
+    terms = [(1.0 + kt, discriminator(Q, cfg, x, cond).mean()), (1.0, discriminator(Q, cfg, G, cond).mean()),
+             (kt, discriminator(Q, cfg, xm, cond).mean()), (cfg.gp_coeff, _gp(gx)), (cfg.gp_coeff, _gp(gc))]
+    scale = {n: 0.0 for n in names}
+    for coef, t in terms:
+        gs = torch.autograd.grad(t, [Q[n] for n in names], allow_unused=True, retain_graph=True)
+        for n, g in zip(names, gs):
+            if g is not None:
+                scale[n] = max(scale[n], abs(coef) * float(g.abs().max()))
+    return scale

@@ -224,3 +224,28 @@ def test_full_size_adjoint_identities(K, case):
 def test_cpu_tensor_is_refused(K):
     with pytest.raises(RuntimeError):
         K.act_fwd(torch.zeros(8), K.ACT_RELU)
+
+
+@pytest.mark.parametrize('tile', [22, 21, 12, 11])
+@pytest.mark.parametrize('splitk', [1, 3])
+def test_every_tile_and_split_config(K, monkeypatch, tile, splitk):
+    """The planner picks tile shape / split-K per launch; here every combination is forced (tuning hooks
+    T2I_FORCE_TILE / T2I_FORCE_SPLITK, direct thin kernels off) on shapes with ragged M, N and K."""
+    from oracle import np_ops as O
+    monkeypatch.setenv('T2I_FORCE_TILE', str(tile))
+    monkeypatch.setenv('T2I_FORCE_SPLITK', str(splitk))
+    monkeypatch.setenv('T2I_NO_THIN', '1')
+    for case in [(3, 16, 16, 40, 72, 4, 4, 2, 'SAME'), (2, 32, 32, 3, 128, 4, 4, 2, 'SAME'), (5, 4, 4, 136, 200, 3, 3, 1, 'SAME'),
+                 (2, 4, 4, 64, 1, 4, 4, 4, 'VALID')]:
+        B, H, W, Ci, Co, KH, KW, s, pad = case
+        rng = np.random.default_rng(tile * 10 + splitk)
+        x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+        w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
+        b = rng.standard_normal(Co).astype(np.float32)
+        d, _ = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad)
+        ws = 256 << 20                       # forced splits can exceed the planner's own workspace estimate
+        y_ref = O.conv2d(x, w, b, (s, s), pad)
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= FWD_TOL, case
+        assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (s, s), pad)) <= GRAD_TOL, case
+        assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), O.conv2d_bwd_filter(x, dy, w.shape, (s, s), pad)) <= GRAD_TOL, case

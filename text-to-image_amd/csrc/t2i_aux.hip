@@ -433,8 +433,10 @@ hipError_t row_scale_launch(const float* g, const float* coef, int B, int64_t pe
 // tf.train.AdamOptimizer over a flat arena
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g,
-                                                      float* __restrict__ m, float* __restrict__ v, size_t n, float lr_t,
-                                                      float b1, float b2, float eps, float gscale) {
+                                                      float* __restrict__ m, float* __restrict__ v, size_t n, float lr_val,
+                                                      const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                                                      float gscale) {
+  const float lr_t = lr_dev ? *lr_dev : lr_val;   // device scalar: a captured graph replays with a new step size
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,10 +465,10 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
   }
 }
 
-hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
-                          float eps, float gscale, hipStream_t stream) {
+hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,
+                          float b1, float b2, float eps, float gscale, hipStream_t stream) {
   hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_blocks(((size_t)n + 3) >> 2)), dim3(256), 0, stream, w, g, m, v, (size_t)n,
-                     lr_t, b1, b2, eps, gscale);
+                     lr_t, lr_dev, b1, b2, eps, gscale);
   return hipGetLastError();
 }
 

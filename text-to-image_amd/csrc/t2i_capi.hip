@@ -36,7 +36,8 @@ hipError_t concat_tile_bwd_launch(const float*, int, int, int, int, float*, floa
 hipError_t transpose_launch(const float*, int, int, int, float*, hipStream_t);
 hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
-hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, float, float, float, float, hipStream_t);
+hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
+                          hipStream_t);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -397,11 +398,12 @@ int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_samp
   return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream), "t2i_row_scale");
 }
 
-int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2, float eps,
+int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
+                float beta2, float eps,
                 float grad_scale, t2i_stream_t stream) {
   if (!w || !g || !m || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
   if (!(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
-  return check(adam_tf_launch(w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
+  return check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
 }
 
 }  // extern "C"

@@ -142,8 +142,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // ---- block -> (tile, split, phase).  blockIdx.x walks M tiles fastest so that consecutive workgroups (which the
   // dispatcher spreads over the 8 XCDs) share the same filter panel in every L2.
   const int tiles_m = p.tiles_m;
-  const int bm = (blockIdx.x % tiles_m) * BM;
-  const int bn = (blockIdx.x / tiles_m) * BN;
+  // XCD-aware remap: the dispatcher places workgroup b on XCD b % 8 (each XCD has its own 4 MB L2).  Give every XCD a
+  // contiguous run of tile ids, so the workgroups sharing one filter panel (consecutive M tiles) hit the same L2.
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any nblk
+  }
+  const int bm = (bid % tiles_m) * BM;
+  const int bn = (bid / tiles_m) * BN;
   const int split = blockIdx.y;
   const PhaseInfo& pi = p.phase[MODE == MODE_BWD_DATA ? blockIdx.z : 0];
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;

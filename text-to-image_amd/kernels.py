@@ -339,13 +339,14 @@ def row_scale(g, coef):
     return out
 
 
-def adam_tf(w, g, m, v, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):
-    """In place on flat arenas."""
+def adam_tf(w, g, m, v, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0, lr_t_dev=None):
+    """In place on flat arenas.  lr_t_dev: optional device scalar that overrides lr_t (graph replay)."""
     for t in (w, g, m, v):
         _chk(t)
     assert w.numel() == g.numel() == m.numel() == v.numel()
     if _live(w):
-        check(lib.t2i_adam_tf(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), lr_t, beta1, beta2, eps, grad_scale, _stream()),
+        check(lib.t2i_adam_tf(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), lr_t, _ptr(lr_t_dev), beta1, beta2, eps, grad_scale,
+                              _stream()),
               't2i_adam_tf')
 
 

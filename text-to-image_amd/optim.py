@@ -50,8 +50,20 @@ class AdamTF(object):
         self.m = torch.zeros_like(arena.flat)
         self.v = torch.zeros_like(arena.flat)
         self.t = 0
+        self.lr_t_dev = torch.zeros(4, dtype=torch.float32, device=arena.flat.device)   # [0] = this step's lr_t
 
-    def step(self, lr, grad_scale=1.0):
+    def prepare(self, lr):
+        """Host half of a step: advance t and publish lr_t to the device scalar (outside any captured graph)."""
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
-        K.adam_tf(self.arena.flat, self.arena.grad, self.m, self.v, lr_t, self.beta1, self.beta2, self.eps, grad_scale)
+        self.lr_t_dev.fill_(lr_t)
+        return lr_t
+
+    def apply(self, grad_scale=1.0):
+        """Device half: one kernel over the arena, step size read from the device scalar (graph-capturable)."""
+        K.adam_tf(self.arena.flat, self.arena.grad, self.m, self.v, 0.0, self.beta1, self.beta2, self.eps, grad_scale,
+                  lr_t_dev=self.lr_t_dev)
+
+    def step(self, lr, grad_scale=1.0):
+        self.prepare(lr)
+        self.apply(grad_scale)
