@@ -176,7 +176,7 @@ static int fill_phases(IgemmParams& p) {
 // the filter gradient reduces over B*Ho*Wo (up to ~2e5 rows) into a small output: allow deep splits there
 static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256 : 32; }
 
-static int run_gemm(int mode, IgemmParams& p, size_t out_elems, bool vec, float* out, const float* bias, int act,
+static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* out, const float* bias, int act,
                     float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
   Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode));
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
@@ -192,7 +192,8 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, bool vec, float*
   } else {
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha;
   }
-  int rc = check(igemm_launch(mode, p, pl.wmt, pl.wnt, vec, stream), what);
+  if (env_int("T2I_NO_UT", 0) && var == 2) var = 1;
+  int rc = check(igemm_launch(mode, p, pl.wmt, pl.wnt, var, stream), what);
   if (rc != T2I_OK) return rc;
   if (pl.splitk > 1)
     rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(ws), pl.splitk, out_elems, bias, p.N, act, alpha, out,
@@ -250,7 +251,8 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
   p.M = d->B * d->Ho * d->Wo; p.N = d->Cout; p.K = d->KH * d->KW * d->Cin;
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-  return run_gemm(MODE_FWD, p, (size_t)p.M * p.N, vec, y, bias, act, alpha, ws, ws_bytes, (hipStream_t)stream,
+  const int var = !vec ? 0 : ((d->Cin % 32 == 0) ? 2 : 1);     // 2: a 32-wide K-tile never straddles a filter tap
+  return run_gemm(MODE_FWD, p, (size_t)p.M * p.N, var, y, bias, act, alpha, ws, ws_bytes, (hipStream_t)stream,
                   "t2i_conv2d_fwd");
 }
 
@@ -274,7 +276,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   p.M = d->B * p.hqwq; p.N = d->Cin;
   p.div_c.set(d->Cout);
   const bool vec = (d->Cout % 4 == 0) && aligned16(dy) && aligned16(w);
-  return run_gemm(MODE_BWD_DATA, p, (size_t)d->B * d->H * d->W * d->Cin, vec, dx, bias, act, alpha, ws, ws_bytes,
+  const int var = !vec ? 0 : ((d->Cout % 32 == 0) ? 2 : 1);
+  return run_gemm(MODE_BWD_DATA, p, (size_t)d->B * d->H * d->W * d->Cin, var, dx, bias, act, alpha, ws, ws_bytes,
                   (hipStream_t)stream, "t2i_conv2d_bwd_data");
 }
 
@@ -291,7 +294,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
-  return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, vec, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
+  return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, vec ? 1 : 0, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
                   (hipStream_t)stream, "t2i_conv2d_bwd_filter");
 }
 

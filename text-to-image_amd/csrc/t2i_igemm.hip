@@ -17,7 +17,9 @@
 //     multiplied), so no ds_read latency sits between MFMAs.
 // Two LDS images, chosen per operand by which global dimension is contiguous:
 //   K-inner  [rows][BK+4]   read with ds_read_b128 (4 k's per lane; row stride 36 dwords = 4*odd -> conflict free)
-//   N-inner  [BK][cols]     read with ds_read_b32  (lane = column; consecutive lanes, conflict free)
+//   N-inner  [BK][cols]     read with ds_read_b32  (lane = column; consecutive lanes, conflict free).  (A k4-interleaved
+//            [BK/4][cols][4] image read with ds_read_b128 was tried: 4x fewer LDS reads but 16 extra v_mov per tile for
+//            the register transpose; measured 1-2% slower, so the plain image stays.)
 // Both feed the same k-permutation: MFMA j of 8-k chunk c consumes k = 8c+j (lanes 0-31) and 8c+4+j (lanes 32-63).
 // Split-K (grid.y) writes full-layout partial slabs that splitk_reduce sums in a fixed order (deterministic),
 // applying bias + activation there; without split-K the epilogue is fused here.
@@ -125,8 +127,14 @@ __device__ __forceinline__ void bT_offset(const IgemmParams& p, const PhaseInfo&
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE, int WMT, int WNT, bool VEC>
+// VAR: 0 = scalar gathers (channels not a multiple of 4); 1 = 16-byte gathers, per-element tap decode;
+//      2 = 16-byte gathers with a TAP-UNIFORM K-tile (gathered channels % 32 == 0): one K-tile never straddles a filter
+//          tap, so (kh,kw,c0) are computed once per tile on the scalar unit and each load costs ~8 VALU instructions
+//          instead of ~25 (measured: the address arithmetic was the largest non-MFMA cost, 10-14% of the kernel).
+template <int MODE, int WMT, int WNT, int VAR>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  constexpr bool VEC = VAR >= 1;
+  constexpr bool UT = VAR == 2;
   using S = Smem<MODE, WMT, WNT>;
   constexpr int BM = S::BM, BN = S::BN;
   constexpr bool A_KINNER = S::A_KINNER, B_KINNER = S::B_KINNER;
@@ -171,6 +179,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) arow[i] = make_row<MODE>(p, pi, bm + r0 + 32 * i);
   }
+  // tap-uniform fast path: everything that does not depend on the K-tile is folded into one per-row constant
+  int a_rowoff[A_KINNER ? A_LD : 1];
+  if (UT && A_KINNER) {
+    const int Wsrc = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+    const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) a_rowoff[i] = (arow[i].base + arow[i].h0 * Wsrc + arow[i].w0) * Csrc + kq * 4;
+  }
   constexpr int A_C4 = BM / 4, B_C4 = BN / 4;          // float4 columns per k-row (N-inner images)
   constexpr int A_KSTEP = 256 / A_C4, B_KSTEP = 256 / B_C4;
   const int a_c4 = tid % A_C4, a_kr0 = tid / A_C4;
@@ -191,12 +207,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   }
 
+  // B operand constants (vector paths)
+  int b_const[B_LD];
+  bool b_nok[B_LD];
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if (B_KINNER) {          // w^T: row n = ci
+        const int n = bn + r0 + 32 * i;
+        b_nok[i] = n < p.N;
+        b_const[i] = n * p.d.Cout + kq * 4;
+      } else {                 // row-major [K, N]
+        const int n = bn + b_c4 * 4;
+        b_nok[i] = n < p.N;
+        b_const[i] = (b_kr0 + B_KSTEP * i) * p.N + n;
+      }
+    }
+  }
+
   float4 areg[A_LD], breg[B_LD];
 
   auto load_tile = [&](int t) {   // tiles past the end read as zeros (k >= kend), so the loop needs no tail branch
     const int k0 = kbeg + t * BK;
     // ---------------- A ----------------
-    if (A_KINNER) {
+    if (A_KINNER && UT) {
+      const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;
+      const int tap = p.div_c.div(k0);            // wave-uniform: scalar unit
+      const int c0 = k0 - tap * Csrc;
+      const bool kok = (k0 + kq * 4) < kend;
+      int s_off, dh, dw;
+      if (MODE == MODE_FWD) {
+        dh = p.div_kw.div(tap);
+        dw = tap - dh * p.d.KW;
+        s_off = (dh * p.d.W + dw) * Csrc + c0;
+      } else {
+        const int jh = pi.div_ntw.div(tap);
+        const int jw = tap - jh * pi.ntw;
+        dh = -jh; dw = -jw;
+        s_off = c0 - (jh * p.d.Wo + jw) * Csrc;
+      }
+      const unsigned Hs = (MODE == MODE_FWD) ? p.d.H : p.d.Ho, Ws = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const bool ok = arow[i].ok & kok & ((unsigned)(arow[i].h0 + dh) < Hs) & ((unsigned)(arow[i].w0 + dw) < Ws);
+        areg[i] = bload4(ra, a_rowoff[i] + s_off, ok);
+      }
+    } else if (A_KINNER) {
       const int k = k0 + kq * 4;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
@@ -244,7 +300,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       }
     }
     // ---------------- B ----------------
-    if (B_KINNER) {  // BWD_DATA: w^T, rows n = ci
+    if (B_KINNER && UT) {   // BWD_DATA, tap-uniform: off = ((kh*KW+kw)*Cin + n)*Cout + c0 + kq*4
+      const int tap = p.div_c.div(k0);
+      const int c0 = k0 - tap * p.d.Cout;
+      const int jh = pi.div_ntw.div(tap);
+      const int jw = tap - jh * pi.ntw;
+      const int s_off = ((pi.kh0 + jh * p.d.SH) * p.d.KW + (pi.kw0 + jw * p.d.SW)) * p.d.Cin * p.d.Cout + c0;
+      const bool kok = (k0 + kq * 4) < kend;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) breg[i] = bload4(rb, b_const[i] + s_off, b_nok[i] & kok);
+    } else if (B_KINNER) {  // BWD_DATA: w^T, rows n = ci
       const int k = k0 + kq * 4;
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
@@ -270,7 +335,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const int k = k0 + b_kr0 + B_KSTEP * i;
         const int n = bn + b_c4 * 4;
         if (VEC) {
-          breg[i] = bload4(rb, k * p.N + n, (k < kend) & (n < p.N));
+          breg[i] = bload4(rb, k0 * p.N + b_const[i], (k < kend) & b_nok[i]);
         } else {
           float v[4];
 #pragma unroll
@@ -347,37 +412,50 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   };
 
   // ---- main loop ---------------------------------------------------------------------------------------------------
-  // registers: tile t+1 | LDS buf[t&1]: tile t | LDS buf[(t+1)&1]: free (its last reader finished before the barrier)
+  // registers: tile t+1 | LDS buf[t&1]: tile t | LDS buf[(t+1)&1]: free until this iteration's store.
+  // ONE barrier per K-tile, placed mid-tile right after the store of tile t+1.  Every ds_read of tile t is issued before
+  // it, so (a) the barrier publishes tile t+1 and (b) it also proves every wave is done reading the buffer that the NEXT
+  // iteration's store will overwrite.  After it, the first two fragment chunks of tile t+1 are fetched while the last
+  // two chunks of tile t multiply: no LDS latency and no barrier at the tile boundary.
+  // sched_barrier(0) pins this order; left alone hipcc sinks every ds_read next to its MFMAs (fewer live registers)
+  // and the LDS latency lands between MFMA groups — ~20% of the matrix pipe idle.
+  Frag fa0, fa1, fb0, fb1;
+  auto k_tile = [&](int t, Frag& c0, Frag& c1, Frag& n0, Frag& n1) {
+    const float* as = As + (t & 1) * S::A_ELEMS;
+    const float* bs = Bs + (t & 1) * S::B_ELEMS;
+    const float* an = As + ((t + 1) & 1) * S::A_ELEMS;
+    const float* bn_ = Bs + ((t + 1) & 1) * S::B_ELEMS;
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c0);                                   // chunk 0 (fetched during the previous tile)
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c0, as, bs, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c1);                                   // chunk 1, with the LDS store of tile t+1 interleaved
+    store_tile((t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c1, as, bs, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frag(n0, an, bn_, 0);                      // tile t+1, chunks 0 and 1
+    read_frag(n1, an, bn_, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(t + 2);                               // zeros past the end; address math + buffer loads behind chunk 2
+    mma_frag(c0);                                   // chunk 2
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c1);                                   // chunk 3
+  };
   load_tile(0);
   store_tile(0);
   load_tile(1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const float* as = As + (t & 1) * S::A_ELEMS;
-    const float* bs = Bs + (t & 1) * S::B_ELEMS;
-    Frag f0, f1;
-    // sched_barrier(0) pins the software pipeline: without it hipcc sinks every ds_read to just before its MFMAs
-    // (fewer live registers) and the LDS latency lands between MFMA groups — ~20% of the matrix pipe idle.
-    read_frag(f0, as, bs, 0);
-    read_frag(f1, as, bs, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_frag(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frag(f0, as, bs, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    // tile t+1: registers -> the other LDS buffer, interleaved with chunk 1's MFMAs
-    mma_frag(f1);
-    store_tile((t + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frag(f1, as, bs, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    // start fetching tile t+2 (zeros past the end): address arithmetic + buffer loads hide behind chunk 2's MFMAs
-    load_tile(t + 2);
-    mma_frag(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_frag(f1);
-    __syncthreads();
+  read_frag(fa0, As, Bs, 0);
+  read_frag(fa1, As, Bs, 1);
+  int t = 0;
+  for (; t + 1 < ntiles; t += 2) {
+    k_tile(t, fa0, fa1, fb0, fb1);
+    k_tile(t + 1, fb0, fb1, fa0, fa1);
   }
+  if (t < ntiles) k_tile(t, fa0, fa1, fb0, fb1);
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -456,10 +534,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* 
 // ------------------------------------------------------------------------------------------------------------------
 // host-side launch
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE, int WMT, int WNT, bool VEC>
+template <int MODE, int WMT, int WNT, int VAR>
 static hipError_t launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t stream) {
   using S = Smem<MODE, WMT, WNT>;
-  auto k = igemm_kernel<MODE, WMT, WNT, VEC>;
+  auto k = igemm_kernel<MODE, WMT, WNT, VAR>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
@@ -471,10 +549,13 @@ static hipError_t launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t stream
 }
 
 template <int MODE>
-static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, bool vec, dim3 grid, hipStream_t stream) {
+static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, dim3 grid, hipStream_t stream) {
+  if (MODE == MODE_BWD_FILTER && var == 2) var = 1;   // the filter gradient's reduction index is a pixel, not a tap
 #define T2I_CASE(a, b)                                                             \
-  if (wmt == a && wnt == b)                                                        \
-    return vec ? launch_cfg<MODE, a, b, true>(p, grid, stream) : launch_cfg<MODE, a, b, false>(p, grid, stream);
+  if (wmt == a && wnt == b) {                                                      \
+    if (var == 2 && MODE != MODE_BWD_FILTER) return launch_cfg<MODE, a, b, (MODE != MODE_BWD_FILTER ? 2 : 1)>(p, grid, stream); \
+    return var >= 1 ? launch_cfg<MODE, a, b, 1>(p, grid, stream) : launch_cfg<MODE, a, b, 0>(p, grid, stream);                 \
+  }
   T2I_CASE(2, 2)
   T2I_CASE(2, 1)
   T2I_CASE(1, 2)
@@ -483,12 +564,12 @@ static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, bool vec, 
   return hipErrorInvalidValue;
 }
 
-hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, bool vec, hipStream_t stream) {
+hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
   switch (mode) {
-    case MODE_FWD: return launch_mode<MODE_FWD>(p, wmt, wnt, vec, grid, stream);
-    case MODE_BWD_DATA: return launch_mode<MODE_BWD_DATA>(p, wmt, wnt, vec, grid, stream);
-    case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER>(p, wmt, wnt, vec, grid, stream);
+    case MODE_FWD: return launch_mode<MODE_FWD>(p, wmt, wnt, var, grid, stream);
+    case MODE_BWD_DATA: return launch_mode<MODE_BWD_DATA>(p, wmt, wnt, var, grid, stream);
+    case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER>(p, wmt, wnt, var, grid, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   }
 }
 
-hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, bool vec, hipStream_t stream);
+hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
                                 float alpha, float* out, hipStream_t stream);
 
