@@ -67,8 +67,9 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx,
                         int act, float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
-/* dw = x (*) dy over all B*Ho*Wo positions.  (tf.gradients wrt `weights`, reference models/wgancls/model.py:94-106.) */
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
+/* dw = x (*) dy over all B*Ho*Wo positions (tf.gradients wrt `weights`, reference models/wgancls/model.py:94-106);
+ * accumulate != 0: dw += x (*) dy in the epilogue, i.e. the gradient is summed straight into the optimizer's arena. */
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                           size_t ws_bytes, t2i_stream_t stream);
 
 /* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
@@ -98,6 +99,10 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
 int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
 /* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream);
+/* Fused activation backward + bias gradient of a conv layer: dx = dy * act'(y) and colsum[c] = sum_r dx[r,c] in one pass
+ * over a [rows, C] view (C % 4 == 0, 16-byte aligned); workspace as t2i_col_reduce. */
+int t2i_act_bwd_colsum(const float* dy, const float* y, int64_t rows, int32_t C, int act, float alpha, float* dx,
+                       float* colsum, void* ws, size_t ws_bytes, t2i_stream_t stream);
 /* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
 /* y = alpha*a + beta*b (b may be NULL). */

@@ -113,6 +113,21 @@ def test_gp_golden(K, golden_ops):
     assert relerr(K.row_scale(gr, coef), golden_ops['gp/dg']) <= FWD_TOL
 
 
+@pytest.mark.parametrize('shape', [(3, 4, 4, 8), (24, 8, 8, 512), (6, 32, 32, 128), (1000, 36)])
+def test_act_bwd_colsum_fused(K, shape):
+    """dx = dy*act'(y) and its column sums (bias gradient) from ONE pass == the two separate kernels == NumPy."""
+    from oracle import np_ops as O
+    rng = np.random.default_rng(sum(shape))
+    dy = rng.standard_normal(shape).astype(np.float32); pre = rng.standard_normal(shape).astype(np.float32)
+    for act, fwd, bwd in ((K.ACT_LRELU, O.lrelu, O.lrelu_bwd), (K.ACT_RELU, O.relu, O.relu_bwd)):
+        y = fwd(pre).astype(np.float32)
+        dx, s = K.act_bwd_colsum(dev(dy), dev(y), act, 0.2)
+        ref = bwd(dy.astype(np.float64), y)
+        assert relerr(dx, ref) <= 1e-7
+        assert relerr(s, ref.reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
+        assert torch.equal(dx, K.act_bwd(dev(dy), dev(y), act, 0.2))
+
+
 # ---- seeded medium shapes vs the NumPy loop oracle: vector path, 128x128 tiles, ragged N, split-K, stride phases --------
 MEDIUM = [  # B, H, W, Cin, Cout, KH, KW, s, pad
     (4, 16, 16, 64, 96, 4, 4, 2, 'SAME'),      # vec, several K tiles, N = 3*32
@@ -160,7 +175,12 @@ def test_conv_medium_vs_oracle(K, case):
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= FWD_TOL
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_TANH), np.tanh(y_ref)) <= FWD_TOL
     assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (s, s), pad)) <= GRAD_TOL
-    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), O.conv2d_bwd_filter(x, dy, w.shape, (s, s), pad)) <= GRAD_TOL
+    dw_ref = O.conv2d_bwd_filter(x, dy, w.shape, (s, s), pad)
+    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= GRAD_TOL
+    # accumulate form (dw += ...), as used to sum gradients straight into the optimizer arena
+    acc = dev(w.copy())
+    assert K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1)) is not None
+    assert relerr(acc, w.astype(np.float64) + dw_ref) <= GRAD_TOL
 
 
 def test_elementwise_and_layout(K):

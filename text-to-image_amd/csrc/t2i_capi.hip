@@ -38,6 +38,7 @@ hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
+hipError_t act_bwd_colsum_launch(const float*, const float*, int64_t, int, int, float, float*, float*, void*, hipStream_t);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -177,7 +178,7 @@ static int fill_phases(IgemmParams& p) {
 static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256 : 32; }
 
 static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* out, const float* bias, int act,
-                    float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+                    float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what, int accumulate = 0) {
   Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode));
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
@@ -188,16 +189,16 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
       return T2I_ERR_WORKSPACE;
     }
     p.c = reinterpret_cast<float*>(ws);
-    p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f;
+    p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
   } else {
-    p.c = out; p.bias = bias; p.act = act; p.alpha = alpha;
+    p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = accumulate;
   }
   if (env_int("T2I_NO_UT", 0) && var == 2) var = 1;
   int rc = check(igemm_launch(mode, p, pl.wmt, pl.wnt, var, stream), what);
   if (rc != T2I_OK) return rc;
   if (pl.splitk > 1)
     rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(ws), pl.splitk, out_elems, bias, p.N, act, alpha, out,
-                                    stream), what);
+                                    accumulate, stream), what);
   return rc;
 }
 
@@ -281,8 +282,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
                   (hipStream_t)stream, "t2i_conv2d_bwd_data");
 }
 
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                          t2i_stream_t stream) {
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                          size_t ws_bytes, t2i_stream_t stream) {
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
@@ -295,7 +296,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
   return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, vec ? 1 : 0, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
-                  (hipStream_t)stream, "t2i_conv2d_bwd_filter");
+                  (hipStream_t)stream, "t2i_conv2d_bwd_filter", accumulate ? 1 : 0);
 }
 
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C) {
@@ -355,6 +356,13 @@ int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_s
 }
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream) {
   return ew_call(1, dy, y, n, act, alpha, 0.f, dx, stream, "t2i_act_bwd", true);
+}
+int t2i_act_bwd_colsum(const float* dy, const float* y, int64_t rows, int32_t C, int act, float alpha, float* dx,
+                       float* colsum, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
+  if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
+  if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
+  return check(act_bwd_colsum_launch(dy, y, rows, C, act, alpha, dx, colsum, ws, (hipStream_t)stream), "t2i_act_bwd_colsum");
 }
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
   return ew_call(2, a, b, n, act, alpha, 0.f, y, stream, "t2i_add_act", true);

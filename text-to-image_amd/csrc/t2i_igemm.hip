@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
           if (fused) {
             if (p.bias) v += p.bias[n];
             v = apply_act(v, p.act, p.alpha);
+            if (p.accumulate) v += out[rowoff + n];
           }
           out[rowoff + n] = v;
         }
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splitk,
                                                             size_t out_elems, const float* __restrict__ bias, int N,
-                                                            int act, float alpha, float* __restrict__ out) {
+                                                            int act, float alpha, float* __restrict__ out, int accumulate) {
   const size_t n4 = out_elems >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(slabs)[i];
@@ -515,6 +516,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     s.x = apply_act(s.x, act, alpha); s.y = apply_act(s.y, act, alpha);
     s.z = apply_act(s.z, act, alpha); s.w = apply_act(s.w, act, alpha);
+    if (accumulate) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
     reinterpret_cast<float4*>(out)[i] = s;
   }
 }
@@ -522,12 +527,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slabs, int splitk,
                                                                    size_t out_elems, const float* __restrict__ bias,
                                                                    int N, int act, float alpha,
-                                                                   float* __restrict__ out) {
+                                                                   float* __restrict__ out, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_elems; i += (size_t)gridDim.x * blockDim.x) {
     float s = slabs[i];
     for (int k = 1; k < splitk; ++k) s += slabs[(size_t)k * out_elems + i];
     if (bias) s += bias[i % (size_t)N];
-    out[i] = apply_act(s, act, alpha);
+    s = apply_act(s, act, alpha);
+    out[i] = accumulate ? s + out[i] : s;
   }
 }
 
@@ -575,20 +581,20 @@ hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int va
 }
 
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
-                                float alpha, float* out, hipStream_t stream) {
+                                float alpha, float* out, int accumulate, hipStream_t stream) {
   if ((out_elems & 3) == 0 && (N & 3) == 0) {
     size_t n4 = out_elems >> 2;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splitk, out_elems, bias, N, act,
-                       alpha, out);
+                       alpha, out, accumulate);
   } else {
     int blocks = (int)((out_elems + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(splitk_reduce_scalar_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splitk, out_elems, bias,
-                       N, act, alpha, out);
+                       N, act, alpha, out, accumulate);
   }
   return hipGetLastError();
 }

@@ -59,6 +59,7 @@ struct IgemmParams {
   int32_t howo, hqwq, Wq;     // Ho*Wo; Hq*Wq; Wq  (Hq = ceil(H/SH))
   FastDiv div_howo, div_wo, div_hqwq, div_wq, div_c, div_kw;
   int32_t nphase;
+  int32_t accumulate;         // epilogue adds the existing contents of the output (dw += ...: gradient accumulation)
   PhaseInfo phase[16];
 };
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
-                                float alpha, float* out, hipStream_t stream);
+                                float alpha, float* out, int accumulate, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
 

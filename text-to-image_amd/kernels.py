@@ -171,13 +171,19 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     return dx
 
 
-def conv_bwd_filter(x, dy, d, ws_bytes):
+def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
+    """dw = x (*) dy.  out: an existing [KH,KW,Cin,Cout]-sized buffer to ACCUMULATE into (dw += ...), e.g. the
+    optimizer's gradient arena; returns it."""
     _chk(x, 'x'); _chk(dy, 'dy')
-    dw = torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+    if out is not None:
+        _chk(out, 'out')
+        assert out.numel() == d.KH * d.KW * d.Cin * d.Cout
+    dw = out if out is not None else torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
-        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), wsp, wsn, _stream()),
+        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, wsp, wsn,
+                                        _stream()),
               't2i_conv2d_bwd_filter')
         if ev is not None:
             ev.record()
@@ -248,6 +254,21 @@ def act_bwd(dy, y, act, alpha=0.2):
     if _live(dy):
         check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _stream()), 't2i_act_bwd')
     return dx
+
+
+def act_bwd_colsum(dy, y, act, alpha=0.2):
+    """-> (dy * act'(y), column sums of that) in one pass (conv-layer activation backward + bias gradient)."""
+    _chk(dy, 'dy'); _chk(y, 'y')
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    dx = torch.empty_like(dy)
+    s = torch.empty(C, dtype=torch.float32, device=dy.device)
+    if _live(dy):
+        need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
+        wsp, wsn = _ws_args(dy, need)
+        check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), rows, C, act, alpha, _ptr(dx), _ptr(s), wsp, wsn, _stream()),
+              't2i_act_bwd_colsum')
+    return dx, s
 
 
 def add_act(a, b, act=ACT_NONE, alpha=0.2):

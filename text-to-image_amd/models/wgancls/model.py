@@ -60,6 +60,9 @@ class WGanCls(object):
         self.g_vars = S.trainable_variables('g_net')
         self.d_arena = optim.Arena(self.d_vars)
         self.g_arena = optim.Arena(self.g_vars)
+        if self.dp is None:          # single replica: filter gradients are accumulated by the GEMM epilogues
+            self.d_arena.enable_sinks()
+            self.g_arena.enable_sinks()
 
     def get_gradient_penalty(self, x, y):
         """reference model.py:62-65: one-sided penalty on the per-sample gradient norm of y wrt x."""
