@@ -150,9 +150,14 @@ def main():
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
 
     dp = None
-    if world > 1:
+    # T2I_FORCE_DP=1 exercises the data-parallel machinery (RCCL communicator, bucket hooks, side stream) on ONE rank
+    use_dp = world > 1 or os.environ.get('T2I_FORCE_DP') == '1'
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
         from t2i_amd.dp import DataParallel
         dp = DataParallel()
@@ -165,11 +170,11 @@ def main():
     feed = synthetic_feed(cfg, device, seed=1 + rank)
 
     def barrier():
-        if world > 1:
+        if use_dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (world == 1) and not args.no_graphs and args.instrument != 'inline'
+    use_graphs = (not use_dp) and not args.no_graphs and args.instrument != 'inline'
     for i in range(args.warmup):
         if use_graphs and i == min(2, args.warmup - 1):
             model.enable_graphs(feed)          # the remaining warm-up and all timed steps are graph replays
@@ -197,7 +202,7 @@ def main():
         K.set_conv_timer(None)
         model._graphs = saved_graphs
 
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -234,7 +239,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

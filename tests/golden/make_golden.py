@@ -130,7 +130,49 @@ def make_step():
     return out
 
 
+GANCLS_TINY = dict(z_dim=12, embed_dim=32, compressed=16, gf=8, df=8, batch=4)
+
+
+def make_gancls_step():
+    """Tiny gancls iteration (reference models/gancls): losses, all gradients, post-update weights and BN moving stats."""
+    from oracle import torch_gancls as GC
+    cfg = GC.Cfg(**GANCLS_TINY)
+    P = GC.init_variables(cfg, seed=0, dtype=torch.float64)
+    rng = np.random.default_rng(11)
+    for n in P:   # the reference's N(0,0.02) kernels make a tiny net almost linear: widen them so every branch is exercised
+        if n.endswith('kernel'):
+            P[n] = P[n] * (12.0 if 'conv' in n else 4.0)
+        if n.endswith('bias') or n.endswith('beta'):
+            P[n] = torch.tensor(rng.standard_normal(tuple(P[n].shape)) * 0.1)
+    feed = GC.synthetic_feed(cfg, seed=1, dtype=torch.float64)
+    for n in P:
+        P[n] = P[n].float().double()
+    for n in feed:
+        feed[n] = feed[n].float().double()
+    out = {}
+    for n, v in P.items():
+        out['param/' + n] = v.numpy().astype(np.float32)
+    for n, v in feed.items():
+        out['feed/' + n] = v.numpy().astype(np.float32)
+    d = GC.d_step(P, cfg, feed)
+    for k_ in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
+        out['d/' + k_] = np.array(d[k_])
+    for n, v in d['grads'].items():
+        out['d/grad/' + n] = v.numpy()
+    out['d/G'] = d['G'].numpy()
+    g = GC.g_step(P, cfg, feed)
+    out['g/G_loss'] = np.array(g['G_loss'])
+    for n, v in g['grads'].items():
+        out['g/grad/' + n] = v.numpy()
+    tr = GC.Trainer(cfg, dict(P))
+    tr.iteration(feed)
+    for n, v in tr.P.items():
+        out['after/' + n] = v.numpy().copy()
+    return out
+
+
 if __name__ == '__main__':
+    np.savez_compressed(os.path.join(HERE, 'gancls_tiny.npz'), **make_gancls_step())
     ops = make_ops()
     np.savez_compressed(os.path.join(HERE, 'ops_tiny.npz'), **ops)
     step = make_step()

@@ -1,0 +1,98 @@
+"""GanClsTrainer — reference models/gancls/trainer.py:12-164: losses, the two Adam optimizers (both under UPDATE_OPS) and
+the D-then-G update order of every iteration."""
+import sys
+import time
+
+import torch
+
+from ... import optim
+from ...utils.ops import update_ops
+
+
+def sigmoid_cross_entropy_with_logits(logits, label):
+    """tf.nn.sigmoid_cross_entropy_with_logits on the [B] logit vector: max(l,0) - l*y + log(1+exp(-|l|))."""
+    return torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))
+
+
+class GanClsTrainer(object):
+    def __init__(self, sess, model, dataset, cfg):
+        self.sess, self.model, self.dataset, self.cfg = sess, model, dataset, cfg     # sess unused (no TF session)
+        self.gen = torch.Generator(device=model.device).manual_seed(1234)
+        self.define_losses()
+
+    def define_losses(self):
+        t = self.cfg.TRAIN
+        self.alpha = float(t.COEFF.ALPHA_MISMATCH_LOSS)
+        self.D_optim = optim.AdamTF(self.model.d_arena, float(t.D_BETA_DECAY), 0.999)
+        self.G_optim = optim.AdamTF(self.model.g_arena, float(t.G_BETA_DECAY), 0.999)
+
+    def d_losses(self, feed):
+        """What sess.run([D_optim, ...]) evaluates before the update (trainer.py:20-34,115-123).  Gradients -> d_arena."""
+        m = self.model
+        x, xw, phi, z = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs'], feed['z']
+        with update_ops():      # D_optim is built under control_dependencies(UPDATE_OPS): every BN moving average moves
+            with torch.no_grad():
+                G = m.generator(z, phi, reuse=True)
+            _, l_fake = m.discriminator(G, phi, reuse=True)
+            _, l_match = m.discriminator(x, phi, reuse=True)
+            _, l_mis = m.discriminator(xw, phi, reuse=True)
+        D_synthetic_loss = sigmoid_cross_entropy_with_logits(l_fake, 0.0).mean()
+        D_real_match_loss = sigmoid_cross_entropy_with_logits(l_match, 0.9).mean()       # one-sided label smoothing
+        D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
+        D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
+        m.d_arena.zero_grad()
+        if m.dp is not None:
+            m.dp.arm(m.d_arena)
+        D_loss.backward(inputs=list(m.d_vars.values()))
+        return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
+                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G)
+
+    def g_losses(self, feed):
+        m = self.model
+        x, xw, phi, z = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs'], feed['z']
+        with update_ops():
+            G = m.generator(z, phi, reuse=True)
+            with m.store.frozen('d_net'):
+                _, l_fake = m.discriminator(G, phi, reuse=True)
+            # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
+            # sess.run too, only to move their batch-norm moving averages (trainer.py:46-51)
+            with torch.no_grad():
+                m.discriminator(x, phi, reuse=True)
+                m.discriminator(xw, phi, reuse=True)
+        G_loss = sigmoid_cross_entropy_with_logits(l_fake, 1.0).mean()
+        m.g_arena.zero_grad()
+        if m.dp is not None:
+            m.dp.arm(m.g_arena)
+        G_loss.backward(inputs=list(m.g_vars.values()))
+        return dict(G_loss=G_loss.detach(), G=G.detach())
+
+    def iteration(self, feed):
+        m = self.model
+        d = self.d_losses(feed)
+        scale = m.dp.allreduce_arena(m.d_arena) if m.dp is not None else 1.0
+        self.D_optim.step(float(self.cfg.TRAIN.D_LR), grad_scale=scale)
+        g = self.g_losses(feed)
+        scale = m.dp.allreduce_arena(m.g_arena) if m.dp is not None else 1.0
+        self.G_optim.step(float(self.cfg.TRAIN.G_LR), grad_scale=scale)
+        return {'d': d, 'g': g}
+
+    def make_feed(self):
+        m = self.model
+        images, wrong_images, embed, _, _ = self.dataset.train.next_batch(m.batch_size, 4, embeddings=True, wrong_img=True)
+        return {'inputs': images, 'wrong_inputs': wrong_images, 'phi_inputs': embed,
+                'z': torch.randn((m.batch_size, m.z_dim), generator=self.gen, device=m.device)}
+
+    def train(self, max_updates=None, log=None):
+        log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
+        t0, counter = time.time(), 1
+        for epoch in range(self.cfg.TRAIN.EPOCH):
+            updates_per_epoch = self.dataset.train.num_examples // self.model.batch_size
+            for idx in range(updates_per_epoch):
+                out = self.iteration(self.make_feed())
+                if counter % 10 == 0:
+                    log('Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f' % (
+                        epoch, idx, updates_per_epoch, time.time() - t0, float(out['d']['D_loss']), float(out['g']['G_loss'])))
+                counter += 1
+                if max_updates is not None and counter > max_updates:
+                    return out
+        return out
