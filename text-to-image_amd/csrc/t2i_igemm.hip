@@ -432,6 +432,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     mma_frag(c1);                                   // chunk 1, with the LDS store of tile t+1 interleaved
     store_tile((t + 1) & 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, (WMT * WNT * 4) / 8 > 0 ? (WMT * WNT * 4) / 8 : 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, (A_LD + B_LD + 7) / 8, 0);                               // DS write
+    }
     __builtin_amdgcn_sched_barrier(0);
     read_frag(c1, as, bs, 3);
     __builtin_amdgcn_sched_barrier(0);
@@ -441,6 +446,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     load_tile(t + 2);                               // zeros past the end; address math + buffer loads behind chunk 2
     mma_frag(c0);                                   // chunk 2
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, (WMT * WNT * 4) / 8 > 0 ? (WMT * WNT * 4) / 8 : 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, (A_LD + B_LD + 7) / 8, 0);                               // VMEM read
+    }
     __builtin_amdgcn_sched_barrier(0);
     mma_frag(c1);                                   // chunk 3
   };
