@@ -255,8 +255,11 @@ def test_every_tile_and_split_config(K, monkeypatch, tile, splitk):
     monkeypatch.setenv('T2I_FORCE_TILE', str(tile))
     monkeypatch.setenv('T2I_FORCE_SPLITK', str(splitk))
     monkeypatch.setenv('T2I_NO_THIN', '1')
+    # the last three shapes have 32-multiple channels and Wo | 32: they take the tap-uniform (fwd / bwd_data) and
+    # pixel-walk (bwd_filter) address paths; every other combination goes through the generic decode
     for case in [(3, 16, 16, 40, 72, 4, 4, 2, 'SAME'), (2, 32, 32, 3, 128, 4, 4, 2, 'SAME'), (5, 4, 4, 136, 200, 3, 3, 1, 'SAME'),
-                 (2, 4, 4, 64, 1, 4, 4, 4, 'VALID')]:
+                 (2, 4, 4, 64, 1, 4, 4, 4, 'VALID'), (3, 8, 8, 64, 96, 3, 3, 1, 'SAME'), (2, 16, 16, 32, 64, 4, 4, 2, 'SAME'),
+                 (5, 16, 8, 64, 32, 4, 4, 1, 'SAME')]:
         B, H, W, Ci, Co, KH, KW, s, pad = case
         rng = np.random.default_rng(tile * 10 + splitk)
         x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)

@@ -295,7 +295,14 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(dy);
-  return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, vec ? 1 : 0, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
+  int var = vec ? 1 : 0;
+  if (vec && (32 % d->Wo) == 0) {        // one K-tile = 32 consecutive pixels = a whole number of output rows
+    const int rows_adv = 32 / d->Wo;
+    p.walk_db = rows_adv / d->Ho;
+    p.walk_doh = rows_adv % d->Ho;
+    var = 2;
+  }
+  return run_gemm(MODE_BWD_FILTER, p, (size_t)p.M * p.N, var, dw, nullptr, T2I_ACT_NONE, 0.f, ws, ws_bytes,
                   (hipStream_t)stream, "t2i_conv2d_bwd_filter", accumulate ? 1 : 0);
 }
 

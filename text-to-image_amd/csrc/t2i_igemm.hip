@@ -225,6 +225,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   }
 
+  // BWD_FILTER "pixel walk" (VAR 2, Wo | 32): the reduction index advances by exactly 32 pixels per K-tile, so each
+  // thread's gather position is decoded ONCE and then walked (oh += doh with carry into b) instead of two divisions per load
+  int wk_b[A_KINNER ? 1 : A_LD], wk_oh[A_KINNER ? 1 : A_LD], wk_ofs[A_KINNER ? 1 : A_LD];
+  bool wk_ok[A_KINNER ? 1 : A_LD];
+  if (!A_KINNER && UT) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int r = kbeg + a_kr0 + A_KSTEP * i;
+      int b = p.div_howo.div(r);
+      int rem = r - b * p.howo;
+      int oh = p.div_wo.div(rem);
+      int ow = rem - oh * p.d.Wo;
+      const int iw = ow * p.d.SW - p.d.pad_l + fa_kw[0];
+      wk_b[i] = b; wk_oh[i] = oh;
+      wk_ok[i] = fa_ok[0] & ((unsigned)iw < (unsigned)p.d.W);
+      wk_ofs[i] = iw * p.d.Cin + fa_ci[0];
+    }
+  }
+
   float4 areg[A_LD], breg[B_LD];
 
   auto load_tile = [&](int t) {   // tiles past the end read as zeros (k >= kend), so the loop needs no tail branch
@@ -270,6 +289,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
           }
           areg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
+      }
+    } else if (UT) {  // BWD_FILTER, pixel walk (load_tile is called with consecutive t)
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int r = k0 + a_kr0 + A_KSTEP * i;
+        const int ih = wk_oh[i] * p.d.SH - p.d.pad_t + fa_kh[0];
+        const bool ok = (r < kend) & wk_ok[i] & ((unsigned)ih < (unsigned)p.d.H);
+        areg[i] = bload4(ra, (wk_b[i] * p.d.H + ih) * p.d.W * p.d.Cin + wk_ofs[i], ok);
+        int oh = wk_oh[i] + p.walk_doh;
+        const bool carry = oh >= p.d.Ho;
+        wk_oh[i] = carry ? oh - p.d.Ho : oh;
+        wk_b[i] += p.walk_db + (carry ? 1 : 0);
       }
     } else {  // BWD_FILTER: A[i, r] = x gathered; the reduction index is r = (b,oh,ow)
 #pragma unroll
@@ -566,11 +597,10 @@ static hipError_t launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t stream
 
 template <int MODE>
 static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, dim3 grid, hipStream_t stream) {
-  if (MODE == MODE_BWD_FILTER && var == 2) var = 1;   // the filter gradient's reduction index is a pixel, not a tap
 #define T2I_CASE(a, b)                                                             \
   if (wmt == a && wnt == b) {                                                      \
-    if (var == 2 && MODE != MODE_BWD_FILTER) return launch_cfg<MODE, a, b, (MODE != MODE_BWD_FILTER ? 2 : 1)>(p, grid, stream); \
-    return var >= 1 ? launch_cfg<MODE, a, b, 1>(p, grid, stream) : launch_cfg<MODE, a, b, 0>(p, grid, stream);                 \
+    if (var == 2) return launch_cfg<MODE, a, b, 2>(p, grid, stream);               \
+    return var >= 1 ? launch_cfg<MODE, a, b, 1>(p, grid, stream) : launch_cfg<MODE, a, b, 0>(p, grid, stream); \
   }
   T2I_CASE(2, 2)
   T2I_CASE(2, 1)

@@ -59,6 +59,8 @@ struct IgemmParams {
   int32_t howo, hqwq, Wq;     // Ho*Wo; Hq*Wq; Wq  (Hq = ceil(H/SH))
   FastDiv div_howo, div_wo, div_hqwq, div_wq, div_c, div_kw;
   int32_t nphase;
+  int32_t walk_doh, walk_db;  // BWD_FILTER pixel walk: advancing the reduction index by one K-tile (32 pixels, Wo | 32)
+                              // moves oh by walk_doh (mod Ho, carry into b) and b by walk_db
   int32_t accumulate;         // epilogue adds the existing contents of the output (dw += ...: gradient accumulation)
   PhaseInfo phase[16];
 };
