@@ -76,8 +76,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);
 /* out0[c] = sum_r a[r,c];  out1[c] = sum_r a[r,c]*b[r,c]  (b == NULL -> a*a; out1 == NULL -> skipped).
  * bias gradients (db = colsum(dy)), BN moments (sum, sum of squares) and BN backward (sum dy, sum dy*x). */
-int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, void* ws,
-                   size_t ws_bytes, t2i_stream_t stream);
+int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, int accumulate,
+                   void* ws, size_t ws_bytes, t2i_stream_t stream); /* accumulate != 0: out += (sums into a gradient arena) */
 
 /* ---- batch norm, training mode: reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm fused, scale=True) --- */
 /* From sum/sumsq over n rows: mean, rstd = 1/sqrt(var_biased+eps); scale = gamma*rstd, shift = beta-mean*scale;
@@ -92,17 +92,21 @@ int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t
  * the kernel converts to the centred form.  Also emits dgamma, dbeta. */
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma,
-               float* dbeta, void* ws /* >= 3*C floats */, size_t ws_bytes, t2i_stream_t stream);
+               float* dbeta, int accumulate /* dgamma/dbeta += */, void* ws /* >= 3*C floats */, size_t ws_bytes,
+               t2i_stream_t stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------------- */
 /* y = act(x) */
 int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
 /* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream);
-/* Fused activation backward + bias gradient of a conv layer: dx = dy * act'(y) and colsum[c] = sum_r dx[r,c] in one pass
- * over a [rows, C] view (C % 4 == 0, 16-byte aligned); workspace as t2i_col_reduce. */
-int t2i_act_bwd_colsum(const float* dy, const float* y, int64_t rows, int32_t C, int act, float alpha, float* dx,
-                       float* colsum, void* ws, size_t ws_bytes, t2i_stream_t stream);
+/* Fused activation backward + column sums: dx = dy * act'(y), colsum[c] = sum_r dx[r,c] and, if x2 != NULL,
+ * colsum_x2[c] = sum_r dx[r,c]*x2[r,c], in ONE pass over a [rows, C] view (C % 4 == 0, 16-byte aligned).  Serves the
+ * bias gradient of a conv layer and the two reductions of the batch-norm backward.  accumulate: sums are added to the
+ * outputs.  Workspace as t2i_col_reduce. */
+int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, int64_t rows, int32_t C, int act, float alpha,
+                       float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       t2i_stream_t stream);
 /* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
 /* y = alpha*a + beta*b (b may be NULL). */

@@ -126,6 +126,20 @@ def test_act_bwd_colsum_fused(K, shape):
         assert relerr(dx, ref) <= 1e-7
         assert relerr(s, ref.reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
         assert torch.equal(dx, K.act_bwd(dev(dy), dev(y), act, 0.2))
+        # with a second operand: sum dx and sum dx*x2 (the two reductions of the batch-norm backward), and the
+        # accumulate form that sums straight into an existing buffer (a gradient-arena slot)
+        x2 = rng.standard_normal(shape).astype(np.float32)
+        dx2, s0, s1 = K.act_bwd_colsum(dev(dy), dev(y), act, 0.2, x2=dev(x2))
+        assert torch.equal(dx2, dx)
+        assert relerr(s0, ref.reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
+        assert relerr(s1, (ref * x2).reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
+        base = rng.standard_normal(shape[-1]).astype(np.float32)
+        acc = dev(base)
+        K.act_bwd_colsum(dev(dy), dev(y), act, 0.2, out=acc)
+        assert relerr(acc, base + ref.reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
+        acc = dev(base)
+        K.col_reduce(dev(dy), out=acc)
+        assert relerr(acc, base + dy.astype(np.float64).reshape(-1, shape[-1]).sum(0)) <= FWD_TOL
 
 
 # ---- seeded medium shapes vs the NumPy loop oracle: vector path, 128x128 tiles, ragged N, split-K, stride phases --------

@@ -25,6 +25,13 @@ _INPUTS_ONLY = [False]
 SINKS = {}
 
 
+def _sink_of(t):
+    """The gradient-arena slot of parameter `t` if sinks are on and this is the final (first-order) backward."""
+    if t is None or torch.is_grad_enabled():
+        return None
+    return SINKS.get(t.data_ptr())
+
+
 def _filter_grad(x, gpre, geom, w):
     """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function."""
     if not torch.is_grad_enabled():
@@ -96,6 +103,7 @@ class Conv2dFn(Function):
         y = K.conv_fwd(x, w, b, d, ws, act, alpha)
         ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
+        ctx.bias_ref = b            # only its address is used (gradient sink lookup)
         return y
 
     @staticmethod
@@ -106,12 +114,17 @@ class Conv2dFn(Function):
         params = not _INPUTS_ONLY[0]
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and params
         gb = None
+        bsink = _sink_of(ctx.bias_ref) if want_b else None
         if (want_b and ctx.act != K.ACT_NONE and not torch.is_grad_enabled() and gy.shape[-1] % 4 == 0):
             # final (first-order) backward: activation backward and bias gradient in ONE pass over the tensor
-            gpre, gb = K.act_bwd_colsum(_c(gy), y, ctx.act, ctx.alpha)
+            gpre, gb = K.act_bwd_colsum(_c(gy), y, ctx.act, ctx.alpha, out=bsink)
+            if bsink is not None:
+                gb = None                       # already summed into the optimizer's arena
         else:
             gpre = _act_bwd(gy, y, ctx.act, ctx.alpha)
-            if want_b:
+            if want_b and bsink is not None:
+                K.col_reduce(_c(gpre), out=bsink)
+            elif want_b:
                 gb = ColSumFn.apply(gpre)
         gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
         gw = _filter_grad(x, gpre, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
@@ -130,6 +143,7 @@ class ConvBwdDataFn(Function):
         out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha)
         ctx.save_for_backward(dy, w, out if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
+        ctx.bias_ref = b
         return out
 
     @staticmethod
@@ -141,7 +155,13 @@ class ConvBwdDataFn(Function):
         params = not _INPUTS_ONLY[0]
         g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
         g_w = _filter_grad(gpre, dy, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
-        g_b = ColSumFn.apply(gpre) if (ctx.has_bias and ctx.needs_input_grad[2] and params) else None
+        g_b = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and params:
+            bsink = _sink_of(ctx.bias_ref)
+            if bsink is not None:
+                K.col_reduce(_c(gpre), out=bsink)
+            else:
+                g_b = ColSumFn.apply(gpre)
         return g_dy, g_w, g_b, None, None, None
 
 
@@ -264,6 +284,7 @@ class BatchNormTrainFn(Function):
         y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
         ctx.act, ctx.alpha = act, alpha
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.mark_non_differentiable(mean, rstd)
         return y, mean, rstd
 
@@ -272,9 +293,16 @@ class BatchNormTrainFn(Function):
     def backward(ctx, gy, _gm, _gr):
         x, gamma, mean, rstd, y = ctx.saved_tensors
         gy = _c(gy)
-        if ctx.act != K.ACT_NONE:
-            gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
-        sum_dy, sum_dy_x = K.col_reduce(gy, x, True)
+        if ctx.act != K.ACT_NONE and gy.shape[-1] % 4 == 0:
+            gy, sum_dy, sum_dy_x = K.act_bwd_colsum(gy, y, ctx.act, ctx.alpha, x2=x)    # mask + both reductions, one pass
+        else:
+            if ctx.act != K.ACT_NONE:
+                gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
+            sum_dy, sum_dy_x = K.col_reduce(gy, x, True)
+        gsink, bsink = _sink_of(ctx.gamma_ref), _sink_of(ctx.beta_ref)
+        if gsink is not None and bsink is not None:
+            dx, _, _ = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=gsink, dbeta_out=bsink)
+            return dx, None, None, None, None, None, None, None, None
         dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict
 // stage 2: one block per 64 columns; 4 row lanes walk the partials (fixed order), LDS joins them
 __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
                                                          int nchunks, int C, float* __restrict__ out0,
-                                                         float* __restrict__ out1) {
+                                                         float* __restrict__ out1, int accumulate) {
   __shared__ float s0[4][64], s1[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -71,8 +71,12 @@ __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict
   s1[ty][tx] = a1;
   __syncthreads();
   if (ty == 0 && c < C) {
-    out0[c] = (s0[0][tx] + s0[1][tx]) + (s0[2][tx] + s0[3][tx]);
-    if (out1) out1[c] = (s1[0][tx] + s1[1][tx]) + (s1[2][tx] + s1[3][tx]);
+    const float r0 = (s0[0][tx] + s0[1][tx]) + (s0[2][tx] + s0[3][tx]);
+    out0[c] = accumulate ? out0[c] + r0 : r0;          // accumulate: sum straight into a gradient arena slot
+    if (out1) {
+      const float r1 = (s1[0][tx] + s1[1][tx]) + (s1[2][tx] + s1[3][tx]);
+      out1[c] = accumulate ? out1[c] + r1 : r1;
+    }
   }
 }
 
@@ -95,15 +99,15 @@ size_t col_reduce_ws(int64_t rows, int C) {
   return (size_t)nc * C * 2 * sizeof(float);
 }
 
-hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C, float* out0, float* out1, void* ws,
-                             hipStream_t stream) {
+hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C, float* out0, float* out1, int accumulate,
+                             void* ws, hipStream_t stream) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
   hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
                      out1 != nullptr);
-  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1);
+  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1, accumulate);
   return hipGetLastError();
 }
 
@@ -162,14 +166,14 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* 
                                    const float* __restrict__ gamma, const float* __restrict__ sum_dy,
                                    const float* __restrict__ sum_dy_x, float n, int C, float* __restrict__ dgamma,
                                    float* __restrict__ dbeta, float* __restrict__ k_dy, float* __restrict__ k_x,
-                                   float* __restrict__ k_0) {
+                                   float* __restrict__ k_0, int accumulate) {
   // dx = g*rs*(dy - sdy/n - xhat*sdyxh/n), xhat = (x-mu)*rs  ==  k_dy*dy + k_x*x + k_0
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float mu = mean[c], rs = rstd[c], g = gamma[c], sdy = sum_dy[c];
   const float sdyxh = rs * (sum_dy_x[c] - mu * sdy);
-  dgamma[c] = sdyxh;
-  dbeta[c] = sdy;
+  dgamma[c] = accumulate ? dgamma[c] + sdyxh : sdyxh;
+  dbeta[c] = accumulate ? dbeta[c] + sdy : sdy;
   const float grs = g * rs;
   k_dy[c] = grs;
   k_x[c] = -grs * rs * sdyxh / n;
@@ -230,12 +234,12 @@ hipError_t bn_apply_launch(const float* x, const float* scale, const float* shif
 // dgamma/dbeta double as scratch-free outputs; k_* coefficients live in the caller-visible dgamma-sized buffers
 hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                          const float* sum_dy, const float* sum_dy_x, int64_t rows, int C, float* dx, float* dgamma,
-                         float* dbeta, float* coef /* 3*C floats */, hipStream_t stream) {
+                         float* dbeta, float* coef /* 3*C floats */, int accumulate, hipStream_t stream) {
   const bool al = C > 0;
   if (C < 0) C = -C;
   float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, mean, rstd, gamma, sum_dy,
-                     sum_dy_x, (float)rows, C, dgamma, dbeta, k_dy, k_x, k_0);
+                     sum_dy_x, (float)rows, C, dgamma, dbeta, k_dy, k_x, k_0, accumulate);
   const size_t n = (size_t)rows * C;
   if (al && (C & 3) == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0,
@@ -289,16 +293,20 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 
 // fused: dx = dy * act'(y)  AND  colsum[c] = sum_r dx[r,c]  — the activation backward and the bias gradient of a conv layer
 // read the same tensor; one pass instead of two (float4 per lane, 16 lanes = 64 columns, 16 row lanes per workgroup).
+template <bool SECOND>   // SECOND: also part1[c] = sum_r dx[r,c] * x2[r,c]  (batch-norm backward needs sum dy and sum dy*x)
 __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             int64_t rows, int C, int64_t rows_per_chunk, int act,
-                                                             float alpha, float* __restrict__ dx, float* __restrict__ part) {
+                                                             const float* __restrict__ x2, int64_t rows, int C,
+                                                             int64_t rows_per_chunk, int act, float alpha,
+                                                             float* __restrict__ dx, float* __restrict__ part,
+                                                             float* __restrict__ part1) {
   __shared__ float4 red[16][16];
+  __shared__ float4 red1[SECOND ? 16 : 1][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
   const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t rend = rbeg + rows_per_chunk;
   if (rend > rows) rend = rows;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
       const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
@@ -308,26 +316,44 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
       d.z = g.z * act_grad_from_output(o.z, act, alpha); d.w = g.w * act_grad_from_output(o.w, act, alpha);
       *reinterpret_cast<float4*>(dx + r * C + c) = d;
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+      if (SECOND) {
+        const float4 v = *reinterpret_cast<const float4*>(x2 + r * C + c);
+        acc1.x += d.x * v.x; acc1.y += d.y * v.y; acc1.z += d.z * v.z; acc1.w += d.w * v.w;
+      }
     }
   }
   red[ty][tx] = acc;
+  if (SECOND) red1[ty][tx] = acc1;
   __syncthreads();
   if (ty == 0 && c < C) {
     float4 s = red[0][tx];
 #pragma unroll
     for (int k = 1; k < 16; ++k) { const float4 v = red[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c) = s;
+    if (SECOND) {
+      float4 s1 = red1[0][tx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) { const float4 v = red1[k][tx]; s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; }
+      *reinterpret_cast<float4*>(part1 + (size_t)blockIdx.y * C + c) = s1;
+    }
   }
 }
 
-hipError_t act_bwd_colsum_launch(const float* dy, const float* y, int64_t rows, int C, int act, float alpha, float* dx,
-                                 float* colsum, void* ws, hipStream_t stream) {
+hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x2, int64_t rows, int C, int act, float alpha,
+                                 float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(act_bwd_colsum_stage1, dim3(ct, nc), dim3(256), 0, stream, dy, y, rows, C, rpc, act, alpha, dx, part);
-  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part, (const float*)nullptr, nc, C, colsum,
-                     (float*)nullptr);
+  float* part1 = part + (size_t)nc * C;
+  const bool second = x2 != nullptr && sum1 != nullptr;
+  if (second)
+    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, rows, C, rpc, act, alpha,
+                       dx, part, part1);
+  else
+    hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, rows, C, rpc, act, alpha,
+                       dx, part, part1);
+  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
+                     sum0, second ? sum1 : (float*)nullptr, accumulate);
   return hipGetLastError();
 }
 

@@ -23,12 +23,12 @@ void set_error(const char* fmt, ...) {
 
 // launchers implemented in t2i_aux.hip
 size_t col_reduce_ws(int64_t rows, int C);
-hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, void*, hipStream_t);
+hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                         int64_t, int, float*, float*, float*, float*, hipStream_t);
+                         int64_t, int, float*, float*, float*, float*, int, hipStream_t);
 hipError_t ew_launch(int, const float*, const float*, size_t, int, float, float, float*, hipStream_t);
 hipError_t interp_launch(const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t concat_tile_fwd_launch(const float*, const float*, int, int, int, int, float*, hipStream_t);
@@ -38,7 +38,8 @@ hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
-hipError_t act_bwd_colsum_launch(const float*, const float*, int64_t, int, int, float, float*, float*, void*, hipStream_t);
+hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
+                                 void*, hipStream_t);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -134,6 +135,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       }
     }
   }
+  if (env_int("T2I_DEBUG_PLAN", 0))
+    fprintf(stderr, "[t2i plan] M=%lld N=%lld K=%lld phases=%d -> tile %dx%d splitk=%d (k/split=%d) model %.1f us\n",
+            (long long)M, (long long)N, (long long)K, nphase, 64 * best.wmt, 64 * best.wnt, best.splitk, best.k_per_split, best_t);
   return best;
 }
 
@@ -311,11 +315,11 @@ size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C) {
   return col_reduce_ws(rows, C);
 }
 
-int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, void* ws,
-                   size_t ws_bytes, t2i_stream_t stream) {
+int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, int accumulate,
+                   void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!a || !out0 || rows <= 0 || C <= 0) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_col_reduce: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(col_reduce_launch(a, b, rows, C, out0, out1, ws, (hipStream_t)stream), "t2i_col_reduce");
+  return check(col_reduce_launch(a, b, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_col_reduce");
 }
 
 int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma, const float* beta,
@@ -339,7 +343,7 @@ int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t
 
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma, float* dbeta,
-               void* ws, size_t ws_bytes, t2i_stream_t stream) {
+               int accumulate, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !sum_dy || !sum_dy_x || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) {
     set_error("t2i_bn_bwd: bad argument");
     return T2I_ERR_INVALID;
@@ -347,7 +351,7 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
   if (!ws || ws_bytes < (size_t)3 * C * sizeof(float) || !aligned16(ws)) { set_error("t2i_bn_bwd: workspace too small"); return T2I_ERR_WORKSPACE; }
   const bool al = aligned16(dy) && aligned16(x) && aligned16(dx);
   return check(bn_bwd_launch(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x, rows, al ? C : -C, dx, dgamma, dbeta,
-                             reinterpret_cast<float*>(ws), (hipStream_t)stream), "t2i_bn_bwd");
+                             reinterpret_cast<float*>(ws), accumulate ? 1 : 0, (hipStream_t)stream), "t2i_bn_bwd");
 }
 
 static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y,
@@ -364,12 +368,15 @@ int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_s
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream) {
   return ew_call(1, dy, y, n, act, alpha, 0.f, dx, stream, "t2i_act_bwd", true);
 }
-int t2i_act_bwd_colsum(const float* dy, const float* y, int64_t rows, int32_t C, int act, float alpha, float* dx,
-                       float* colsum, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, int64_t rows, int32_t C, int act, float alpha,
+                       float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       t2i_stream_t stream) {
+  if ((x2 == nullptr) != (colsum_x2 == nullptr) || (x2 && !aligned16(x2))) { set_error("t2i_act_bwd_colsum: x2 / colsum_x2 must come together, 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
   if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(act_bwd_colsum_launch(dy, y, rows, C, act, alpha, dx, colsum, ws, (hipStream_t)stream), "t2i_act_bwd_colsum");
+  return check(act_bwd_colsum_launch(dy, y, x2, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
+                                     (hipStream_t)stream), "t2i_act_bwd_colsum");
 }
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
   return ew_call(2, a, b, n, act, alpha, 0.f, y, stream, "t2i_add_act", true);

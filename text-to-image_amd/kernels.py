@@ -190,12 +190,15 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
     return dw
 
 
-def col_reduce(a, b=None, want_second=False):
-    """a viewed as [rows, C] (C = last dim).  -> (colsum(a), colsum(a*b or a*a) or None)."""
+def col_reduce(a, b=None, want_second=False, out=None):
+    """a viewed as [rows, C] (C = last dim).  -> (colsum(a), colsum(a*b or a*a) or None).
+    out: an existing [C] buffer to ACCUMULATE colsum(a) into (a bias slot of the gradient arena)."""
     _chk(a, 'a')
     C = a.shape[-1]
     rows = a.numel() // C
-    out0 = torch.empty(C, dtype=torch.float32, device=a.device)
+    if out is not None:
+        assert out.numel() == C and not want_second
+    out0 = out if out is not None else torch.empty(C, dtype=torch.float32, device=a.device)
     out1 = torch.empty(C, dtype=torch.float32, device=a.device) if want_second else None
     if b is not None:
         _chk(b, 'b')
@@ -203,7 +206,8 @@ def col_reduce(a, b=None, want_second=False):
     if _live(a):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(a, need)
-        check(lib.t2i_col_reduce(_ptr(a), _ptr(b), rows, C, _ptr(out0), _ptr(out1), wsp, wsn, _stream()), 't2i_col_reduce')
+        check(lib.t2i_col_reduce(_ptr(a), _ptr(b), rows, C, _ptr(out0), _ptr(out1), 1 if out is not None else 0, wsp, wsn,
+                                 _stream()), 't2i_col_reduce')
     return out0, out1
 
 
@@ -227,16 +231,20 @@ def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
     return y
 
 
-def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x):
+def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=None, dbeta_out=None):
+    """dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into instead of fresh tensors."""
     _chk(dy, 'dy'); _chk(x, 'x')
     C = x.shape[-1]
     dx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    acc = dgamma_out is not None
+    assert acc == (dbeta_out is not None)
+    dgamma = dgamma_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, 3 * C * 4)
         check(lib.t2i_bn_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)), _ptr(sum_dy), _ptr(sum_dy_x),
-                             x.numel() // C, C, _ptr(dx), _ptr(dgamma), _ptr(dbeta), wsp, wsn, _stream()), 't2i_bn_bwd')
+                             x.numel() // C, C, _ptr(dx), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn, _stream()),
+              't2i_bn_bwd')
     return dx, dgamma, dbeta
 
 
@@ -256,19 +264,25 @@ def act_bwd(dy, y, act, alpha=0.2):
     return dx
 
 
-def act_bwd_colsum(dy, y, act, alpha=0.2):
-    """-> (dy * act'(y), column sums of that) in one pass (conv-layer activation backward + bias gradient)."""
+def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None):
+    """-> (dx = dy*act'(y), colsum(dx)[, colsum(dx*x2)]) in one pass: a conv layer's activation backward + bias gradient,
+    or (with x2) the masked gradient and both reductions of the batch-norm backward.
+    out: gradient-arena slot to ACCUMULATE colsum(dx) into (then the second return value is `out`)."""
     _chk(dy, 'dy'); _chk(y, 'y')
     C = dy.shape[-1]
     rows = dy.numel() // C
     dx = torch.empty_like(dy)
-    s = torch.empty(C, dtype=torch.float32, device=dy.device)
+    s = out if out is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+    s2 = torch.empty(C, dtype=torch.float32, device=dy.device) if x2 is not None else None
+    if x2 is not None:
+        _chk(x2, 'x2')
+        assert out is None
     if _live(dy):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(dy, need)
-        check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), rows, C, act, alpha, _ptr(dx), _ptr(s), wsp, wsn, _stream()),
-              't2i_act_bwd_colsum')
-    return dx, s
+        check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), rows, C, act, alpha, _ptr(dx), _ptr(s), _ptr(s2),
+                                     1 if out is not None else 0, wsp, wsn, _stream()), 't2i_act_bwd_colsum')
+    return (dx, s) if x2 is None else (dx, s, s2)
 
 
 def add_act(a, b, act=ACT_NONE, alpha=0.2):

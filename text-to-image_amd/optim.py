@@ -39,9 +39,8 @@ class Arena(object):
     def enable_sinks(self):
         """Let the filter-gradient GEMMs accumulate directly into this arena (autograd.SINKS)."""
         from . import autograd as A
-        for n, v in self.vars.items():
-            if v.dim() >= 2:          # conv / deconv / dense kernels; biases and BN affine stay with autograd
-                A.SINKS[v.data_ptr()] = self.grad_of(n).view(-1)
+        for n, v in self.vars.items():     # kernels, biases, BN gamma/beta: every gradient is summed in place by its kernel
+            A.SINKS[v.data_ptr()] = self.grad_of(n).view(-1)
 
     def grad_of(self, name):
         o, k = self.offsets[name]
