@@ -43,6 +43,10 @@ hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+bool head_conv_eligible(const t2i_conv_desc& d);
+hipError_t head_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+hipError_t head_bwd_data_launch(const t2i_conv_desc&, const float*, const float*, float*, hipStream_t);
+hipError_t head_bwd_filter_launch(const t2i_conv_desc&, const float*, const float*, float*, int, hipStream_t);
 bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
 hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
 
@@ -246,8 +250,12 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
-  if (tiny_conv_eligible(*d, false) && !env_int("T2I_NO_THIN", 0))
-    return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
+  if (!env_int("T2I_NO_THIN", 0)) {
+    if (head_conv_eligible(*d))
+      return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
+    if (tiny_conv_eligible(*d, false))
+      return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
+  }
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -267,6 +275,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
   if (!env_int("T2I_NO_THIN", 0)) {
+    if (head_conv_eligible(*d) && !bias && act == T2I_ACT_NONE)
+      return check(head_bwd_data_launch(*d, dy, w, dx, (hipStream_t)stream), "t2i_conv2d_bwd_data(head)");
     if (tiny_conv_eligible(*d, true))
       return check(tiny_conv_launch(*d, true, dy, w, bias, dx, act, alpha, (hipStream_t)stream), "t2i_conv2d_bwd_data(tiny)");
     if (thin_deconv_eligible(*d) && aligned16(dy) && aligned16(w))
@@ -291,6 +301,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
+  if (head_conv_eligible(*d) && !env_int("T2I_NO_THIN", 0))
+    return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;

@@ -23,7 +23,7 @@ template <int CI>
 __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ dx,
                                                                int H, int W, int Co, int act, float alpha) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [10][10][Co+4]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [10][10][Co+4] dy patch, then [16][CI][Co] filter
   const int Ho = H >> 1, Wo = W >> 1;
   const int PS = Co + 4;                       // pixel stride in LDS
   const int b = blockIdx.z;
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __re
       v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * Co + c4 * 4);
     *reinterpret_cast<float4*>(&tile[pix * PS + c4 * 4]) = v;
   }
+  float* wlds = tile + 100 * PS;               // the whole filter [16 taps][CI][Co]
+  for (int i = threadIdx.x; i < 4 * CI * Co; i += 256)
+    reinterpret_cast<float4*>(wlds)[i] = reinterpret_cast<const float4*>(w)[i];
   __syncthreads();
   // ---- wave = stride phase; lane = one of its 8x8 pixels --------------------------------------------------------------
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -56,12 +59,15 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __re
     for (int jw = 0; jw < 2; ++jw) {
       const int r = py + 1 + ph - jh, c = px + 1 + pw - jw;           // patch coordinates of the contributing dy pixel
       const float* src = &tile[(r * 10 + c) * PS];
-      const float* wt = w + (size_t)(((kh0 + 2 * jh) * 4 + (kw0 + 2 * jw)) * CI) * Co;   // wave-uniform
+      // this tap's filter rows in LDS: every lane of the wave reads the SAME address (broadcast, conflict-free).
+      // (v1 read them with scalar loads straight from global: 384 dependent s_load per wave, ~35 us of the kernel's 65.)
+      const float* wt = wlds + (((kh0 + 2 * jh) * 4 + (kw0 + 2 * jw)) * CI) * Co;
+#pragma unroll 4
       for (int c4 = 0; c4 < c4n; ++c4) {
         const float4 d = *reinterpret_cast<const float4*>(src + c4 * 4);
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
-          const float4 f = *reinterpret_cast<const float4*>(wt + ci * Co + c4 * 4);     // scalar load (uniform address)
+          const float4 f = *reinterpret_cast<const float4*>(wt + ci * Co + c4 * 4);
           acc[ci] = fmaf(d.x, f.x, fmaf(d.y, f.y, fmaf(d.z, f.z, fmaf(d.w, f.w, acc[ci]))));
         }
       }
@@ -81,7 +87,7 @@ bool thin_deconv_eligible(const t2i_conv_desc& d) {
 
 hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx,
                               int act, float alpha, hipStream_t stream) {
-  const size_t lds = (size_t)100 * (d.Cout + 4) * sizeof(float);
+  const size_t lds = ((size_t)100 * (d.Cout + 4) + (size_t)16 * d.Cin * d.Cout) * sizeof(float);
   dim3 grid(d.W / 16, d.H / 16, d.B);
 #define T2I_THIN(CI)                                                                                              \
   case CI: {                                                                                                      \
@@ -158,6 +164,109 @@ hipError_t tiny_conv_launch(const t2i_conv_desc& d, bool bwd, const float* in, c
     hipLaunchKernelGGL(tiny_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, in, w, bias, out, d, act, alpha);
   else
     hipLaunchKernelGGL(tiny_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, in, w, bias, out, d, act, alpha);
+  return hipGetLastError();
+}
+
+}  // namespace t2i
+
+// ------------------------------------------------------------------------------------------------------------------
+// "head" conv: the whole HxWxCin map of one image is reduced to 1x1xCout with Cout <= 4 (the critic's logit layer, k4 s4
+// VALID on a 4x4x1024 map: one 16384-long dot product per sample).  As a GEMM it is M = B, N = 1: pure latency.
+//   head_fwd   y[b,co]  = act(bias[co] + sum_j x[b,j] * w[j,co])          one workgroup per sample, wave64 shuffle reduce
+//   head_bwd_data    dx[b,j]  = sum_co dy[b,co] * w[j,co]                 elementwise
+//   head_bwd_filter  dw[j,co] (+)= sum_b x[b,j] * dy[b,co]                one thread per j, coalesced over j
+// ------------------------------------------------------------------------------------------------------------------
+namespace t2i {
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int K,
+                                                       int Co, int act, float alpha) {
+  __shared__ float red[4][4];
+  const float* row = x + (size_t)blockIdx.x * K;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = threadIdx.x; j < K; j += 256) {
+    const float v = row[j];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+      if (co < Co) acc[co] = fmaf(v, w[(size_t)j * Co + co], acc[co]);
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][co] = acc[co];
+  }
+  __syncthreads();
+  if (threadIdx.x < Co) {
+    const int co = threadIdx.x;
+    const float s = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]) + (bias ? bias[co] : 0.f);
+    y[(size_t)blockIdx.x * Co + co] = apply_act(s, act, alpha);
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int B, int K, int Co) {
+  const size_t n = (size_t)B * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / K;
+    const int j = (int)(i - b * K);
+    float s = 0.f;
+    for (int co = 0; co < Co; ++co) s = fmaf(dy[b * Co + co], w[(size_t)j * Co + co], s);
+    dx[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_filter_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, int B, int K, int Co, int accumulate) {
+  // 64 consecutive j per workgroup (coalesced), the batch split over 4 row lanes, joined through LDS in a fixed order
+  __shared__ float red[4][64][4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < K) {
+    for (int b = ty; b < B; b += 4) {
+      const float v = x[(size_t)b * K + j];
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < Co) acc[co] = fmaf(v, dy[b * Co + co], acc[co]);
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) red[ty][tx][co] = acc[co];
+  __syncthreads();
+  if (ty == 0 && j < K) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+      if (co < Co) {
+        const float s = (red[0][tx][co] + red[1][tx][co]) + (red[2][tx][co] + red[3][tx][co]);
+        float* o = dw + (size_t)j * Co + co;
+        *o = accumulate ? *o + s : s;
+      }
+  }
+}
+
+bool head_conv_eligible(const t2i_conv_desc& d) {
+  return d.Ho == 1 && d.Wo == 1 && d.KH == d.H && d.KW == d.W && d.pad_t == 0 && d.pad_l == 0 && d.Cout <= 4;
+}
+
+hipError_t head_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act,
+                           float alpha, hipStream_t stream) {
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(d.B), dim3(256), 0, stream, x, w, bias, y, d.H * d.W * d.Cin, d.Cout, act, alpha);
+  return hipGetLastError();
+}
+
+hipError_t head_bwd_data_launch(const t2i_conv_desc& d, const float* dy, const float* w, float* dx, hipStream_t stream) {
+  const int K = d.H * d.W * d.Cin;
+  size_t blocks = ((size_t)d.B * K + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(head_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dy, w, dx, d.B, K, d.Cout);
+  return hipGetLastError();
+}
+
+hipError_t head_bwd_filter_launch(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate,
+                                  hipStream_t stream) {
+  const int K = d.H * d.W * d.Cin;
+  hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((K + 63) / 64), dim3(256), 0, stream, x, dy, dw, d.B, K, d.Cout, accumulate);
   return hipGetLastError();
 }
 
