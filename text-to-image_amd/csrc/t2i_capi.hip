@@ -43,6 +43,9 @@ hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+bool tiny_bwdw_eligible(const t2i_conv_desc& d);
+size_t tiny_bwdw_ws(const t2i_conv_desc& d);
+hipError_t tiny_bwdw_launch(const t2i_conv_desc&, const float*, const float*, float*, int, void*, hipStream_t);
 bool head_conv_eligible(const t2i_conv_desc& d);
 hipError_t head_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
 hipError_t head_bwd_data_launch(const t2i_conv_desc&, const float*, const float*, float*, hipStream_t);
@@ -242,6 +245,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (b > need) need = b;
   b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER)).ws_bytes;
   if (b > need) need = b;
+  if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
   return need;
 }
 
@@ -301,8 +305,15 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
-  if (head_conv_eligible(*d) && !env_int("T2I_NO_THIN", 0))
-    return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
+  if (!env_int("T2I_NO_THIN", 0)) {
+    if (head_conv_eligible(*d))
+      return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
+    if (tiny_bwdw_eligible(*d)) {
+      const size_t need = tiny_bwdw_ws(*d);
+      if (!ws || ws_bytes < need || !aligned16(ws)) { set_error("t2i_conv2d_bwd_filter: workspace %zu B < %zu B required", ws_bytes, need); return T2I_ERR_WORKSPACE; }
+      return check(tiny_bwdw_launch(*d, x, dy, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_conv2d_bwd_filter(tiny)");
+    }
+  }
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;

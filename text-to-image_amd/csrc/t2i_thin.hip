@@ -271,3 +271,101 @@ hipError_t head_bwd_filter_launch(const t2i_conv_desc& d, const float* x, const 
 }
 
 }  // namespace t2i
+
+// Measured and dropped (round 1): direct VALU kernels for the Cin = 3 k4 s2 forward / filter gradient (critic layer 1).
+// Three variants (LDS-broadcast patch, multi-row, SGPR patch via s_load) all ran 34-38 us at B = 64 against 31 us for the
+// igemm path: 48 dependent scalar-fp32 FMAs per output sit at the non-packed VALU rate (~10 us) and the per-pixel
+// overhead doubles it; the filter gradient came out equal to igemm (60 us).  See DESIGN.md section 4.5.
+namespace t2i {
+
+size_t col_reduce_ws(int64_t rows, int C);
+hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------------------------
+// tiny filter gradient (Cin, Cout <= 3, k <= 3: the generator's 3 -> 3 output conv): 81 sums over B*H*W pixels.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void tiny_bwdw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ part, t2i_conv_desc d) {
+  __shared__ float red[4][9 * CI * CO];
+  float acc[9][CI][CO];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) acc[t][ci][co] = 0.f;
+  const size_t npix = (size_t)d.B * d.Ho * d.Wo;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const int ow = (int)(p % d.Wo);
+    const size_t t = p / d.Wo;
+    const int oh = (int)(t % d.Ho), b = (int)(t / d.Ho);
+    float g[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) g[co] = dy[p * CO + co];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * d.SH - d.pad_t + kh;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * d.SW - d.pad_l + kw;
+        if (kh < d.KH && kw < d.KW && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) {
+          const float* s = x + ((size_t)(b * d.H + ih) * d.W + iw) * CI;
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) {
+            const float v = s[ci];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[kh * 3 + kw][ci][co] = fmaf(v, g[co], acc[kh * 3 + kw][ci][co]);
+          }
+        }
+      }
+    }
+  }
+  // wave64 shuffle reduction of each of the 9*CI*CO sums, then across the 4 waves through LDS
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        float v = acc[t][ci][co];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][(t * CI + ci) * CO + co] = v;
+      }
+  __syncthreads();
+  if (threadIdx.x < 9 * CI * CO) {
+    const int i = threadIdx.x;                 // (t, ci, co) with t = kh*3+kw over a 3x3 grid
+    const int t = i / (CI * CO), r = i - t * (CI * CO);
+    const int kh = t / 3, kw = t - kh * 3;
+    if (kh < d.KH && kw < d.KW)
+      part[(size_t)blockIdx.x * (d.KH * d.KW * CI * CO) + (kh * d.KW + kw) * (CI * CO) + r] =
+          (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+bool tiny_bwdw_eligible(const t2i_conv_desc& d) { return d.Cin == 3 && d.Cout == 3 && d.KH <= 3 && d.KW <= 3; }
+
+static int tiny_bwdw_blocks(const t2i_conv_desc& d) {
+  size_t npix = (size_t)d.B * d.Ho * d.Wo;
+  size_t blocks = (npix + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+size_t tiny_bwdw_ws(const t2i_conv_desc& d) {
+  const int nb = tiny_bwdw_blocks(d), C = d.KH * d.KW * 9;
+  return (size_t)nb * C * sizeof(float) + col_reduce_ws(nb, C) + 256;
+}
+
+hipError_t tiny_bwdw_launch(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                            hipStream_t stream) {
+  const int nb = tiny_bwdw_blocks(d), C = d.KH * d.KW * 9;
+  float* part = reinterpret_cast<float*>(ws);
+  char* ws2 = reinterpret_cast<char*>(ws) + (((size_t)nb * C * sizeof(float) + 255) & ~(size_t)255);
+  hipLaunchKernelGGL((tiny_bwdw_kernel<3, 3>), dim3(nb), dim3(256), 0, stream, x, dy, part, d);
+  return col_reduce_launch(part, nullptr, nb, C, dw, nullptr, accumulate, ws2, stream);
+}
+
+}  // namespace t2i
