@@ -130,6 +130,8 @@ def main():
     ap.add_argument('--no-graphs', action='store_true', help='keep the step eager (default: hipGraph replay on 1 GPU)')
     ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
                     help='where the per-launch HIP events for the roofline block are recorded')
+    ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
+                    help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
     ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -175,6 +177,9 @@ def main():
         torch.cuda.synchronize()
 
     use_graphs = (not use_dp) and not args.no_graphs and args.instrument != 'inline'
+    from t2i_amd import autograd as A
+    if args.side_stream:
+        A.enable_side_stream(True)
     for i in range(args.warmup):
         if use_graphs and i == min(2, args.warmup - 1):
             model.enable_graphs(feed)          # the remaining warm-up and all timed steps are graph replays
@@ -195,6 +200,7 @@ def main():
     if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
         inst_steps = min(args.steps, 3)
         saved_graphs, model._graphs = model._graphs, None      # per-launch events need eager launches
+        A.enable_side_stream(False)                            # ... and one stream, so durations are per kernel
         K.set_conv_timer(timer)
         for i in range(inst_steps):
             trainer.iteration(1 + args.warmup + args.steps + i, feed)

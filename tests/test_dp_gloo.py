@@ -54,6 +54,12 @@ def _worker(rank, world, port, mode, q):
             use = names if mode != 'unused' else names[:-2]      # leave two parameters out of the graph
             return sum((params[n] * data[n]).sum() * (i + 1) for i, n in enumerate(use))
 
+        if mode == 'sinks':
+            _sinks_mode(dp, arena, params, data, rank, world)
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, 'ok'))
+            return
         arena.zero_grad()
         if mode in ('hooks', 'unused'):
             dp.arm(arena)                           # overlap path: hooks launch buckets as they complete
@@ -80,7 +86,57 @@ def _worker(rank, world, port, mode, q):
         q.put((rank, 'FAIL: %s\n%s' % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused'])
+def _sinks_mode(dp, arena, params, data, rank, world):
+    """Gradient sinks (autograd.SINKS/NOTIFY): contributions are summed into the arena by the "kernels" (here: plain
+    in-place adds) and announced through autograd.NOTIFY; AccumulateGrad never runs.  Step 1 learns the per-parameter
+    contribution counts (exchange after backward), steps 2-3 launch each bucket as soon as its last contribution is
+    announced; a structure change (one contribution too many) must raise."""
+    from t2i_amd import autograd as A
+    arena.enable_sinks()
+    names = list(params)
+    contrib = {n: 1 + (i % 3) for i, n in enumerate(names)}          # 1..3 contributions per parameter
+    launches = []
+    orig_launch = dp._launch
+
+    def spy(st, bi):
+        launches.append((bi, sum(st['seen'].values())))
+        return orig_launch(st, bi)
+    dp._launch = spy
+    for step in range(3):
+        arena.zero_grad()
+        dp.arm(arena)
+        assert A.NOTIFY[0] is not None
+        launches.clear()
+        for n in reversed(names):                                     # backward order: last-created first
+            for c in range(contrib[n]):
+                A.SINKS[params[n].data_ptr()].add_((data[n] * (step + 1)).reshape(-1))
+                A._notify(params[n])
+        total_notes = sum(contrib.values())
+        if step == 0:
+            assert launches == []                                     # learning step: nothing goes out early
+        else:
+            assert launches and launches[0][1] < total_notes          # first bucket left before the backward ended
+            assert [b for b, _ in launches] == sorted(b for b, _ in launches)
+        scale = dp.allreduce_arena(arena)
+        assert scale == 1.0 / world
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {n: data[n] * (step + 1) * contrib[n] for n in names})
+        for n in names:
+            want = sum(g[n] for g in gathered)
+            assert torch.allclose(arena.grad_of(n), want, atol=1e-4), (step, n)
+    # one contribution more than learned -> loud failure, not a silently stale all-reduce
+    arena.zero_grad()
+    dp.arm(arena)
+    n = names[-1]
+    with pytest.raises(RuntimeError, match='structure changed'):
+        for c in range(contrib[n] + 1):
+            A._notify(params[n])
+    dp.allreduce_arena(arena)                                         # drain so both ranks stay in lockstep
+    A.NOTIFY[0] = None
+    A.SINKS.clear()
+
+
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks'])
 def test_dp_allreduce_two_ranks(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

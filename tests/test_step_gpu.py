@@ -244,3 +244,57 @@ def test_graph_replay_matches_eager(gpu, golden_step):
     assert kt0 == kt1 and d0 == d1 and g0 == g1
     for n in s0:
         assert torch.equal(s0[n], s1[n]), n
+
+
+def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
+    """Three launch schedules of the same iteration give the same bits: (a) one stream; (b) sunk filter gradients on the
+    second HIP stream (autograd.SIDE); (c) = (b) under dp.DataParallel with an RCCL communicator of world size 1, where
+    the gradient buckets are all-reduced on the communication stream as autograd.NOTIFY completes them (first step learns
+    the counts, later steps overlap).  Same kernels and accumulation order in all three."""
+    import socket
+    import torch.distributed as dist
+    from t2i_amd import autograd as A
+    from t2i_amd.dp import DataParallel
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    gs = golden_step
+    cfg = _cfg(8, 32, 16, 8, 8, 4)
+    params = {k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')}
+    feeds = []
+    g = torch.Generator(device=gpu).manual_seed(6)
+    for _ in range(3):
+        f = _feed(gs, gpu)
+        f['x'] = torch.rand(f['x'].shape, generator=g, device=gpu) * 2 - 1
+        f['z'] = torch.randn(f['z'].shape, generator=g, device=gpu)
+        feeds.append(f)
+
+    def run(side, dp):
+        A.enable_side_stream(side)
+        try:
+            m = WGanCls(cfg, device=gpu, dp=dp)
+            m.store.load(params)
+            tr = WGanClsTrainer(None, m, None, cfg)
+            outs = [tr.iteration(1 + i, feeds[i]) for i in range(3)]
+            torch.cuda.synchronize()
+            return ({n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt), float(outs[-1]['d']['D_loss']),
+                    float(outs[-1]['g']['G_loss']))
+        finally:
+            A.enable_side_stream(False)
+            A.NOTIFY[0] = None
+
+    plain = run(False, None)
+    side = run(True, None)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        dp = DataParallel(bucket_bytes=4096)          # several buckets even on the tiny model
+        both = run(True, dp)
+        st = next(iter(dp._arenas.values()))
+        assert st['expect'] and len(st['buckets']) > 1      # counts were learned; the overlap path was live on steps 2-3
+    finally:
+        dist.destroy_process_group()
+    for other in (side, both):
+        assert plain[1:] == other[1:]
+        for n in plain[0]:
+            assert torch.equal(plain[0][n], other[0][n]), n

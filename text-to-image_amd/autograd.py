@@ -9,6 +9,7 @@ norm) are first-order (``once_differentiable``), exactly what the reference's tw
 there only d/d(input) is wanted, so filter / bias gradients are not launched.
 """
 import contextlib
+import os
 
 import torch
 from torch.autograd import Function
@@ -21,8 +22,17 @@ _INPUTS_ONLY = [False]
 # Gradient sinks: weight storage address -> view of the optimizer's gradient arena.  In the final (first-order) backward
 # a filter gradient whose weight has a sink is ACCUMULATED by the GEMM epilogue straight into the arena and autograd gets
 # `None` for it: no temporary dw tensor, no separate `grad += dw` pass (0.55 ms/iteration of elementwise adds before).
-# Registered by optim.Arena.enable_sinks(); not used with data parallelism (the overlap hooks need AccumulateGrad).
+# Registered by optim.Arena.enable_sinks().  NOTIFY[0], if set (dp.DataParallel), is called with the parameter's address
+# after each contribution has been issued: sunk gradients never reach AccumulateGrad, so the data-parallel bucket
+# overlap counts these notifications instead of post-accumulate hooks.
 SINKS = {}
+NOTIFY = [None]
+
+
+def _notify(t):
+    cb = NOTIFY[0]
+    if cb is not None and t is not None:
+        cb(t.data_ptr())
 
 
 def _sink_of(t):
@@ -32,12 +42,49 @@ def _sink_of(t):
     return SINKS.get(t.data_ptr())
 
 
+class _Side:
+    """Filter-gradient stream.  A sunk filter gradient feeds nothing but the optimizer, so it is off the backward's
+    critical path (which is the bwd-data chain): launched on a second HIP stream it runs CONCURRENTLY with the next
+    layers' bwd-data kernels and fills their tail waves (and vice versa).  All sunk filter gradients share this one
+    stream, so accumulations into a slot keep their program order and the sums stay bit-identical to the one-stream
+    schedule.  Inputs are kept alive until side_join() because the caching allocator only orders reuse on one stream."""
+    stream = None
+    keep = []
+
+
+SIDE = _Side()
+
+
+def enable_side_stream(on=True):
+    SIDE.stream = torch.cuda.Stream(priority=int(os.environ.get('T2I_SIDE_PRIO', '0'))) if on else None
+    SIDE.keep = []
+
+
+def side_join():
+    """Make the current stream wait for every filter gradient issued so far (call before the optimizer reads the arena)."""
+    if SIDE.stream is not None:
+        torch.cuda.current_stream().wait_stream(SIDE.stream)
+        SIDE.keep.clear()
+
+
 def _filter_grad(x, gpre, geom, w):
     """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function."""
     if not torch.is_grad_enabled():
         sink = SINKS.get(w.data_ptr())
         if sink is not None:
-            K.conv_bwd_filter(_c(x), _c(gpre), geom[0], geom[1], out=sink)
+            xs, gs = _c(x), _c(gpre)
+            if SIDE.stream is not None:
+                SIDE.stream.wait_stream(torch.cuda.current_stream())      # x, gpre and the zeroed arena are ready
+                K.WS_LANE[0] = 1                                          # its own split-K workspace
+                try:
+                    with torch.cuda.stream(SIDE.stream):
+                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink)
+                finally:
+                    K.WS_LANE[0] = 0
+                SIDE.keep.append((xs, gs))
+            else:
+                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink)
+            _notify(w)
             return None
     return ConvBwdFilterFn.apply(x, gpre, geom)
 
@@ -120,10 +167,12 @@ class Conv2dFn(Function):
             gpre, gb = K.act_bwd_colsum(_c(gy), y, ctx.act, ctx.alpha, out=bsink)
             if bsink is not None:
                 gb = None                       # already summed into the optimizer's arena
+                _notify(ctx.bias_ref)
         else:
             gpre = _act_bwd(gy, y, ctx.act, ctx.alpha)
             if want_b and bsink is not None:
                 K.col_reduce(_c(gpre), out=bsink)
+                _notify(ctx.bias_ref)
             elif want_b:
                 gb = ColSumFn.apply(gpre)
         gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
@@ -160,6 +209,7 @@ class ConvBwdDataFn(Function):
             bsink = _sink_of(ctx.bias_ref)
             if bsink is not None:
                 K.col_reduce(_c(gpre), out=bsink)
+                _notify(ctx.bias_ref)
             else:
                 g_b = ColSumFn.apply(gpre)
         return g_dy, g_w, g_b, None, None, None
@@ -302,6 +352,7 @@ class BatchNormTrainFn(Function):
         gsink, bsink = _sink_of(ctx.gamma_ref), _sink_of(ctx.beta_ref)
         if gsink is not None and bsink is not None:
             dx, _, _ = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=gsink, dbeta_out=bsink)
+            _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
             return dx, None, None, None, None, None, None, None, None
         dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x)
         return dx, dgamma, dbeta, None, None, None, None, None, None

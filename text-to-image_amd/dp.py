@@ -5,9 +5,12 @@ kt and Adam state, sees its own slice of the global batch, and gradients are ave
 replicas at local batch b behave as the reference at BATCH_SIZE = N*b with per-replica batch-norm statistics.
 
 Exchange step: the gradient arena (optim.Arena.grad, one flat buffer per optimizer) is cut into contiguous buckets in
-REVERSE creation order (the order backward produces them).  A post-accumulate hook counts finished parameters; when a
-bucket is complete its all-reduce is issued on a side HIP stream while the main stream keeps running the remaining
-backward kernels.  xGMI is point-to-point (7 links x ~153 GB/s), ring all-reduce is per-link bound, so buckets are
+REVERSE creation order (the order backward produces them).  Finished parameters are counted — by a post-accumulate
+hook for gradients that go through autograd's AccumulateGrad, by autograd.NOTIFY for gradients that the kernels sum
+straight into the arena (gradient sinks: those never reach AccumulateGrad; how many contributions each parameter gets
+per backward is learned on the first armed step, which therefore exchanges after the backward).  When a bucket is
+complete its all-reduce is issued on a side HIP stream while the main stream keeps running the remaining backward
+kernels.  xGMI is point-to-point (7 links x ~153 GB/s), ring all-reduce is per-link bound, so buckets are
 large (default 32 MB) — few, big collectives.  The sum is turned into a mean inside the Adam kernel (grad_scale).
 """
 import torch
@@ -23,6 +26,7 @@ class DataParallel(object):
         self.rank = dist.get_rank(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._arenas = {}
+        self._by_ptr = {}
         self._side = None
 
     # ---- bucket plan ---------------------------------------------------------------------------------------------------
@@ -48,22 +52,48 @@ class DataParallel(object):
         key = id(arena)
         if key in self._arenas:
             return self._arenas[key]
-        st = {'buckets': self._plan(arena), 'pending': None, 'works': [], 'armed': False, 'arena': arena}
+        st = {'buckets': self._plan(arena), 'pending': None, 'works': [], 'armed': False, 'arena': arena,
+              'expect': None, 'seen': {}, 'owner_ptr': {}, 'launched': set()}
         owner = {}
         for bi, (_, _, names) in enumerate(st['buckets']):
             for n in names:
                 owner[n] = bi
         for n, v in arena.vars.items():
             v.register_post_accumulate_grad_hook(self._make_hook(st, owner[n]))
+            st['owner_ptr'][v.data_ptr()] = owner[n]
+            self._by_ptr[v.data_ptr()] = st
         self._arenas[key] = st
+        from . import autograd as A
+        A.NOTIFY[0] = self.notify
         return st
+
+    def notify(self, ptr):
+        """autograd.NOTIFY target: one more contribution to the parameter at `ptr` has been issued into its sink."""
+        st = self._by_ptr.get(ptr)
+        if st is None or not st['armed']:
+            return
+        c = st['seen'].get(ptr, 0) + 1
+        st['seen'][ptr] = c
+        exp = st['expect']
+        if exp is None:
+            return                                  # first armed step: only learning the counts
+        want = exp.get(ptr, 0)
+        if c == want:
+            bi = st['owner_ptr'][ptr]
+            st['pending'][bi] -= 1
+            if st['pending'][bi] == 0:
+                self._launch(st, bi)
+        elif c > want:
+            raise RuntimeError('data-parallel overlap: parameter received %d sunk gradient contributions, %d were learned '
+                               'on the first step (its bucket may already be in flight); the backward structure changed' %
+                               (c, want))
 
     def _make_hook(self, st, bi):
         def hook(_param):
             if not st['armed']:
                 return
             st['pending'][bi] -= 1
-            if st['pending'][bi] == 0:
+            if st['pending'][bi] == 0:             # (sunk parameters do not count down on the learning step)
                 self._launch(st, bi)
         return hook
 
@@ -72,15 +102,23 @@ class DataParallel(object):
         st = self.attach(arena)
         st['pending'] = [len(names) for _, _, names in st['buckets']]
         st['works'] = []
+        st['seen'] = {}
+        st['launched'] = set()
         st['armed'] = True
 
     def _launch(self, st, bi):
         start, end, _ = st['buckets'][bi]
+        if bi in st['launched']:
+            return
+        st['launched'].add(bi)
         buf = st['arena'].grad[start:end]
         if buf.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=buf.device)
             self._side.wait_stream(torch.cuda.current_stream(buf.device))   # gradients of this bucket are final
+            from . import autograd as A
+            if A.SIDE.stream is not None:                                   # ... including the filter-gradient stream's
+                self._side.wait_stream(A.SIDE.stream)
             with torch.cuda.stream(self._side):
                 st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -91,11 +129,13 @@ class DataParallel(object):
         summed gradients into the mean.  `extra`: a small tensor (the kt gradient) summed in place alongside."""
         st = self.attach(arena)
         if st['armed']:
-            for bi, left in enumerate(st['pending']):
-                if left > 0:                       # parameter unused this step: bucket never completed by hooks
-                    self._launch(st, bi)
+            if st['seen'] and st['expect'] is None:
+                st['expect'] = dict(st['seen'])    # contributions per sunk parameter, fixed by the model's structure
+            for bi in range(len(st['buckets'])):   # whatever hooks / notifications did not complete (unused parameters,
+                self._launch(st, bi)               # the learning step): launched now; _launch skips the ones in flight
         else:                                      # hooks were not armed: plain bucketed all-reduce after backward
             st['works'] = []
+            st['launched'] = set()
             for bi in range(len(st['buckets'])):
                 self._launch(st, bi)
         if extra is not None:

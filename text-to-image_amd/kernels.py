@@ -59,13 +59,15 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# ---- workspace: one grow-only buffer per device; all users are ordered on the current stream ---------------------------
+# ---- workspace: one grow-only buffer per (device, lane); all users of a buffer are ordered on one stream.  Lane 0 is the
+# caller's current stream; autograd's filter-gradient side stream launches under lane 1 (WS_LANE) -----------------------
+WS_LANE = [0]
 _WS = {}
 _WS_MIN = 64 << 20
 
 
 def workspace(device, nbytes):
-    key = (device.type, device.index)
+    key = (device.type, device.index, WS_LANE[0])
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing():

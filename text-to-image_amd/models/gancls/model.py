@@ -44,9 +44,10 @@ class GanCls(object):
         self.g_vars = S.trainable_variables('g_net')
         self.d_arena = optim.Arena(self.d_vars)
         self.g_arena = optim.Arena(self.g_vars)
-        if self.dp is None:
-            self.d_arena.enable_sinks()
-            self.g_arena.enable_sinks()
+        # gradients are accumulated by the kernels' epilogues straight into the optimizer arenas (autograd.SINKS); with
+        # data parallelism the bucket overlap follows autograd.NOTIFY instead of AccumulateGrad hooks (dp.py)
+        self.d_arena.enable_sinks()
+        self.g_arena.enable_sinks()
 
     def sampler(self, z_sample, phi_sample):
         with torch.no_grad():

@@ -5,6 +5,7 @@ import time
 
 import torch
 
+from ... import autograd as A
 from ... import optim
 from ...utils.ops import update_ops
 
@@ -44,6 +45,7 @@ class GanClsTrainer(object):
         if m.dp is not None:
             m.dp.arm(m.d_arena)
         D_loss.backward(inputs=list(m.d_vars.values()))
+        A.side_join()
         return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
                     D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G)
 
@@ -64,6 +66,7 @@ class GanClsTrainer(object):
         if m.dp is not None:
             m.dp.arm(m.g_arena)
         G_loss.backward(inputs=list(m.g_vars.values()))
+        A.side_join()
         return dict(G_loss=G_loss.detach(), G=G.detach())
 
     def iteration(self, feed):

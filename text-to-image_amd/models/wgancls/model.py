@@ -60,9 +60,10 @@ class WGanCls(object):
         self.g_vars = S.trainable_variables('g_net')
         self.d_arena = optim.Arena(self.d_vars)
         self.g_arena = optim.Arena(self.g_vars)
-        if self.dp is None:          # single replica: filter gradients are accumulated by the GEMM epilogues
-            self.d_arena.enable_sinks()
-            self.g_arena.enable_sinks()
+        # gradients are accumulated by the kernels' epilogues straight into the optimizer arenas (autograd.SINKS); with
+        # data parallelism the bucket overlap follows autograd.NOTIFY instead of AccumulateGrad hooks (dp.py)
+        self.d_arena.enable_sinks()
+        self.g_arena.enable_sinks()
 
     def get_gradient_penalty(self, x, y):
         """reference model.py:62-65: one-sided penalty on the per-sample gradient norm of y wrt x."""
@@ -126,6 +127,7 @@ class WGanCls(object):
         if self.dp is not None:
             self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this backward
         D_loss.backward(inputs=list(self.d_vars.values()))
+        A.side_join()                          # filter gradients issued on the side stream are in the arena
         with torch.no_grad():
             wd, wd2 = wdist.detach(), wdist2.detach()
             out = dict(D_loss=D_loss.detach(), D_loss_real=D_loss_real.detach(), D_loss_fake=D_loss_fake.detach(),
@@ -172,6 +174,7 @@ class WGanCls(object):
         if self.dp is not None:
             self.dp.arm(self.g_arena)
         G_loss.backward(inputs=list(self.g_vars.values()))
+        A.side_join()
         return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), D_loss_fake=D_loss_fake.detach(), G=G.detach())
 
     def _g_body(self, feed):
