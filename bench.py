@@ -23,6 +23,7 @@ import torch  # noqa: E402
 G_FWD_MAC = 969478144
 D_FWD_MAC = 694304768
 NOMINAL_FLOP_PER_IMAGE = 2 * (4 * G_FWD_MAC + 17 * D_FWD_MAC)      # 31.362 GFLOP, the survey's nominal count
+BF16_MATRIX_PEAK_TFLOPS = 2500.0                                   # dense bf16 MFMA peak (same guide)
 FP32_MATRIX_PEAK_TFLOPS = 157.3                                    # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
 
 
@@ -130,6 +131,9 @@ def main():
     ap.add_argument('--no-graphs', action='store_true', help='keep the step eager (default: hipGraph replay on 1 GPU)')
     ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
                     help='where the per-launch HIP events for the roofline block are recorded')
+    ap.add_argument('--math', choices=['f32', 'bf16'], default='f32',
+                    help="conv arithmetic: f32 = BASELINE config 2 (the headline metric); bf16 = config 3 (bf16 MFMA "
+                         "operands, fp32 accumulation and fp32 tensors) -- reported with dtype 'bf16', never the default")
     ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
                     help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
     ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
@@ -164,6 +168,7 @@ def main():
         from t2i_amd.dp import DataParallel
         dp = DataParallel()
 
+    K.set_math(args.math)
     cfg = make_cfg(args.batch)
     model = WGanCls(cfg, device=device, seed=0, dp=dp)
     if dp is not None:
@@ -217,9 +222,10 @@ def main():
 
     out = {'metric': 'images/sec (G+D step) at 64x64 batch=64', 'value': value, 'unit': 'images/sec', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': 'wgancls 64x64 batch=%d/GPU fp32, synthetic images + random 1024-d text embeddings, '
-                                  'D step (+kt) then G step, Adam(b1=0,b2=0.9)' % args.batch,
+           'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
+           'config': {'workload': 'wgancls 64x64 batch=%d/GPU ' % args.batch + ('fp32' if args.math == 'f32' else
+                                  'bf16-MFMA operands / fp32 accumulate+tensors (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
+                                  'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                       'launch': 'hipGraph replay (2 graphs/iteration)' if use_graphs else 'eager'},
            'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
@@ -229,15 +235,18 @@ def main():
             info = K.device_info(local_rank)
             achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
             traffic, traffic_src = None, None
-            try:   # HBM-side bytes per launch measured by rocprofv3 PMC passes over this same command (tools/pmc_summary.py)
+            peak = FP32_MATRIX_PEAK_TFLOPS if args.math == 'f32' else BF16_MATRIX_PEAK_TFLOPS
+            try:
+                if args.math != 'f32':
+                    raise KeyError('the PMC passes were taken in f32 mode')   # HBM-side bytes per launch measured by rocprofv3 PMC passes over this same command (tools/pmc_summary.py)
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_igemm.json')))
                 traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_pmc_igemm.json (FETCH_SIZE x2 + WRITE_SIZE)'
             except Exception:
                 pass
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
-                'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
                 'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
                 'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,

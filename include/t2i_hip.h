@@ -45,10 +45,15 @@ typedef struct t2i_conv_desc {
   int32_t Ho, Wo, Cout;  /* output [B,Ho,Wo,Cout] */
   int32_t KH, KW, SH, SW;
   int32_t pad_t, pad_l;  /* TF SAME puts the odd pixel bottom/right, so only top/left are needed */
+  int32_t math;          /* T2I_MATH_F32 (0): exact fp32 matrix pipe.  T2I_MATH_BF16 (1): operands rounded to bf16 (RNE)
+                          * inside the kernel, v_mfma_*_bf16 with fp32 accumulation; tensors in memory stay fp32
+                          * (BASELINE config 3).  The direct kernels for thin layers (Cin or Cout <= 4, the logit
+                          * head) compute in fp32 in both modes. */
 } t2i_conv_desc;
+enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 1 */
+int t2i_version(void);            /* ABI version, currently 2 (v2: t2i_conv_desc.math) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);

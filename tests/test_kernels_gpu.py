@@ -260,12 +260,23 @@ def test_cpu_tensor_is_refused(K):
         K.act_fwd(torch.zeros(8), K.ACT_RELU)
 
 
+def _bf16_round(a):
+    """fp32 -> nearest-even bf16 -> fp32 (what the bf16 math mode does to both operands inside the kernel)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).bfloat16().float().numpy()
+
+
 @pytest.mark.parametrize('tile', [22, 21, 12, 11])
 @pytest.mark.parametrize('splitk', [1, 3])
-def test_every_tile_and_split_config(K, monkeypatch, tile, splitk):
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_every_tile_and_split_config(K, monkeypatch, tile, splitk, math):
     """The planner picks tile shape / split-K per launch; here every combination is forced (tuning hooks
-    T2I_FORCE_TILE / T2I_FORCE_SPLITK, direct thin kernels off) on shapes with ragged M, N and K."""
+    T2I_FORCE_TILE / T2I_FORCE_SPLITK, direct thin kernels off) on shapes with ragged M, N and K.
+    math='bf16' (t2i_conv_desc.math = T2I_MATH_BF16, BASELINE config 3): the kernel rounds both operands to bf16 and
+    accumulates their exact products in fp32, so against the float64 oracle evaluated ON THE ROUNDED OPERANDS it must
+    meet the same tolerance as the fp32 path; the raw fp32 inputs are what is handed to the kernel."""
     from oracle import np_ops as O
+    rnd = _bf16_round if math == 'bf16' else (lambda a: a)
+    mcode = K.MATH_BF16 if math == 'bf16' else K.MATH_F32
     monkeypatch.setenv('T2I_FORCE_TILE', str(tile))
     monkeypatch.setenv('T2I_FORCE_SPLITK', str(splitk))
     monkeypatch.setenv('T2I_NO_THIN', '1')
@@ -279,10 +290,16 @@ def test_every_tile_and_split_config(K, monkeypatch, tile, splitk):
         x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
         w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
         b = rng.standard_normal(Co).astype(np.float32)
-        d, _ = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad)
+        d, _ = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad, math=mcode)
+        assert d.math == mcode
         ws = 256 << 20                       # forced splits can exceed the planner's own workspace estimate
-        y_ref = O.conv2d(x, w, b, (s, s), pad)
+        y_ref = O.conv2d(rnd(x), rnd(w), b, (s, s), pad)
         dy = rng.standard_normal(y_ref.shape).astype(np.float32)
         assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= FWD_TOL, case
-        assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (s, s), pad)) <= GRAD_TOL, case
-        assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), O.conv2d_bwd_filter(x, dy, w.shape, (s, s), pad)) <= GRAD_TOL, case
+        assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws),
+                      O.conv2d_bwd_data(rnd(dy), rnd(w), x.shape, (s, s), pad)) <= GRAD_TOL, case
+        assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws),
+                      O.conv2d_bwd_filter(rnd(x), rnd(dy), w.shape, (s, s), pad)) <= GRAD_TOL, case
+        if math == 'bf16':   # and it IS a reduced-precision product: visibly off the unrounded fp32 answer
+            e = relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), O.conv2d(x, w, b, (s, s), pad))
+            assert 1e-4 < e < 2e-2, (case, e)

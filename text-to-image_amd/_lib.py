@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get('T2I_HIP_LIB', os.path.join(_HERE, 'lib', 'libt2i_hip.
 class ConvDesc(ctypes.Structure):
     """t2i_conv_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in
-                ('B', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'SH', 'SW', 'pad_t', 'pad_l')]
+                ('B', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'SH', 'SW', 'pad_t', 'pad_l', 'math')]
 
 
 _p = ctypes.c_void_p

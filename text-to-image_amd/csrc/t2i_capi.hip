@@ -69,6 +69,7 @@ static int validate_desc(const t2i_conv_desc* d) {
     return T2I_ERR_INVALID;
   }
   if (d->SH > 4 || d->SW > 4) { set_error("stride > 4 unsupported (16 phases max)"); return T2I_ERR_INVALID; }
+  if (d->math != T2I_MATH_F32 && d->math != T2I_MATH_BF16) { set_error("unknown math mode %d in conv descriptor", d->math); return T2I_ERR_INVALID; }
   // the last output pixel must start inside the padded image (true for TF SAME / VALID geometries)
   if ((d->Ho - 1) * d->SH - d->pad_t >= d->H || (d->Wo - 1) * d->SW - d->pad_l >= d->W) {
     set_error("output extent inconsistent with input/stride/pad");
@@ -219,7 +220,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 1; }
+int t2i_version(void) { return 2; }
 
 const char* t2i_last_error(void) { return g_err; }
 

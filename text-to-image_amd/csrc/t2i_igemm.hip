@@ -21,6 +21,12 @@
 //            [BK/4][cols][4] image read with ds_read_b128 was tried: 4x fewer LDS reads but 16 extra v_mov per tile for
 //            the register transpose; measured 1-2% slower, so the plain image stays.)
 // Both feed the same k-permutation: MFMA j of 8-k chunk c consumes k = 8c+j (lanes 0-31) and 8c+4+j (lanes 32-63).
+// MATH = 1 (T2I_MATH_BF16): same gathers, same epilogue, but the operands are rounded to bf16 (RNE) on their way into LDS
+// and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE config 3: "bf16 MFMA + fp32 accumulate /
+// master"; tensors in HBM stay fp32).  Both LDS images are then K-inner [rows][32 bf16 + 16 B pad] read with one
+// ds_read_b128 per 16-k MFMA operand; an operand whose global layout is N-inner is transposed in registers by its
+// loader (each thread fetches LD consecutive k-rows of one 4-column group and packs k-pairs), because the bf16 MFMA
+// wants 8 consecutive k per lane for A and for B.
 // Split-K (grid.y) writes full-layout partial slabs that splitk_reduce sums in a fixed order (deterministic),
 // applying bias + activation there; without split-K the epilogue is fused here.
 #include <hip/hip_runtime.h>
@@ -32,21 +38,31 @@ namespace t2i {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32;
 constexpr int KPAD = 4;              // K-inner row stride = 36 dwords
 constexpr int KSTRIDE = BK + KPAD;
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every legal buffer: the load returns 0
+constexpr int HSTRIDE = 20;          // bf16 image: row stride in dwords (32 bf16 = 16 dwords + 4 pad; 20r mod 64 is conflict
+                                     // free for ds_read_b128's 16-lane groups)
 
-template <int MODE, int WMT, int WNT>
+template <int MODE, int WMT, int WNT, int MATH>
 struct Smem {
   static constexpr int BM = 64 * WMT, BN = 64 * WNT;
   static constexpr bool A_KINNER = (MODE != MODE_BWD_FILTER);
   static constexpr bool B_KINNER = (MODE == MODE_BWD_DATA);
-  static constexpr int A_ELEMS = A_KINNER ? BM * KSTRIDE : BK * BM;
-  static constexpr int B_ELEMS = B_KINNER ? BN * KSTRIDE : BK * BN;
+  static constexpr int A_ELEMS = MATH ? BM * HSTRIDE : (A_KINNER ? BM * KSTRIDE : BK * BM);   // dwords per buffer
+  static constexpr int B_ELEMS = MATH ? BN * HSTRIDE : (B_KINNER ? BN * KSTRIDE : BK * BN);
   static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
 };
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32: round to nearest even
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)elem_off * 4u : OOB, 0, 0);
@@ -131,11 +147,12 @@ __device__ __forceinline__ void bT_offset(const IgemmParams& p, const PhaseInfo&
 //      2 = 16-byte gathers with a TAP-UNIFORM K-tile (gathered channels % 32 == 0): one K-tile never straddles a filter
 //          tap, so (kh,kw,c0) are computed once per tile on the scalar unit and each load costs ~8 VALU instructions
 //          instead of ~25 (measured: the address arithmetic was the largest non-MFMA cost, 10-14% of the kernel).
-template <int MODE, int WMT, int WNT, int VAR>
+template <int MODE, int WMT, int WNT, int VAR, int MATH>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr bool VEC = VAR >= 1;
   constexpr bool UT = VAR == 2;
-  using S = Smem<MODE, WMT, WNT>;
+  constexpr bool BF = MATH == 1;
+  using S = Smem<MODE, WMT, WNT, MATH>;
   constexpr int BM = S::BM, BN = S::BN;
   constexpr bool A_KINNER = S::A_KINNER, B_KINNER = S::B_KINNER;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -188,9 +205,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     for (int i = 0; i < A_LD; ++i) a_rowoff[i] = (arow[i].base + arow[i].h0 * Wsrc + arow[i].w0) * Csrc + kq * 4;
   }
   constexpr int A_C4 = BM / 4, B_C4 = BN / 4;          // float4 columns per k-row (N-inner images)
-  constexpr int A_KSTEP = 256 / A_C4, B_KSTEP = 256 / B_C4;
-  const int a_c4 = tid % A_C4, a_kr0 = tid / A_C4;
-  const int b_c4 = tid % B_C4, b_kr0 = tid / B_C4;
+  // fp32: thread -> (column quad, k rows kr0 + KSTEP*i).  bf16: thread -> (k group of LD CONSECUTIVE rows, column quad),
+  // k group fastest over lanes, so that the packed k-pairs of one column are a contiguous run of LDS words (conflict-free
+  // transposing store) while a wave still fetches whole 128-byte lines.
+  constexpr int A_KSTEP = BF ? 1 : 256 / A_C4, B_KSTEP = BF ? 1 : 256 / B_C4;
+  constexpr int A_KG = BK / (A_KINNER ? 1 : A_LD), B_KG = BK / (B_KINNER ? 1 : B_LD);
+  const int a_c4 = BF ? tid / A_KG : tid % A_C4, a_kr0 = BF ? (tid % A_KG) * (A_KINNER ? 1 : A_LD) : tid / A_C4;
+  const int b_c4 = BF ? tid / B_KG : tid % B_C4, b_kr0 = BF ? (tid % B_KG) * (B_KINNER ? 1 : B_LD) : tid / B_C4;
   // BWD_FILTER A (x gathered, rows i=(kh,kw,ci) contiguous in ci): per-thread fixed (kh,kw,ci) for its 4 columns
   int fa_kh[4], fa_kw[4], fa_ci[4];
   bool fa_ok[4];
@@ -380,6 +401,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   auto store_tile = [&](int buf) {
     float* as = As + buf * S::A_ELEMS;
     float* bs = Bs + buf * S::B_ELEMS;
+    if (BF) {
+      unsigned* au = reinterpret_cast<unsigned*>(as);
+      unsigned* bu = reinterpret_cast<unsigned*>(bs);
+      if (A_KINNER) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+          *reinterpret_cast<uint2*>(&au[(r0 + 32 * i) * HSTRIDE + kq * 2]) =
+              make_uint2(pk_bf16(areg[i].x, areg[i].y), pk_bf16(areg[i].z, areg[i].w));
+      } else {   // areg[i] = 4 columns of k-row a_kr0 + i: transpose to [column][k]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned* dst = &au[(a_c4 * 4 + j) * HSTRIDE + (a_kr0 >> 1)];
+#pragma unroll
+          for (int i = 0; i < A_LD; i += 2)
+            dst[i >> 1] = pk_bf16(reinterpret_cast<const float*>(&areg[i])[j], reinterpret_cast<const float*>(&areg[i + 1])[j]);
+        }
+      }
+      if (B_KINNER) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+          *reinterpret_cast<uint2*>(&bu[(r0 + 32 * i) * HSTRIDE + kq * 2]) =
+              make_uint2(pk_bf16(breg[i].x, breg[i].y), pk_bf16(breg[i].z, breg[i].w));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned* dst = &bu[(b_c4 * 4 + j) * HSTRIDE + (b_kr0 >> 1)];
+#pragma unroll
+          for (int i = 0; i < B_LD; i += 2)
+            dst[i >> 1] = pk_bf16(reinterpret_cast<const float*>(&breg[i])[j], reinterpret_cast<const float*>(&breg[i + 1])[j]);
+        }
+      }
+      return;
+    }
     if (A_KINNER) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = areg[i];
@@ -404,6 +458,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  if constexpr (BF) {
+    // ---- bf16 main loop: 2 MFMA k-steps of 16 per K-tile; the loop is bound by the fp32 operand fetch, not by the MFMAs
+    // (8 per wave-tile, 32 cycles each), so the schedule is the plain one: fragments of tile t -> registers, tile t+1
+    // registers -> the other LDS buffer, loads of tile t+2, MFMAs, one barrier.
+    struct FragH { bf16x8 a[WMT][2]; bf16x8 b[WNT][2]; };
+    auto read_h = [&](FragH& f, const float* as, const float* bs) {
+      const unsigned* au = reinterpret_cast<const unsigned*>(as);
+      const unsigned* bu = reinterpret_cast<const unsigned*>(bs);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+          f.a[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+              &au[(wm * 32 * WMT + i * 32 + l31) * HSTRIDE + s * 8 + lh * 4]));
+#pragma unroll
+        for (int i = 0; i < WNT; ++i)
+          f.b[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+              &bu[(wn * 32 * WNT + i * 32 + l31) * HSTRIDE + s * 8 + lh * 4]));
+      }
+    };
+    load_tile(0);
+    store_tile(0);
+    load_tile(1);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      FragH f;
+      read_h(f, As + (t & 1) * S::A_ELEMS, Bs + (t & 1) * S::B_ELEMS);
+      store_tile((t + 1) & 1);
+      load_tile(t + 2);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int n = 0; n < WNT; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][s], f.b[n][s], acc[i][n], 0, 0, 0);
+      __syncthreads();
+    }
+  } else {
   // fragments of one 8-k chunk: 4 MFMA steps x (WMT + WNT) operands
   struct Frag { float a[WMT][4]; float b[WNT][4]; };
 
@@ -497,6 +590,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     k_tile(t + 1, fb0, fb1, fa0, fa1);
   }
   if (t < ntiles) k_tile(t, fa0, fa1, fb0, fb1);
+  }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -581,10 +675,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* 
 // ------------------------------------------------------------------------------------------------------------------
 // host-side launch
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE, int WMT, int WNT, int VAR>
+template <int MODE, int WMT, int WNT, int VAR, int MATH>
 static hipError_t launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = Smem<MODE, WMT, WNT>;
-  auto k = igemm_kernel<MODE, WMT, WNT, VAR>;
+  using S = Smem<MODE, WMT, WNT, MATH>;
+  auto k = igemm_kernel<MODE, WMT, WNT, VAR, MATH>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
@@ -595,12 +689,12 @@ static hipError_t launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t stream
   return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, int MATH>
 static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, dim3 grid, hipStream_t stream) {
 #define T2I_CASE(a, b)                                                             \
   if (wmt == a && wnt == b) {                                                      \
-    if (var == 2) return launch_cfg<MODE, a, b, 2>(p, grid, stream);               \
-    return var >= 1 ? launch_cfg<MODE, a, b, 1>(p, grid, stream) : launch_cfg<MODE, a, b, 0>(p, grid, stream); \
+    if (var == 2) return launch_cfg<MODE, a, b, 2, MATH>(p, grid, stream);         \
+    return var >= 1 ? launch_cfg<MODE, a, b, 1, MATH>(p, grid, stream) : launch_cfg<MODE, a, b, 0, MATH>(p, grid, stream); \
   }
   T2I_CASE(2, 2)
   T2I_CASE(2, 1)
@@ -612,10 +706,18 @@ static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, d
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
+  if (p.d.math == T2I_MATH_BF16) {
+    switch (mode) {
+      case MODE_FWD: return launch_mode<MODE_FWD, 1>(p, wmt, wnt, var, grid, stream);
+      case MODE_BWD_DATA: return launch_mode<MODE_BWD_DATA, 1>(p, wmt, wnt, var, grid, stream);
+      case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER, 1>(p, wmt, wnt, var, grid, stream);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (mode) {
-    case MODE_FWD: return launch_mode<MODE_FWD>(p, wmt, wnt, var, grid, stream);
-    case MODE_BWD_DATA: return launch_mode<MODE_BWD_DATA>(p, wmt, wnt, var, grid, stream);
-    case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER>(p, wmt, wnt, var, grid, stream);
+    case MODE_FWD: return launch_mode<MODE_FWD, 0>(p, wmt, wnt, var, grid, stream);
+    case MODE_BWD_DATA: return launch_mode<MODE_BWD_DATA, 0>(p, wmt, wnt, var, grid, stream);
+    case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER, 0>(p, wmt, wnt, var, grid, stream);
   }
   return hipErrorInvalidValue;
 }

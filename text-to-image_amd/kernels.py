@@ -86,10 +86,25 @@ def same_pad(in_size, k, s):
 
 _DESC_CACHE = {}
 
+# Arithmetic of the conv family (t2i_conv_desc.math): 'f32' = exact fp32 matrix pipe (default, BASELINE config 2);
+# 'bf16' = operands rounded to bf16 inside the kernel, bf16 MFMA with fp32 accumulation, fp32 tensors (config 3).
+MATH_F32, MATH_BF16 = 0, 1
+_MATH = [MATH_F32]
 
-def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
+
+def set_math(mode):
+    """Select the arithmetic of every conv/deconv/dense descriptor created from now on: 'f32' or 'bf16'."""
+    _MATH[0] = {'f32': MATH_F32, 'fp32': MATH_F32, 'bf16': MATH_BF16}[str(mode).lower()]
+
+
+def get_math():
+    return 'bf16' if _MATH[0] == MATH_BF16 else 'f32'
+
+
+def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding, math=None):
     """-> (ConvDesc, workspace_bytes) for y = conv(x[B,H,W,Cin], w[KH,KW,Cin,Cout]) with a TF padding string."""
-    key = (B, H, W, Cin, Cout, KH, KW, SH, SW, padding.upper())
+    math = _MATH[0] if math is None else math
+    key = (B, H, W, Cin, Cout, KH, KW, SH, SW, padding.upper(), math)
     hit = _DESC_CACHE.get(key)
     if hit is not None:
         return hit
@@ -103,13 +118,13 @@ def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
         raise ValueError('Invalid padding %s' % padding)
     if Ho <= 0 or Wo <= 0:
         raise ValueError('convolution output is empty for input %dx%d kernel %dx%d' % (H, W, KH, KW))
-    d = ConvDesc(B, H, W, Cin, Ho, Wo, Cout, KH, KW, SH, SW, pt, pl)
+    d = ConvDesc(B, H, W, Cin, Ho, Wo, Cout, KH, KW, SH, SW, pt, pl, math)
     ws = int(lib.t2i_conv2d_workspace_bytes(ctypes.byref(d)))
     _DESC_CACHE[key] = (d, ws)
     return d, ws
 
 
-def deconv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
+def deconv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding, math=None):
     """Descriptor of the ADJOINT conv of a TF conv2d_transpose x[B,H,W,Cin] -> [B,Hout,Wout,Cout]: that conv maps
     [B,Hout,Wout,Cout] -> [B,H,W,Cin] with HWIO filter [KH,KW,Cout,Cin] (the TF deconv layout)."""
     p = padding.upper()
@@ -119,7 +134,7 @@ def deconv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding):
         Hout, Wout = (H - 1) * SH + KH, (W - 1) * SW + KW
     else:
         raise ValueError('Invalid padding %s' % padding)
-    d, ws = conv_desc(B, Hout, Wout, Cout, Cin, KH, KW, SH, SW, padding)
+    d, ws = conv_desc(B, Hout, Wout, Cout, Cin, KH, KW, SH, SW, padding, math)
     if (d.Ho, d.Wo) != (H, W):
         raise ValueError('conv2d_transpose geometry mismatch: adjoint conv gives %dx%d, input is %dx%d' % (d.Ho, d.Wo, H, W))
     return d, ws

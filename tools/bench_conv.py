@@ -42,7 +42,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--filter', default='')
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16'])
     a = ap.parse_args()
+    K.set_math(a.math)
     tot = {'fwd': [0, 0], 'bwd_data': [0, 0], 'bwd_filter': [0, 0]}
     print('%-6s %5s %22s %10s | %8s %6s | %8s %6s | %8s %6s' % ('layer', 'B', 'shape', 'GFLOP', 'fwd us', 'TF/s', 'bwdD us', 'TF/s', 'bwdF us', 'TF/s'))
     for name, H, W, Ci, Co, k, s, pad in LAYERS:
