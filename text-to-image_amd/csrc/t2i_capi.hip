@@ -97,15 +97,24 @@ static int env_int(const char* name, int dflt) {
 // last partial round (each CU works through its workgroups at a fixed MFMA rate; co-resident workgroups time-share).
 // So: for every tile shape and split factor estimate  rounds x (K-tiles per split + fixed overhead) x tile work
 // (+ the split-K reduction traffic) and take the cheapest.
-static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32) {
+// bf16 math: the MFMAs are 16x faster but the operands are still fetched as fp32, so the kernel is bound by the L2 -> LDS
+// operand stream (measured ~16 TB/s chip-wide on 128x128 tiles): bytes per FLOP scale with 1/tile edge, which is what
+// rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
+static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0) {
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
-  static const double rel_eff[4] = {1.0, 0.97, 0.97, 0.93};   // MFMA efficiency relative to the 128x128 tile
-  static const int max_resident[4] = {2, 3, 3, 4};            // co-resident workgroups per CU (LDS / VGPR limited)
+  static const double rel_eff_f32[4] = {1.0, 0.97, 0.97, 0.93};   // MFMA efficiency relative to the 128x128 tile
+  static const double rel_eff_bf16[4] = {1.0, 0.74, 0.74, 0.55};
+  static const int max_resident_f32[4] = {2, 3, 3, 4};            // co-resident workgroups per CU (LDS / VGPR limited)
+  static const int max_resident_bf16[4] = {3, 4, 4, 4};
   // sustained rate of a CU as a function of how many workgroups it time-shares: one workgroup alone leaves the matrix
   // pipe idle during its barrier / LDS-fill phases (measured: 128x128 tiles, 256 vs 512 workgroups: 0.80 vs 0.95)
-  static const double share_eff[5] = {0.0, 0.80, 0.95, 1.0, 1.0};
-  const double unit_us = 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
-  const double overhead_tiles = 3.0; // prologue + epilogue of a workgroup, in K-tile steps
+  static const double share_eff_f32[5] = {0.0, 0.80, 0.95, 1.0, 1.0};
+  static const double share_eff_bf16[5] = {0.0, 0.62, 0.86, 1.0, 1.0};
+  const double* rel_eff = math ? rel_eff_bf16 : rel_eff_f32;
+  const int* max_resident = math ? max_resident_bf16 : max_resident_f32;
+  const double* share_eff = math ? share_eff_bf16 : share_eff_f32;
+  const double unit_us = math ? 0.135 : 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
+  const double overhead_tiles = math ? 8.0 : 3.0;   // prologue + epilogue of a workgroup, in K-tile steps
   const int64_t ktiles = (K + 31) / 32;
   int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
@@ -133,7 +142,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
       double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * share_eff[resident]);
-      if (sk_eff > 1) t += 4.0 + (double)out_elems * 4.0 * (double)(sk_eff + 1) / 4.0e6;   // slabs out + in at ~4 TB/s
+      if (sk_eff > 1) t += (math ? 2.0 : 4.0) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
       if (t < best_t) {
         best_t = t;
         best.wmt = wmt; best.wnt = wnt;
@@ -191,7 +200,7 @@ static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256
 
 static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* out, const float* bias, int act,
                     float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what, int accumulate = 0) {
-  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode));
+  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode), p.d.math);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
   p.out_elems = out_elems;
@@ -240,11 +249,11 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   fill_common(p, d);
   const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout,
                nw = (size_t)d->KH * d->KW * d->Cin * d->Cout;
-  size_t need = make_plan((int64_t)d->B * d->Ho * d->Wo, d->Cout, (int64_t)d->KH * d->KW * d->Cin, 1, ny).ws_bytes;
+  size_t need = make_plan((int64_t)d->B * d->Ho * d->Wo, d->Cout, (int64_t)d->KH * d->KW * d->Cin, 1, ny, 32, d->math).ws_bytes;
   int kmax = fill_phases(p);
-  size_t b = make_plan((int64_t)d->B * p.hqwq, d->Cin, kmax, p.nphase, nx).ws_bytes;
+  size_t b = make_plan((int64_t)d->B * p.hqwq, d->Cin, kmax, p.nphase, nx, 32, d->math).ws_bytes;
   if (b > need) need = b;
-  b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER)).ws_bytes;
+  b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER), d->math).ws_bytes;
   if (b > need) need = b;
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
   return need;

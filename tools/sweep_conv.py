@@ -11,6 +11,8 @@ from tools.bench_conv import LAYERS, timeit  # noqa: E402
 
 WANT = [('D2', 64), ('D3', 64), ('D4', 64), ('D7', 64), ('D10', 64), ('G5c', 64), ('G8c', 64), ('G4c', 64), ('D4', 192),
         ('D10', 192), ('D2', 192)]
+if os.environ.get('T2I_SWEEP_MATH'):
+    K.set_math(os.environ['T2I_SWEEP_MATH'])
 if len(sys.argv) > 1:
     WANT = [(a.split(':')[0], int(a.split(':')[1])) for a in sys.argv[1:]]
 L = {l[0]: l for l in LAYERS}
