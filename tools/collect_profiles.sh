@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh).
+# Kernel trace and each PMC group are separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
+# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/r01/.
+set -u
+REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+OUT="$REPO/gpurun_out/r01"; rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -o r -- $BENCH --steps 5 --warmup 2 > "$OUT/ktrace.log" 2>&1
+cp "$(find "$OUT/ktrace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bench_s5w2.csv"
+python "$REPO/tools/prof_summary.py" "$OUT/ktrace" 7 45 > "$OUT/kernel_stats_summary.txt" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+  tag=$(echo "$grp" | cut -d' ' -f1)
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$tag" -o r -- $BENCH --steps 3 --warmup 2 --no-graphs > "$OUT/pmc_$tag.log" 2>&1
+done
+python "$REPO/tools/pmc_summary.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES" 5 "$OUT/pmc_igemm.json" > "$OUT/pmc_summary.log" 2>&1
+cd "$REPO"
+timeout 300 python tools/bench_conv.py --batch 64 > "$OUT/conv_microbench_B64.txt" 2>&1
+timeout 300 python tools/bench_conv.py --batch 192 --filter D > "$OUT/conv_microbench_B192.txt" 2>&1
+timeout 300 python tools/bench_conv.py --batch 64 --math bf16 > "$OUT/conv_microbench_bf16_B64.txt" 2>&1
+timeout 300 python bench.py --math bf16 --no-cpu-baseline 2>/dev/null | grep '"metric"' > "$OUT/bench_line_bf16.json"
+timeout 600 python bench.py 2>/dev/null | grep '"metric"' > "$OUT/bench_line.json"
+# drop the bulky raw traces, keep the per-pass counter csv of the MFMA pass for reference
+rm -rf "$OUT/ktrace" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES"
+ls -la "$OUT"; cat "$OUT/pmc_summary.log" | tail -30; cat "$OUT/bench_line.json"

@@ -9,7 +9,7 @@ import sys
 
 
 def agg(d):
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'))[0]
     tot = collections.defaultdict(float)
     seen, dur = set(), 0
     for r in csv.DictReader(open(f)):

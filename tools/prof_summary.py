@@ -6,7 +6,7 @@ import sys
 
 d, iters = sys.argv[1], float(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-f = glob.glob(d + '/*/*kernel_stats.csv')[0]
+f = (glob.glob(d + '/*/*kernel_stats.csv') + glob.glob(d + '/*kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 ig = sum(float(r['TotalDurationNs']) for r in rows if 'igemm_kernel' in r['Name'])
