@@ -171,7 +171,61 @@ def make_gancls_step():
     return out
 
 
+STACKGAN1_TINY = dict(z_dim=8, embed_dim=32, compressed=16, gf=8, df=8, batch=4)
+STACKGAN2_TINY = dict(z_dim=8, embed_dim=16, compressed=8, gf=4, df=2, batch=2, out_size=256, real_label=0.95)
+STACKGAN_EPOCH = 150          # lr = D_LR * 0.5 ** (150 // 100): the decay schedule is part of the fixture
+
+
+def make_stackgan_step(stage):
+    """Tiny StackGAN Stage-I / Stage-II iteration (reference models/stackgan/stage{I,II}): losses, all gradients and the
+    post-update weights + BN moving statistics after one trainer iteration.  Stage II carries the Stage-I generator's
+    variables too (it runs inside the Stage-II graph).  Image inputs are quantised to 256 levels so the file deflates."""
+    from oracle import torch_stackgan as SG
+    c1 = SG.Cfg(**STACKGAN1_TINY)
+    cfg = c1 if stage == 1 else SG.Cfg(**STACKGAN2_TINY)
+    cfg1 = None if stage == 1 else SG.Cfg(**dict(STACKGAN1_TINY, embed_dim=STACKGAN2_TINY['embed_dim'], batch=STACKGAN2_TINY['batch']))
+    P = SG.init_variables(cfg, stage, cfg1, seed=0)
+    rng = np.random.default_rng(21 + stage)
+    for n in P:   # N(0,0.02) / He kernels at these widths make the nets almost linear: widen them so every branch is live
+        if n.endswith('weights') or n.endswith('kernel'):
+            he = n.startswith('stageII_g_net') and 'Conv2d_transpose' not in n and 'dense' not in n
+            P[n] = P[n] * (1.5 if he else (12.0 if 'Conv' in n else 4.0))
+        if n.endswith('biases') or n.endswith('bias') or n.endswith('beta'):
+            P[n] = torch.tensor(rng.standard_normal(tuple(P[n].shape)) * 0.1)
+    feed = SG.synthetic_feed(cfg, stage, cfg1, seed=1)
+    for k in ('x', 'x_mismatch'):
+        feed[k] = torch.round((feed[k] + 1.0) * 127.5) / 127.5 - 1.0
+    for n in P:
+        P[n] = P[n].float().double()
+    for n in feed:
+        feed[n] = feed[n].float().double()
+    out = {}
+    for n, v in P.items():
+        out['param/' + n] = v.numpy().astype(np.float32)
+    for n, v in feed.items():
+        out['feed/' + n] = v.numpy().astype(np.float32)
+    d = SG.d_step(P, cfg, feed, stage, cfg1)
+    for k_ in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
+        out['d/' + k_] = np.array(d[k_])
+    for n, v in d['grads'].items():
+        out['d/grad/' + n] = v.numpy().astype(np.float32)
+    g = SG.g_step(P, cfg, feed, stage, cfg1)
+    for k_ in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
+        out['g/' + k_] = np.array(g[k_])
+    for n, v in g['grads'].items():
+        out['g/grad/' + n] = v.numpy().astype(np.float32)
+    gimg = g['G'].numpy()
+    out['g/G_sample'] = gimg[:, ::4, ::4, :].astype(np.float32)          # a strided sample of the generated image
+    tr = SG.Trainer(cfg, dict(P), stage, cfg1)
+    tr.iteration(feed, epoch=STACKGAN_EPOCH)
+    for n, v in tr.P.items():
+        out['after/' + n] = v.numpy().astype(np.float32)
+    return out
+
+
 if __name__ == '__main__':
+    np.savez_compressed(os.path.join(HERE, 'stackgan1_tiny.npz'), **make_stackgan_step(1))
+    np.savez_compressed(os.path.join(HERE, 'stackgan2_tiny.npz'), **make_stackgan_step(2))
     np.savez_compressed(os.path.join(HERE, 'gancls_tiny.npz'), **make_gancls_step())
     ops = make_ops()
     np.savez_compressed(os.path.join(HERE, 'ops_tiny.npz'), **ops)

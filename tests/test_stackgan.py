@@ -1,0 +1,172 @@
+"""StackGAN Stage-I / Stage-II (reference models/stackgan): host-side variable registry on CPU,
+whole-iteration parity on the GPU against the committed golden steps (tests/golden/stackgan{1,2}_tiny.npz, generated
+by oracle/torch_stackgan.py in float64)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(z, e, c, gf, df, B, size):
+    from t2i_amd.utils.config import AttrDict
+    return AttrDict({'MODEL': {'Z_DIM': z, 'OUTPUT_SIZE': size, 'EMBED_DIM': e, 'COMPRESSED_EMBED_DIM': c, 'GF_DIM': gf,
+                               'DF_DIM': df, 'IMAGE_SHAPE': {'W': size, 'H': size, 'D': 3}},
+                     'TRAIN': {'BATCH_SIZE': B, 'SAMPLE_NUM': 4, 'EPOCH': 1, 'D_LR': 2e-4, 'D_BETA_DECAY': 0.5, 'G_LR': 2e-4,
+                               'G_BETA_DECAY': 0.5, 'COEFF': {'ALPHA_MISMATCH_LOSS': 0.5, 'KL': 2.0}}})
+
+
+def _make_golden():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    return mg
+
+
+def _models(stage, dev, tiny=True):
+    import t2i_amd  # noqa: F401
+    from t2i_amd.models.stackgan.stageI.model import ConditionalGan as StageI
+    from t2i_amd.models.stackgan.stageII.model import ConditionalGan as StageII
+    mg = _make_golden()
+    t1, t2 = mg.STACKGAN1_TINY, mg.STACKGAN2_TINY
+    if stage == 1:
+        return StageI(_cfg(t1['z_dim'], t1['embed_dim'], t1['compressed'], t1['gf'], t1['df'], t1['batch'], 64), device=dev)
+    s1 = StageI(_cfg(t1['z_dim'], t2['embed_dim'], t1['compressed'], t1['gf'], t1['df'], t2['batch'], 64), build_model=False,
+                device=dev)
+    return StageII(s1, _cfg(t2['z_dim'], t2['embed_dim'], t2['compressed'], t2['gf'], t2['df'], t2['batch'], 256))
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_stackgan_registry_matches_oracle(stage):
+    """Variable names (tf.contrib.layers / tf.layers auto-names), shapes and creation order of the full-width models =
+    the oracle's independent restatement of the reference graphs; spot checks of the reference's initializers."""
+    import t2i_amd  # noqa: F401
+    from oracle import torch_stackgan as SG
+    from t2i_amd.models.stackgan.stageI.model import ConditionalGan as StageI
+    from t2i_amd.models.stackgan.stageII.model import ConditionalGan as StageII
+    from t2i_amd.utils.config import config_from_yaml
+    base = os.path.join(ROOT, 'text-to-image_amd', 'models', 'stackgan')
+    c1 = config_from_yaml(os.path.join(base, 'stageI', 'cfg', 'flowers.yml'))
+    c1.TRAIN.BATCH_SIZE = 2
+    if stage == 1:
+        m = StageI(c1, device='cpu')
+        ref = SG.init_variables(SG.Cfg(), 1)
+    else:
+        c2 = config_from_yaml(os.path.join(base, 'stageII', 'cfg', 'flowers.yml'))
+        c2.TRAIN.BATCH_SIZE = 2
+        m = StageII(StageI(c1, build_model=False, device='cpu'), c2)
+        ref = SG.init_variables(SG.Cfg(out_size=256, real_label=0.95), 2, SG.Cfg())
+    mine = [(n, tuple(v.shape)) for n, v in m.store.vars.items()]
+    assert mine == [(n, tuple(v.shape)) for n, v in ref.items()]
+    V = m.store.vars
+    if stage == 1:
+        assert tuple(V['d_net/Conv_7/weights'].shape) == (1, 1, 512 + 128, 512) and tuple(V['d_net/Conv_8/weights'].shape) == (4, 4, 512, 1)
+        assert tuple(V['g_net/dense_2/kernel'].shape) == (100 + 128, 128 * 8 * 16)
+        assert abs(float(V['g_net/Conv_2/weights'].std()) / 0.02 - 1) < 0.02                    # w_init = N(0, 0.02)
+        assert list(m.g_vars)[0] == 'g_net/dense/kernel' and all(n.startswith('d_net/') for n in m.d_vars)
+    else:
+        assert tuple(V['stageII_g_net/Conv_3/weights'].shape) == (3, 3, 512 + 128, 512)          # encoded image ++ text code
+        assert tuple(V['stageII_g_net/Conv_4/weights'].shape) == (4, 4, 512, 512)                # residual layer: k4 s1
+        assert tuple(V['stageII_d_net/Conv_5/weights'].shape) == (4, 4, 1024, 2048)
+        w = V['stageII_g_net/Conv_4/weights']                                                    # no init passed: He
+        assert abs(float(w.std()) / (0.87962566 * (1.3 * 2.0 / (16 * 512)) ** 0.5) - 1) < 0.02
+        assert abs(float(V['stageII_g_net/Conv2d_transpose/weights'].std()) / 0.02 - 1) < 0.02   # init=w_init
+        assert all(n.startswith('stageII_g_net/') for n in m.g_vars)                             # Stage-I G is frozen
+        assert 'g_net/dense/kernel' in V and 'd_net/Conv/weights' not in V
+    g = V[('d_net' if stage == 1 else 'stageII_d_net') + '/BatchNorm_2/gamma']
+    assert abs(float(g.mean()) - 1) < 0.01 and 0.01 < float(g.std()) < 0.03                      # gamma ~ N(1, 0.02)
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_stackgan_golden_regenerates(stage):
+    golden = np.load(os.path.join(ROOT, 'tests', 'golden', 'stackgan%d_tiny.npz' % stage))
+    fresh = _make_golden().make_stackgan_step(stage)
+    assert sorted(fresh) == sorted(golden.files)
+    for k in fresh:
+        np.testing.assert_allclose(fresh[k], golden[k], rtol=1e-6, atol=1e-9, err_msg=k)
+
+
+def relerr(got, ref, floor=1e-30):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), floor))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stage', [1, 2])
+def test_stackgan_tiny_iteration_matches_golden(stage):
+    """Stage-I: losses rel <= 1e-4, gradients max-norm <= 2e-3 per tensor (exact-zero ones: abs <= 1e-4); Stage-II (much
+    deeper, tolerances in the body): 1e-3 / 2e-2.  Then one full trainer
+    iteration at epoch 150 (lr = D_LR / 2): Adam(beta1=.5) step and every batch-norm moving average — including, for
+    Stage-II, those of the frozen Stage-I generator that runs inside the graph in training mode."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from t2i_amd.models.stackgan.stageI.trainer import ConditionalGanTrainer as T1
+    from t2i_amd.models.stackgan.stageII.trainer import ConditionalGanTrainer as T2
+    gs = np.load(os.path.join(ROOT, 'tests', 'golden', 'stackgan%d_tiny.npz' % stage))
+    dev = torch.device('cuda')
+    m = _models(stage, dev)
+    params = {k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')}
+    m.store.load(params)
+    f = {k[len('feed/'):]: torch.tensor(gs[k], dtype=torch.float32, device=dev) for k in gs.files if k.startswith('feed/')}
+    feed = {'inputs': f['x'], 'wrong_inputs': f['x_mismatch'], 'phi_inputs': f['cond'], 'z': f['z']}
+    feed.update({k: v for k, v in f.items() if k.startswith('ca_noise')})
+    moving0 = {n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n}
+    Trainer = T1 if stage == 1 else T2
+    tr = Trainer(None, m, None, m.cfg)
+    d = tr.d_losses(feed)
+    # Stage-II stacks ~45 conv + batch-norm layers whose statistics are taken over as few as 32 values (B=2, 4x4 maps,
+    # kernels widened 12x): fp32 rounding reaches the logits at ~1e-3, so its scalar tolerance is 1e-3 instead of 1e-4
+    # (torch-CPU fp32 is at 4e-5 on the same tensors: the ~35x ratio is the sequential fp32 MFMA accumulation)
+    ltol, gtol, itol, mtol = (1e-4, 2e-3, 1e-3, 5e-4) if stage == 1 else (1e-3, 2e-2, 5e-3, 5e-3)
+    for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
+        assert abs(float(d[k]) - float(gs['d/' + k])) <= ltol * max(abs(float(gs['d/' + k])), 1.0), (k, float(d[k]), float(gs['d/' + k]))
+
+    def check(arena, names, prefix, tol=None):
+        tol = tol or gtol
+        for n in names:
+            ref = gs[prefix + n]
+            if np.abs(ref).max() < 1e-9:
+                assert float(arena.grad_of(n).abs().max()) <= 1e-4, n
+            else:
+                assert relerr(arena.grad_of(n), ref) <= tol, (n, relerr(arena.grad_of(n), ref))
+        got = torch.cat([arena.grad_of(n).reshape(-1).double().cpu() for n in names])
+        want = torch.cat([torch.from_numpy(np.asarray(gs[prefix + n], np.float64)).reshape(-1) for n in names])
+        assert float((got * want).sum() / (got.norm() * want.norm())) >= 0.9995
+    check(m.d_arena, m.d_vars, 'd/grad/')
+    with torch.no_grad():                      # undo the moving-average side effect of the probe pass above
+        for n, v in moving0.items():
+            m.store.vars[n].copy_(v)
+    g = tr.g_losses(feed)
+    for k in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
+        assert abs(float(g[k]) - float(gs['g/' + k])) <= ltol * max(abs(float(gs['g/' + k])), 1.0), k
+    assert relerr(g['G'][:, ::4, ::4, :], gs['g/G_sample']) <= itol
+    # Stage-II generator gradients come back through the 25-layer critic AND ~40 generator layers: the fp32 forward noise
+    # (1.5e-3 at the image) flips a few relu/lrelu masks per layer; measured 1.3e-2 relative L2 overall (cosine 0.99991),
+    # worst tensor 4e-2 — a wrong kernel gives O(1)
+    check(m.g_arena, m.g_vars, 'g/grad/', None if stage == 1 else 8e-2)
+    # full iteration from the initial state
+    m.store.load(params)
+    tr = Trainer(None, m, None, m.cfg)
+    epoch = _make_golden().STACKGAN_EPOCH
+    tr.iteration(feed, epoch=epoch)
+    torch.cuda.synchronize()
+    lr = 2e-4 * 0.5 ** (epoch // 100)
+    frozen = 0
+    for n, v in m.store.vars.items():
+        ref = gs['after/' + n]
+        if 'moving' in n:
+            assert relerr(v, ref, floor=1e-6) <= mtol, n
+        else:
+            delta = np.abs(v.detach().double().cpu().numpy() - ref)
+            assert delta.max() <= 2.0 * lr * 1.001 + 1e-7, (n, delta.max())
+            if stage == 2 and n.startswith('g_net/'):
+                frozen += 1
+                assert np.array_equal(v.detach().cpu().numpy(), params[n]), n          # Stage-I weights never move
+    if stage == 2:
+        assert frozen > 40
+        moved = [n for n in moving0 if n.startswith('g_net/') and not torch.equal(moving0[n], m.store.vars[n])]
+        assert len(moved) == len([n for n in moving0 if n.startswith('g_net/')])      # ... but its moving averages do

@@ -1,0 +1,115 @@
+"""ConditionalGanTrainer (Stage-I) — reference models/stackgan/stageI/trainer.py:11-165: sigmoid cross-entropy losses
+(real label 0.9), KL term of the conditioning augmentation, two Adam optimizers on ONE learning-rate placeholder
+(D_LR * 0.5 ** (epoch // 100)), both under tf.GraphKeys.UPDATE_OPS, D update then G update every iteration."""
+import sys
+import time
+
+import torch
+
+from .... import autograd as A
+from .... import optim
+from ....utils.ops import update_ops
+
+
+def sigmoid_cross_entropy_with_logits(logits, label):
+    """tf.nn.sigmoid_cross_entropy_with_logits: max(l,0) - l*y + log(1+exp(-|l|))."""
+    return torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))
+
+
+class ConditionalGanTrainer(object):
+    REAL_LABEL = 0.9                     # trainer.py:26 (Stage-II overrides with 0.95)
+
+    def __init__(self, sess, model, dataset, cfg):
+        self.sess, self.model, self.dataset, self.cfg = sess, model, dataset, cfg     # sess unused (no TF session)
+        self.lr = float(cfg.TRAIN.D_LR)
+        self.gen = torch.Generator(device=model.device).manual_seed(1234)
+        self.define_losses()
+
+    def define_losses(self):
+        t = self.cfg.TRAIN
+        self.alpha, self.kl_coeff = float(t.COEFF.ALPHA_MISMATCH_LOSS), float(t.COEFF.KL)
+        self.D_optim = optim.AdamTF(self.model.d_arena, float(t.D_BETA_DECAY), 0.999)
+        self.G_optim = optim.AdamTF(self.model.g_arena, float(t.G_BETA_DECAY), 0.999)
+
+    @staticmethod
+    def kl_loss(mean, log_sigma):
+        return (-log_sigma + 0.5 * (-1.0 + torch.exp(2.0 * log_sigma) + mean * mean)).mean()
+
+    # what the model's generator consumes differs per stage (Stage-II feeds the Stage-I image): one hook
+    def _generate(self, feed, which):
+        m = self.model
+        return m.generator(feed['z'], feed['phi_inputs'], reuse=True, noise=feed.get('ca_noise_' + which))
+
+    def d_losses(self, feed):
+        """What sess.run([D_optim, ...]) evaluates before the update (trainer.py:19-41).  Gradients -> d_arena."""
+        m = self.model
+        x, xw, phi = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs']
+        with update_ops():      # D_optim sits under control_dependencies(UPDATE_OPS): every BN moving average moves
+            with torch.no_grad():
+                G, _, _ = self._generate(feed, 'd')
+            _, l_fake = m.discriminator(G, phi, reuse=True)
+            _, l_match = m.discriminator(x, phi, reuse=True)
+            _, l_mis = m.discriminator(xw, phi, reuse=True)
+        D_synthetic_loss = sigmoid_cross_entropy_with_logits(l_fake, 0.0).mean()
+        D_real_match_loss = sigmoid_cross_entropy_with_logits(l_match, self.REAL_LABEL).mean()
+        D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
+        D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
+        m.d_arena.zero_grad()
+        if m.dp is not None:
+            m.dp.arm(m.d_arena)
+        D_loss.backward(inputs=list(m.d_vars.values()))
+        A.side_join()
+        return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
+                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G)
+
+    def g_losses(self, feed):
+        m = self.model
+        x, xw, phi = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs']
+        with update_ops():
+            G, mean, log_sigma = self._generate(feed, 'g')
+            with m.store.frozen(m.d_scope):
+                _, l_fake = m.discriminator(G, phi, reuse=True)
+            # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
+            # sess.run too, only to move their batch-norm moving averages (trainer.py:50-55)
+            with torch.no_grad():
+                m.discriminator(x, phi, reuse=True)
+                m.discriminator(xw, phi, reuse=True)
+        G_gan_loss = sigmoid_cross_entropy_with_logits(l_fake, 1.0).mean()
+        G_kl_loss = self.kl_loss(mean, log_sigma)
+        G_loss = G_gan_loss + self.kl_coeff * G_kl_loss
+        m.g_arena.zero_grad()
+        if m.dp is not None:
+            m.dp.arm(m.g_arena)
+        G_loss.backward(inputs=list(m.g_vars.values()))
+        A.side_join()
+        return dict(G_loss=G_loss.detach(), G_gan_loss=G_gan_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
+
+    def iteration(self, feed, epoch=0):
+        m = self.model
+        lr = self.lr * (0.5 ** (epoch // 100))                       # trainer.py:119,127
+        d = self.d_losses(feed)
+        scale = m.dp.allreduce_arena(m.d_arena) if m.dp is not None else 1.0
+        self.D_optim.step(lr, grad_scale=scale)
+        g = self.g_losses(feed)
+        scale = m.dp.allreduce_arena(m.g_arena) if m.dp is not None else 1.0
+        self.G_optim.step(lr, grad_scale=scale)
+        return {'d': d, 'g': g}
+
+    def make_feed(self):
+        m = self.model
+        images, wrong_images, embed, _, _ = self.dataset.train.next_batch(m.batch_size, 4, embeddings=True, wrong_img=True)
+        return {'inputs': images, 'wrong_inputs': wrong_images, 'phi_inputs': embed,
+                'z': torch.randn((m.batch_size, m.z_dim), generator=self.gen, device=m.device)}
+
+    def train(self, max_updates=None, log=None):
+        log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
+        t0, counter = time.time(), 1
+        for epoch in range(self.cfg.TRAIN.EPOCH):
+            updates_per_epoch = self.dataset.train.num_examples // self.model.batch_size
+            for idx in range(updates_per_epoch):
+                out = self.iteration(self.make_feed(), epoch)
+                log('Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f' % (
+                    epoch, idx, updates_per_epoch, time.time() - t0, float(out['d']['D_loss']), float(out['g']['G_loss'])))
+                counter += 1
+                if max_updates is not None and counter > max_updates:
+                    return
