@@ -143,6 +143,22 @@ int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_samp
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
                 float beta2, float eps, float grad_scale, t2i_stream_t stream);
 
+/* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
+/* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):
+ * src [N,S,S,3] uint8 resident on the device; out [B,out_size,out_size,3] float32 with
+ *   out[b,r,c,:] = u8 * (2/255) - 1  at  src[ids[b], row0[b]+r, col0[b] + (flip[b] ? out_size-1-c : c), :]
+ * in float32 without fused multiply-add, i.e. bit-identical to NumPy's `images.astype(float32) * (2./255) - 1.`.
+ * ids/row0/col0/flip are device int32[B]; the caller guarantees ids < N and row0/col0 + out_size <= S (the reference
+ * draws them as floor((S - out_size) * U[0,1))). */
+int t2i_crop_flip_normalize(const uint8_t* src, int64_t N, int32_t S, const int32_t* ids, const int32_t* row0,
+                            const int32_t* col0, const int32_t* flip, int32_t B, int32_t out_size, float* out,
+                            t2i_stream_t stream);
+/* out[b,:] = mean_j emb[ids[b], choice[b,j], :]  (reference Dataset.sample_embeddings, dataset.py:98-120: mean of `k`
+ * of the image's caption embeddings).  emb [N,En,D] float32, choice device int32[B,k]; sequential fp32 sum in choice
+ * order then division by k — bit-identical to np.mean(e[choice], axis=0). */
+int t2i_gather_mean(const float* emb, int64_t N, int32_t En, int32_t D, const int32_t* ids, const int32_t* choice, int32_t B,
+                    int32_t k, float* out, t2i_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,4 +542,64 @@ hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data pipeline (reference preprocess/dataset.py:83-96,98-120,150): the per-batch image work — gather by id from the
+// resident uint8 store, scale to [-1,1], random crop, horizontal flip — and the mean of `k` chosen caption embeddings.
+// Pure byte / gather work: HBM-bound, one pass, coalesced over the channel-innermost output.
+// Bit-exact with the NumPy reference: v = fl32(fl32(u8 * fl32(2/255)) - 1) with NO fused multiply-add, and the mean is
+// the sequential fp32 sum in choice order followed by an IEEE division by k (np.mean over axis 0 of a [k,D] array).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_flip_normalize_kernel(const uint8_t* __restrict__ src, int S,
+                                                                  const int32_t* __restrict__ ids,
+                                                                  const int32_t* __restrict__ row0,
+                                                                  const int32_t* __restrict__ col0,
+                                                                  const int32_t* __restrict__ flip, int out_size,
+                                                                  float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const size_t img = (size_t)ids[b] * S * S * 3;
+  const int r0 = row0[b], c0 = col0[b], fl = flip[b];
+  const int per = out_size * out_size * 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+    const int ch = i % 3, px = i / 3;
+    const int c = px % out_size, r = px / out_size;
+    const int sc = fl ? (c0 + out_size - 1 - c) : (c0 + c);
+    const float u = (float)src[img + ((size_t)(r0 + r) * S + sc) * 3 + ch];
+    float v;
+    {
+#pragma clang fp contract(off)      // hipcc contracts a*b-c into one fma by default; NumPy rounds the product first
+      const float prod = u * 0.00784313725490196f;
+      v = prod - 1.0f;
+    }
+    out[(size_t)b * per + i] = v;
+  }
+}
+
+hipError_t crop_flip_normalize_launch(const uint8_t* src, int S, const int32_t* ids, const int32_t* row0, const int32_t* col0,
+                                      const int32_t* flip, int B, int out_size, float* out, hipStream_t stream) {
+  const int per = out_size * out_size * 3;
+  int bx = (per + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(crop_flip_normalize_kernel, dim3(bx, B), dim3(256), 0, stream, src, S, ids, row0, col0, flip, out_size, out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ emb, int En, int D,
+                                                          const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ choice, int k,
+                                                          float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const float* base = emb + (size_t)ids[b] * En * D;
+  for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < D; d += gridDim.x * blockDim.x) {
+    float s = base[(size_t)choice[b * k] * D + d];
+    for (int j = 1; j < k; ++j) s = __fadd_rn(s, base[(size_t)choice[b * k + j] * D + d]);
+    out[(size_t)b * D + d] = k > 1 ? __fdiv_rn(s, (float)k) : s;
+  }
+}
+
+hipError_t gather_mean_launch(const float* emb, int En, int D, const int32_t* ids, const int32_t* choice, int B, int k,
+                              float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_mean_kernel, dim3((D + 255) / 256, B), dim3(256), 0, stream, emb, En, D, ids, choice, k, out);
+  return hipGetLastError();
+}
+
 }  // namespace t2i

@@ -36,6 +36,8 @@ hipError_t concat_tile_bwd_launch(const float*, int, int, int, int, float*, floa
 hipError_t transpose_launch(const float*, int, int, int, float*, hipStream_t);
 hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
+hipError_t crop_flip_normalize_launch(const uint8_t*, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
+hipError_t gather_mean_launch(const float*, int, int, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
@@ -454,6 +456,26 @@ int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, 
 int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream) {
   if (!g || !coef || !out || B <= 0 || per_sample <= 0) { set_error("t2i_row_scale: bad argument"); return T2I_ERR_INVALID; }
   return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream), "t2i_row_scale");
+}
+
+int t2i_crop_flip_normalize(const uint8_t* src, int64_t N, int32_t S, const int32_t* ids, const int32_t* row0,
+                            const int32_t* col0, const int32_t* flip, int32_t B, int32_t out_size, float* out,
+                            t2i_stream_t stream) {
+  if (!src || !ids || !row0 || !col0 || !flip || !out || N <= 0 || S <= 0 || B <= 0 || out_size <= 0 || out_size > S) {
+    set_error("t2i_crop_flip_normalize: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  return check(crop_flip_normalize_launch(src, S, ids, row0, col0, flip, B, out_size, out, (hipStream_t)stream),
+               "t2i_crop_flip_normalize");
+}
+
+int t2i_gather_mean(const float* emb, int64_t N, int32_t En, int32_t D, const int32_t* ids, const int32_t* choice, int32_t B,
+                    int32_t k, float* out, t2i_stream_t stream) {
+  if (!emb || !ids || !choice || !out || N <= 0 || En <= 0 || D <= 0 || B <= 0 || k <= 0 || k > En) {
+    set_error("t2i_gather_mean: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  return check(gather_mean_launch(emb, En, D, ids, choice, B, k, out, (hipStream_t)stream), "t2i_gather_mean");
 }
 
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,

@@ -407,3 +407,29 @@ def device_info(device=0):
     arch = ctypes.create_string_buffer(64)
     check(lib.t2i_device_info(device, ctypes.byref(cu), ctypes.byref(clk), arch, 64), 't2i_device_info')
     return dict(cu_count=cu.value, clock_khz=clk.value, arch=arch.value.decode())
+
+
+# ---- data pipeline (reference preprocess/dataset.py) --------------------------------------------------------------------
+def crop_flip_normalize(src_u8, ids, row0, col0, flip, out_size):
+    """src_u8 [N,S,S,3] uint8 (device); ids/row0/col0/flip int32 [B] (device) -> float32 [B,out_size,out_size,3]."""
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3 or src_u8.shape[1] != src_u8.shape[2]:
+        raise ValueError('crop_flip_normalize expects a uint8 [N,S,S,3] store, got %s %s' % (src_u8.dtype, tuple(src_u8.shape)))
+    B = ids.numel()
+    out = torch.empty((B, out_size, out_size, 3), dtype=torch.float32, device=src_u8.device)
+    if _live(src_u8):
+        a, b, c, d = ids.to(torch.int32).contiguous(), row0.to(torch.int32).contiguous(), col0.to(torch.int32).contiguous(), flip.to(torch.int32).contiguous()
+        check(lib.t2i_crop_flip_normalize(_ptr(src_u8.contiguous()), src_u8.shape[0], src_u8.shape[1], _ptr(a), _ptr(b), _ptr(c),
+                                          _ptr(d), B, out_size, _ptr(out), _stream()), 't2i_crop_flip_normalize')
+    return out
+
+
+def gather_mean(emb, ids, choice):
+    """emb [N,En,D] float32; ids int32 [B]; choice int32 [B,k] -> [B,D] mean of the chosen rows, in choice order."""
+    _chk(emb, 'emb')
+    B, k = choice.shape
+    out = torch.empty((B, emb.shape[2]), dtype=torch.float32, device=emb.device)
+    if _live(emb):
+        a, c = ids.to(torch.int32).contiguous(), choice.to(torch.int32).contiguous()
+        check(lib.t2i_gather_mean(_ptr(emb), emb.shape[0], emb.shape[1], emb.shape[2], _ptr(a), _ptr(c), B, k, _ptr(out), _stream()),
+              't2i_gather_mean')
+    return out

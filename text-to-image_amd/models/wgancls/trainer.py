@@ -52,11 +52,38 @@ class WGanClsTrainer(object):
         self.last = out
         return out
 
-    def train(self, max_steps=None, start_point=0, log=None):
-        """reference trainer.py:49-126 without the TF summaries / PNG grids / checkpoints (DESIGN.md "next" rows): the
-        scalars they would log are returned by every iteration instead."""
+    def make_saver(self):
+        """tf.train.Saver(max_to_keep=CHECKPOINTS_TO_KEEP) (reference trainer.py:51): every variable under its TF name, the
+        two optimizers' Adam slots and step counts, and the kt balance scalar."""
+        from ...utils.saver import Saver
+        m = self.model
+
+        def set_kt(v):
+            m.kt.fill_(float(v))
+        return Saver(m.store, {'D_optim': m.D_optim, 'G_optim': m.G_optim}, {'kt': (lambda: m.kt.detach().cpu().numpy(), set_kt)},
+                     max_to_keep=int(getattr(self.cfg.TRAIN, 'CHECKPOINTS_TO_KEEP', 5)))
+
+    def train(self, max_steps=None, start_point=None, log=None, side_effects=False):
+        """reference trainer.py:49-126.  With side_effects=True the periodic work around the hot path is on as in the
+        reference: resume from the latest checkpoint in cfg.CHECKPOINT_DIR, captions of the fixed sample batch, a PNG grid
+        of `sampler` outputs every TRAIN.SAMPLE_PERIOD iterations, a checkpoint when idx % 500 == 2.  TF summaries are
+        replaced by the scalar log line (every SUMMARY_PERIOD iterations); the scalars are also returned per iteration."""
+        from ...utils.saver import load, save
+        from ...utils.utils import get_balanced_factorization, save_captions, save_images
         log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
         end = max_steps if max_steps is not None else self.cfg.TRAIN.MAX_STEPS
+        m = self.model
+        if side_effects:
+            self.saver = self.make_saver()
+            sample_z = torch.randn((m.sample_num, m.z_dim), generator=self.gen, device=m.device)
+            _, sample_cond, _, captions = self.dataset.test.next_batch_test(m.sample_num, 0, 1)
+            sample_cond = sample_cond[0]
+            save_captions(self.cfg.SAMPLE_DIR, captions)
+            could_load, counter = load(self.saver, None, self.cfg.CHECKPOINT_DIR)
+            if start_point is None:
+                start_point = counter if could_load else 0
+            log(' [*] Load SUCCESS' if could_load else ' [!] Load failed...')
+        start_point = start_point or 0
         t0 = time.time()
         for idx in range(start_point + 1, end):
             out = self.iteration(idx)
@@ -65,4 +92,12 @@ class WGanClsTrainer(object):
                 log('[%6d] D_loss %.4f G_loss %.4f wdist %.4f wdist2 %.4f gp %.4f gp2 %.4f kt %.4f (%.1fs)' % (
                     idx, float(d['D_loss']), float(g.get('G_loss', float('nan'))), float(d['wdist']), float(d['wdist2']),
                     float(d['real_gp']), float(d['real_gp2']), float(self.model.kt), time.time() - t0))
+            if side_effects:
+                epoch = idx // max(self.dataset.train.num_examples // m.batch_size, 1)
+                if idx % self.cfg.TRAIN.SAMPLE_PERIOD == 0:
+                    samples = m.sampler(sample_z, sample_cond)
+                    save_images(samples, get_balanced_factorization(samples.shape[0]),
+                                '{}train_{:02d}_{:04d}.png'.format(self.cfg.SAMPLE_DIR, epoch, idx))
+                if idx % 500 == 2:
+                    save(self.saver, None, self.cfg.CHECKPOINT_DIR, idx)
         return self.last
