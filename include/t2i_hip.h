@@ -143,6 +143,20 @@ int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_samp
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
                 float beta2, float eps, float grad_scale, t2i_stream_t stream);
 
+/* ---- PGGAN operators: reference utils/ops.py:74-81 (layer_norm), :100-101 (pool), :109-111 (upscale) ------------ */
+/* y[b,h,w,:] = scale * sum of the 2x2 window of x [B,H,W,C] (H, W even) -> [B,H/2,W/2,C].  scale = 1/4 is
+ * ops.pool(x, 2) (AVG, SAME, even extents); scale = 1 is the backward of t2i_upscale2. */
+int t2i_pool2_sum(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float scale, float* y, t2i_stream_t stream);
+/* y[b,2h+i,2w+j,:] = scale * x[b,h,w,:]: ops.upscale(x, 2) (nearest neighbour) for scale = 1; scale = 1/4 is the
+ * backward of the average pool. */
+int t2i_upscale2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float scale, float* y, t2i_stream_t stream);
+/* s1[b] = sum_i a[b,i]; s2[b] = sum_i a[b,i]*b[b,i] (b = a when NULL): the per-sample moments of layer norm. */
+int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, t2i_stream_t stream);
+/* out[b,i] = a[b,i]*alpha[b] + b[b,i]*gamma[b] + delta[b]  (b/gamma and delta optional): layer-norm normalise and its
+ * backward. */
+int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int32_t B,
+                 int64_t per_sample, float* out, t2i_stream_t stream);
+
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):
  * src [N,S,S,3] uint8 resident on the device; out [B,out_size,out_size,3] float32 with

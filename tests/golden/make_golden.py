@@ -223,7 +223,54 @@ def make_stackgan_step(stage):
     return out
 
 
+PGGAN_TINY = dict(z_dim=8, embed_dim=32, compressed=16, batch=3, base=32, cap=16)
+PGGAN_STAGE, PGGAN_STEPS, PGGAN_IDX = 3, 10, 3          # 16x16 output, transition stage, alpha = 3/10
+
+
+def make_pggan_step(trans=True):
+    """Tiny PGGAN iteration (reference models/pggan/pggan.py) at stage 3: losses incl. both gradient penalties, all
+    gradients (double backward through pool / fade-in / convs), post-update weights after one trainer iteration."""
+    from oracle import torch_pggan as PG
+    cfg = PG.Cfg(**PGGAN_TINY)
+    P = PG.init_variables(cfg, PGGAN_STAGE, trans, seed=0)
+    rng = np.random.default_rng(31)
+    for n in P:   # widen the critic so that both hinged penalties are active; non-trivial biases / layer-norm affine
+        if n.startswith('d_net') and (n.endswith('weights') or n.endswith('kernel')):
+            P[n] = P[n] * 1.6
+        if n.endswith('biases') or n.endswith('bias') or n.endswith('beta'):
+            P[n] = torch.tensor(rng.standard_normal(tuple(P[n].shape)) * 0.1)
+        if n.endswith('gamma'):
+            P[n] = torch.tensor(1.0 + rng.standard_normal(tuple(P[n].shape)) * 0.1)
+    feed = PG.synthetic_feed(cfg, PGGAN_STAGE, seed=1)
+    for n in P:
+        P[n] = P[n].float().double()
+    for n in feed:
+        feed[n] = feed[n].float().double()
+    out = {}
+    for n, v in P.items():
+        out['param/' + n] = v.numpy().astype(np.float32)
+    for n, v in feed.items():
+        out['feed/' + n] = v.numpy().astype(np.float32)
+    alpha = PGGAN_IDX / float(PGGAN_STEPS)
+    d = PG.d_step(P, cfg, feed, PGGAN_STAGE, trans, alpha)
+    for k_ in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
+        out['d/' + k_] = np.array(d[k_])
+    out['d/G'] = d['G'].numpy(); out['d/Dx_hat'] = d['Dx_hat'].numpy()
+    for n, v in d['grads'].items():
+        out['d/grad/' + n] = v.numpy()
+    g = PG.g_step(P, cfg, feed, PGGAN_STAGE, trans, alpha)
+    out['g/G_loss'] = np.array(g['G_loss']); out['g/G_kl_loss'] = np.array(g['G_kl_loss']); out['g/G'] = g['G'].numpy()
+    for n, v in g['grads'].items():
+        out['g/grad/' + n] = v.numpy()
+    tr = PG.Trainer(cfg, dict(P), PGGAN_STAGE, trans, PGGAN_STEPS)
+    tr.iteration(PGGAN_IDX, feed)
+    for n, v in tr.P.items():
+        out['after/' + n] = v.numpy().copy()
+    return out
+
+
 if __name__ == '__main__':
+    np.savez_compressed(os.path.join(HERE, 'pggan_tiny.npz'), **make_pggan_step())
     np.savez_compressed(os.path.join(HERE, 'stackgan1_tiny.npz'), **make_stackgan_step(1))
     np.savez_compressed(os.path.join(HERE, 'stackgan2_tiny.npz'), **make_stackgan_step(2))
     np.savez_compressed(os.path.join(HERE, 'gancls_tiny.npz'), **make_gancls_step())

@@ -109,7 +109,7 @@ def _sinks_mode(dp, arena, params, data, rank, world):
         launches.clear()
         for n in reversed(names):                                     # backward order: last-created first
             for c in range(contrib[n]):
-                A.SINKS[params[n].data_ptr()].add_((data[n] * (step + 1)).reshape(-1))
+                A.sink_at(params[n].data_ptr()).add_((data[n] * (step + 1)).reshape(-1))
                 A._notify(params[n])
         total_notes = sum(contrib.values())
         if step == 0:

@@ -10,6 +10,7 @@ there only d/d(input) is wanted, so filter / bias gradients are not launched.
 """
 import contextlib
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -25,8 +26,25 @@ _INPUTS_ONLY = [False]
 # Registered by optim.Arena.enable_sinks().  NOTIFY[0], if set (dp.DataParallel), is called with the parameter's address
 # after each contribution has been issued: sunk gradients never reach AccumulateGrad, so the data-parallel bucket
 # overlap counts these notifications instead of post-accumulate hooks.
-SINKS = {}
+SINKS = {}          # address -> (weakref to the parameter leaf, its slot of the gradient arena as a flat view)
 NOTIFY = [None]
+
+
+def register_sink(param, slot):
+    SINKS[param.data_ptr()] = (weakref.ref(param), slot)
+
+
+def sink_at(ptr):
+    """The arena slot registered for the parameter stored at `ptr`, or None.  An entry whose parameter has been freed is
+    dropped: the allocator may hand its address to an unrelated tensor (a stale entry would swallow that tensor's
+    gradient into a dead arena)."""
+    e = SINKS.get(ptr)
+    if e is None:
+        return None
+    if e[0]() is None:
+        del SINKS[ptr]
+        return None
+    return e[1]
 
 
 def _notify(t):
@@ -39,7 +57,7 @@ def _sink_of(t):
     """The gradient-arena slot of parameter `t` if sinks are on and this is the final (first-order) backward."""
     if t is None or torch.is_grad_enabled():
         return None
-    return SINKS.get(t.data_ptr())
+    return sink_at(t.data_ptr())
 
 
 class _Side:
@@ -70,7 +88,7 @@ def side_join():
 def _filter_grad(x, gpre, geom, w):
     """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function."""
     if not torch.is_grad_enabled():
-        sink = SINKS.get(w.data_ptr())
+        sink = sink_at(w.data_ptr())
         if sink is not None:
             xs, gs = _c(x), _c(gpre)
             if SIDE.stream is not None:
@@ -375,3 +393,90 @@ class GpSlopesFn(Function):
         g, s = ctx.saved_tensors
         coef = torch.where(s > 0, ds / s.clamp_min(1e-30), torch.zeros_like(s))   # [B] scalars per sample
         return K.row_scale(g, _c(coef))
+
+
+# ---- PGGAN operators (reference utils/ops.py:74-81,100-101,109-111) ------------------------------------------------------
+class Pool2Fn(Function):
+    """scale * 2x2 window sum, stride 2 (scale = 1/4: tf.nn.pool AVG SAME on even extents).  Linear; its adjoint is the
+    nearest-neighbour replication with the same scale, so the pair is closed under differentiation of any order (the
+    critic of PGGAN is differentiated twice by the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        ctx.set_materialize_grads(False)
+        return K.pool2_sum(_c(x), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        return Upscale2Fn.apply(g, ctx.scale), None
+
+
+class Upscale2Fn(Function):
+    """scale * nearest-neighbour x2 (scale = 1: ops.upscale)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        ctx.set_materialize_grads(False)
+        return K.upscale2(_c(x), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        return Pool2Fn.apply(g, ctx.scale), None
+
+
+class AxpbyFn(Function):
+    """alpha*a + beta*b with host scalars: the fade-in mix of a new resolution (reference models/pggan/pggan.py:267,314)."""
+
+    @staticmethod
+    def forward(ctx, a, alpha, b, beta):
+        ctx.alpha, ctx.beta, ctx.has_b = alpha, beta, b is not None
+        ctx.set_materialize_grads(False)
+        return K.axpby(_c(a), alpha, _c(b) if b is not None else None, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        ga = AxpbyFn.apply(g, ctx.alpha, None, 0.0) if ctx.needs_input_grad[0] else None
+        gb = AxpbyFn.apply(g, ctx.beta, None, 0.0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return ga, None, gb, None
+
+
+class LayerNormFn(Function):
+    """tf.contrib.layers.layer_norm(x, begin_norm_axis=1, begin_params_axis=-1) + activation (reference utils/ops.py:74-81):
+    each sample is normalised over all of its elements (biased variance, eps = 1e-12), then scaled and shifted per
+    last-axis channel.  Generator only in the reference (models/pggan/pggan.py:289-309) => first order."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, alpha):
+        x = _c(x)
+        B = x.shape[0]
+        n = x.numel() // B
+        s1, s2 = K.row_moments(x)
+        mean = s1 / n
+        var = torch.clamp(s2 / n - mean * mean, min=0.0)
+        rstd = torch.rsqrt(var + eps)
+        xhat = K.row_fma2(x, rstd, delta=-mean * rstd)
+        y = K.bn_apply(xhat, gamma, beta, act, alpha)               # per-channel affine + activation
+        ctx.save_for_backward(xhat, rstd, gamma, y if act != K.ACT_NONE else None)
+        ctx.act, ctx.alpha, ctx.n = act, alpha, n
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xhat, rstd, gamma, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act != K.ACT_NONE:
+            gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
+        dbeta, dgamma = K.col_reduce(gy, xhat, True)                  # sum gy, sum gy * xhat over rows of [*, C]
+        g = K.bn_apply(gy, gamma, torch.zeros_like(gamma), K.ACT_NONE, 0.0)
+        t1, t2 = K.row_moments(g, xhat)
+        dx = K.row_fma2(g, rstd, xhat, -rstd * t2 / ctx.n, -rstd * t1 / ctx.n)
+        return dx, dgamma, dbeta, None, None, None

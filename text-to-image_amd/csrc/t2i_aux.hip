@@ -602,4 +602,85 @@ hipError_t gather_mean_launch(const float* emb, int En, int D, const int32_t* id
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PGGAN operators (reference utils/ops.py:74-81 layer_norm, :100-101 pool, :109-111 upscale)
+//   resample2<POOL>   2x2 stride-2 window sum (POOL) or nearest x2 replication, times a scalar.  avg pool = sum * 1/4;
+//                     the two are adjoint up to that factor, so each is the other's backward (and double backward).
+//   row_moments       per-sample sums over everything but the batch axis: s1 = sum a, s2 = sum a*b (b = a if NULL)
+//   row_fma2          out[b,i] = a[b,i]*alpha[b] + b_[b,i]*gamma[b] + delta[b]  (per-sample scalars)
+// Layer norm = row_moments -> row_fma2 (normalise) -> the per-channel affine + activation of bn_apply; its backward =
+// col_reduce (dgamma, dbeta) + row_moments + row_fma2.  All HBM-bound single passes.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256) void resample2_kernel(const float* __restrict__ x, int Ho, int Wo, int C, float scale,
+                                                        size_t n_out, float* __restrict__ y) {
+  // POOL: x [B,2Ho,2Wo,C] -> y [B,Ho,Wo,C];  else: x [B,Ho/2,Wo/2,C] -> y [B,Ho,Wo,C]
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int w = (int)(p % Wo); p /= Wo;
+    const int h = (int)(p % Ho);
+    const size_t b = p / Ho;
+    if (POOL) {
+      const size_t Wi = (size_t)2 * Wo;
+      const float* s = x + ((b * 2 * Ho + 2 * h) * Wi + 2 * w) * C + c;
+      y[i] = scale * ((s[0] + s[C]) + (s[Wi * C] + s[Wi * C + C]));
+    } else {
+      y[i] = scale * x[((b * (Ho >> 1) + (h >> 1)) * (Wo >> 1) + (w >> 1)) * C + c];
+    }
+  }
+}
+
+hipError_t resample2_launch(bool pool, const float* x, int B, int Ho, int Wo, int C, float scale, float* y, hipStream_t stream) {
+  const size_t n = (size_t)B * Ho * Wo * C;
+  if (pool) hipLaunchKernelGGL(resample2_kernel<true>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
+  else hipLaunchKernelGGL(resample2_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t per,
+                                                          float* __restrict__ s1, float* __restrict__ s2) {
+  __shared__ float red[2][4];
+  const float* ra = a + (size_t)blockIdx.x * per;
+  const float* rb = b ? b + (size_t)blockIdx.x * per : ra;
+  float acc1 = 0.f, acc2 = 0.f;
+  for (size_t i = threadIdx.x; i < per; i += 256) {
+    const float v = ra[i];
+    acc1 += v;
+    acc2 += v * rb[i];
+  }
+  acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc1; red[1][threadIdx.x >> 6] = acc2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+hipError_t row_moments_launch(const float* a, const float* b, int B, int64_t per, float* s1, float* s2, hipStream_t stream) {
+  hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, stream, a, b, (size_t)per, s1, s2);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void row_fma2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ alpha, const float* __restrict__ gamma,
+                                                       const float* __restrict__ delta, size_t n, size_t per,
+                                                       float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / per;
+    float v = a[i] * alpha[r];
+    if (b) v += b[i] * gamma[r];
+    if (delta) v += delta[r];
+    out[i] = v;
+  }
+}
+
+hipError_t row_fma2_launch(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int B,
+                           int64_t per, float* out, hipStream_t stream) {
+  const size_t n = (size_t)B * per;
+  hipLaunchKernelGGL(row_fma2_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, alpha, gamma, delta, n, (size_t)per, out);
+  return hipGetLastError();
+}
+
 }  // namespace t2i

@@ -38,6 +38,9 @@ hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
 hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t crop_flip_normalize_launch(const uint8_t*, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t gather_mean_launch(const float*, int, int, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
+hipError_t resample2_launch(bool, const float*, int, int, int, int, float, float*, hipStream_t);
+hipError_t row_moments_launch(const float*, const float*, int, int64_t, float*, float*, hipStream_t);
+hipError_t row_fma2_launch(const float*, const float*, const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
@@ -476,6 +479,27 @@ int t2i_gather_mean(const float* emb, int64_t N, int32_t En, int32_t D, const in
     return T2I_ERR_INVALID;
   }
   return check(gather_mean_launch(emb, En, D, ids, choice, B, k, out, (hipStream_t)stream), "t2i_gather_mean");
+}
+
+int t2i_pool2_sum(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float scale, float* y, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) { set_error("t2i_pool2_sum: bad argument (H, W must be even)"); return T2I_ERR_INVALID; }
+  return check(resample2_launch(true, x, B, H / 2, W / 2, C, scale, y, (hipStream_t)stream), "t2i_pool2_sum");
+}
+
+int t2i_upscale2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float scale, float* y, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) { set_error("t2i_upscale2: bad argument"); return T2I_ERR_INVALID; }
+  return check(resample2_launch(false, x, B, 2 * H, 2 * W, C, scale, y, (hipStream_t)stream), "t2i_upscale2");
+}
+
+int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, t2i_stream_t stream) {
+  if (!a || !s1 || !s2 || B <= 0 || per_sample <= 0) { set_error("t2i_row_moments: bad argument"); return T2I_ERR_INVALID; }
+  return check(row_moments_launch(a, b, B, per_sample, s1, s2, (hipStream_t)stream), "t2i_row_moments");
+}
+
+int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int32_t B,
+                 int64_t per_sample, float* out, t2i_stream_t stream) {
+  if (!a || !alpha || !out || B <= 0 || per_sample <= 0 || ((b == nullptr) != (gamma == nullptr))) { set_error("t2i_row_fma2: bad argument"); return T2I_ERR_INVALID; }
+  return check(row_fma2_launch(a, b, alpha, gamma, delta, B, per_sample, out, (hipStream_t)stream), "t2i_row_fma2");
 }
 
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,

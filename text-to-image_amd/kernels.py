@@ -433,3 +433,52 @@ def gather_mean(emb, ids, choice):
         check(lib.t2i_gather_mean(_ptr(emb), emb.shape[0], emb.shape[1], emb.shape[2], _ptr(a), _ptr(c), B, k, _ptr(out), _stream()),
               't2i_gather_mean')
     return out
+
+
+# ---- PGGAN operators (reference utils/ops.py:74-81,100-101,109-111) ------------------------------------------------------
+def pool2_sum(x, scale):
+    """x [B,H,W,C] (H, W even) -> scale * 2x2 window sums [B,H/2,W/2,C]."""
+    _chk(x, 'x')
+    B, H, W, C = x.shape
+    if H % 2 or W % 2:
+        raise ValueError('pool(x, 2): odd extents %dx%d are not supported (the reference only pools powers of two)' % (H, W))
+    y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    if _live(x):
+        check(lib.t2i_pool2_sum(_ptr(x), B, H, W, C, scale, _ptr(y), _stream()), 't2i_pool2_sum')
+    return y
+
+
+def upscale2(x, scale=1.0):
+    """x [B,H,W,C] -> scale * nearest-neighbour x2 [B,2H,2W,C]."""
+    _chk(x, 'x')
+    B, H, W, C = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    if _live(x):
+        check(lib.t2i_upscale2(_ptr(x), B, H, W, C, scale, _ptr(y), _stream()), 't2i_upscale2')
+    return y
+
+
+def row_moments(a, b=None):
+    """a (and b) [B, ...] -> (sum over everything but axis 0 of a, of a*b or a*a)."""
+    _chk(a, 'a')
+    B = a.shape[0]
+    s1 = torch.empty(B, dtype=torch.float32, device=a.device); s2 = torch.empty_like(s1)
+    if _live(a):
+        check(lib.t2i_row_moments(_ptr(a), _ptr(_chk(b, 'b') if b is not None else None), B, a.numel() // B, _ptr(s1), _ptr(s2),
+                                  _stream()), 't2i_row_moments')
+    return s1, s2
+
+
+def row_fma2(a, alpha, b=None, gamma=None, delta=None):
+    """out[r,...] = a[r,...]*alpha[r] + b[r,...]*gamma[r] + delta[r]   (per-sample scalars; b/gamma and delta optional)."""
+    _chk(a, 'a')
+    B = a.shape[0]
+    out = torch.empty_like(a)
+    if _live(a):
+        al = _chk(alpha.reshape(-1), 'alpha')
+        ga = _chk(gamma.reshape(-1), 'gamma') if gamma is not None else None
+        de = _chk(delta.reshape(-1), 'delta') if delta is not None else None
+        assert al.numel() == B and (ga is None or ga.numel() == B) and (de is None or de.numel() == B)
+        check(lib.t2i_row_fma2(_ptr(a), _ptr(_chk(b, 'b') if b is not None else None), _ptr(al), _ptr(ga), _ptr(de), B,
+                               a.numel() // B, _ptr(out), _stream()), 't2i_row_fma2')
+    return out

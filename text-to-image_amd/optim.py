@@ -40,7 +40,7 @@ class Arena(object):
         """Let the filter-gradient GEMMs accumulate directly into this arena (autograd.SINKS)."""
         from . import autograd as A
         for n, v in self.vars.items():     # kernels, biases, BN gamma/beta: every gradient is summed in place by its kernel
-            A.SINKS[v.data_ptr()] = self.grad_of(n).view(-1)
+            A.register_sink(v, self.grad_of(n).view(-1))
 
     def grad_of(self, name):
         o, k = self.offsets[name]

@@ -173,6 +173,50 @@ def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df
     return post(y) if post else y
 
 
+def layer_norm(x, act=None, scope=None, df=NHWC):
+    """reference utils/ops.py:74-81 (tf.contrib.layers.layer_norm, begin_params_axis = channel axis).  Rank-4 NHWC or
+    rank-2.  Variables: <scope>/LayerNorm[_k]/{beta [C] zeros, gamma [C] ones}."""
+    st = S.default_store()
+    _check_df(df)
+    if x.dim() == 4:
+        xp = _phys(x, df)
+    elif x.dim() == 2:
+        xp = x
+    else:
+        raise ValueError('layer_norm expects rank 2 or 4, got shape %s' % (tuple(x.shape),))
+    C = xp.shape[-1]
+    kind, alpha, post = _split_act(act)
+    with st.variable_scope(scope or st.unique_op_name('LayerNorm'), reuse=st.reuse()):
+        beta = st.get_variable('beta', (C,), S.constant_init(0.0))
+        gamma = st.get_variable('gamma', (C,), S.constant_init(1.0))
+    y = A.LayerNormFn.apply(xp, gamma, beta, 1e-12, kind, alpha)
+    if x.dim() == 4:
+        y = _logical(y, df)
+    return post(y) if post else y
+
+
+def pool(x, s=2, p_type='AVG', df=NHWC):
+    """reference utils/ops.py:100-101 (tf.nn.pool, window = stride = s, SAME).  The reference only calls pool(x, 2) with
+    the default average type on power-of-two maps: that case is built."""
+    if s != 2 or p_type != 'AVG':
+        raise NotImplementedError('pool: only the 2x2 average pool the reference uses is built (got s=%r, %r)' % (s, p_type))
+    _check_df(df)
+    return _logical(A.Pool2Fn.apply(_phys(x, df), 0.25), df)
+
+
+def upscale(x, s=2):
+    """reference utils/ops.py:109-111: nearest-neighbour resize to (h*s, w*s), NHWC."""
+    if s != 2:
+        raise NotImplementedError('upscale: only the factor 2 the reference uses is built (got %r)' % (s,))
+    return A.Upscale2Fn.apply(x, 1.0)
+
+
+def lerp(a, b, t):
+    """(1 - t)*a + t*b with a host scalar t: the fade-in of a new resolution (tf.multiply / tf.add on the `alpha_tra`
+    variable, reference models/pggan/pggan.py:267,314)."""
+    return A.AxpbyFn.apply(a, 1.0 - float(t), b, float(t))
+
+
 def to_nchw(x):
     """reference utils/ops.py:129-130.  Logical transpose only: storage stays NHWC."""
     return x.permute(0, 3, 1, 2)
