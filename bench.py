@@ -251,7 +251,7 @@ def main():
                 'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
                 'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
                 'device': info}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if use_dp:
