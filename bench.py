@@ -147,6 +147,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
+    # Pre-flight hooks for boxes with ONE GPU: T2I_SAME_DEVICE=1 puts every rank on device 0 and T2I_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device), so the whole multi-process path — rendezvous, bucket order,
+    # overlap hooks, barriers, max-over-ranks timing — runs for real, minus the xGMI transport.  Never set by the driver.
+    if os.environ.get('T2I_SAME_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
@@ -164,7 +169,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('T2I_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
         from t2i_amd.dp import DataParallel
         dp = DataParallel()
 
@@ -213,6 +222,16 @@ def main():
         K.set_conv_timer(None)
         model._graphs = saved_graphs
 
+    if use_dp and os.environ.get('T2I_CHECK_SYNC') == '1':      # replicas must still hold identical weights, Adam state and kt
+        sig = torch.stack([model.d_arena.flat.double().sum(), model.g_arena.flat.double().sum(), model.D_optim.v.double().sum(),
+                           model.kt.double()])
+        lo, hi = sig.clone(), sig.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit('replicas diverged: %s vs %s' % (lo.tolist(), hi.tolist()))
+        if rank == 0:
+            sys.stderr.write('[bench] replica sync check passed: %s\n' % sig.tolist())
     if use_dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
