@@ -151,7 +151,9 @@ int t2i_pool2_sum(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, fl
  * backward of the average pool. */
 int t2i_upscale2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float scale, float* y, t2i_stream_t stream);
 /* s1[b] = sum_i a[b,i]; s2[b] = sum_i a[b,i]*b[b,i] (b = a when NULL): the per-sample moments of layer norm. */
-int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, t2i_stream_t stream);
+size_t t2i_row_moments_workspace_bytes(int32_t B);
+int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, void* ws,
+                    size_t ws_bytes, t2i_stream_t stream);
 /* out[b,i] = a[b,i]*alpha[b] + b[b,i]*gamma[b] + delta[b]  (b/gamma and delta optional): layer-norm normalise and its
  * backward. */
 int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int32_t B,

@@ -46,7 +46,8 @@ SIGNATURES = {
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_pool2_sum': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
     't2i_upscale2': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
-    't2i_row_moments': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _p, _p]),
+    't2i_row_moments_workspace_bytes': (ctypes.c_size_t, [_i32]),
+    't2i_row_moments': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _p, _p, _sz, _p]),
     't2i_row_fma2': (ctypes.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _p, _p]),
     't2i_crop_flip_normalize': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p]),
     't2i_gather_mean': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _i32, _i32, _p, _p]),

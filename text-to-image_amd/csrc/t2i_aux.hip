@@ -17,6 +17,14 @@ static inline int ew_blocks(size_t n_items) {
   return (int)b;
 }
 
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+__device__ __forceinline__ float vsplat(float s, float) { return s; }
+__device__ __forceinline__ float4 vsplat(float s, float4) { return make_float4(s, s, s, s); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -80,13 +88,94 @@ __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict
   }
 }
 
+// 16-byte variants (C % 4 == 0, 16-byte aligned operands): a lane owns 4 adjacent columns, 16 lanes = 64 columns, 16 row
+// lanes per workgroup; the row loop is unrolled so that several independent 16-byte loads are in flight per lane.
+// (The scalar stage 1 above streamed 67 MB at 1.5 TB/s; this one is bound by HBM like the other elementwise kernels.)
+template <bool WANT1, bool HAS_B>
+__global__ __launch_bounds__(256) void col_reduce_stage1_v4(const float* __restrict__ a, const float* __restrict__ b,
+                                                            int64_t rows, int C, int64_t rows_per_chunk,
+                                                            float* __restrict__ part0, float* __restrict__ part1) {
+  __shared__ float4 red[16][16];
+  __shared__ float4 red1[WANT1 ? 16 : 1][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t rend = rbeg + rows_per_chunk;
+  if (rend > rows) rend = rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+#pragma unroll 4
+    for (int64_t r = rbeg + ty; r < rend; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      if (WANT1) {
+        const float4 w = HAS_B ? *reinterpret_cast<const float4*>(b + r * C + c) : v;
+        acc1.x += v.x * w.x; acc1.y += v.y * w.y; acc1.z += v.z * w.z; acc1.w += v.w * w.w;
+      }
+    }
+  }
+  red[ty][tx] = acc;
+  if (WANT1) red1[ty][tx] = acc1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float4 s0 = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = red[k][tx]; s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w; }
+    *reinterpret_cast<float4*>(part0 + (size_t)blockIdx.y * C + c) = s0;
+    if (WANT1) {
+      float4 s1 = red1[0][tx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) { const float4 v = red1[k][tx]; s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; }
+      *reinterpret_cast<float4*>(part1 + (size_t)blockIdx.y * C + c) = s1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void col_reduce_stage2_v4(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                            int nchunks, int C, float* __restrict__ out0,
+                                                            float* __restrict__ out1, int accumulate) {
+  __shared__ float4 red[16][16], red1[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    for (int k = ty; k < nchunks; k += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c);
+      a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+      if (out1) {
+        const float4 w = *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c);
+        a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+      }
+    }
+  }
+  red[ty][tx] = a0;
+  red1[ty][tx] = a1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float4 s0 = red[0][tx], s1 = red1[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][tx], w = red1[k][tx];
+      s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+      s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+    }
+    // outputs may be arbitrary arena slots (only 4-byte aligned): scalar stores
+    const float r0[4] = {s0.x, s0.y, s0.z, s0.w}, r1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      out0[c + e] = accumulate ? out0[c + e] + r0[e] : r0[e];
+      if (out1) out1[c + e] = accumulate ? out1[c + e] + r1[e] : r1[e];
+    }
+  }
+}
+
 static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int64_t* rows_per_chunk) {
   *ctiles = (C + 63) / 64;
-  int64_t want = 1024 / *ctiles;              // ~1024 blocks in flight
+  int64_t want = 768 / *ctiles;               // ~3 workgroups per CU in flight
   if (want < 1) want = 1;
   int64_t maxchunks = (rows + 63) / 64;       // at least 64 rows per chunk
   if (want > maxchunks) want = maxchunks;
-  if (want > 256) want = 256;                 // keeps the second stage short
+  if (want > 192) want = 192;                 // keeps the second stage short
   if (want < 1) want = 1;
   *rows_per_chunk = (rows + want - 1) / want;
   *nchunks = (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);
@@ -105,6 +194,19 @@ hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
+  const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                                     reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
+  if (v4) {
+    if (out1 == nullptr)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
+    else if (b)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
+    else
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
+    hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part0, (const float*)(out1 ? part1 : nullptr), nc, C,
+                       out0, out1, accumulate);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
                      out1 != nullptr);
   hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1, accumulate);
@@ -308,6 +410,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
+#pragma unroll 2
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
       const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
       const float4 o = *reinterpret_cast<const float4*>(y + r * C + c);
@@ -352,7 +455,7 @@ hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x
   else
     hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, rows, C, rpc, act, alpha,
                        dx, part, part1);
-  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
+  hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
                      sum0, second ? sum1 : (float*)nullptr, accumulate);
   return hipGetLastError();
 }
@@ -611,9 +714,9 @@ hipError_t gather_mean_launch(const float* emb, int En, int D, const int32_t* id
 // Layer norm = row_moments -> row_fma2 (normalise) -> the per-channel affine + activation of bn_apply; its backward =
 // col_reduce (dgamma, dbeta) + row_moments + row_fma2.  All HBM-bound single passes.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool POOL>
-__global__ __launch_bounds__(256) void resample2_kernel(const float* __restrict__ x, int Ho, int Wo, int C, float scale,
-                                                        size_t n_out, float* __restrict__ y) {
+template <bool POOL, typename T>     // T = float4 (C % 4 == 0, aligned) or float; C is then counted in units of T
+__global__ __launch_bounds__(256) void resample2_kernel(const T* __restrict__ x, int Ho, int Wo, int C, float scale,
+                                                        size_t n_out, T* __restrict__ y) {
   // POOL: x [B,2Ho,2Wo,C] -> y [B,Ho,Wo,C];  else: x [B,Ho/2,Wo/2,C] -> y [B,Ho,Wo,C]
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -623,55 +726,105 @@ __global__ __launch_bounds__(256) void resample2_kernel(const float* __restrict_
     const size_t b = p / Ho;
     if (POOL) {
       const size_t Wi = (size_t)2 * Wo;
-      const float* s = x + ((b * 2 * Ho + 2 * h) * Wi + 2 * w) * C + c;
-      y[i] = scale * ((s[0] + s[C]) + (s[Wi * C] + s[Wi * C + C]));
+      const T* s = x + ((b * 2 * Ho + 2 * h) * Wi + 2 * w) * C + c;
+      y[i] = vscale(vadd(vadd(s[0], s[C]), vadd(s[Wi * C], s[Wi * C + C])), scale);
     } else {
-      y[i] = scale * x[((b * (Ho >> 1) + (h >> 1)) * (Wo >> 1) + (w >> 1)) * C + c];
+      y[i] = vscale(x[((b * (Ho >> 1) + (h >> 1)) * (Wo >> 1) + (w >> 1)) * C + c], scale);
     }
   }
 }
 
 hipError_t resample2_launch(bool pool, const float* x, int B, int Ho, int Wo, int C, float scale, float* y, hipStream_t stream) {
+  const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (v4) {
+    const size_t n = (size_t)B * Ho * Wo * (C >> 2);
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    float4* yv = reinterpret_cast<float4*>(y);
+    if (pool) hipLaunchKernelGGL((resample2_kernel<true, float4>), dim3(ew_blocks(n)), dim3(256), 0, stream, xv, Ho, Wo, C >> 2, scale, n, yv);
+    else hipLaunchKernelGGL((resample2_kernel<false, float4>), dim3(ew_blocks(n)), dim3(256), 0, stream, xv, Ho, Wo, C >> 2, scale, n, yv);
+    return hipGetLastError();
+  }
   const size_t n = (size_t)B * Ho * Wo * C;
-  if (pool) hipLaunchKernelGGL(resample2_kernel<true>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
-  else hipLaunchKernelGGL(resample2_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
+  if (pool) hipLaunchKernelGGL((resample2_kernel<true, float>), dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
+  else hipLaunchKernelGGL((resample2_kernel<false, float>), dim3(ew_blocks(n)), dim3(256), 0, stream, x, Ho, Wo, C, scale, n, y);
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t per,
-                                                          float* __restrict__ s1, float* __restrict__ s2) {
+// per-sample moments in two deterministic levels: grid (chunks, B) partial sums with 16-byte loads, then one small block
+// per sample adds its chunks in order.  (A first version used one workgroup per sample: 64 workgroups streaming 1 MB each
+// reached 0.27 TB/s.)
+constexpr int ROW_CHUNKS_MAX = 64;
+static int row_chunks(int64_t per) {
+  int64_t c = (per + 8191) / 8192;
+  if (c > ROW_CHUNKS_MAX) c = ROW_CHUNKS_MAX;
+  return c < 1 ? 1 : (int)c;
+}
+size_t row_moments_ws(int B) { return (size_t)B * ROW_CHUNKS_MAX * 2 * sizeof(float); }
+
+__global__ __launch_bounds__(256) void row_moments_stage1(const float* __restrict__ a, const float* __restrict__ b, size_t per,
+                                                          size_t per_chunk, int vec, float* __restrict__ part) {
   __shared__ float red[2][4];
-  const float* ra = a + (size_t)blockIdx.x * per;
-  const float* rb = b ? b + (size_t)blockIdx.x * per : ra;
+  const size_t beg = (size_t)blockIdx.x * per_chunk;
+  size_t end = beg + per_chunk;
+  if (end > per) end = per;
+  const float* ra = a + (size_t)blockIdx.y * per;
+  const float* rb = b ? b + (size_t)blockIdx.y * per : ra;
   float acc1 = 0.f, acc2 = 0.f;
-  for (size_t i = threadIdx.x; i < per; i += 256) {
-    const float v = ra[i];
-    acc1 += v;
-    acc2 += v * rb[i];
+  if (vec) {       // per, per_chunk multiples of 4 and 16-byte aligned bases
+#pragma unroll 4
+    for (size_t i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += 256) {
+      const float4 v = reinterpret_cast<const float4*>(ra)[i];
+      const float4 w = reinterpret_cast<const float4*>(rb)[i];
+      acc1 += (v.x + v.y) + (v.z + v.w);
+      acc2 += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+    }
+  } else {
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+      const float v = ra[i];
+      acc1 += v;
+      acc2 += v * rb[i];
+    }
   }
   acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc1; red[1][threadIdx.x >> 6] = acc2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    s1[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    s2[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    float* o = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
 
-hipError_t row_moments_launch(const float* a, const float* b, int B, int64_t per, float* s1, float* s2, hipStream_t stream) {
-  hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, stream, a, b, (size_t)per, s1, s2);
+__global__ void row_moments_stage2(const float* __restrict__ part, int B, int chunks, float* __restrict__ s1, float* __restrict__ s2) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < chunks; ++k) { a += part[((size_t)r * chunks + k) * 2]; b += part[((size_t)r * chunks + k) * 2 + 1]; }
+  s1[r] = a; s2[r] = b;
+}
+
+hipError_t row_moments_launch(const float* a, const float* b, int B, int64_t per, float* s1, float* s2, void* ws, hipStream_t stream) {
+  int chunks = row_chunks(per);
+  const bool vec = (per & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+  size_t per_chunk = ((size_t)per + chunks - 1) / chunks;
+  if (vec) per_chunk = (per_chunk + 3) & ~(size_t)3;
+  chunks = (int)(((size_t)per + per_chunk - 1) / per_chunk);
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(row_moments_stage1, dim3(chunks, B), dim3(256), 0, stream, a, b, (size_t)per, per_chunk, vec ? 1 : 0, part);
+  hipLaunchKernelGGL(row_moments_stage2, dim3((B + 63) / 64), dim3(64), 0, stream, part, B, chunks, s1, s2);
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void row_fma2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>       // T = float4: n and per are counted in float4 units
+__global__ __launch_bounds__(256) void row_fma2_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                        const float* __restrict__ alpha, const float* __restrict__ gamma,
                                                        const float* __restrict__ delta, size_t n, size_t per,
-                                                       float* __restrict__ out) {
+                                                       T* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / per;
-    float v = a[i] * alpha[r];
-    if (b) v += b[i] * gamma[r];
-    if (delta) v += delta[r];
+    T v = vscale(a[i], alpha[r]);
+    if (b) v = vadd(v, vscale(b[i], gamma[r]));
+    if (delta) v = vadd(v, vsplat(delta[r], v));
     out[i] = v;
   }
 }
@@ -679,7 +832,12 @@ __global__ __launch_bounds__(256) void row_fma2_kernel(const float* __restrict__
 hipError_t row_fma2_launch(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int B,
                            int64_t per, float* out, hipStream_t stream) {
   const size_t n = (size_t)B * per;
-  hipLaunchKernelGGL(row_fma2_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, alpha, gamma, delta, n, (size_t)per, out);
+  const bool v4 = (per & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(row_fma2_kernel<float4>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, reinterpret_cast<const float4*>(a),
+                       reinterpret_cast<const float4*>(b), alpha, gamma, delta, n >> 2, (size_t)per >> 2, reinterpret_cast<float4*>(out));
+  else
+    hipLaunchKernelGGL(row_fma2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, alpha, gamma, delta, n, (size_t)per, out);
   return hipGetLastError();
 }
 

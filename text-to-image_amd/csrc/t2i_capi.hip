@@ -39,7 +39,8 @@ hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hi
 hipError_t crop_flip_normalize_launch(const uint8_t*, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t gather_mean_launch(const float*, int, int, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t resample2_launch(bool, const float*, int, int, int, int, float, float*, hipStream_t);
-hipError_t row_moments_launch(const float*, const float*, int, int64_t, float*, float*, hipStream_t);
+hipError_t row_moments_launch(const float*, const float*, int, int64_t, float*, float*, void*, hipStream_t);
+size_t row_moments_ws(int B);
 hipError_t row_fma2_launch(const float*, const float*, const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
@@ -491,9 +492,13 @@ int t2i_upscale2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, flo
   return check(resample2_launch(false, x, B, 2 * H, 2 * W, C, scale, y, (hipStream_t)stream), "t2i_upscale2");
 }
 
-int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, t2i_stream_t stream) {
+size_t t2i_row_moments_workspace_bytes(int32_t B) { return B > 0 ? row_moments_ws(B) : 0; }
+
+int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sample, float* s1, float* s2, void* ws,
+                    size_t ws_bytes, t2i_stream_t stream) {
   if (!a || !s1 || !s2 || B <= 0 || per_sample <= 0) { set_error("t2i_row_moments: bad argument"); return T2I_ERR_INVALID; }
-  return check(row_moments_launch(a, b, B, per_sample, s1, s2, (hipStream_t)stream), "t2i_row_moments");
+  if (!ws || ws_bytes < row_moments_ws(B)) { set_error("t2i_row_moments: workspace too small"); return T2I_ERR_WORKSPACE; }
+  return check(row_moments_launch(a, b, B, per_sample, s1, s2, ws, (hipStream_t)stream), "t2i_row_moments");
 }
 
 int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int32_t B,

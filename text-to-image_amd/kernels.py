@@ -464,8 +464,9 @@ def row_moments(a, b=None):
     B = a.shape[0]
     s1 = torch.empty(B, dtype=torch.float32, device=a.device); s2 = torch.empty_like(s1)
     if _live(a):
+        wsp, wsn = _ws_args(a, int(lib.t2i_row_moments_workspace_bytes(B)))
         check(lib.t2i_row_moments(_ptr(a), _ptr(_chk(b, 'b') if b is not None else None), B, a.numel() // B, _ptr(s1), _ptr(s2),
-                                  _stream()), 't2i_row_moments')
+                                  wsp, wsn, _stream()), 't2i_row_moments')
     return s1, s2
 
 
