@@ -135,6 +135,23 @@ int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, 
 /* out[b,:] = coef[b] * g[b,:]  (per-sample scaling: backward of the slope norm, and its own double backward). */
 int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream);
 
+/* ---- loss heads: reference models/wgancls/model.py:72-92 (critic losses) and :117-127 (conditioning augmentation) --- */
+/* From the critic's 3B logits (fake | real | mismatch, each B) and the two per-sample slope vectors: the loss scalars
+ *   scalars[0..11] = D_loss, D_loss_real, D_loss_fake, D_loss_mismatch, wdist, wdist2, real_gp, real_gp2, reg_loss,
+ *                    balance_loss, d balance_loss / d kt, kt
+ * with D_loss = -wdist - kt*wdist2 + gp_coeff*(real_gp + real_gp2), real_gp = mean(max(0, slope-1)^2), and the seeds
+ * of the backward pass dD_loss/dlogits [3B], dD_loss/dslopes1 [B], dD_loss/dslopes2 [B].  kt_dev: device scalar, or NULL
+ * for kt = 1 (models/pggan/pggan.py:104).  One workgroup; replaces ~40 elementwise launches. */
+int t2i_wgan_d_head(const float* logits, const float* slopes1, const float* slopes2, const float* kt_dev, int32_t B,
+                    float gp_coeff, float* seed_logits, float* seed_slopes1, float* seed_slopes2, float* scalars,
+                    t2i_stream_t stream);
+/* code = mean + exp(log_sigma)*eps (eps: the truncated-normal draw) and kl[0] = mean(-ls + .5(-1 + exp(2 ls) + mean^2))
+ * over the n = B*D elements; bwd: dmean = dcode + dkl/n * mean, dlog_sigma = dcode*eps*exp(ls) + dkl/n * (exp(2 ls) - 1)
+ * (dcode and/or dkl may be NULL = zero). */
+int t2i_ca_kl_fwd(const float* mean, const float* log_sigma, const float* eps, int64_t n, float* code, float* kl, t2i_stream_t stream);
+int t2i_ca_kl_bwd(const float* mean, const float* log_sigma, const float* eps, const float* dcode, const float* dkl, int64_t n,
+                  float* dmean, float* dlog_sigma, t2i_stream_t stream);
+
 /* ---- optimizer: tf.train.AdamOptimizer as used at reference models/wgancls/model.py:94-106 ---------------------- */
 /* m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; w -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller (epsilon outside the bias correction).  One launch over a flat parameter arena. grad_scale multiplies g

@@ -480,3 +480,26 @@ class LayerNormFn(Function):
         t1, t2 = K.row_moments(g, xhat)
         dx = K.row_fma2(g, rstd, xhat, -rstd * t2 / ctx.n, -rstd * t1 / ctx.n)
         return dx, dgamma, dbeta, None, None, None
+
+
+class CaSampleKlFn(Function):
+    """(code, kl) = (mean + exp(log_sigma)*eps, KL(N(mean, sigma) || N(0,1)) averaged over all elements): the conditioning
+    augmentation of reference models/wgancls/model.py:117-127 as one forward and one backward launch."""
+
+    @staticmethod
+    def forward(ctx, mean, log_sigma, eps):
+        mean, log_sigma, eps = _c(mean), _c(log_sigma), _c(eps)
+        ctx.save_for_backward(mean, log_sigma, eps)
+        ctx.set_materialize_grads(False)
+        code, kl = K.ca_kl_fwd(mean, log_sigma, eps)
+        return code, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcode, dkl):
+        mean, log_sigma, eps = ctx.saved_tensors
+        if dcode is None and dkl is None:
+            return None, None, None
+        dmean, dls = K.ca_kl_bwd(mean, log_sigma, eps, _c(dcode) if dcode is not None else None,
+                                 _c(dkl).reshape(1) if dkl is not None else None)
+        return dmean, dls, None

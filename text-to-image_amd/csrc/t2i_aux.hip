@@ -841,4 +841,101 @@ hipError_t row_fma2_launch(const float* a, const float* b, const float* alpha, c
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Loss heads: the scalar-per-sample tail of the critic / generator losses in ONE launch each instead of ~40 four-microsecond
+// elementwise launches of a tensor library (means, hinges, their backward seeds).
+//   wgan_d_head    reference models/wgancls/model.py:72-92: from the 3B logits (fake | real | mismatch) and the two slope
+//                  vectors, every loss scalar the trainer logs AND dD_loss/d(logit), dD_loss/d(slope) — the seeds that
+//                  start the backward pass.  kt is read from device memory (graph-capturable).
+//   ca_kl_fwd/bwd  conditioning augmentation c = mean + exp(log_sigma) * eps with the KL term
+//                  mean(-ls + .5(-1 + exp(2 ls) + mean^2)) (model.py:117-127) and the joint backward.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* red) {      // red: 4 floats of LDS; all threads get the sum
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void wgan_d_head_kernel(const float* __restrict__ logits, const float* __restrict__ s1,
+                                                          const float* __restrict__ s2, const float* __restrict__ kt_dev,
+                                                          int B, float gp_coeff, float use_kt, float* __restrict__ seed_l,
+                                                          float* __restrict__ seed_s1, float* __restrict__ seed_s2,
+                                                          float* __restrict__ scal) {
+  __shared__ float red[4];
+  const float kt = use_kt != 0.f ? *kt_dev : 1.0f;
+  const float invB = 1.0f / (float)B;
+  float af = 0.f, ar = 0.f, am = 0.f, am2 = 0.f, h1 = 0.f, h2 = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float f = logits[i], r = logits[B + i], m = logits[2 * B + i];
+    af += f; ar += r; am += m; am2 += m * m;
+    const float a = fmaxf(s1[i] - 1.f, 0.f), b = fmaxf(s2[i] - 1.f, 0.f);
+    h1 += a * a; h2 += b * b;
+    seed_l[i] = invB;                       // D_loss = -wdist - kt*wdist2 + ...,  wdist = real - fake
+    seed_l[B + i] = -(1.f + kt) * invB;
+    seed_l[2 * B + i] = kt * invB;
+    seed_s1[i] = gp_coeff * 2.f * a * invB;
+    seed_s2[i] = gp_coeff * 2.f * b * invB;
+  }
+  af = block_sum256(af, red); ar = block_sum256(ar, red); am = block_sum256(am, red);
+  am2 = block_sum256(am2, red); h1 = block_sum256(h1, red); h2 = block_sum256(h2, red);
+  if (threadIdx.x == 0) {
+    const float fake = af * invB, real = ar * invB, mis = am * invB;
+    const float wd = real - fake, wd2 = real - mis, gp1 = h1 * invB, gp2 = h2 * invB;
+    const float bal = kt * wd2 - wd;
+    scal[0] = -wd - kt * wd2 + gp_coeff * (gp1 + gp2);    // D_loss
+    scal[1] = real; scal[2] = fake; scal[3] = mis; scal[4] = wd; scal[5] = wd2; scal[6] = gp1; scal[7] = gp2;
+    scal[8] = am2 * invB;                                   // reg_loss
+    scal[9] = bal * bal;                                    // balance_loss
+    scal[10] = 2.f * bal * wd2;                             // d balance_loss / d kt
+    scal[11] = kt;
+  }
+}
+
+hipError_t wgan_d_head_launch(const float* logits, const float* s1, const float* s2, const float* kt_dev, int B, float gp_coeff,
+                              float* seed_l, float* seed_s1, float* seed_s2, float* scal, hipStream_t stream) {
+  hipLaunchKernelGGL(wgan_d_head_kernel, dim3(1), dim3(256), 0, stream, logits, s1, s2, kt_dev, B, gp_coeff, kt_dev ? 1.f : 0.f,
+                     seed_l, seed_s1, seed_s2, scal);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void ca_kl_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ ls,
+                                                        const float* __restrict__ eps, int n, float* __restrict__ code,
+                                                        float* __restrict__ kl) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float m = mean[i], l = ls[i], e = expf(l);
+    code[i] = m + e * eps[i];
+    acc += -l + 0.5f * (-1.f + e * e + m * m);
+  }
+  acc = block_sum256(acc, red);
+  if (threadIdx.x == 0) kl[0] = acc / (float)n;
+}
+
+__global__ __launch_bounds__(256) void ca_kl_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ ls,
+                                                        const float* __restrict__ eps, const float* __restrict__ dcode,
+                                                        const float* __restrict__ dkl, int n, float* __restrict__ dmean,
+                                                        float* __restrict__ dls) {
+  const float k = dkl ? dkl[0] / (float)n : 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float m = mean[i], e = expf(ls[i]);
+    const float dc = dcode ? dcode[i] : 0.f;
+    dmean[i] = dc + k * m;
+    dls[i] = dc * eps[i] * e + k * (e * e - 1.f);
+  }
+}
+
+hipError_t ca_kl_fwd_launch(const float* mean, const float* ls, const float* eps, int n, float* code, float* kl, hipStream_t stream) {
+  hipLaunchKernelGGL(ca_kl_fwd_kernel, dim3(1), dim3(256), 0, stream, mean, ls, eps, n, code, kl);
+  return hipGetLastError();
+}
+
+hipError_t ca_kl_bwd_launch(const float* mean, const float* ls, const float* eps, const float* dcode, const float* dkl, int n,
+                            float* dmean, float* dls, hipStream_t stream) {
+  hipLaunchKernelGGL(ca_kl_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, stream, mean, ls, eps, dcode, dkl, n, dmean, dls);
+  return hipGetLastError();
+}
+
 }  // namespace t2i

@@ -42,6 +42,9 @@ hipError_t resample2_launch(bool, const float*, int, int, int, int, float, float
 hipError_t row_moments_launch(const float*, const float*, int, int64_t, float*, float*, void*, hipStream_t);
 size_t row_moments_ws(int B);
 hipError_t row_fma2_launch(const float*, const float*, const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
+hipError_t wgan_d_head_launch(const float*, const float*, const float*, const float*, int, float, float*, float*, float*, float*, hipStream_t);
+hipError_t ca_kl_fwd_launch(const float*, const float*, const float*, int, float*, float*, hipStream_t);
+hipError_t ca_kl_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
@@ -505,6 +508,28 @@ int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float
                  int64_t per_sample, float* out, t2i_stream_t stream) {
   if (!a || !alpha || !out || B <= 0 || per_sample <= 0 || ((b == nullptr) != (gamma == nullptr))) { set_error("t2i_row_fma2: bad argument"); return T2I_ERR_INVALID; }
   return check(row_fma2_launch(a, b, alpha, gamma, delta, B, per_sample, out, (hipStream_t)stream), "t2i_row_fma2");
+}
+
+int t2i_wgan_d_head(const float* logits, const float* slopes1, const float* slopes2, const float* kt_dev, int32_t B,
+                    float gp_coeff, float* seed_logits, float* seed_slopes1, float* seed_slopes2, float* scalars,
+                    t2i_stream_t stream) {
+  if (!logits || !slopes1 || !slopes2 || !seed_logits || !seed_slopes1 || !seed_slopes2 || !scalars || B <= 0) {
+    set_error("t2i_wgan_d_head: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  return check(wgan_d_head_launch(logits, slopes1, slopes2, kt_dev, B, gp_coeff, seed_logits, seed_slopes1, seed_slopes2, scalars,
+                                  (hipStream_t)stream), "t2i_wgan_d_head");
+}
+
+int t2i_ca_kl_fwd(const float* mean, const float* log_sigma, const float* eps, int64_t n, float* code, float* kl, t2i_stream_t stream) {
+  if (!mean || !log_sigma || !eps || !code || !kl || n <= 0 || n > (1 << 24)) { set_error("t2i_ca_kl_fwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(ca_kl_fwd_launch(mean, log_sigma, eps, (int)n, code, kl, (hipStream_t)stream), "t2i_ca_kl_fwd");
+}
+
+int t2i_ca_kl_bwd(const float* mean, const float* log_sigma, const float* eps, const float* dcode, const float* dkl, int64_t n,
+                  float* dmean, float* dlog_sigma, t2i_stream_t stream) {
+  if (!mean || !log_sigma || !eps || !dmean || !dlog_sigma || n <= 0 || n > (1 << 24)) { set_error("t2i_ca_kl_bwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(ca_kl_bwd_launch(mean, log_sigma, eps, dcode, dkl, (int)n, dmean, dlog_sigma, (hipStream_t)stream), "t2i_ca_kl_bwd");
 }
 
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,

@@ -483,3 +483,40 @@ def row_fma2(a, alpha, b=None, gamma=None, delta=None):
         check(lib.t2i_row_fma2(_ptr(a), _ptr(_chk(b, 'b') if b is not None else None), _ptr(al), _ptr(ga), _ptr(de), B,
                                a.numel() // B, _ptr(out), _stream()), 't2i_row_fma2')
     return out
+
+
+# ---- loss heads (reference models/wgancls/model.py:72-92,117-127) -------------------------------------------------------
+D_HEAD_KEYS = ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'reg_loss',
+               'balance_loss', 'kt_grad', 'kt')
+
+
+def wgan_d_head(logits, slopes1, slopes2, kt, gp_coeff):
+    """logits [3B] (fake | real | mismatch), slopes [B], kt: device scalar tensor or None (= 1).
+    -> (scalars [12] in D_HEAD_KEYS order, dD/dlogits [3B], dD/dslopes1 [B], dD/dslopes2 [B])"""
+    _chk(logits, 'logits'); _chk(slopes1, 'slopes1'); _chk(slopes2, 'slopes2')
+    B = slopes1.numel()
+    assert logits.numel() == 3 * B and slopes2.numel() == B
+    scal = torch.empty(12, dtype=torch.float32, device=logits.device)
+    sl, s1, s2 = torch.empty_like(logits), torch.empty_like(slopes1), torch.empty_like(slopes2)
+    if _live(logits):
+        check(lib.t2i_wgan_d_head(_ptr(logits), _ptr(slopes1), _ptr(slopes2), _ptr(kt), B, gp_coeff, _ptr(sl), _ptr(s1), _ptr(s2),
+                                  _ptr(scal), _stream()), 't2i_wgan_d_head')
+    return scal, sl, s1, s2
+
+
+def ca_kl_fwd(mean, log_sigma, eps):
+    _chk(mean, 'mean'); _chk(log_sigma, 'log_sigma'); _chk(eps, 'eps')
+    code = torch.empty_like(mean)
+    kl = torch.empty(1, dtype=torch.float32, device=mean.device)
+    if _live(mean):
+        check(lib.t2i_ca_kl_fwd(_ptr(mean), _ptr(log_sigma), _ptr(eps), mean.numel(), _ptr(code), _ptr(kl), _stream()), 't2i_ca_kl_fwd')
+    return code, kl
+
+
+def ca_kl_bwd(mean, log_sigma, eps, dcode, dkl):
+    dmean, dls = torch.empty_like(mean), torch.empty_like(mean)
+    if _live(mean):
+        check(lib.t2i_ca_kl_bwd(_ptr(mean), _ptr(log_sigma), _ptr(eps), _ptr(_chk(dcode, 'dcode') if dcode is not None else None),
+                                _ptr(_chk(dkl, 'dkl') if dkl is not None else None), mean.numel(), _ptr(dmean), _ptr(dls),
+                                _stream()), 't2i_ca_kl_bwd')
+    return dmean, dls

@@ -42,6 +42,8 @@ class WGanCls(object):
         self.dp = dp
         self.global_step = 0
         self._graphs = None
+        self._consts = {}
+        self._kl = None
 
         if build_model:
             self.build_model()
@@ -74,6 +76,17 @@ class WGanCls(object):
     def get_gradient_penalty2(self, x, y):
         """reference model.py:67-70 (same, for the rank-2 text embedding)."""
         return self.get_gradient_penalty(x, y)
+
+    def _const_like(self, t, value):
+        """A cached constant tensor shaped like `t` (backward seeds): filled once, so nothing is launched per step."""
+        key = (tuple(t.shape), float(value), t.device)
+        c = self._consts.get(key)
+        if c is None:
+            c = self._consts[key] = torch.full(tuple(t.shape), float(value), dtype=torch.float32, device=t.device)
+        return c
+
+    def _ones_like(self, t):
+        return self._const_like(t, 1.0)
 
     @staticmethod
     def _penalty(grad_y):
@@ -115,26 +128,21 @@ class WGanCls(object):
         cond_inp = (cond + 0.0).requires_grad_(True)
         Dx_hat_logit = self.discriminator(x_hat, cond_inp, reuse=True)
         with A.input_grads_only():
-            gx, gc = torch.autograd.grad(Dx_hat_logit.sum(), [x_hat, cond_inp], create_graph=True)
-        real_gp, real_gp2 = self._penalty(gx), self._penalty(gc)
-
-        D_loss_real, D_loss_fake, D_loss_mismatch = Dx_logit.mean(), Dg_logit.mean(), Dxmi_logit.mean()
-        wdist = D_loss_real - D_loss_fake
-        wdist2 = D_loss_real - D_loss_mismatch
-        D_loss = -wdist - self.kt * wdist2 + self.gp_coeff * (real_gp + real_gp2)
-
+            # d(sum of logits)/d(inputs): seeded with ones directly (no .sum() node, no ones_like fill in its backward)
+            gx, gc = torch.autograd.grad(Dx_hat_logit, [x_hat, cond_inp], grad_outputs=self._ones_like(Dx_hat_logit),
+                                         create_graph=True)
+        slopes1, slopes2 = A.GpSlopesFn.apply(gx), A.GpSlopesFn.apply(gc)
+        # loss head (model.py:72-92) in one launch: every logged scalar + the seeds dD_loss/dlogits, dD_loss/dslopes
+        scal, seed_l, seed_s1, seed_s2 = K.wgan_d_head(logits.detach().reshape(-1), slopes1.detach(), slopes2.detach(), self.kt,
+                                                        self.gp_coeff)
         self.d_arena.zero_grad()
         if self.dp is not None:
             self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this backward
-        D_loss.backward(inputs=list(self.d_vars.values()))
+        torch.autograd.backward([logits, slopes1, slopes2], [seed_l.view_as(logits), seed_s1, seed_s2],
+                                inputs=list(self.d_vars.values()))
         A.side_join()                          # filter gradients issued on the side stream are in the arena
-        with torch.no_grad():
-            wd, wd2 = wdist.detach(), wdist2.detach()
-            out = dict(D_loss=D_loss.detach(), D_loss_real=D_loss_real.detach(), D_loss_fake=D_loss_fake.detach(),
-                       D_loss_mismatch=D_loss_mismatch.detach(), wdist=wd, wdist2=wd2, real_gp=real_gp.detach(),
-                       real_gp2=real_gp2.detach(), reg_loss=(Dxmi_logit.detach() ** 2).mean(),
-                       balance_loss=(self.kt * wd2 - wd) ** 2, kt_grad=2.0 * (self.kt * wd2 - wd) * wd2, kt=self.kt.clone(),
-                       G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
+        out = {k: scal[i] for i, k in enumerate(K.D_HEAD_KEYS)}
+        out.update(G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
         return out
 
     def _d_body(self, feed):
@@ -167,15 +175,21 @@ class WGanCls(object):
             G, mean, log_sigma = self.generator(z, cond, reuse=True)
         with self.store.frozen('d_net'):
             Dg_logit = self.discriminator(G, cond, reuse=True)
-        D_loss_fake = Dg_logit.mean()
-        G_kl_loss = self.kl_std_normal_loss(mean, log_sigma)
-        G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
+        # G_loss = -mean(D(G)) + kl_coeff * KL (model.py:90-92): the KL value came out of the fused conditioning-augmentation
+        # kernel; the backward is seeded with dG_loss/dlogit = -1/B and dG_loss/dKL = kl_coeff
+        G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
+        B = Dg_logit.numel()
         self.g_arena.zero_grad()
         if self.dp is not None:
             self.dp.arm(self.g_arena)
-        G_loss.backward(inputs=list(self.g_vars.values()))
+        torch.autograd.backward([Dg_logit, G_kl], [self._const_like(Dg_logit, -1.0 / B), self._const_like(G_kl, self.kl_coeff)],
+                                inputs=list(self.g_vars.values()))
         A.side_join()
-        return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), D_loss_fake=D_loss_fake.detach(), G=G.detach())
+        with torch.no_grad():
+            D_loss_fake = Dg_logit.detach().mean()
+            G_kl_loss = G_kl.detach().reshape(())
+            G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
+        return dict(G_loss=G_loss, G_kl_loss=G_kl_loss, D_loss_fake=D_loss_fake, G=G.detach())
 
     def _g_body(self, feed):
         out = self.g_losses(feed)
@@ -243,13 +257,15 @@ class WGanCls(object):
     def sample_normal_conditional(self, mean, log_sigma, cond_noise=True):
         """c = mu + exp(log sigma) * eps, eps ~ truncated N(0,1) (reference model.py:117-122).  The draw comes from the
         feed (`ca_noise_d` / `ca_noise_g`) when given so that runs are reproducible; [B,128] scalar math stays in torch."""
+        self._kl = None
         if not cond_noise:
             return mean
         eps = getattr(self, '_noise', None)
         if eps is None or eps.shape != mean.shape:
             eps = torch.empty_like(mean)
             torch.nn.init.trunc_normal_(eps, mean=0.0, std=1.0, a=-2.0, b=2.0)
-        return mean + torch.exp(log_sigma) * eps
+        code, self._kl = A.CaSampleKlFn.apply(mean, log_sigma, eps)     # one launch; the KL term rides along
+        return code
 
     def kl_std_normal_loss(self, mean, log_sigma):
         """KL(N(mu, sigma) || N(0, 1)) averaged over batch and features (reference model.py:124-127)."""
