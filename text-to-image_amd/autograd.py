@@ -354,11 +354,14 @@ class BatchNormTrainFn(Function):
         ctx.act, ctx.alpha = act, alpha
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.mark_non_differentiable(mean, rstd)
+        ctx.set_materialize_grads(False)     # else the engine zero-fills a gradient for mean and rstd on every backward
         return y, mean, rstd
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _gm, _gr):
+        if gy is None:
+            return (None,) * 9
         x, gamma, mean, rstd, y = ctx.saved_tensors
         gy = _c(gy)
         if ctx.act != K.ACT_NONE and gy.shape[-1] % 4 == 0:
