@@ -4,6 +4,7 @@
 // All are HBM-bound: 16-byte accesses where the shape allows, grid-stride loops capped at 2048 blocks (256 CUs x 8),
 // wave64 shuffle reductions, fixed summation order (deterministic).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "t2i_internal.h"
@@ -640,7 +641,10 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
 
 hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,
                           float b1, float b2, float eps, float gscale, hipStream_t stream) {
-  hipLaunchKernelGGL(adam_tf_kernel, dim3(ew_blocks(((size_t)n + 3) >> 2)), dim3(256), 0, stream, w, g, m, v, (size_t)n,
+  static const int adam_cap = getenv("T2I_ADAM_BLOCKS") ? atoi(getenv("T2I_ADAM_BLOCKS")) : 2048;
+  size_t nb = ((((size_t)n + 3) >> 2) + 255) / 256;
+  if (nb > (size_t)adam_cap) nb = adam_cap;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)nb), dim3(256), 0, stream, w, g, m, v, (size_t)n,
                      lr_t, lr_dev, b1, b2, eps, gscale);
   return hipGetLastError();
 }

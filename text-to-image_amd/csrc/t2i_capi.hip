@@ -151,7 +151,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
       double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * share_eff[resident]);
-      if (sk_eff > 1) t += (math ? 2.0 : 4.0) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
+      static const double split_cost = getenv("T2I_SPLIT_COST") ? atof(getenv("T2I_SPLIT_COST")) : 4.0;   // us per extra launch
+      if (sk_eff > 1) t += (math ? 2.0 : split_cost) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
       if (t < best_t) {
         best_t = t;
         best.wmt = wmt; best.wnt = wnt;

@@ -19,6 +19,11 @@ cd "$REPO"
 timeout 300 python tools/bench_conv.py --batch 64 > "$OUT/conv_microbench_B64.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 192 --filter D > "$OUT/conv_microbench_B192.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 64 --math bf16 > "$OUT/conv_microbench_bf16_B64.txt" 2>&1
+timeout 300 python tools/bench_aux.py 2>&1 | grep -v amdgpu > "$OUT/hbm_kernels.txt"
+{ for b in 8 64; do timeout 200 python text-to-image_amd/models/stackgan/run.py --stage 1 --batch $b 2>&1 | tail -1; done
+  for b in 8 32; do timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch $b --steps 5 2>&1 | tail -1; done
+  timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch 32 --steps 5 --math bf16 2>&1 | tail -1
+  timeout 600 python text-to-image_amd/models/pggan/train_pggan.py --bench --iters 8 --first 6 --last 12 2>&1 | grep "^pggan"; } > "$OUT/next_rows_throughput.txt"
 timeout 300 python bench.py --math bf16 --no-cpu-baseline 2>/dev/null | grep '"metric"' > "$OUT/bench_line_bf16.json"
 timeout 600 python bench.py 2>/dev/null | grep '"metric"' > "$OUT/bench_line.json"
 # drop the bulky raw traces, keep the per-pass counter csv of the MFMA pass for reference
