@@ -176,6 +176,10 @@ int t2i_row_moments(const float* a, const float* b, int32_t B, int64_t per_sampl
 int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float* gamma, const float* delta, int32_t B,
                  int64_t per_sample, float* out, t2i_stream_t stream);
 
+/* Fade-in mix with the weight t in device memory (reference models/pggan/pggan.py:267,314 reads the `alpha_tra` variable):
+ * mode 0: out = (1-t)*a + t*b;  mode 1: out = t*a;  mode 2: out = (1-t)*a  (modes 1, 2 = the backward of mode 0). */
+int t2i_lerp_dev(const float* a, const float* b, const float* t_dev, int32_t mode, int64_t n, float* out, t2i_stream_t stream);
+
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):
  * src [N,S,S,3] uint8 resident on the device; out [B,out_size,out_size,3] float32 with

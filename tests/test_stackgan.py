@@ -170,3 +170,43 @@ def test_stackgan_tiny_iteration_matches_golden(stage):
         assert frozen > 40
         moved = [n for n in moving0 if n.startswith('g_net/') and not torch.equal(moving0[n], m.store.vars[n])]
         assert len(moved) == len([n for n in moving0 if n.startswith('g_net/')])      # ... but its moving averages do
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stage', [1, 2])
+def test_stackgan_graph_replay_matches_eager(stage):
+    """The two halves of the iteration captured into hipGraphs (graphs.StepGraphs) and replayed == the eager launches, bit
+    for bit, over 3 iterations with fresh inputs and conditioning noise each time."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from t2i_amd.models.stackgan.stageI.trainer import ConditionalGanTrainer as T1
+    from t2i_amd.models.stackgan.stageII.trainer import ConditionalGanTrainer as T2
+    gs = np.load(os.path.join(ROOT, 'tests', 'golden', 'stackgan%d_tiny.npz' % stage))
+    dev = torch.device('cuda')
+    params = {k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')}
+    f = {k[len('feed/'):]: torch.tensor(gs[k], dtype=torch.float32, device=dev) for k in gs.files if k.startswith('feed/')}
+    g = torch.Generator(device=dev).manual_seed(9)
+    feeds = []
+    for _ in range(4):
+        fd = {'inputs': torch.rand(f['x'].shape, generator=g, device=dev) * 2 - 1, 'wrong_inputs': f['x_mismatch'],
+              'phi_inputs': torch.randn(f['cond'].shape, generator=g, device=dev), 'z': torch.randn(f['z'].shape, generator=g, device=dev)}
+        for k in f:
+            if k.startswith('ca_noise'):
+                fd[k] = torch.randn(f[k].shape, generator=g, device=dev).clamp(-2, 2)
+        feeds.append(fd)
+    states = []
+    for use_graphs in (False, True):
+        m = _models(stage, dev)
+        m.store.load(params)
+        tr = (T1 if stage == 1 else T2)(None, m, None, m.cfg)
+        tr.iteration(feeds[0], epoch=0)
+        if use_graphs:
+            tr.enable_graphs(feeds[0])
+        outs = [tr.iteration(feeds[1 + i], epoch=100 * i) for i in range(3)]       # the learning rate changes between replays
+        torch.cuda.synchronize()
+        states.append(({n: v.detach().clone() for n, v in m.store.vars.items()}, float(outs[-1]['d']['D_loss']),
+                       float(outs[-1]['g']['G_loss'])))
+    (s0, d0, g0), (s1, d1, g1) = states
+    assert d0 == d1 and g0 == g1
+    for n in s0:
+        assert torch.equal(s0[n], s1[n]), n

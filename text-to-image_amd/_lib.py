@@ -47,6 +47,7 @@ SIGNATURES = {
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     't2i_ca_kl_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    't2i_lerp_dev': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
     't2i_pool2_sum': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
     't2i_upscale2': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
     't2i_row_moments_workspace_bytes': (ctypes.c_size_t, [_i32]),

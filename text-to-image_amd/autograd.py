@@ -506,3 +506,24 @@ class CaSampleKlFn(Function):
         dmean, dls = K.ca_kl_bwd(mean, log_sigma, eps, _c(dcode) if dcode is not None else None,
                                  _c(dkl).reshape(1) if dkl is not None else None)
         return dmean, dls, None
+
+
+class LerpDevFn(Function):
+    """mode 0: (1-t)*a + t*b;  1: t*a;  2: (1-t)*a, t in device memory (graph-replayable fade-in).  Closed under
+    differentiation: the gradients are modes 2 and 1 of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, t_dev, mode):
+        ctx.t_dev, ctx.mode = t_dev, mode
+        ctx.set_materialize_grads(False)
+        return K.lerp_dev(_c(a), _c(b) if b is not None else None, t_dev, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        if ctx.mode == 0:
+            ga = LerpDevFn.apply(g, None, ctx.t_dev, 2) if ctx.needs_input_grad[0] else None
+            gb = LerpDevFn.apply(g, None, ctx.t_dev, 1) if ctx.needs_input_grad[1] else None
+            return ga, gb, None, None
+        return (LerpDevFn.apply(g, None, ctx.t_dev, ctx.mode) if ctx.needs_input_grad[0] else None), None, None, None

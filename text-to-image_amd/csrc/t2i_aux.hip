@@ -942,4 +942,19 @@ hipError_t ca_kl_bwd_launch(const float* mean, const float* ls, const float* eps
   return hipGetLastError();
 }
 
+// fade-in with the mixing weight in DEVICE memory (so that a captured graph can be replayed with the next iteration's
+// alpha): mode 0: out = (1-t)*a + t*b;  mode 1: out = t*a;  mode 2: out = (1-t)*a   (1 and 2 are the backward of 0)
+__global__ __launch_bounds__(256) void lerp_dev_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ t_dev, int mode, size_t n,
+                                                       float* __restrict__ out) {
+  const float t = *t_dev, u = 1.f - t;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = mode == 0 ? u * a[i] + t * b[i] : (mode == 1 ? t * a[i] : u * a[i]);
+}
+
+hipError_t lerp_dev_launch(const float* a, const float* b, const float* t_dev, int mode, size_t n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(lerp_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, t_dev, mode, n, out);
+  return hipGetLastError();
+}
+
 }  // namespace t2i

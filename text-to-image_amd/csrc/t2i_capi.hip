@@ -45,6 +45,7 @@ hipError_t row_fma2_launch(const float*, const float*, const float*, const float
 hipError_t wgan_d_head_launch(const float*, const float*, const float*, const float*, int, float, float*, float*, float*, float*, hipStream_t);
 hipError_t ca_kl_fwd_launch(const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t ca_kl_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
+hipError_t lerp_dev_launch(const float*, const float*, const float*, int, size_t, float*, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
@@ -531,6 +532,11 @@ int t2i_ca_kl_bwd(const float* mean, const float* log_sigma, const float* eps, c
                   float* dmean, float* dlog_sigma, t2i_stream_t stream) {
   if (!mean || !log_sigma || !eps || !dmean || !dlog_sigma || n <= 0 || n > (1 << 24)) { set_error("t2i_ca_kl_bwd: bad argument"); return T2I_ERR_INVALID; }
   return check(ca_kl_bwd_launch(mean, log_sigma, eps, dcode, dkl, (int)n, dmean, dlog_sigma, (hipStream_t)stream), "t2i_ca_kl_bwd");
+}
+
+int t2i_lerp_dev(const float* a, const float* b, const float* t_dev, int32_t mode, int64_t n, float* out, t2i_stream_t stream) {
+  if (!a || !t_dev || !out || n <= 0 || mode < 0 || mode > 2 || (mode == 0 && !b)) { set_error("t2i_lerp_dev: bad argument"); return T2I_ERR_INVALID; }
+  return check(lerp_dev_launch(a, b, t_dev, mode, (size_t)n, out, (hipStream_t)stream), "t2i_lerp_dev");
 }
 
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,

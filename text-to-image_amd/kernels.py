@@ -520,3 +520,13 @@ def ca_kl_bwd(mean, log_sigma, eps, dcode, dkl):
                                 _ptr(_chk(dkl, 'dkl') if dkl is not None else None), mean.numel(), _ptr(dmean), _ptr(dls),
                                 _stream()), 't2i_ca_kl_bwd')
     return dmean, dls
+
+
+def lerp_dev(a, b, t_dev, mode=0):
+    """mode 0: (1-t)*a + t*b;  1: t*a;  2: (1-t)*a   with t a 1-element device tensor."""
+    _chk(a, 'a')
+    out = torch.empty_like(a)
+    if _live(a):
+        check(lib.t2i_lerp_dev(_ptr(a), _ptr(_chk(b, 'b') if b is not None else None), _ptr(_chk(t_dev, 't')), mode, a.numel(), _ptr(out),
+                               _stream()), 't2i_lerp_dev')
+    return out

@@ -69,15 +69,43 @@ class GanClsTrainer(object):
         A.side_join()
         return dict(G_loss=G_loss.detach(), G=G.detach())
 
-    def iteration(self, feed):
+    # ---- device-only halves of an iteration (graph-capturable) ------------------------------------------------------------
+    def _d_body(self, feed):
         m = self.model
         d = self.d_losses(feed)
         scale = m.dp.allreduce_arena(m.d_arena) if m.dp is not None else 1.0
-        self.D_optim.step(float(self.cfg.TRAIN.D_LR), grad_scale=scale)
+        self.D_optim.apply(grad_scale=scale)
+        return d
+
+    def _g_body(self, feed):
+        m = self.model
         g = self.g_losses(feed)
         scale = m.dp.allreduce_arena(m.g_arena) if m.dp is not None else 1.0
-        self.G_optim.step(float(self.cfg.TRAIN.G_LR), grad_scale=scale)
-        return {'d': d, 'g': g}
+        self.G_optim.apply(grad_scale=scale)
+        return g
+
+    def enable_graphs(self, feed):
+        """Capture the two halves into hipGraphs and replay them from then on (single GPU; call after one eager iteration)."""
+        from ...graphs import StepGraphs
+        if self.model.dp is not None:
+            raise RuntimeError('graph capture with data parallelism is not supported yet')
+        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'))
+        self._graphs.capture('d', self._d_body)
+        self._graphs.capture('g', self._g_body)
+
+    def iteration(self, feed):
+        lr_d, lr_g = float(self.cfg.TRAIN.D_LR), float(self.cfg.TRAIN.G_LR)
+        graphs = getattr(self, '_graphs', None)
+        if graphs is not None:
+            graphs.load(feed)
+            self.D_optim.prepare(lr_d)
+            d = graphs.replay('d')
+            self.G_optim.prepare(lr_g)
+            return {'d': d, 'g': graphs.replay('g')}
+        self.D_optim.prepare(lr_d)
+        d = self._d_body(feed)
+        self.G_optim.prepare(lr_g)
+        return {'d': d, 'g': self._g_body(feed)}
 
     def make_feed(self):
         m = self.model

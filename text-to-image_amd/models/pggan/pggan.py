@@ -45,6 +45,8 @@ class PGGAN(object):
         self.store = S.set_default_store(store or S.VariableStore(device=device, seed=seed))
         self.device = self.store.device
         self.alpha_tra = 0.0                      # tf.Variable(0.0, trainable=False, name='alpha_tra')
+        self._alpha_dev = torch.zeros(1, device=self.device)      # ... kept in device memory: graph-replayable fade-in
+        self._graphs = None
         self.dp = None
         if build_model:
             self.build_model()
@@ -133,14 +135,58 @@ class PGGAN(object):
         A.side_join()
         return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
 
+    def set_alpha(self, value):
+        self.alpha_tra = float(value)
+        self._alpha_dev.fill_(self.alpha_tra)
+
+    def _d_body(self, feed):
+        d = self.d_losses(feed)
+        self.D_optimizer.apply()
+        return d
+
+    def _g_body(self, feed):
+        g = self.g_losses(feed)
+        self.G_optimizer.apply()
+        return g
+
+    def enable_graphs(self, feed):
+        """Capture the two halves of the iteration into hipGraphs (call after one eager iteration).  alpha then lives in
+        device memory, and the in-graph random draws of the reference (eps of x_hat, the conditioning noise) become static
+        buffers that are re-drawn before every replay."""
+        from ...graphs import StepGraphs
+        B, dev = feed['x'].shape[0], self.device
+        feed = dict(feed)
+        for k, shape in (('eps_graph', (B,)), ('ca_noise_d', (B, self.compr_embed_dim)), ('ca_noise_g', (B, self.compr_embed_dim))):
+            if feed.get(k) is None:
+                feed[k] = torch.empty(shape, device=dev)
+        self._graphs = StepGraphs(feed, ('x', 'x_mismatch', 'cond', 'z', 'eps_graph', 'ca_noise_d', 'ca_noise_g'))
+        self._redraw(feed)
+        self._graphs.load(feed)
+        self._graphs.capture('d', self._d_body)
+        self._graphs.capture('g', self._g_body)
+
+    def _redraw(self, feed):
+        st = self._graphs.static
+        if feed.get('eps_graph') is None or feed['eps_graph'] is st['eps_graph']:
+            st['eps_graph'].uniform_(0.0, 1.0)
+        for k in ('ca_noise_d', 'ca_noise_g'):
+            if feed.get(k) is None or feed[k] is st[k]:
+                torch.nn.init.trunc_normal_(st[k], 0.0, 1.0, -2.0, 2.0)
+
     def iteration(self, idx, feed):
         """One D update then one G update (pggan.py:196-197)."""
-        self.alpha_tra = float(idx) / float(self.steps)          # alpha_assign (see the module docstring)
-        d = self.d_losses(feed)
-        self.D_optimizer.step(self.adam_lr)
-        g = self.g_losses(feed)
-        self.G_optimizer.step(self.adam_lr)
-        return {'d': d, 'g': g}
+        self.set_alpha(float(idx) / float(self.steps))           # alpha_assign (see the module docstring)
+        if self._graphs is not None:
+            self._redraw(feed)
+            self._graphs.load(feed)
+            self.D_optimizer.prepare(self.adam_lr)
+            d = self._graphs.replay('d')
+            self.G_optimizer.prepare(self.adam_lr)
+            return {'d': d, 'g': self._graphs.replay('g')}
+        self.D_optimizer.prepare(self.adam_lr)
+        d = self._d_body(feed)
+        self.G_optimizer.prepare(self.adam_lr)
+        return {'d': d, 'g': self._g_body(feed)}
 
     def sampler(self, z_sample, cond_sample):
         with torch.no_grad():
@@ -150,7 +196,7 @@ class PGGAN(object):
     # ---- networks ------------------------------------------------------------------------------------------------------
     def discriminator(self, inp, cond, stages, t, reuse=False):
         """-> logits [B]  (pggan.py:251-281)"""
-        alpha_trans = self.alpha_tra
+        alpha_trans = self._alpha_dev
         act = lrelu_act()
         with S.variable_scope('d_net', reuse=reuse):
             x_iden = None
@@ -174,7 +220,7 @@ class PGGAN(object):
 
     def generator(self, z_var, cond_inp, stages, t, reuse=False, cond_noise=True):
         """-> (image NHWC, mean, log_sigma)  (pggan.py:283-316)"""
-        alpha_trans = self.alpha_tra
+        alpha_trans = self._alpha_dev
         with S.variable_scope('g_net', reuse=reuse):
             with S.variable_scope(self.get_conv_scope_name(0), reuse=reuse):
                 mean_lr, log_sigma_lr = self.generate_conditionals(cond_inp)

@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument('--first', type=int, default=0, help='index into the 15-entry schedule to start from')
     ap.add_argument('--last', type=int, default=len(STAGE) - 1)
     ap.add_argument('--math', choices=['f32', 'bf16'], default='f32')
+    ap.add_argument('--eager', action='store_true', help='--bench: keep eager launches instead of hipGraph replay')
     ap.add_argument('--bench', action='store_true', help='time `--iters` iterations of each entry instead of training with side effects')
     args = ap.parse_args(argv)
     K.set_math(args.math)
@@ -52,6 +53,8 @@ def main(argv=None):
             gen = torch.Generator(device=dev).manual_seed(0)
             feed = pggan.make_feed(gen)
             for k in range(3):
+                if k == 2 and not args.eager:
+                    pggan.enable_graphs(feed)
                 pggan.iteration(1 + k, feed)
             torch.cuda.synchronize()
             n = args.iters or 10
@@ -61,7 +64,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             print('pggan stage %d%s  %3dx%-3d batch %2d  %s  %.2f ms/iteration  %.1f images/s' % (
-                STAGE[i], 't' if t else ' ', size, size, batch_size, args.math, dt * 1e3, batch_size / dt))
+                STAGE[i], 't' if t else ' ', size, size, batch_size, args.math + (' eager' if args.eager else ' graphs'), dt * 1e3, batch_size / dt))
         else:
             pggan.train(max_steps=args.iters, side_effects=True)
         del pggan

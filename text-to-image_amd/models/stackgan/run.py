@@ -36,6 +36,7 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--batch', type=int, default=None, help='override TRAIN.BATCH_SIZE')
     ap.add_argument('--math', choices=['f32', 'bf16'], default='f32')
+    ap.add_argument('--graphs', type=int, default=1, help='1: replay the two halves of the iteration as hipGraphs (default)')
     args = ap.parse_args(argv)
     from t2i_amd import kernels as K
     K.set_math(args.math)
@@ -45,7 +46,9 @@ def main(argv=None):
         cfg.TRAIN.BATCH_SIZE = cfg1.TRAIN.BATCH_SIZE = args.batch
     model, trainer = build(args.stage, cfg, cfg1)
     feed = trainer.make_feed()
-    for _ in range(3):
+    for i in range(3):
+        if args.graphs and i == 2:
+            trainer.enable_graphs(feed)
         trainer.iteration(feed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,8 +56,8 @@ def main(argv=None):
         out = trainer.iteration(feed)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print('stackgan stage %d  batch %d  %s  %.2f ms/iteration  %.1f images/s  d_loss %.4f g_loss %.4f' % (
-        args.stage, model.batch_size, args.math, dt * 1e3, model.batch_size / dt, float(out['d']['D_loss']), float(out['g']['G_loss'])))
+    print('stackgan stage %d  batch %d  %s %s  %.2f ms/iteration  %.1f images/s  d_loss %.4f g_loss %.4f' % (
+        args.stage, model.batch_size, args.math, 'graphs' if args.graphs else 'eager', dt * 1e3, model.batch_size / dt, float(out['d']['D_loss']), float(out['g']['G_loss'])))
 
 
 if __name__ == '__main__':

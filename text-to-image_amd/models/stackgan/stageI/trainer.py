@@ -84,15 +84,64 @@ class ConditionalGanTrainer(object):
         A.side_join()
         return dict(G_loss=G_loss.detach(), G_gan_loss=G_gan_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
 
-    def iteration(self, feed, epoch=0):
+    # ---- device-only halves of an iteration (graph-capturable: Adam reads its step size from device memory) -----------------
+    def _d_body(self, feed):
         m = self.model
-        lr = self.lr * (0.5 ** (epoch // 100))                       # trainer.py:119,127
         d = self.d_losses(feed)
         scale = m.dp.allreduce_arena(m.d_arena) if m.dp is not None else 1.0
-        self.D_optim.step(lr, grad_scale=scale)
+        self.D_optim.apply(grad_scale=scale)
+        return d
+
+    def _g_body(self, feed):
+        m = self.model
         g = self.g_losses(feed)
         scale = m.dp.allreduce_arena(m.g_arena) if m.dp is not None else 1.0
-        self.G_optim.step(lr, grad_scale=scale)
+        self.G_optim.apply(grad_scale=scale)
+        return g
+
+    NOISE_KEYS = ('ca_noise_d', 'ca_noise_g')
+
+    def enable_graphs(self, feed):
+        """Capture the two halves into hipGraphs and replay them from then on (single GPU).  Call after at least one eager
+        iteration with the same shapes.  The conditioning-augmentation noise lives in static buffers that are re-drawn
+        before every replay (the reference draws it inside the graph on every run)."""
+        from ....graphs import StepGraphs
+        m = self.model
+        if m.dp is not None:
+            raise RuntimeError('graph capture with data parallelism is not supported yet')
+        feed = dict(feed)
+        for k in self.NOISE_KEYS:
+            if feed.get(k) is None:
+                feed[k] = torch.empty(feed['z'].shape[0], self._noise_dim(k), device=m.device)
+        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z') + tuple(self.NOISE_KEYS))
+        self._draw_noise(feed)
+        self._graphs.load(feed)
+        self._graphs.capture('d', self._d_body)
+        self._graphs.capture('g', self._g_body)
+
+    def _noise_dim(self, key):
+        return self.model.compressed_embed_dim
+
+    def _draw_noise(self, feed):
+        for k in self.NOISE_KEYS:
+            if feed.get(k) is None or feed[k] is self._graphs.static.get(k):
+                torch.nn.init.trunc_normal_(self._graphs.static[k], 0.0, 1.0, -2.0, 2.0)
+
+    def iteration(self, feed, epoch=0):
+        lr = self.lr * (0.5 ** (epoch // 100))                       # trainer.py:119,127
+        graphs = getattr(self, '_graphs', None)
+        if graphs is not None:
+            self._draw_noise(feed)
+            graphs.load(feed)
+            self.D_optim.prepare(lr)
+            d = graphs.replay('d')
+            self.G_optim.prepare(lr)
+            g = graphs.replay('g')
+            return {'d': d, 'g': g}
+        self.D_optim.prepare(lr)
+        d = self._d_body(feed)
+        self.G_optim.prepare(lr)
+        g = self._g_body(feed)
         return {'d': d, 'g': g}
 
     def make_feed(self):

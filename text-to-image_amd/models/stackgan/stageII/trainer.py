@@ -8,6 +8,10 @@ from ..stageI.trainer import ConditionalGanTrainer as _StageITrainer
 
 class ConditionalGanTrainer(_StageITrainer):
     REAL_LABEL = 0.95
+    NOISE_KEYS = ('ca_noise_d', 'ca_noise_g', 'ca_noise_d_s1', 'ca_noise_g_s1')
+
+    def _noise_dim(self, key):
+        return self.model.stagei.compressed_embed_dim if key.endswith('_s1') else self.model.compressed_embed_dim
 
     def __init__(self, sess, model, dataset, cfg, cfg_stage_i=None):
         self.cfg_stage_i = cfg_stage_i

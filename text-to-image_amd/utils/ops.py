@@ -214,6 +214,8 @@ def upscale(x, s=2):
 def lerp(a, b, t):
     """(1 - t)*a + t*b with a host scalar t: the fade-in of a new resolution (tf.multiply / tf.add on the `alpha_tra`
     variable, reference models/pggan/pggan.py:267,314)."""
+    if isinstance(t, torch.Tensor):          # weight in device memory: the step can be captured into a hipGraph
+        return A.LerpDevFn.apply(a, b, t, 0)
     return A.AxpbyFn.apply(a, 1.0 - float(t), b, float(t))
 
 
