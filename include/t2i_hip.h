@@ -66,6 +66,15 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fw
 int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                    float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
+/* t2i_conv2d_fwd that also hands the batch norm behind it its statistics: if the launch takes the unsplit path,
+ * *chunks = number of M-tiles and stats = [2][chunks][Cout] per-tile column sums of y and of y*y (finish with
+ * t2i_col_reduce_partials(stats, stats + chunks*Cout, chunks, Cout, sum, sumsq, ...)); otherwise *chunks = 0 and the
+ * caller reduces y itself (t2i_col_reduce).  stats must hold t2i_conv2d_stats_bytes(d). */
+size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d);
+int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, void* ws, size_t ws_bytes,
+                         t2i_stream_t stream);
+
 /* dx = conv^T(dy, w) (+ bias over Cin if non-NULL, then act).  This IS ops.conv2d_transpose (utils/ops.py:66-71):
  * TF stores the deconv filter as [KH,KW,Cout_deconv,Cin_deconv], i.e. the HWIO filter of the adjoint conv, so the
  * descriptor is that adjoint conv's (d->Cin = deconv output channels) and no re-layout is needed. */
@@ -85,6 +94,9 @@ int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, floa
                    void* ws, size_t ws_bytes, t2i_stream_t stream); /* accumulate != 0: out += (sums into a gradient arena) */
 
 /* ---- batch norm, training mode: reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm fused, scale=True) --- */
+/* Second stage alone: out0[c] = sum_k part0[k*C + c] (k < chunks, fixed order), same for part1/out1 when given. */
+int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chunks, int32_t C, float* out0, float* out1,
+                            int accumulate, t2i_stream_t stream);
 /* From sum/sumsq over n rows: mean, rstd = 1/sqrt(var_biased+eps); scale = gamma*rstd, shift = beta-mean*scale;
  * and, if moving_mean != NULL, moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
 int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma,

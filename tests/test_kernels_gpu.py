@@ -303,3 +303,40 @@ def test_every_tile_and_split_config(K, monkeypatch, tile, splitk, math):
         if math == 'bf16':   # and it IS a reduced-precision product: visibly off the unrounded fp32 answer
             e = relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), O.conv2d(x, w, b, (s, s), pad))
             assert 1e-4 < e < 2e-2, (case, e)
+
+
+def test_conv_epilogue_batch_norm_statistics(K):
+    """conv_fwd_stats: the GEMM epilogue's per-tile column sums, finished by take_stats, == column sums of the output (1e-5 of
+    their scale) for every tile shape; when the planner splits K the fused path declines and nothing is cached."""
+    import os
+    rng = np.random.default_rng(12)
+    for tile, case in ((22, (4, 16, 16, 64, 136, 3, 3, 1, 'SAME')), (21, (3, 8, 8, 32, 64, 3, 3, 1, 'SAME')), (12, (2, 32, 32, 16, 128, 1, 1, 1, 'VALID')),
+                       (11, (5, 4, 4, 64, 40, 3, 3, 1, 'SAME')), (0, (64, 8, 8, 128, 128, 3, 3, 1, 'SAME'))):
+        B, H, W, Ci, Co, KH, KW, s, pad = case
+        if tile:
+            os.environ['T2I_FORCE_TILE'] = str(tile); os.environ['T2I_FORCE_SPLITK'] = '1'
+        try:
+            x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+            w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
+            b = rng.standard_normal(Co).astype(np.float32)
+            d, ws = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad)
+            y = K.conv_fwd_stats(dev(x), dev(w), dev(b), d, 256 << 20)
+            got = K.take_stats(y)
+            assert K.take_stats(y) is None                              # consumed
+            ref = y.double().reshape(-1, Co)
+            if got is not None:
+                scale = float((ref * ref).sum(0).sqrt().max())                 # column sums of +-values: compare on the scale of |y|
+                assert float((got[0].double().cpu() - ref.sum(0).cpu()).abs().max()) <= 1e-5 * scale * np.sqrt(ref.shape[0])
+                assert relerr(got[1], (ref * ref).sum(0).cpu().numpy()) <= 1e-5
+            else:
+                assert tile == 0                                        # only the planner's own choice may decline (split-K)
+            assert relerr(y, K.conv_fwd(dev(x), dev(w), dev(b), d, 256 << 20).double().cpu().numpy()) == 0.0
+        finally:
+            os.environ.pop('T2I_FORCE_TILE', None); os.environ.pop('T2I_FORCE_SPLITK', None)
+    os.environ['T2I_FORCE_SPLITK'] = '3'
+    try:
+        d, ws = K.conv_desc(2, 4, 4, 512, 256, 3, 3, 1, 1, 'SAME')
+        y = K.conv_fwd_stats(dev(rng.standard_normal((2, 4, 4, 512)).astype(np.float32)), dev(rng.standard_normal((3, 3, 512, 256)).astype(np.float32)), None, d, 256 << 20)
+        assert K.take_stats(y) is None
+    finally:
+        os.environ.pop('T2I_FORCE_SPLITK', None)

@@ -161,11 +161,12 @@ class Conv2dFn(Function):
     """y = act(conv(x, w) + b): reference utils/ops.py:58-63.  geom = (ConvDesc, workspace_bytes)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, geom, act, alpha):
+    def forward(ctx, x, w, b, geom, act, alpha, want_stats=False):
         d, ws = geom
         x = _c(x)
         ctx.set_materialize_grads(False)   # an undefined upstream gradient must not become a zero-filled conv launch
-        y = K.conv_fwd(x, w, b, d, ws, act, alpha)
+        # want_stats: a batch norm consumes this output next; the GEMM epilogue leaves it the per-tile column sums
+        y = K.conv_fwd_stats(x, w, b, d, ws, act, alpha) if want_stats else K.conv_fwd(x, w, b, d, ws, act, alpha)
         ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
         ctx.bias_ref = b            # only its address is used (gradient sink lookup)
@@ -174,7 +175,7 @@ class Conv2dFn(Function):
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         params = not _INPUTS_ONLY[0]
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and params
@@ -195,7 +196,7 @@ class Conv2dFn(Function):
                 gb = ColSumFn.apply(gpre)
         gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
         gw = _filter_grad(x, gpre, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class ConvBwdDataFn(Function):
@@ -347,7 +348,8 @@ class BatchNormTrainFn(Function):
         x = _c(x)
         C = x.shape[-1]
         n = x.numel() // C
-        s, ss = K.col_reduce(x, None, True)
+        hit = K.take_stats(x)                     # left by the producing conv's epilogue (ops.conv2d(..., stats=True))
+        s, ss = hit if hit is not None else K.col_reduce(x, None, True)
         mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean, moving_var)
         y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)

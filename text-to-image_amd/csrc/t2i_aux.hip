@@ -183,6 +183,15 @@ static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int6
   if (*nchunks < 1) *nchunks = 1;
 }
 
+hipError_t col_reduce_partials_launch(const float* part0, const float* part1, int chunks, int C, float* out0, float* out1,
+                                      int accumulate, hipStream_t stream) {
+  const int ct = (C + 63) / 64;
+  const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(part0) | reinterpret_cast<uintptr_t>(part1)) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part0, part1, chunks, C, out0, out1, accumulate);
+  else hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, chunks, C, out0, out1, accumulate);
+  return hipGetLastError();
+}
+
 size_t col_reduce_ws(int64_t rows, int C) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);

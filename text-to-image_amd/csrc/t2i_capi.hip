@@ -46,6 +46,7 @@ hipError_t wgan_d_head_launch(const float*, const float*, const float*, const fl
 hipError_t ca_kl_fwd_launch(const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t ca_kl_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t lerp_dev_launch(const float*, const float*, const float*, int, size_t, float*, hipStream_t);
+hipError_t col_reduce_partials_launch(const float*, const float*, int, int, float*, float*, int, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
@@ -210,8 +211,13 @@ static int fill_phases(IgemmParams& p) {
 static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256 : 32; }
 
 static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* out, const float* bias, int act,
-                    float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what, int accumulate = 0) {
+                    float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what, int accumulate = 0,
+                    int* stats_chunks = nullptr) {
   Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode), p.d.math);
+  if (stats_chunks) {          // epilogue statistics exist only on the unsplit path; the caller falls back otherwise
+    if (pl.splitk > 1) { p.stats = nullptr; *stats_chunks = 0; }
+    else *stats_chunks = pl.tiles_m;
+  }
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
   p.out_elems = out_elems;
@@ -270,11 +276,36 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   return need;
 }
 
+size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d) {
+  if (validate_desc(d) != T2I_OK) return 0;
+  const size_t tiles = ((size_t)d->B * d->Ho * d->Wo + 63) / 64;        // smallest M tile
+  return tiles * 2 * (size_t)d->Cout * sizeof(float);
+}
+
+static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                           float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
 int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                    float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  return conv2d_fwd_impl(d, x, w, bias, y, act, alpha, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, void* ws, size_t ws_bytes,
+                         t2i_stream_t stream) {
+  if (!stats || !chunks || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
+  int c = 0;
+  const int rc = conv2d_fwd_impl(d, x, w, bias, y, act, alpha, stats, &c, ws, ws_bytes, stream);
+  *chunks = c;
+  return rc;
+}
+
+static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                           float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
+  if (stats_chunks) *stats_chunks = 0;
   if (!env_int("T2I_NO_THIN", 0)) {
     if (head_conv_eligible(*d))
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
@@ -290,8 +321,9 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
   p.div_c.set(d->Cin);
   const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
   const int var = !vec ? 0 : ((d->Cin % 32 == 0) ? 2 : 1);     // 2: a 32-wide K-tile never straddles a filter tap
+  p.stats = stats;
   return run_gemm(MODE_FWD, p, (size_t)p.M * p.N, var, y, bias, act, alpha, ws, ws_bytes, (hipStream_t)stream,
-                  "t2i_conv2d_fwd");
+                  "t2i_conv2d_fwd", 0, stats_chunks);
 }
 
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
@@ -364,6 +396,13 @@ int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, floa
   if (!a || !out0 || rows <= 0 || C <= 0) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_col_reduce: workspace too small"); return T2I_ERR_WORKSPACE; }
   return check(col_reduce_launch(a, b, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_col_reduce");
+}
+
+int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chunks, int32_t C, float* out0, float* out1,
+                            int accumulate, t2i_stream_t stream) {
+  if (!part0 || !out0 || chunks <= 0 || C <= 0 || ((part1 == nullptr) != (out1 == nullptr))) { set_error("t2i_col_reduce_partials: bad argument"); return T2I_ERR_INVALID; }
+  return check(col_reduce_partials_launch(part0, part1, chunks, C, out0, out1, accumulate ? 1 : 0, (hipStream_t)stream),
+               "t2i_col_reduce_partials");
 }
 
 int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma, const float* beta,

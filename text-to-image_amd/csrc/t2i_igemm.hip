@@ -596,6 +596,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
   const bool fused = (p.splitk == 1);
+  const bool want_stats = MODE == MODE_FWD && fused && p.stats != nullptr;
+  float cs[WNT], cq[WNT];      // this lane's column partials over its rows (batch-norm statistics of the layer output)
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
 #pragma unroll
   for (int i = 0; i < WMT; ++i) {
 #pragma unroll
@@ -626,8 +630,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             if (p.accumulate) v += out[rowoff + n];
           }
           out[rowoff + n] = v;
+          if (want_stats) { cs[j] += v; cq[j] += v * v; }
         }
       }
+    }
+  }
+  // ---- fused batch-norm statistics: the tile's column sums of y and y^2 (the conv that feeds a batch norm hands it the
+  // partials, so the normalisation needs no extra pass over the tensor to find its mean and variance).  Lane l and l^32
+  // hold the same column; the two waves stacked along M meet in LDS; one float per column and M-tile goes to memory and
+  // a short fixed-order reduction over the M-tiles finishes the job (col_reduce_stage2).
+  if (want_stats) {
+    __syncthreads();                                   // every wave is done with the operand tiles in LDS
+    float* red = smem;                                 // [2 (wm)][2 (sum, sumsq)][BN]
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const float s0 = cs[j] + __shfl_xor(cs[j], 32, 64);
+      const float q0 = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (lh == 0) {
+        const int col = wn * 32 * WNT + j * 32 + l31;
+        red[(wm * 2 + 0) * BN + col] = s0;
+        red[(wm * 2 + 1) * BN + col] = q0;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && bn + tid < p.N) {
+      const size_t tm = (size_t)(bid % tiles_m);
+      p.stats[tm * p.N + bn + tid] = red[0 * BN + tid] + red[2 * BN + tid];
+      p.stats[((size_t)tiles_m + tm) * p.N + bn + tid] = red[1 * BN + tid] + red[3 * BN + tid];
     }
   }
 }

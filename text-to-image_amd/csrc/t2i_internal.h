@@ -62,6 +62,7 @@ struct IgemmParams {
   int32_t walk_doh, walk_db;  // BWD_FILTER pixel walk: advancing the reduction index by one K-tile (32 pixels, Wo | 32)
                               // moves oh by walk_doh (mod Ho, carry into b) and b by walk_db
   int32_t accumulate;         // epilogue adds the existing contents of the output (dw += ...: gradient accumulation)
+  float* stats;               // FWD, unsplit: per-M-tile column partials [2][tiles_m][N] (sum, sum of squares) of the output
   PhaseInfo phase[16];
 };
 

@@ -174,6 +174,48 @@ def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     return y
 
 
+# Batch-norm statistics produced by a conv epilogue, waiting for the batch norm that consumes that conv's output:
+# output address -> (partials [2, chunks, C], chunks).  Filled by conv_fwd(..., stats=True), emptied by take_stats().
+_STATS = {}
+
+
+def take_stats(x):
+    """(column sums, column sums of squares) of `x` if the conv that produced it left its epilogue partials, else None."""
+    hit = _STATS.pop(x.data_ptr(), None)
+    if hit is None:
+        return None
+    part, chunks, shape = hit
+    if tuple(x.shape) != shape:
+        return None
+    C = x.shape[-1]
+    s0 = torch.empty(C, dtype=torch.float32, device=x.device); s1 = torch.empty_like(s0)
+    check(lib.t2i_col_reduce_partials(_ptr(part), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks, C, _ptr(s0), _ptr(s1), 0,
+                                      _stream()), 't2i_col_reduce_partials')
+    return s0, s1
+
+
+def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
+    """conv_fwd whose epilogue also leaves the per-tile column sums of y, y*y for the batch norm behind it (take_stats)."""
+    _chk(x, 'x'); _chk(w, 'w')
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, ws_bytes)
+        nbytes = int(lib.t2i_conv2d_stats_bytes(ctypes.byref(d)))
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        chunks = ctypes.c_int32(0)
+        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
+                                       _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), wsp, wsn, _stream()),
+              't2i_conv2d_fwd_stats')
+        if ev is not None:
+            ev.record()
+        if chunks.value > 0:
+            if len(_STATS) > 64:
+                _STATS.clear()
+            _STATS[y.data_ptr()] = (part, int(chunks.value), tuple(y.shape))
+    return y
+
+
 def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     _chk(dy, 'dy'); _chk(w, 'w')
     dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dy.device)

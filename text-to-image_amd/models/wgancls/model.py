@@ -292,14 +292,15 @@ class WGanCls(object):
     # -- generator (reference model.py:163-225) ---------------------------------------------------------------------------
     def _g_bottleneck(self, x, mid, out, train, fmt):
         """1x1 -> BN/ReLU -> 3x3 -> BN/ReLU -> 3x3 -> BN, added to x, ReLU (model.py:184-191 and :200-207)."""
-        r = batch_norm(conv2d(x, mid, ks=(1, 1), s=(1, 1), padding='valid', df=fmt), train=train, act=relu, df=fmt)
-        r = batch_norm(conv2d(r, mid, ks=(3, 3), s=(1, 1), df=fmt), train=train, act=relu, df=fmt)
-        r = batch_norm(conv2d(r, out, ks=(3, 3), s=(1, 1), df=fmt), train=train, act=None, df=fmt)
+        # stats=train: the conv epilogue hands the batch norm its column sums (no separate statistics pass)
+        r = batch_norm(conv2d(x, mid, ks=(1, 1), s=(1, 1), padding='valid', df=fmt, stats=train), train=train, act=relu, df=fmt)
+        r = batch_norm(conv2d(r, mid, ks=(3, 3), s=(1, 1), df=fmt, stats=train), train=train, act=relu, df=fmt)
+        r = batch_norm(conv2d(r, out, ks=(3, 3), s=(1, 1), df=fmt, stats=train), train=train, act=None, df=fmt)
         return add(x, r, act=relu, df=fmt)
 
     def _g_upsample(self, x, nf, train, fmt, act):
         """k4s2 transposed conv -> 3x3 conv -> BN(+act) (model.py:194-196, 210-216)."""
-        u = conv2d(conv2d_transpose(x, nf, ks=(4, 4), s=(2, 2), df=fmt), nf, ks=(3, 3), s=(1, 1), df=fmt)
+        u = conv2d(conv2d_transpose(x, nf, ks=(4, 4), s=(2, 2), df=fmt), nf, ks=(3, 3), s=(1, 1), df=fmt, stats=train)
         return batch_norm(u, train=train, act=act, df=fmt)
 
     def generator(self, z, embed, reuse=False, is_training=True, df=NCHW, cond_noise=True):

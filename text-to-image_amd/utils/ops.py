@@ -76,8 +76,10 @@ def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
 
-def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=None, df=NHWC):
-    """reference utils/ops.py:58-63.  Variables: <scope>/Conv[_k]/{weights [kh,kw,Cin,f] (He), biases [f] (zeros)}."""
+def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=None, df=NHWC, stats=False):
+    """reference utils/ops.py:58-63.  Variables: <scope>/Conv[_k]/{weights [kh,kw,Cin,f] (He), biases [f] (zeros)}.
+    stats=True (not in the reference; a hint, results are unchanged): a batch_norm consumes this output next, so the GEMM
+    epilogue also emits the per-tile column sums the normalisation needs and batch_norm skips its own pass over the tensor."""
     st = S.default_store()
     xp = _phys(x, df)
     B, H, W, Cin = xp.shape
@@ -87,7 +89,7 @@ def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=
         w = st.get_variable('weights', (kh, kw, Cin, f), init or S.he_init(kh * kw * Cin))
         b = st.get_variable('biases', (f,), S.constant_init(0.0))
     geom = K.conv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
-    y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha)
+    y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha, bool(stats) and kind == K.ACT_NONE and post is None)
     y = _logical(y, df)
     return post(y) if post else y
 
