@@ -16,7 +16,6 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import np_ops
 from .torch_step import AdamTF, _bn, _conv, _deconv_k4s2, is_trainable, trainable  # noqa: F401
 
 

@@ -3,7 +3,6 @@ operator surface / variable naming / trainer schedule are reproduced, and CPU te
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 

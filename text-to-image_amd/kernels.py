@@ -11,7 +11,6 @@ import ctypes
 
 import torch
 
-from . import _lib
 from ._lib import ConvDesc, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3

@@ -17,7 +17,7 @@ from ... import autograd as A
 from ... import kernels as K
 from ... import optim
 from ... import scope as S
-from ...utils.ops import (NCHW, NHWC, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
+from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
                           reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
 
 
