@@ -219,6 +219,7 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
     else *stats_chunks = pl.tiles_m;
   }
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
   p.out_elems = out_elems;
   if (pl.splitk > 1) {

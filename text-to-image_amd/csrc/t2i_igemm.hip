@@ -174,8 +174,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any nblk
   }
-  const int bm = (bid % tiles_m) * BM;
-  const int bn = (bid / tiles_m) * BN;
+  // Grouped rasterisation inside each XCD's run: tile ids walk GROUP_N output-column tiles for every M tile before moving
+  // down, so the ~64-96 workgroups an XCD runs at once form a block of (8-12 M tiles) x (GROUP_N N tiles) and share BOTH
+  // operand panels through that XCD's 4 MB L2 (M-fastest order shared only the filter panel: every A panel was
+  // re-fetched from HBM once per N tile — 220 MB of HBM-side traffic per launch against ~20 MB of operands).
+  int tile_m, tile_n;
+  {
+    const int g = p.group_n;                       // min(tiles_n, 8), host side
+    const int per_group = g * tiles_m;
+    const int grp = bid / per_group;
+    const int r = bid - grp * per_group;
+    const int n0 = grp * g;
+    const int width = min(g, p.tiles_n - n0);
+    tile_m = r / width;
+    tile_n = n0 + (r - tile_m * width);
+  }
+  const int bm = tile_m * BM;
+  const int bn = tile_n * BN;
   const int split = blockIdx.y;
   const PhaseInfo& pi = p.phase[MODE == MODE_BWD_DATA ? blockIdx.z : 0];
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
@@ -654,7 +669,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
     __syncthreads();
     if (tid < BN && bn + tid < p.N) {
-      const size_t tm = (size_t)(bid % tiles_m);
+      const size_t tm = (size_t)tile_m;
       p.stats[tm * p.N + bn + tid] = red[0 * BN + tid] + red[2 * BN + tid];
       p.stats[((size_t)tiles_m + tm) * p.N + bn + tid] = red[1 * BN + tid] + red[3 * BN + tid];
     }

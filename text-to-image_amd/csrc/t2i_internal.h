@@ -53,6 +53,7 @@ struct IgemmParams {
   float alpha;
   int32_t M, N, K;            // GEMM extents (BWD_DATA: M per phase; K = max over phases, per-phase K in phase[])
   int32_t tiles_m, tiles_n;
+  int32_t group_n;            // rasterisation: N tiles walked per M tile before moving to the next M tile (L2 reuse)
   int32_t splitk, k_per_split;
   size_t out_elems;           // slab stride for split-K
   uint32_t a_bytes, b_bytes;  // extents of the two operand buffers (buffer-load range check: out of range reads 0)

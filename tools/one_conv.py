@@ -9,6 +9,7 @@ import t2i_amd  # noqa: E402,F401
 from t2i_amd import kernels as K  # noqa: E402
 from tools.bench_conv import LAYERS  # noqa: E402
 
+K.set_math(os.environ.get('T2I_ONE_MATH', 'f32'))
 name, B, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 _, H, W, Ci, Co, k, s, pad = {l[0]: l for l in LAYERS}[name]
