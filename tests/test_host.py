@@ -139,3 +139,24 @@ def test_config_keys_match_reference_yaml(t2i):
     assert (cfg.MODEL.Z_DIM, cfg.MODEL.EMBED_DIM, cfg.MODEL.COMPRESSED_EMBED_DIM, cfg.MODEL.GF_DIM, cfg.MODEL.DF_DIM) == \
         (128, 1024, 128, 128, 128)
     assert (cfg.TRAIN.D_LR, cfg.TRAIN.BETA1, cfg.TRAIN.BETA2, cfg.TRAIN.N_CRITIC, cfg.TRAIN.COEFF.KL) == (1e-4, 0.0, 0.9, 1, 1.0)
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """The bench line kept with the profiles (profiles/r01_bench_line.json, written by bench.py on the GPU box) carries every
+    key of the driver's contract, the roofline block and the CPU baseline block."""
+    import json
+    line = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_line.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    assert line['unit'] == 'images/sec' and line['dtype'] == 'f32' and line['higher_is_better'] is True and line['scaling'] == 'weak'
+    assert line['vs_baseline'] is None and line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
+    assert abs(line['value'] - 64 * line['n_gpus'] * 1e3 / line['ms_per_step']) <= 1e-6 * line['value']
+    r = line['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    c = line['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
