@@ -340,3 +340,30 @@ def test_conv_epilogue_batch_norm_statistics(K):
         assert K.take_stats(y) is None
     finally:
         os.environ.pop('T2I_FORCE_SPLITK', None)
+
+
+@pytest.mark.parametrize('case', [(2, 4, 4, 256, 288, 'critic 4x4 map'), (3, 8, 8, 320, 256, 'generator 8x8'), (1, 16, 16, 256, 256, '16x16'),
+                                  (5, 4, 6, 512, 256, 'non-square')])
+def test_winograd_3x3_matches_oracle(K, case):
+    """3x3 stride-1 SAME convs with >= 256 channels on small maps take the Winograd F(2x2,3x3) path (transforms + 16 batched
+    GEMMs in one launch) in conv_fwd and conv_bwd_data.  Against the float64 direct oracle: 2e-5 of the output scale (the
+    transforms add a few ulps to the 1e-5 of the direct kernel); bias + activation in the output transform; and the same
+    call with T2I_WINOGRAD=0 semantics is covered by the other conv tests (smaller channel counts never take this path)."""
+    from oracle import np_ops as O
+    B, H, W, Ci, Co, _ = case
+    rng = np.random.default_rng(B * 1000 + H * 10 + Ci)
+    x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Ci, Co)) / np.sqrt(9 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    d, ws = K.conv_desc(B, H, W, Ci, Co, 3, 3, 1, 1, 'SAME')
+    y_ref = O.conv2d(x, w, b, (1, 1), 'SAME')
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
+    assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (1, 1), 'SAME')) <= 2e-5
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (1, 1), 'SAME')) <= 2e-5
+    # adjoint identity between the two Winograd paths: <conv(x), dy> == <x, conv^T(dy)>
+    yk = K.conv_fwd(dev(x), dev(w), None, d, ws).double()
+    lhs = float((yk * dev(dy).double()).sum())
+    rhs = float((dev(x).double() * K.conv_bwd_data(dev(dy), dev(w), None, d, ws).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())      # on the scale of the two vectors

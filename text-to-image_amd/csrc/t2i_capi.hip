@@ -241,6 +241,38 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
   return rc;
 }
 
+// nbatch independent GEMMs of one shape in one launch (Winograd's 16 tile positions), as 1x1 convolutions over T "pixels":
+//   fwd: c[T, Cout] = a[T, Cin] * b[Cin, Cout]        (MODE_FWD,      b row-major [K][N])
+//   bwd: c[T, Cin]  = a[T, Cout] * b[Cin, Cout]^T     (MODE_BWD_DATA, b read as its K-inner image [n][k])
+// grid.z = batch.  Never split: nbatch x tiles already fill the chip.
+int run_batched_gemm(const t2i_conv_desc& gd, bool bwd, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb,
+                     int64_t sc, hipStream_t stream, const char* what) {
+  IgemmParams p;
+  fill_common(p, &gd);
+  p.a = a; p.b = b;
+  const int K = bwd ? gd.Cout : gd.Cin, N = bwd ? gd.Cin : gd.Cout;
+  p.a_bytes = (uint32_t)((size_t)gd.B * K * 4);
+  p.b_bytes = (uint32_t)((size_t)gd.Cin * gd.Cout * 4);
+  p.M = gd.B; p.N = N; p.K = K;
+  if (bwd) {
+    const int kmax = fill_phases(p);          // 1x1 stride 1: one phase, K = Cout
+    p.K = kmax;
+    p.div_c.set(gd.Cout);
+  } else {
+    p.div_c.set(gd.Cin);
+  }
+  p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
+  Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+  p.splitk = 1; p.k_per_split = pl.k_per_split;
+  p.out_elems = (size_t)p.M * p.N;
+  p.c = c; p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
+  const bool vec = (gd.Cin % 4 == 0) && (gd.Cout % 4 == 0) && aligned16(a) && aligned16(b);
+  const int var = !vec ? 0 : ((K % 32 == 0) ? 2 : 1);
+  return check(igemm_launch(bwd ? MODE_BWD_DATA : MODE_FWD, p, pl.wmt, pl.wnt, var, stream), what);
+}
+
 }  // namespace t2i
 
 using namespace t2i;
@@ -274,6 +306,8 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER), d->math).ws_bytes;
   if (b > need) need = b;
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
+  if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
+  if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
   return need;
 }
 
@@ -313,6 +347,8 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
     if (tiny_conv_eligible(*d, false))
       return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
   }
+  if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
+    return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -340,6 +376,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
     if (thin_deconv_eligible(*d) && aligned16(dy) && aligned16(w))
       return check(thin_deconv_launch(*d, dy, w, bias, dx, act, alpha, (hipStream_t)stream), "t2i_conv2d_bwd_data(thin)");
   }
+  if (winograd_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
+    return winograd_conv(*d, true, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;

@@ -192,14 +192,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int bm = tile_m * BM;
   const int bn = tile_n * BN;
   const int split = blockIdx.y;
-  const PhaseInfo& pi = p.phase[MODE == MODE_BWD_DATA ? blockIdx.z : 0];
+  const PhaseInfo& pi = p.phase[(MODE == MODE_BWD_DATA && p.nbatch <= 1) ? blockIdx.z : 0];     // batched launches: one phase
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
   const int kbeg = split * p.k_per_split;
   const int kend = min(Kdim, kbeg + p.k_per_split);
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), (short)0, (int)p.b_bytes, 0x00020000);
+  // FWD launches may carry several independent GEMMs of one shape (grid.z): operand and output bases step per batch
+  const int64_t bz = (MODE != MODE_BWD_FILTER && p.nbatch > 1) ? (int64_t)blockIdx.z : 0;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + bz * p.batch_a), (short)0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + bz * p.batch_b), (short)0, (int)p.b_bytes, 0x00020000);
 
   // ---- per-thread loader state ---------------------------------------------------------------------------------
   // K-inner image: thread -> (k quad kq = tid&7, rows r0 + 32*i).   N-inner image: thread -> (col quad, k rows).
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  float* out = p.c + bz * p.batch_c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
   const bool fused = (p.splitk == 1);
   const bool want_stats = MODE == MODE_FWD && fused && p.stats != nullptr;
   float cs[WNT], cq[WNT];      // this lane's column partials over its rows (batch-norm statistics of the layer output)
@@ -749,7 +751,7 @@ static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, d
 }
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream) {
-  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 1 ? p.nbatch : (mode == MODE_BWD_DATA ? p.nphase : 1));
   if (p.d.math == T2I_MATH_BF16) {
     switch (mode) {
       case MODE_FWD: return launch_mode<MODE_FWD, 1>(p, wmt, wnt, var, grid, stream);

@@ -63,6 +63,8 @@ struct IgemmParams {
   int32_t walk_doh, walk_db;  // BWD_FILTER pixel walk: advancing the reduction index by one K-tile (32 pixels, Wo | 32)
                               // moves oh by walk_doh (mod Ho, carry into b) and b by walk_db
   int32_t accumulate;         // epilogue adds the existing contents of the output (dw += ...: gradient accumulation)
+  int32_t nbatch;             // FWD: independent GEMMs of identical shape in one launch (grid.z; Winograd's 16 tile positions)
+  int64_t batch_a, batch_b, batch_c;   // element strides between them
   float* stats;               // FWD, unsplit: per-M-tile column partials [2][tiles_m][N] (sum, sum of squares) of the output
   PhaseInfo phase[16];
 };
@@ -75,6 +77,14 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     default: return v;
   }
 }
+
+// Winograd F(2x2, 3x3) for 3x3 stride-1 SAME convolutions with many channels (t2i_winograd.hip)
+bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data);
+size_t winograd_ws(const t2i_conv_desc& d, bool bwd_data);
+int winograd_conv(const t2i_conv_desc& d, bool bwd_data, const float* in, const float* w, const float* bias, float* out, int act,
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream);
+int run_batched_gemm(const t2i_conv_desc& gd, bool bwd, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb, int64_t sc,
+                     hipStream_t stream, const char* what);
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,

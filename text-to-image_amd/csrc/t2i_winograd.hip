@@ -1,0 +1,203 @@
+// t2i_winograd.hip — Winograd F(2x2, 3x3) for the 3x3 stride-1 SAME convolutions with many channels on few pixels
+// (critic 4x4 maps with 512-1152 channels, generator 8x8x512 / 16x16x256): 2.25x fewer multiply-adds than the direct
+// implicit GEMM at the price of three HBM-bound transform passes, which only pays when channels >> pixels per image.
+//   y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d (pad 1), 3x3 filter g
+//   U[xi][k][n]   = (G g G^T)[xi]      filter transform, once per call          wino_filter_kernel
+//   V[xi][t][k]   = (B^T d B)[xi]      input transform, t = (b, ty, tx)         wino_input_kernel
+//   M[xi][t][n]   = V[xi] * U[xi]      16 independent [T x K] x [K x N] GEMMs in ONE launch of igemm_kernel (grid.z)
+//   y[b,2ty+i,2tx+j,n] = (A^T M A)[i][j] + bias, activation                     wino_output_kernel
+// Both conv_fwd and conv_bwd_data take this path: the input gradient of a 3x3 stride-1 SAME conv is the same
+// correlation with the filter flipped and its channel axes swapped, done by the filter transform's index map.
+// fp32 throughout (the GEMM follows the descriptor's math mode); transforms use only +, - and *0.5.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+static inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static inline int wino_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  return b < 1 ? 1 : (int)b;
+}
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// U[xi][ci][co] = (G g G^T)[xi] with g[r][c] = w[r][c][ci][co] (fwd) or w[2-r][2-c][ci][co] (bwd: the flipped filter; the
+// channel swap of the input-gradient conv is left to the GEMM, which reads U as [n = ci][k = co] — its K-inner B image).
+// Reads and writes are both contiguous along co.
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cin, int Cout, int bwd,
+                                                          float* __restrict__ U) {
+  const int K = Cin, N = Cout;
+  const size_t total = (size_t)K * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), k = (int)(i / N);
+    const int ci = k, co = n;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int rr = bwd ? 2 - r : r, cc = bwd ? 2 - c : c;
+        g[r][c] = w[((size_t)(rr * 3 + cc) * Cin + ci) * Cout + co];
+      }
+    float s[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s[0][c] = g[0][c];
+      s[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+      s[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+      s[3][c] = g[2][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u0 = s[r][0], u1 = 0.5f * (s[r][0] + s[r][1] + s[r][2]), u2 = 0.5f * (s[r][0] - s[r][1] + s[r][2]), u3 = s[r][2];
+      U[((size_t)(r * 4 + 0) * K + k) * N + n] = u0;
+      U[((size_t)(r * 4 + 1) * K + k) * N + n] = u1;
+      U[((size_t)(r * 4 + 2) * K + k) * N + n] = u2;
+      U[((size_t)(r * 4 + 3) * K + k) * N + n] = u3;
+    }
+  }
+}
+
+// V[xi][t][c]: one thread = one tile x 4 channels
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw,
+                                                         size_t T, float* __restrict__ V) {
+  const int C4 = C >> 2;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const size_t t = i / C4;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ih = 2 * ty - 1 + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int iw = 2 * tx - 1 + c;
+        d[r][c] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                      ? reinterpret_cast<const float4*>(x + ((b * H + ih) * W + iw) * C)[c4]
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 tt[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tt[0][c] = f4sub(d[0][c], d[2][c]);
+      tt[1][c] = f4add(d[1][c], d[2][c]);
+      tt[2][c] = f4sub(d[2][c], d[1][c]);
+      tt[3][c] = f4sub(d[1][c], d[3][c]);
+    }
+    float4* o = reinterpret_cast<float4*>(V) + t * C4 + c4;
+    const size_t plane = T * C4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[(size_t)(r * 4 + 0) * plane] = f4sub(tt[r][0], tt[r][2]);
+      o[(size_t)(r * 4 + 1) * plane] = f4add(tt[r][1], tt[r][2]);
+      o[(size_t)(r * 4 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
+      o[(size_t)(r * 4 + 3) * plane] = f4sub(tt[r][1], tt[r][3]);
+    }
+  }
+}
+
+// y[b, 2ty+i, 2tx+j, n] = act((A^T M A)[i][j] + bias[n]): one thread = one tile x 4 output channels
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, int H,
+                                                          int W, int N, int Th, int Tw, size_t T, int act, float alpha,
+                                                          float* __restrict__ y) {
+  const int N4 = N >> 2;
+  const size_t total = T * N4;
+  const size_t plane = T * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const size_t t = i / N4;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    const float4* m = reinterpret_cast<const float4*>(Mx) + t * N4 + n4;
+    float4 z[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 m0 = m[(size_t)(0 * 4 + c) * plane], m1 = m[(size_t)(1 * 4 + c) * plane], m2 = m[(size_t)(2 * 4 + c) * plane],
+                   m3 = m[(size_t)(3 * 4 + c) * plane];
+      z[0][c] = f4add(f4add(m0, m1), m2);
+      z[1][c] = f4sub(f4sub(m1, m2), m3);
+    }
+    const float4 bs = bias ? reinterpret_cast<const float4*>(bias)[n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float4 y0 = f4add(f4add(f4add(z[r][0], z[r][1]), z[r][2]), bs);
+      float4 y1 = f4add(f4sub(f4sub(z[r][1], z[r][2]), z[r][3]), bs);
+      y0.x = apply_act(y0.x, act, alpha); y0.y = apply_act(y0.y, act, alpha); y0.z = apply_act(y0.z, act, alpha); y0.w = apply_act(y0.w, act, alpha);
+      y1.x = apply_act(y1.x, act, alpha); y1.y = apply_act(y1.y, act, alpha); y1.z = apply_act(y1.z, act, alpha); y1.w = apply_act(y1.w, act, alpha);
+      float4* o = reinterpret_cast<float4*>(y + ((b * H + 2 * ty + r) * W + 2 * tx) * N) + n4;
+      o[0] = y0;
+      o[N4] = y1;
+    }
+  }
+}
+
+static int wino_min_channels() {
+  static const int v = getenv("T2I_WINOGRAD_MINC") ? atoi(getenv("T2I_WINOGRAD_MINC")) : 256;
+  return v;
+}
+
+bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
+  static const int on = getenv("T2I_WINOGRAD") ? atoi(getenv("T2I_WINOGRAD")) : 1;
+  if (!on || d.math != T2I_MATH_F32) return false;     // bf16 math: the direct kernel is operand-stream bound, 16 GEMMs would stream 4x more
+  if (!(d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W)) return false;
+  if ((d.H & 1) || (d.W & 1) || (d.Cin % 32) || (d.Cout % 32)) return false;
+  // pays when the GEMM work dominates the three transform passes: many channels on small maps
+  const int cmin = d.Cin < d.Cout ? d.Cin : d.Cout;
+  if (cmin < wino_min_channels() || (int64_t)d.H * d.W > 256) return false;
+  // ... and the 16 GEMMs are big enough to fill the chip after the fixed cost of the filter transform (measured: the
+  // 4x4x256->512 critic layer at B=64, T*K*N = 3.4e7, loses 12%; 4x4x256->1024, 6.7e7, gains 10%)
+  const int64_t T = (int64_t)d.B * (d.H / 2) * (d.W / 2);
+  return T * d.Cin * d.Cout >= 50000000LL;
+}
+
+static void wino_dims(const t2i_conv_desc& d, bool bwd, size_t* T, int* K, int* N) {
+  *T = (size_t)d.B * (d.H / 2) * (d.W / 2);
+  *K = bwd ? d.Cout : d.Cin;
+  *N = bwd ? d.Cin : d.Cout;
+}
+
+size_t winograd_ws(const t2i_conv_desc& d, bool bwd) {
+  size_t T; int K, N;
+  wino_dims(d, bwd, &T, &K, &N);
+  return al256((size_t)16 * K * N * 4) + al256(16 * T * K * 4) + al256(16 * T * N * 4);
+}
+
+int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float* w, const float* bias, float* out, int act,
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
+  size_t T; int K, N;
+  wino_dims(d, bwd, &T, &K, &N);
+  if (!ws || ws_bytes < winograd_ws(d, bwd) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    set_error("winograd conv: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_ws(d, bwd));
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  float* U = reinterpret_cast<float*>(base);
+  float* V = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4));
+  float* Mx = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4) + al256(16 * T * K * 4));
+  const int Th = d.H / 2, Tw = d.W / 2;
+  hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, bwd ? 1 : 0, U);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V);
+  t2i_conv_desc gd = d;                // the 16 GEMMs as a batch of 1x1 convolutions over T "pixels" (fwd) / their input gradient (bwd)
+  gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;   // Cin, Cout as in d
+  const int rc = run_batched_gemm(gd, bwd, 16, V, U, Mx, (int64_t)T * K, (int64_t)d.Cin * d.Cout, (int64_t)T * N, stream, "winograd gemm");
+  if (rc != T2I_OK) return rc;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks(T * (N / 4))), dim3(256), 0, stream, Mx, bias, d.H, d.W, N, Th, Tw, T, act, alpha, out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("winograd conv: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
+}  // namespace t2i
