@@ -346,7 +346,7 @@ def test_conv_epilogue_batch_norm_statistics(K):
                                   (5, 4, 6, 512, 256, 'non-square')])
 def test_winograd_3x3_matches_oracle(K, case):
     """3x3 stride-1 SAME convs with >= 256 channels on small maps take the Winograd F(2x2,3x3) path (transforms + 16 batched
-    GEMMs in one launch) in conv_fwd and conv_bwd_data.  Against the float64 direct oracle: 2e-5 of the output scale (the
+    GEMMs in one launch) in conv_fwd, conv_bwd_data and conv_bwd_filter.  Against the float64 direct oracle: 2e-5 of the output scale (the
     transforms add a few ulps to the 1e-5 of the direct kernel); bias + activation in the output transform; and the same
     call with T2I_WINOGRAD=0 semantics is covered by the other conv tests (smaller channel counts never take this path)."""
     from oracle import np_ops as O
@@ -362,6 +362,11 @@ def test_winograd_3x3_matches_oracle(K, case):
     assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (1, 1), 'SAME')) <= 2e-5
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (1, 1), 'SAME')) <= 2e-5
+    dw_ref = O.conv2d_bwd_filter(x, dy, w.shape, (1, 1), 'SAME')
+    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= 2e-5
+    acc = dev(w.copy())
+    K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1))               # accumulate form (gradient sink)
+    assert relerr(acc, w.astype(np.float64) + dw_ref) <= 2e-5
     # adjoint identity between the two Winograd paths: <conv(x), dy> == <x, conv^T(dy)>
     yk = K.conv_fwd(dev(x), dev(w), None, d, ws).double()
     lhs = float((yk * dev(dy).double()).sum())

@@ -245,11 +245,29 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
 //   fwd: c[T, Cout] = a[T, Cin] * b[Cin, Cout]        (MODE_FWD,      b row-major [K][N])
 //   bwd: c[T, Cin]  = a[T, Cout] * b[Cin, Cout]^T     (MODE_BWD_DATA, b read as its K-inner image [n][k])
 // grid.z = batch.  Never split: nbatch x tiles already fill the chip.
-int run_batched_gemm(const t2i_conv_desc& gd, bool bwd, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb,
+//   flt: c[Cin, Cout] = a[T, Cin]^T * b[T, Cout]     (MODE_BWD_FILTER, reduction over the T "pixels")
+int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb,
                      int64_t sc, hipStream_t stream, const char* what) {
   IgemmParams p;
   fill_common(p, &gd);
   p.a = a; p.b = b;
+  if (gmode == MODE_BWD_FILTER) {
+    p.a_bytes = (uint32_t)((size_t)gd.B * gd.Cin * 4);
+    p.b_bytes = (uint32_t)((size_t)gd.B * gd.Cout * 4);
+    p.M = gd.Cin; p.N = gd.Cout; p.K = gd.B;
+    p.div_c.set(gd.Cin);
+    p.walk_db = 32; p.walk_doh = 0;               // 1x1 maps: one K-tile = 32 consecutive "images"
+    p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
+    Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math);
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+    { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+    p.splitk = 1; p.k_per_split = pl.k_per_split;
+    p.out_elems = (size_t)p.M * p.N;
+    p.c = c; p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
+    const bool vec = (gd.Cin % 4 == 0) && (gd.Cout % 4 == 0) && aligned16(a) && aligned16(b);
+    return check(igemm_launch(MODE_BWD_FILTER, p, pl.wmt, pl.wnt, vec ? 2 : 0, stream), what);
+  }
+  const bool bwd = gmode == MODE_BWD_DATA;
   const int K = bwd ? gd.Cout : gd.Cin, N = bwd ? gd.Cin : gd.Cout;
   p.a_bytes = (uint32_t)((size_t)gd.B * K * 4);
   p.b_bytes = (uint32_t)((size_t)gd.Cin * gd.Cout * 4);
@@ -308,6 +326,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
+  if (winograd_eligible(*d, false) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
   return need;
 }
 
@@ -406,6 +425,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
       return check(tiny_bwdw_launch(*d, x, dy, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_conv2d_bwd_filter(tiny)");
     }
   }
+  if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
+    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;

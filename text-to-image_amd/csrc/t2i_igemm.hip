@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   // FWD launches may carry several independent GEMMs of one shape (grid.z): operand and output bases step per batch
-  const int64_t bz = (MODE != MODE_BWD_FILTER && p.nbatch > 1) ? (int64_t)blockIdx.z : 0;
+  const int64_t bz = p.nbatch > 1 ? (int64_t)blockIdx.z : 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + bz * p.batch_a), (short)0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + bz * p.batch_b), (short)0, (int)p.b_bytes, 0x00020000);
 

@@ -83,7 +83,10 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data);
 size_t winograd_ws(const t2i_conv_desc& d, bool bwd_data);
 int winograd_conv(const t2i_conv_desc& d, bool bwd_data, const float* in, const float* w, const float* bias, float* out, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t stream);
-int run_batched_gemm(const t2i_conv_desc& gd, bool bwd, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb, int64_t sc,
+size_t winograd_filter_grad_ws(const t2i_conv_desc& d);
+int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
+int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb, int64_t sc,
                      hipStream_t stream, const char* what);
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);

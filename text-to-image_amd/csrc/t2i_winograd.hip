@@ -192,11 +192,107 @@ int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float
   hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V);
   t2i_conv_desc gd = d;                // the 16 GEMMs as a batch of 1x1 convolutions over T "pixels" (fwd) / their input gradient (bwd)
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;   // Cin, Cout as in d
-  const int rc = run_batched_gemm(gd, bwd, 16, V, U, Mx, (int64_t)T * K, (int64_t)d.Cin * d.Cout, (int64_t)T * N, stream, "winograd gemm");
+  const int rc = run_batched_gemm(gd, bwd ? MODE_BWD_DATA : MODE_FWD, 16, V, U, Mx, (int64_t)T * K, (int64_t)d.Cin * d.Cout, (int64_t)T * N, stream, "winograd gemm");
   if (rc != T2I_OK) return rc;
   hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks(T * (N / 4))), dim3(256), 0, stream, Mx, bias, d.H, d.W, N, Th, Tw, T, act, alpha, out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("winograd conv: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient:  dw = G^T [ (B^T d B) (.) (A dy A^T) ] G  summed over tiles — the adjoint of the forward identity.
+//   V[xi][t][ci] = B^T d B        (the forward's input transform)
+//   Z[xi][t][co] = A dy A^T       wino_dy_kernel (2x2 output-gradient tile -> 4x4)
+//   P[xi][ci][co] = sum_t V[xi][t][ci] Z[xi][t][co]     16 batched filter-gradient GEMMs (reduction over tiles)
+//   dw[r][c][ci][co] (+)= (G^T P G)[r][c]               wino_dw_kernel
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int H, int W, int N, int Th, int Tw, size_t T,
+                                                      float* __restrict__ Z) {
+  const int N4 = N >> 2;
+  const size_t total = T * N4, plane = T * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const size_t t = i / N4;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    const float4* src = reinterpret_cast<const float4*>(dy + ((b * H + 2 * ty) * W + 2 * tx) * N) + n4;
+    const float4 d00 = src[0], d01 = src[N4], d10 = src[(size_t)W * N4], d11 = src[(size_t)W * N4 + N4];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // s[r][j] = sum_i A[r][i] d[i][j],  A = [1 0; 1 1; 1 -1; 0 -1]
+    const float4 s[4][2] = {{d00, d01}, {f4add(d00, d10), f4add(d01, d11)}, {f4sub(d00, d10), f4sub(d01, d11)}, {f4sub(zero, d10), f4sub(zero, d11)}};
+    float4* o = reinterpret_cast<float4*>(Z) + t * N4 + n4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[(size_t)(r * 4 + 0) * plane] = s[r][0];
+      o[(size_t)(r * 4 + 1) * plane] = f4add(s[r][0], s[r][1]);
+      o[(size_t)(r * 4 + 2) * plane] = f4sub(s[r][0], s[r][1]);
+      o[(size_t)(r * 4 + 3) * plane] = f4sub(zero, s[r][1]);
+    }
+  }
+}
+
+__device__ __forceinline__ float4 f4half(float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
+
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ P, int Cin, int Cout, int accumulate,
+                                                      float* __restrict__ dw) {
+  const int N4 = Cout >> 2;
+  const size_t total = (size_t)Cin * N4, plane = total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float4* p = reinterpret_cast<const float4*>(P) + i;
+    float4 q[3][4];     // q[r][c'] = sum_rho GT[r][rho] P[rho][c'],  GT = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 p0 = p[(size_t)(0 * 4 + c) * plane], p1 = p[(size_t)(1 * 4 + c) * plane], p2 = p[(size_t)(2 * 4 + c) * plane],
+                   p3 = p[(size_t)(3 * 4 + c) * plane];
+      const float4 hs = f4half(f4add(p1, p2)), hd = f4half(f4sub(p1, p2));
+      q[0][c] = f4add(p0, hs);
+      q[1][c] = hd;
+      q[2][c] = f4add(hs, p3);
+    }
+    float4* o = reinterpret_cast<float4*>(dw) + i;        // dw [3][3][Cin][Cout]: tap plane stride = Cin*Cout/4
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 hs = f4half(f4add(q[r][1], q[r][2])), hd = f4half(f4sub(q[r][1], q[r][2]));
+      float4 w0 = f4add(q[r][0], hs), w1 = hd, w2 = f4add(hs, q[r][3]);
+      if (accumulate) {
+        w0 = f4add(w0, o[(size_t)(r * 3 + 0) * plane]); w1 = f4add(w1, o[(size_t)(r * 3 + 1) * plane]); w2 = f4add(w2, o[(size_t)(r * 3 + 2) * plane]);
+      }
+      o[(size_t)(r * 3 + 0) * plane] = w0;
+      o[(size_t)(r * 3 + 1) * plane] = w1;
+      o[(size_t)(r * 3 + 2) * plane] = w2;
+    }
+  }
+}
+
+size_t winograd_filter_grad_ws(const t2i_conv_desc& d) {
+  const size_t T = (size_t)d.B * (d.H / 2) * (d.W / 2);
+  return al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4) + al256((size_t)16 * d.Cin * d.Cout * 4);
+}
+
+int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  const size_t T = (size_t)d.B * (d.H / 2) * (d.W / 2);
+  if (!ws || ws_bytes < winograd_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    set_error("winograd filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_filter_grad_ws(d));
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  float* V = reinterpret_cast<float*>(base);
+  float* Z = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4));
+  float* P = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4));
+  const int Th = d.H / 2, Tw = d.W / 2;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.H, d.W, d.Cout, Th, Tw, T, Z);
+  t2i_conv_desc gd = d;
+  gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  const int rc = run_batched_gemm(gd, MODE_BWD_FILTER, 16, V, Z, P, (int64_t)T * d.Cin, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, stream,
+                                  "winograd filter-gradient gemm");
+  if (rc != T2I_OK) return rc;
+  hipLaunchKernelGGL(wino_dw_kernel, dim3(wino_blocks((size_t)d.Cin * (d.Cout / 4))), dim3(256), 0, stream, P, d.Cin, d.Cout, accumulate, dw);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("winograd filter gradient: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
   return T2I_OK;
 }
 
