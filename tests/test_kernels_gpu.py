@@ -372,3 +372,20 @@ def test_winograd_3x3_matches_oracle(K, case):
     lhs = float((yk * dev(dy).double()).sum())
     rhs = float((dev(x).double() * K.conv_bwd_data(dev(dy), dev(w), None, d, ws).double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())      # on the scale of the two vectors
+
+
+@pytest.mark.parametrize('case', [(2, 8, 8, 128, 160), (3, 16, 16, 256, 128), (1, 4, 12, 136, 128), (2, 32, 32, 128, 256)])
+def test_winograd_k4s2_matches_oracle(K, case):
+    """4x4 stride-2 SAME convs with >= 128 channels take the F(2x2,2x2) path in conv_fwd (space-to-depth phases, 9 batched
+    GEMMs).  Against the float64 direct oracle: 2e-5 of the output scale, with bias and activation."""
+    from oracle import np_ops as O
+    B, H, W, Ci, Co = case
+    rng = np.random.default_rng(B * 100 + H + Ci)
+    x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, Ci, Co)) / np.sqrt(16 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    d, ws = K.conv_desc(B, H, W, Ci, Co, 4, 4, 2, 2, 'SAME')
+    y_ref = O.conv2d(x, w, b, (2, 2), 'SAME')
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
+    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
+    assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (2, 2), 'SAME')) <= 2e-5

@@ -327,6 +327,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
   if (winograd_eligible(*d, false) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
+  if (winograd_k4s2_eligible(*d) && winograd_k4s2_ws(*d) > need) need = winograd_k4s2_ws(*d);
   return need;
 }
 
@@ -368,6 +369,8 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  if (winograd_k4s2_eligible(*d) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
+    return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;

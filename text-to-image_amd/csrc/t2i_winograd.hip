@@ -296,4 +296,156 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
   return T2I_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 4x4 stride-2 SAME convolutions (the critic trunk; the input gradient of the generator's deconvs) by Winograd F(2x2, 2x2):
+// a k4 s2 conv is the sum over the 4 input phases (p,q) of a 2x2 stride-1 correlation,
+//     y[oh][ow] = sum_{p,q} sum_{a,b} X_pq[oh+a][ow+b] w[2a+p][2b+q],    X_pq[r][c] = x[2r+p-1][2c+q-1],
+// i.e. ONE 2x2 stride-1 conv over the space-to-depth image with 4*Cin channels.  F(2x2,2x2) computes a 2x2 output tile from
+// a 3x3 patch with 9 multiplies instead of 16: 1.78x fewer multiply-adds.
+//   V[xi][t][(p,q,ci)] = B^T X_pq B   (3x3 per phase; the 4 phases partition the tile's 6x6 input patch)   BT = [1 -1 0; 0 1 0; 0 -1 1]
+//   U[xi][(p,q,ci)][co] = G g_pq G^T  (2x2 -> 3x3)                                                         G  = [1 0; 1 1; 0 1]
+//   M[xi] = V[xi] * U[xi]             9 batched GEMMs [T x 4Cin] x [4Cin x Cout]
+//   y tile = A^T M A + bias, act      (3x3 -> 2x2)                                                          AT = [1 1 0; 0 1 1]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino2_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+  const int N4 = Cout >> 2;
+  const size_t total = (size_t)4 * Cin * N4;             // (phase, ci, co4)
+  const size_t plane = (size_t)4 * Cin * N4;             // one xi plane of U, in float4
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const int ci = (int)((i / N4) % Cin);
+    const int ph = (int)(i / ((size_t)N4 * Cin));
+    const int p = ph >> 1, q = ph & 1;
+    float4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        g[a][b] = reinterpret_cast<const float4*>(w + ((size_t)((2 * a + p) * 4 + (2 * b + q)) * Cin + ci) * Cout)[n4];
+    float4 s[3][2] = {{g[0][0], g[0][1]}, {f4add(g[0][0], g[1][0]), f4add(g[0][1], g[1][1])}, {g[1][0], g[1][1]}};
+    float4* o = reinterpret_cast<float4*>(U) + ((size_t)ph * Cin + ci) * N4 + n4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
+      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
+      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino2_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw, size_t T,
+                                                          float* __restrict__ V) {
+  const int C4 = C >> 2;
+  const size_t total = T * 4 * C4;                        // (tile, phase, ci4)
+  const size_t plane = T * 4 * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int ph = (int)((i / C4) & 3);
+    const size_t t = i / ((size_t)4 * C4);
+    const int p = ph >> 1, q = ph & 1;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    float4 d[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = 4 * ty - 1 + 2 * r + p;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int iw = 4 * tx - 1 + 2 * c + q;
+        d[r][c] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                      ? reinterpret_cast<const float4*>(x + ((b * H + ih) * W + iw) * C)[c4]
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 tt[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tt[0][c] = f4sub(d[0][c], d[1][c]);
+      tt[1][c] = d[1][c];
+      tt[2][c] = f4sub(d[2][c], d[1][c]);
+    }
+    float4* o = reinterpret_cast<float4*>(V) + (t * 4 + ph) * C4 + c4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[(size_t)(r * 3 + 0) * plane] = f4sub(tt[r][0], tt[r][1]);
+      o[(size_t)(r * 3 + 1) * plane] = tt[r][1];
+      o[(size_t)(r * 3 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino2_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, int Ho, int Wo,
+                                                           int N, int Th, int Tw, size_t T, int act, float alpha,
+                                                           float* __restrict__ y) {
+  const int N4 = N >> 2;
+  const size_t total = T * N4, plane = T * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const size_t t = i / N4;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    const float4* m = reinterpret_cast<const float4*>(Mx) + t * N4 + n4;
+    float4 z[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 m0 = m[(size_t)(0 * 3 + c) * plane], m1 = m[(size_t)(1 * 3 + c) * plane], m2 = m[(size_t)(2 * 3 + c) * plane];
+      z[0][c] = f4add(m0, m1);
+      z[1][c] = f4add(m1, m2);
+    }
+    const float4 bs = bias ? reinterpret_cast<const float4*>(bias)[n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float4 y0 = f4add(f4add(z[r][0], z[r][1]), bs);
+      float4 y1 = f4add(f4add(z[r][1], z[r][2]), bs);
+      y0.x = apply_act(y0.x, act, alpha); y0.y = apply_act(y0.y, act, alpha); y0.z = apply_act(y0.z, act, alpha); y0.w = apply_act(y0.w, act, alpha);
+      y1.x = apply_act(y1.x, act, alpha); y1.y = apply_act(y1.y, act, alpha); y1.z = apply_act(y1.z, act, alpha); y1.w = apply_act(y1.w, act, alpha);
+      float4* o = reinterpret_cast<float4*>(y + ((b * Ho + 2 * ty + r) * Wo + 2 * tx) * N) + n4;
+      o[0] = y0;
+      o[N4] = y1;
+    }
+  }
+}
+
+bool winograd_k4s2_eligible(const t2i_conv_desc& d) {
+  static const int on = getenv("T2I_WINOGRAD_K4S2") ? atoi(getenv("T2I_WINOGRAD_K4S2")) : 1;
+  static const int minc = getenv("T2I_WINOGRAD_K4S2_MINC") ? atoi(getenv("T2I_WINOGRAD_K4S2_MINC")) : 128;
+  if (!on || d.math != T2I_MATH_F32) return false;
+  if (!(d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1)) return false;
+  if ((d.H & 3) || (d.W & 3) || d.Ho * 2 != d.H || d.Wo * 2 != d.W) return false;          // 2x2 output tiles, no ragged edge
+  if ((d.Cin % 8) || (d.Cout % 32)) return false;
+  return d.Cin >= minc && d.Cout >= minc;
+}
+
+size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
+  return al256(9 * K * d.Cout * 4) + al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4);
+}
+
+int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                      void* ws, size_t ws_bytes, hipStream_t stream) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
+  if (!ws || ws_bytes < winograd_k4s2_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    set_error("winograd k4s2 conv: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_ws(d));
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  float* U = reinterpret_cast<float*>(base);
+  float* V = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4));
+  float* Mx = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4) + al256(9 * T * K * 4));
+  const int Th = d.Ho / 2, Tw = d.Wo / 2;
+  hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  t2i_conv_desc gd = d;
+  gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.Cin = (int32_t)K; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  const int rc = run_batched_gemm(gd, MODE_FWD, 9, V, U, Mx, (int64_t)T * K, (int64_t)K * d.Cout, (int64_t)T * d.Cout, stream, "winograd k4s2 gemm");
+  if (rc != T2I_OK) return rc;
+  hipLaunchKernelGGL(wino2_output_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, Mx, bias, d.Ho, d.Wo, d.Cout, Th, Tw, T, act,
+                     alpha, y);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("winograd k4s2 conv: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
 }  // namespace t2i
