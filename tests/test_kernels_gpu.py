@@ -374,7 +374,8 @@ def test_winograd_3x3_matches_oracle(K, case):
     assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())      # on the scale of the two vectors
 
 
-@pytest.mark.parametrize('case', [(2, 8, 8, 128, 160), (3, 16, 16, 256, 128), (1, 4, 12, 136, 128), (2, 32, 32, 128, 256)])
+@pytest.mark.parametrize('case', [(2, 8, 8, 128, 160), (3, 16, 16, 256, 128), (1, 4, 12, 136, 128), (2, 32, 32, 128, 256),
+                                  (1, 8, 8, 256, 288), (3, 4, 8, 320, 256), (16, 32, 32, 128, 128)])
 def test_winograd_k4s2_matches_oracle(K, case):
     """4x4 stride-2 SAME convs with >= 128 channels take the F(2x2,2x2) path in conv_fwd (space-to-depth phases, 9 batched
     GEMMs).  Against the float64 direct oracle: 2e-5 of the output scale, with bias and activation."""
@@ -389,3 +390,19 @@ def test_winograd_k4s2_matches_oracle(K, case):
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
     assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (2, 2), 'SAME')) <= 2e-5
+    # input gradient / tf conv2d_transpose forward: 4 output phases x 9 batched GEMMs when Cin % 32 == 0 as well
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    bi = rng.standard_normal(Ci).astype(np.float32)
+    dx_ref = O.conv2d_bwd_data(dy, w, x.shape, (2, 2), 'SAME')
+    assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), dx_ref) <= 2e-5
+    assert relerr(K.conv_bwd_data(dev(dy), dev(w), dev(bi), d, ws, K.ACT_RELU), np.maximum(dx_ref + bi, 0)) <= 2e-5
+    yk = K.conv_fwd(dev(x), dev(w), None, d, ws).double()
+    lhs = float((yk * dev(dy).double()).sum())
+    rhs = float((dev(x).double() * K.conv_bwd_data(dev(dy), dev(w), None, d, ws).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())
+    # filter gradient (adjoint of the forward identity; tile chunks in the batch dimension when 9 GEMMs leave CUs idle)
+    dw_ref = O.conv2d_bwd_filter(x, dy, w.shape, (2, 2), 'SAME')
+    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= 2e-5
+    acc = dev(w.copy())
+    K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1))
+    assert relerr(acc, w.astype(np.float64) + dw_ref) <= 2e-5

@@ -327,7 +327,9 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
   if (winograd_eligible(*d, false) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
-  if (winograd_k4s2_eligible(*d) && winograd_k4s2_ws(*d) > need) need = winograd_k4s2_ws(*d);
+  if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_ws(*d) > need) need = winograd_k4s2_ws(*d);
+  if (winograd_k4s2_eligible(*d, true) && winograd_k4s2_bwd_ws(*d) > need) need = winograd_k4s2_bwd_ws(*d);
+  if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_filter_grad_ws(*d) > need) need = winograd_k4s2_filter_grad_ws(*d);
   return need;
 }
 
@@ -369,7 +371,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
-  if (winograd_k4s2_eligible(*d) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
+  if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
@@ -400,6 +402,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   }
   if (winograd_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
     return winograd_conv(*d, true, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  if (winograd_k4s2_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
+    return winograd_k4s2_bwd_data(*d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
@@ -430,6 +434,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+  if (winograd_k4s2_eligible(*d, false) && env_int("T2I_WINOGRAD_K4S2_BWDF", 1) && aligned16(x) && aligned16(dy) && aligned16(dw))
+    return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;

@@ -83,7 +83,13 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data);
 size_t winograd_ws(const t2i_conv_desc& d, bool bwd_data);
 int winograd_conv(const t2i_conv_desc& d, bool bwd_data, const float* in, const float* w, const float* bias, float* out, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t stream);
-bool winograd_k4s2_eligible(const t2i_conv_desc& d);
+bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data);
+size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d);
+int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                              hipStream_t stream);
+size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d);
+int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx, int act, float alpha,
+                           void* ws, size_t ws_bytes, hipStream_t stream);
 size_t winograd_k4s2_ws(const t2i_conv_desc& d);
 int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha, void* ws,
                       size_t ws_bytes, hipStream_t stream);

@@ -408,14 +408,18 @@ __global__ __launch_bounds__(256) void wino2_output_kernel(const float* __restri
   }
 }
 
-bool winograd_k4s2_eligible(const t2i_conv_desc& d) {
+bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data) {
   static const int on = getenv("T2I_WINOGRAD_K4S2") ? atoi(getenv("T2I_WINOGRAD_K4S2")) : 1;
   static const int minc = getenv("T2I_WINOGRAD_K4S2_MINC") ? atoi(getenv("T2I_WINOGRAD_K4S2_MINC")) : 128;
   if (!on || d.math != T2I_MATH_F32) return false;
   if (!(d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1)) return false;
   if ((d.H & 3) || (d.W & 3) || d.Ho * 2 != d.H || d.Wo * 2 != d.W) return false;          // 2x2 output tiles, no ragged edge
-  if ((d.Cin % 8) || (d.Cout % 32)) return false;
-  return d.Cin >= minc && d.Cout >= minc;
+  if (bwd_data ? ((d.Cout % 32) || (d.Cin % 32)) : ((d.Cin % 8) || (d.Cout % 32))) return false;
+  // the input-gradient form transforms dy once per output phase (9x its bytes through the workspace): it only pays
+  // from 256 channels up (32x32x128->256 measured 13 % slower, 16x16x256->512 11 % faster than the direct GEMM)
+  static const int minc_bwd = getenv("T2I_WINOGRAD_K4S2_BWD_MINC") ? atoi(getenv("T2I_WINOGRAD_K4S2_BWD_MINC")) : 256;
+  const int m = bwd_data ? minc_bwd : minc;
+  return d.Cin >= m && d.Cout >= m;
 }
 
 size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
@@ -445,6 +449,254 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
                      alpha, y);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("winograd k4s2 conv: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input gradient of a 4x4 stride-2 SAME conv (= tf conv2d_transpose k4 s2: the generator's up-sampling layers) by the
+// same F(2x2, 2x2): each output phase (ph, pw) of dx is a 2x2 stride-1 correlation of dy with the flipped sub-filter
+//     dx[2q+ph][2r+pw][ci] = sum_{a,b,co} dy[q + oh_off - 1 + a][r + ow_off - 1 + b][co] * w[kh0 + 2(1-a)][kw0 + 2(1-b)][ci][co]
+// (kh0 = 1 - ph, oh_off = ph for pad 1).  36 batched GEMMs (4 phases x 9 tile positions) [T x Cout] x [Cin x Cout]^T.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino2b_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+  const int N4 = Cout >> 2;
+  const size_t total = (size_t)4 * Cin * N4;             // (phase, ci, co4)
+  const size_t plane = (size_t)Cin * N4;                 // one [ci][co] matrix, in float4
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const int ci = (int)((i / N4) % Cin);
+    const int phs = (int)(i / ((size_t)N4 * Cin));
+    const int ph = phs >> 1, pw = phs & 1;
+    const int kh0 = 1 - ph, kw0 = 1 - pw;
+    float4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        g[a][b] = reinterpret_cast<const float4*>(w + ((size_t)((kh0 + 2 * (1 - a)) * 4 + (kw0 + 2 * (1 - b))) * Cin + ci) * Cout)[n4];
+    float4 s[3][2] = {{g[0][0], g[0][1]}, {f4add(g[0][0], g[1][0]), f4add(g[0][1], g[1][1])}, {g[1][0], g[1][1]}};
+    float4* o = reinterpret_cast<float4*>(U) + (size_t)phs * 9 * plane + (size_t)ci * N4 + n4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
+      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
+      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino2b_input_kernel(const float* __restrict__ dy, int Ho, int Wo, int C, int Th, int Tw, size_t T,
+                                                           float* __restrict__ V) {
+  const int C4 = C >> 2;
+  const size_t total = T * 4 * C4;                        // (phase, tile, co4)
+  const size_t plane = T * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const size_t t = (i / C4) % T;
+    const int phs = (int)(i / ((size_t)C4 * T));
+    const int ph = phs >> 1, pw = phs & 1;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    float4 d[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int oh = 2 * ty + ph - 1 + r;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int ow = 2 * tx + pw - 1 + c;
+        d[r][c] = ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo)
+                      ? reinterpret_cast<const float4*>(dy + ((b * Ho + oh) * Wo + ow) * C)[c4]
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 tt[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tt[0][c] = f4sub(d[0][c], d[1][c]);
+      tt[1][c] = d[1][c];
+      tt[2][c] = f4sub(d[2][c], d[1][c]);
+    }
+    float4* o = reinterpret_cast<float4*>(V) + (size_t)phs * 9 * plane + t * C4 + c4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[(size_t)(r * 3 + 0) * plane] = f4sub(tt[r][0], tt[r][1]);
+      o[(size_t)(r * 3 + 1) * plane] = tt[r][1];
+      o[(size_t)(r * 3 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino2b_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, int H, int W,
+                                                            int N, int Th, int Tw, size_t T, int act, float alpha,
+                                                            float* __restrict__ dx) {
+  const int N4 = N >> 2;
+  const size_t total = T * 4 * N4, plane = T * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const size_t t = (i / N4) % T;
+    const int phs = (int)(i / ((size_t)N4 * T));
+    const int ph = phs >> 1, pw = phs & 1;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    const float4* m = reinterpret_cast<const float4*>(Mx) + (size_t)phs * 9 * plane + t * N4 + n4;
+    float4 z[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 m0 = m[(size_t)(0 * 3 + c) * plane], m1 = m[(size_t)(1 * 3 + c) * plane], m2 = m[(size_t)(2 * 3 + c) * plane];
+      z[0][c] = f4add(m0, m1);
+      z[1][c] = f4add(m1, m2);
+    }
+    const float4 bs = bias ? reinterpret_cast<const float4*>(bias)[n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float4 y0 = f4add(f4add(z[r][0], z[r][1]), bs);
+      float4 y1 = f4add(f4add(z[r][1], z[r][2]), bs);
+      y0.x = apply_act(y0.x, act, alpha); y0.y = apply_act(y0.y, act, alpha); y0.z = apply_act(y0.z, act, alpha); y0.w = apply_act(y0.w, act, alpha);
+      y1.x = apply_act(y1.x, act, alpha); y1.y = apply_act(y1.y, act, alpha); y1.z = apply_act(y1.z, act, alpha); y1.w = apply_act(y1.w, act, alpha);
+      // q = 2*ty + r, columns r' = 2*tx, 2*tx+1  ->  pixels (2q+ph, 2r'+pw)
+      const size_t ih = (size_t)2 * (2 * ty + r) + ph;
+      float4* o0 = reinterpret_cast<float4*>(dx + ((b * H + ih) * W + (size_t)2 * (2 * tx) + pw) * N) + n4;
+      float4* o1 = reinterpret_cast<float4*>(dx + ((b * H + ih) * W + (size_t)2 * (2 * tx + 1) + pw) * N) + n4;
+      *o0 = y0;
+      *o1 = y1;
+    }
+  }
+}
+
+size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2);
+  return al256((size_t)36 * d.Cin * d.Cout * 4) + al256(36 * T * d.Cout * 4) + al256(36 * T * d.Cin * 4);
+}
+
+int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx, int act, float alpha,
+                           void* ws, size_t ws_bytes, hipStream_t stream) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2);
+  if (!ws || ws_bytes < winograd_k4s2_bwd_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    set_error("winograd k4s2 input gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_bwd_ws(d));
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  float* U = reinterpret_cast<float*>(base);
+  float* V = reinterpret_cast<float*>(base + al256((size_t)36 * d.Cin * d.Cout * 4));
+  float* Mx = reinterpret_cast<float*>(base + al256((size_t)36 * d.Cin * d.Cout * 4) + al256(36 * T * d.Cout * 4));
+  const int Th = d.Ho / 2, Tw = d.Wo / 2;
+  hipLaunchKernelGGL(wino2b_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  hipLaunchKernelGGL(wino2b_input_kernel, dim3(wino_blocks(T * d.Cout)), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, V);
+  t2i_conv_desc gd = d;
+  gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  const int rc = run_batched_gemm(gd, MODE_BWD_DATA, 36, V, U, Mx, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, (int64_t)T * d.Cin, stream,
+                                  "winograd k4s2 input-gradient gemm");
+  if (rc != T2I_OK) return rc;
+  hipLaunchKernelGGL(wino2b_output_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, Mx, bias, d.H, d.W, d.Cin, Th, Tw, T, act, alpha, dx);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("winograd k4s2 input gradient: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient of the 4x4 stride-2 conv through the same F(2x2,2x2) identity (adjoint of winograd_k4s2_fwd):
+//   V[xi][t][(p,q,ci)] = B^T X_pq B                      (the forward's input transform)
+//   Z[xi][t][co]       = A dy A^T, A = [1 0; 1 1; 0 1]   (2x2 output-gradient tile -> 3x3)
+//   P[s][xi][(p,q,ci)][co] = sum_{t in chunk s} V Z      9*S batched filter-gradient GEMMs (S tile chunks fill the chip
+//                                                        when 9 * tiles is below the CU count; summed in the last step)
+//   dw[2a+p][2b+q][ci][co] (+)= (G^T P G)[a][b]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino2_dy_kernel(const float* __restrict__ dy, int Ho, int Wo, int N, int Th, int Tw, size_t T,
+                                                       float* __restrict__ Z) {
+  const int N4 = N >> 2;
+  const size_t total = T * N4, plane = T * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const size_t t = i / N4;
+    const int tx = (int)(t % Tw);
+    const int ty = (int)((t / Tw) % Th);
+    const size_t b = t / ((size_t)Tw * Th);
+    const float4* src = reinterpret_cast<const float4*>(dy + ((b * Ho + 2 * ty) * Wo + 2 * tx) * N) + n4;
+    const float4 d00 = src[0], d01 = src[N4], d10 = src[(size_t)Wo * N4], d11 = src[(size_t)Wo * N4 + N4];
+    const float4 s[3][2] = {{d00, d01}, {f4add(d00, d10), f4add(d01, d11)}, {d10, d11}};
+    float4* o = reinterpret_cast<float4*>(Z) + t * N4 + n4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
+      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
+      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino2_dw_kernel(const float* __restrict__ P, int Cin, int Cout, int nslab, int accumulate,
+                                                       float* __restrict__ dw) {
+  const int N4 = Cout >> 2;
+  const size_t total = (size_t)4 * Cin * N4;              // (phase, ci, co4) = one xi plane of P
+  const size_t plane = total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    const int ci = (int)((i / N4) % Cin);
+    const int ph = (int)(i / ((size_t)N4 * Cin));
+    const int p = ph >> 1, q = ph & 1;
+    float4 m[9];
+#pragma unroll
+    for (int xi = 0; xi < 9; ++xi) m[xi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < nslab; ++sl) {                  // P is [xi][slab][K][Cout]
+      const float4* src = reinterpret_cast<const float4*>(P) + (size_t)sl * plane + i;
+#pragma unroll
+      for (int xi = 0; xi < 9; ++xi) m[xi] = f4add(m[xi], src[(size_t)xi * nslab * plane]);
+    }
+    float4 z[2][3];                                       // z[a][c] = sum_r G[r][a] m[r][c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      z[0][c] = f4add(m[0 * 3 + c], m[1 * 3 + c]);
+      z[1][c] = f4add(m[1 * 3 + c], m[2 * 3 + c]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float4 g0 = f4add(z[a][0], z[a][1]), g1 = f4add(z[a][1], z[a][2]);
+      float4* o0 = reinterpret_cast<float4*>(dw + ((size_t)((2 * a + p) * 4 + (0 + q)) * Cin + ci) * Cout) + n4;
+      float4* o1 = reinterpret_cast<float4*>(dw + ((size_t)((2 * a + p) * 4 + (2 + q)) * Cin + ci) * Cout) + n4;
+      if (accumulate) { g0 = f4add(g0, *o0); g1 = f4add(g1, *o1); }
+      *o0 = g0;
+      *o1 = g1;
+    }
+  }
+}
+
+static int wino2_slabs(const t2i_conv_desc& d, size_t T) {
+  const size_t tiles = (size_t)((4 * d.Cin + 127) / 128) * ((d.Cout + 127) / 128) * 9;
+  int S = 1;
+  while (tiles * S < 256 && S < 8 && (T % (size_t)(2 * S)) == 0 && T / (2 * S) >= 256) S *= 2;
+  return S;
+}
+
+size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
+  return al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4) + al256((size_t)9 * wino2_slabs(d, T) * K * d.Cout * 4);
+}
+
+int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
+  if (!ws || ws_bytes < winograd_k4s2_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    set_error("winograd k4s2 filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_filter_grad_ws(d));
+    return T2I_ERR_WORKSPACE;
+  }
+  const int S = wino2_slabs(d, T);
+  char* base = reinterpret_cast<char*>(ws);
+  float* V = reinterpret_cast<float*>(base);
+  float* Z = reinterpret_cast<float*>(base + al256(9 * T * K * 4));
+  float* P = reinterpret_cast<float*>(base + al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4));
+  const int Th = d.Ho / 2, Tw = d.Wo / 2;
+  hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  hipLaunchKernelGGL(wino2_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, Z);
+  t2i_conv_desc gd = d;
+  gd.B = (int32_t)(T / S); gd.Cin = (int32_t)K; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  const int rc = run_batched_gemm(gd, MODE_BWD_FILTER, 9 * S, V, Z, P, (int64_t)(T / S) * K, (int64_t)(T / S) * d.Cout, (int64_t)K * d.Cout, stream,
+                                  "winograd k4s2 filter-gradient gemm");
+  if (rc != T2I_OK) return rc;
+  hipLaunchKernelGGL(wino2_dw_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, P, d.Cin, d.Cout, S, accumulate, dw);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("winograd k4s2 filter gradient: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
   return T2I_OK;
 }
 
