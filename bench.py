@@ -190,7 +190,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (not use_dp) and not args.no_graphs and args.instrument != 'inline'
+    # N > 1: each half of the iteration is cut at its exchange step ([losses+backward] | all-reduce | [Adam]); the collectives
+    # themselves are never captured.  T2I_DP_GRAPHS=0 keeps the data-parallel step eager (bucketed overlap, dp.py).
+    use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
     from t2i_amd import autograd as A
     if args.side_stream:
         A.enable_side_stream(True)
@@ -246,7 +248,7 @@ def main():
                                   'bf16-MFMA operands / fp32 accumulate+tensors (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                      'launch': 'hipGraph replay (2 graphs/iteration)' if use_graphs else 'eager'},
+                      'launch': ('hipGraph replay (%s)' % ('4 graphs + 2 eager all-reduces/iteration' if use_dp else '2 graphs/iteration')) if use_graphs else 'eager'},
            'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
     if rank == 0:
         if args.instrument != 'off':
@@ -272,10 +274,20 @@ def main():
                 'device': info}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
     if use_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    # RCCL writes its version banner (NCCL_DEBUG=VERSION in this image) into the C stdio buffer, which would otherwise be
+    # flushed at exit, AFTER the JSON line: flush it first so the JSON line is the last thing on stdout
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == '__main__':

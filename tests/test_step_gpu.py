@@ -250,7 +250,8 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
     """Three launch schedules of the same iteration give the same bits: (a) one stream; (b) sunk filter gradients on the
     second HIP stream (autograd.SIDE); (c) = (b) under dp.DataParallel with an RCCL communicator of world size 1, where
     the gradient buckets are all-reduced on the communication stream as autograd.NOTIFY completes them (first step learns
-    the counts, later steps overlap).  Same kernels and accumulation order in all three."""
+    the counts, later steps overlap); (d) data parallelism with the iteration replayed from hipGraph segments cut at the
+    exchange steps.  Same kernels and accumulation order in all four."""
     import socket
     import torch.distributed as dist
     from t2i_amd import autograd as A
@@ -268,13 +269,17 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
         f['z'] = torch.randn(f['z'].shape, generator=g, device=gpu)
         feeds.append(f)
 
-    def run(side, dp):
+    def run(side, dp, graphs=False):
         A.enable_side_stream(side)
         try:
             m = WGanCls(cfg, device=gpu, dp=dp)
             m.store.load(params)
             tr = WGanClsTrainer(None, m, None, cfg)
-            outs = [tr.iteration(1 + i, feeds[i]) for i in range(3)]
+            outs = []
+            for i in range(3):
+                if graphs and i == 1:                # [losses+backward] | eager all-reduce | [Adam] graph segments
+                    m.enable_graphs(feeds[0])
+                outs.append(tr.iteration(1 + i, feeds[i]))
             torch.cuda.synchronize()
             return ({n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt), float(outs[-1]['d']['D_loss']),
                     float(outs[-1]['g']['G_loss']))
@@ -292,9 +297,10 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
         both = run(True, dp)
         st = next(iter(dp._arenas.values()))
         assert st['expect'] and len(st['buckets']) > 1      # counts were learned; the overlap path was live on steps 2-3
+        cut = run(False, DataParallel(bucket_bytes=4096), graphs=True)
     finally:
         dist.destroy_process_group()
-    for other in (side, both):
+    for other in (side, both, cut):
         assert plain[1:] == other[1:]
         for n in plain[0]:
             assert torch.equal(plain[0][n], other[0][n]), n

@@ -42,6 +42,7 @@ class WGanCls(object):
         self.dp = dp
         self.global_step = 0
         self._graphs = None
+        self._capturing = False
         self._consts = {}
         self._kl = None
 
@@ -136,7 +137,7 @@ class WGanCls(object):
         scal, seed_l, seed_s1, seed_s2 = K.wgan_d_head(logits.detach().reshape(-1), slopes1.detach(), slopes2.detach(), self.kt,
                                                         self.gp_coeff)
         self.d_arena.zero_grad()
-        if self.dp is not None:
+        if self.dp is not None and not self._capturing:
             self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this backward
         torch.autograd.backward([logits, slopes1, slopes2], [seed_l.view_as(logits), seed_s1, seed_s2],
                                 inputs=list(self.d_vars.values()))
@@ -145,16 +146,19 @@ class WGanCls(object):
         out.update(G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
         return out
 
+    def _d_update(self, out, scale):
+        """Adam on the critic arena + the kt step; `scale` turns rank-summed gradients into the mean."""
+        self.D_optim.apply(grad_scale=scale)
+        with torch.no_grad():
+            self.kt -= (self.kt_lr * scale) * out['kt_grad']          # GradientDescentOptimizer(0.001) on balance_loss
+
     def _d_body(self, feed):
         """Device work of the critic step (graph-capturable): losses, backward, [all-reduce], Adam, kt."""
         out = self.d_losses(feed)
         scale = 1.0
         if self.dp is not None:
             scale = self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
-            out['kt_grad'] = out['kt_grad'] * scale
-        self.D_optim.apply(grad_scale=scale)
-        with torch.no_grad():
-            self.kt -= self.kt_lr * out['kt_grad']          # GradientDescentOptimizer(0.001) on balance_loss
+        self._d_update(out, scale)
         return out
 
     def d_step(self, feed):
@@ -163,6 +167,9 @@ class WGanCls(object):
             self._load_static(feed)
             self._graphs['d'].replay()
             out = self._graphs['d_out']
+            if self.dp is not None:            # the exchange step runs between the two captured halves
+                self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
+                self._graphs['d_upd'].replay()
         else:
             out = self._d_body(feed)
         self.global_step += 1
@@ -180,7 +187,7 @@ class WGanCls(object):
         G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
         B = Dg_logit.numel()
         self.g_arena.zero_grad()
-        if self.dp is not None:
+        if self.dp is not None and not self._capturing:
             self.dp.arm(self.g_arena)
         torch.autograd.backward([Dg_logit, G_kl], [self._const_like(Dg_logit, -1.0 / B), self._const_like(G_kl, self.kl_coeff)],
                                 inputs=list(self.g_vars.values()))
@@ -206,6 +213,9 @@ class WGanCls(object):
                 self._load_static(feed)
             self._graphs['loaded'] = False
             self._graphs['g'].replay()
+            if self.dp is not None:
+                self.dp.allreduce_arena(self.g_arena)
+                self._graphs['g_upd'].replay()
             return self._graphs['g_out']
         return self._g_body(feed)
 
@@ -224,9 +234,9 @@ class WGanCls(object):
         ~1000 launches become two graph launches (the host was within 25% of being the bottleneck: 15.9 ms to issue an
         iteration that runs 21 ms).  Shapes are static; per-step scalars (Adam's lr_t, kt) live in device memory.  Call
         after at least one eager iteration with the same shapes (workspace and kernel attributes are then settled).
-        Single-GPU only for now: the data-parallel exchange stays eager."""
-        if self.dp is not None:
-            raise RuntimeError('graph capture with data parallelism is not supported yet')
+        With data parallelism each half is cut at the exchange step: [losses + backward] | RCCL all-reduce of the gradient
+        arena, issued eagerly | [Adam (+ kt)] — four graph launches and two collectives per iteration, no collective is
+        ever captured."""
         static = {k: feed[k].clone() for k in self._STATIC_KEYS if feed.get(k) is not None}
         for k in ('ca_noise_d', 'ca_noise_g'):
             if k not in static:   # fixed-shape device draw, refreshed by the caller if wanted
@@ -234,11 +244,30 @@ class WGanCls(object):
                     torch.empty(feed['cond'].shape[0], self.compressed_embed_dim, device=self.device), 0.0, 1.0, -2.0, 2.0)
         torch.cuda.synchronize(self.device)
         gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gd):
-            d_out = self._d_body(static)
-        with torch.cuda.graph(gg, pool=gd.pool()):
-            g_out = self._g_body(static)
-        self._graphs = {'d': gd, 'g': gg, 'd_out': d_out, 'g_out': g_out, 'static': static, 'loaded': False}
+        if self.dp is None:
+            with torch.cuda.graph(gd):
+                d_out = self._d_body(static)
+            with torch.cuda.graph(gg, pool=gd.pool()):
+                g_out = self._g_body(static)
+            self._graphs = {'d': gd, 'g': gg, 'd_out': d_out, 'g_out': g_out, 'static': static, 'loaded': False}
+            return
+        # thread-local capture mode: the process group's watchdog thread polls events while we capture
+        gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        scale = 1.0 / self.dp.world
+        self._capturing = True
+        try:
+            with torch.cuda.graph(gd, capture_error_mode='thread_local'):
+                d_out = self.d_losses(static)
+            with torch.cuda.graph(gdu, pool=gd.pool(), capture_error_mode='thread_local'):
+                self._d_update(d_out, scale)
+            with torch.cuda.graph(gg, pool=gd.pool(), capture_error_mode='thread_local'):
+                g_out = self.g_losses(static)
+            with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode='thread_local'):
+                self.G_optim.apply(grad_scale=scale)
+        finally:
+            self._capturing = False
+        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'd_out': d_out, 'g_out': g_out, 'static': static,
+                        'loaded': False}
 
     def sampler(self, z_sample, cond_sample):
         """eval-mode generator on fixed samples (reference model.py:57)"""
