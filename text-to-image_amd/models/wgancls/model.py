@@ -219,6 +219,28 @@ class WGanCls(object):
             return self._graphs['g_out']
         return self._g_body(feed)
 
+    def dg_step(self, feed):
+        """d_step followed by g_step on the same feed (reference trainer.py:97-102).  Under graph replay the two halves
+        are ONE graph launch where that is possible (single GPU): a graph launch costs ~0.15 ms of idle GPU on this stack
+        (tools/dp_phase_times.py); with data parallelism the critic's Adam segment and the generator half share a graph."""
+        g = self._graphs
+        if g is None:
+            return self.d_step(feed), self.g_step(feed)
+        self.D_optim.prepare(float(feed['learning_rate_d']))
+        self.G_optim.prepare(float(feed['learning_rate_g']))
+        self._load_static(feed)
+        g['loaded'] = False
+        if self.dp is None:
+            g['dg'].replay()
+        else:
+            g['d'].replay()
+            self.dp.allreduce_arena(self.d_arena, extra=g['d_out']['kt_grad'])
+            g['dupd_g'].replay()
+            self.dp.allreduce_arena(self.g_arena)
+            g['g_upd'].replay()
+        self.global_step += 1
+        return g['dg_out']
+
     # ---- hipGraph capture of the two halves of the iteration ---------------------------------------------------------------
     _STATIC_KEYS = ('x', 'x_mismatch', 'cond', 'z', 'epsilon', 'ca_noise_d', 'ca_noise_g')
 
@@ -249,7 +271,12 @@ class WGanCls(object):
                 d_out = self._d_body(static)
             with torch.cuda.graph(gg, pool=gd.pool()):
                 g_out = self._g_body(static)
-            self._graphs = {'d': gd, 'g': gg, 'd_out': d_out, 'g_out': g_out, 'static': static, 'loaded': False}
+            gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
+            with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
+                d_out2 = self._d_body(static)
+                g_out2 = self._g_body(static)
+            self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
+                            'static': static, 'loaded': False}
             return
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -264,10 +291,14 @@ class WGanCls(object):
                 g_out = self.g_losses(static)
             with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode='thread_local'):
                 self.G_optim.apply(grad_scale=scale)
+            gdug = torch.cuda.CUDAGraph()                # dg_step: the critic's update and the generator half in one launch
+            with torch.cuda.graph(gdug, pool=gd.pool(), capture_error_mode='thread_local'):
+                self._d_update(d_out, scale)
+                g_out2 = self.g_losses(static)
         finally:
             self._capturing = False
-        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'd_out': d_out, 'g_out': g_out, 'static': static,
-                        'loaded': False}
+        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'dupd_g': gdug, 'd_out': d_out, 'g_out': g_out,
+                        'dg_out': (d_out, g_out2), 'static': static, 'loaded': False}
 
     def sampler(self, z_sample, cond_sample):
         """eval-mode generator on fixed samples (reference model.py:57)"""

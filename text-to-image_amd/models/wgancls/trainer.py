@@ -46,9 +46,11 @@ class WGanClsTrainer(object):
     def iteration(self, idx, feed=None):
         """One "G+D step" (reference trainer.py:97-102)."""
         feed = feed if feed is not None else self.make_feed(idx)
-        out = {'d': self.model.d_step(feed)}
         if idx % self.cfg.TRAIN.N_CRITIC == 0:
-            out['g'] = self.model.g_step(feed)
+            d, g = self.model.dg_step(feed)              # D then G on the same feed; one graph launch under replay
+            out = {'d': d, 'g': g}
+        else:
+            out = {'d': self.model.d_step(feed)}
         self.last = out
         return out
 

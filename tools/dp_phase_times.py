@@ -17,8 +17,11 @@ from t2i_amd.models.wgancls.trainer import WGanClsTrainer  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
-dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29544', rank=0, world_size=1, device_id=dev)
-dp = DataParallel()
+use_dp = os.environ.get('DP', '1') == '1'
+dp = None
+if use_dp:
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29544', rank=0, world_size=1, device_id=dev)
+    dp = DataParallel()
 cfg = bench.make_cfg(64)
 m = WGanCls(cfg, device=dev, seed=0, dp=dp)
 tr = WGanClsTrainer(None, m, None, cfg)
@@ -29,9 +32,12 @@ m.enable_graphs(feed)
 for i in range(3):
     tr.iteration(4 + i, feed)
 g = m._graphs
-steps = [('d graph', lambda: g['d'].replay()), ('d exchange', lambda: dp.allreduce_arena(m.d_arena, extra=g['d_out']['kt_grad'])),
-         ('d update', lambda: g['d_upd'].replay()), ('g graph', lambda: g['g'].replay()),
-         ('g exchange', lambda: dp.allreduce_arena(m.g_arena)), ('g update', lambda: g['g_upd'].replay())]
+if not use_dp:
+    steps = [('d graph', lambda: g['d'].replay()), ('g graph', lambda: g['g'].replay())]
+else:
+  steps = [('d graph', lambda: g['d'].replay()), ('d exchange', lambda: dp.allreduce_arena(m.d_arena, extra=g['d_out']['kt_grad'])),
+           ('d update', lambda: g['d_upd'].replay()), ('g graph', lambda: g['g'].replay()),
+           ('g exchange', lambda: dp.allreduce_arena(m.g_arena)), ('g update', lambda: g['g_upd'].replay())]
 gpu = {n: 0.0 for n, _ in steps}
 host = {n: 0.0 for n, _ in steps}
 torch.cuda.synchronize()
@@ -51,4 +57,5 @@ wall = (time.perf_counter() - t_all) / iters * 1e3
 for n, _ in steps:
     print('%-12s gpu %7.3f ms   host %7.3f ms' % (n, gpu[n] / iters, host[n] / iters * 1e3))
 print('sum gpu %.3f ms, wall %.3f ms/iter (with a sync per iteration)' % (sum(gpu.values()) / iters, wall))
-dist.destroy_process_group()
+if use_dp:
+    dist.destroy_process_group()
