@@ -111,9 +111,11 @@ static int env_int(const char* name, int dflt) {
 // bf16 math: the MFMAs are 16x faster but the operands are still fetched as fp32, so the kernel is bound by the L2 -> LDS
 // operand stream (measured ~16 TB/s chip-wide on 128x128 tiles): bytes per FLOP scale with 1/tile edge, which is what
 // rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
-static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false) {
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
-  static const double rel_eff_f32[4] = {1.0, 0.97, 0.97, 0.93};   // MFMA efficiency relative to the 128x128 tile
+  // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
+  // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
+  static const double rel_eff_f32[4] = {1.0, 0.93, 0.93, 0.94};
   static const double rel_eff_bf16[4] = {1.0, 0.74, 0.74, 0.55};
   static const int max_resident_f32[4] = {2, 3, 3, 4};            // co-resident workgroups per CU (LDS / VGPR limited)
   static const int max_resident_bf16[4] = {3, 4, 4, 4};
@@ -137,7 +139,11 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   for (int c = 0; c < 4; ++c) {
     const int wmt = cand[c][0], wnt = cand[c][1];
     if (ft) { if (ft != wmt * 10 + wnt) continue; }
-    else {
+    else if (batched && !math) {
+      // batched (Winograd) GEMMs: K = channels only, 9-36 GEMMs per launch -> short K loops, many workgroups; 64x64 tiles
+      // (4 co-resident workgroups hide each other's prologue/epilogue) won or tied every case of the sweep (up to -13 %)
+      if (wmt != 1 || wnt != 1) continue;
+    } else {
       if (wmt == 2 && M <= 64) continue;
       if (wnt == 2 && N <= 64) continue;
     }
@@ -258,7 +264,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
     p.div_c.set(gd.Cin);
     p.walk_db = 32; p.walk_doh = 0;               // 1x1 maps: one K-tile = 32 consecutive "images"
     p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
-    Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math);
+    Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
     { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
     p.splitk = 1; p.k_per_split = pl.k_per_split;
@@ -280,7 +286,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
     p.div_c.set(gd.Cin);
   }
   p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
-  Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math);
+  Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
   p.splitk = 1; p.k_per_split = pl.k_per_split;

@@ -25,8 +25,14 @@ LAYERS = [
 
 
 def timeit(fn, reps):
-    for _ in range(3):
+    import time
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or time.perf_counter() - t0 < 0.02:      # >= 20 ms of back-to-back launches: clocks ramped, caches warm
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
