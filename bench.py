@@ -248,7 +248,7 @@ def main():
                                   'bf16-MFMA operands / fp32 accumulate+tensors (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                      'launch': ('hipGraph replay (%s)' % ('3 graphs + 2 eager all-reduces/iteration' if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
+                      'launch': ('hipGraph replay (%s)' % ('4 graphs + 2 eager all-reduces/iteration, critic exchange overlapped with the generator forward' if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
            'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
     if rank == 0:
         if args.instrument != 'off':

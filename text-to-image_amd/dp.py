@@ -127,6 +127,13 @@ class DataParallel(object):
     def allreduce_arena(self, arena, extra=None):
         """Finish the exchange for `arena` (launch whatever the hooks did not, wait) and return the factor that turns the
         summed gradients into the mean.  `extra`: a small tensor (the kt gradient) summed in place alongside."""
+        self.start_allreduce(arena, extra)
+        return self.finish_allreduce(arena)
+
+    def start_allreduce(self, arena, extra=None):
+        """Issue every all-reduce of `arena` that is not in flight yet (communication stream; the calling stream is not
+        blocked).  Work enqueued on the calling stream between this and finish_allreduce overlaps the exchange — it must not
+        touch the arena's gradients."""
         st = self.attach(arena)
         if st['armed']:
             if st['seen'] and st['expect'] is None:
@@ -139,7 +146,16 @@ class DataParallel(object):
             for bi in range(len(st['buckets'])):
                 self._launch(st, bi)
         if extra is not None:
-            st['works'].append(dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if extra.is_cuda and self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream(extra.device))
+                with torch.cuda.stream(self._side):
+                    st['works'].append(dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                st['works'].append(dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_allreduce(self, arena):
+        """Make the calling stream wait for the exchange started by start_allreduce; returns 1/world."""
+        st = self.attach(arena)
         for w in st['works']:
             w.wait()
         if self._side is not None and arena.grad.is_cuda:

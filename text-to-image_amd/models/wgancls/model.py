@@ -175,16 +175,23 @@ class WGanCls(object):
         self.global_step += 1
         return out
 
-    def g_losses(self, feed):
+    def _g_forward(self, feed):
+        """The generator's forward of the G step: depends on the generator's variables only, so under data parallelism
+        it can run while the critic's gradients are still being exchanged (dg_step)."""
         cond, z = feed['cond'], feed['z']
         self._noise = self._ca_noise(feed, 'ca_noise_g', cond[:, :self.compressed_embed_dim])
         with update_ops():   # G_optim runs under control_dependencies(UPDATE_OPS) (model.py:102)
             G, mean, log_sigma = self.generator(z, cond, reuse=True)
+        G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
+        return G, G_kl
+
+    def g_losses(self, feed, fwd=None):
+        cond = feed['cond']
+        G, G_kl = fwd if fwd is not None else self._g_forward(feed)
         with self.store.frozen('d_net'):
             Dg_logit = self.discriminator(G, cond, reuse=True)
         # G_loss = -mean(D(G)) + kl_coeff * KL (model.py:90-92): the KL value came out of the fused conditioning-augmentation
         # kernel; the backward is seeded with dG_loss/dlogit = -1/B and dG_loss/dKL = kl_coeff
-        G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
         B = Dg_logit.numel()
         self.g_arena.zero_grad()
         if self.dp is not None and not self._capturing:
@@ -234,7 +241,9 @@ class WGanCls(object):
             g['dg'].replay()
         else:
             g['d'].replay()
-            self.dp.allreduce_arena(self.d_arena, extra=g['d_out']['kt_grad'])
+            self.dp.start_allreduce(self.d_arena, extra=g['d_out']['kt_grad'])
+            g['g_fwd'].replay()                    # generator forward overlaps the critic's gradient exchange
+            self.dp.finish_allreduce(self.d_arena)
             g['dupd_g'].replay()
             self.dp.allreduce_arena(self.g_arena)
             g['g_upd'].replay()
@@ -291,13 +300,19 @@ class WGanCls(object):
                 g_out = self.g_losses(static)
             with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode='thread_local'):
                 self.G_optim.apply(grad_scale=scale)
-            gdug = torch.cuda.CUDAGraph()                # dg_step: the critic's update and the generator half in one launch
+            # dg_step: generator forward on its own (replayed while the critic's gradients are on the wire), then the critic's
+            # update + the rest of the generator half in one launch; the autograd graph of the first capture is consumed by
+            # the second (both allocate from the same private pool, replayed in capture order)
+            ggf, gdug = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ggf, pool=gd.pool(), capture_error_mode='thread_local'):
+                fwd = self._g_forward(static)
             with torch.cuda.graph(gdug, pool=gd.pool(), capture_error_mode='thread_local'):
                 self._d_update(d_out, scale)
-                g_out2 = self.g_losses(static)
+                g_out2 = self.g_losses(static, fwd=fwd)
+            del fwd
         finally:
             self._capturing = False
-        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'dupd_g': gdug, 'd_out': d_out, 'g_out': g_out,
+        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'g_fwd': ggf, 'dupd_g': gdug, 'd_out': d_out, 'g_out': g_out,
                         'dg_out': (d_out, g_out2), 'static': static, 'loaded': False}
 
     def sampler(self, z_sample, cond_sample):
