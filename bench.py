@@ -178,6 +178,7 @@ def main():
         dp = DataParallel()
 
     K.set_math(args.math)
+    K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # transformed Winograd filters reused until Adam changes them
     cfg = make_cfg(args.batch)
     model = WGanCls(cfg, device=device, seed=0, dp=dp)
     if dp is not None:

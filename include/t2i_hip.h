@@ -192,6 +192,20 @@ int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float
  * mode 0: out = (1-t)*a + t*b;  mode 1: out = t*a;  mode 2: out = (1-t)*a  (modes 1, 2 = the backward of mode 0). */
 int t2i_lerp_dev(const float* a, const float* b, const float* t_dev, int32_t mode, int64_t n, float* out, t2i_stream_t stream);
 
+/* ---- transformed-filter cache (optional) -------------------------------------------------------------------------
+ * The Winograd paths of the three conv entry points transform the filter (U = G g G^T) on every call.  A training step
+ * uses each critic filter in up to six convs between two optimizer updates; with the cache on, the transform is kept in
+ * a library-owned device buffer keyed by (filter pointer, transform kind, Cin, Cout) and reused until the filter changes.
+ * CONTRACT when enabled: filter memory may be modified only by t2i_adam_tf (which drops the entries of the arena it
+ * updates) or must be followed by t2i_filter_cache_invalidate(ptr, bytes) (ptr NULL = everything) — this includes
+ * initialisation, checkpoint loads, broadcasts, and replaying a captured graph that contains t2i_adam_tf from a process
+ * that also issues eager convs.  Launches captured into a hipGraph reuse only transforms filled in the same capture, so a
+ * graph always contains every transform it depends on; buffers are allocated on eager calls only (run the step once
+ * before capturing).  Results are bit-identical with and without the cache.  Off by default; returns the previous state. */
+int t2i_filter_cache_enable(int on);
+void t2i_filter_cache_invalidate(const void* ptr, size_t bytes);
+size_t t2i_filter_cache_bytes(void);            /* device memory currently held by the cache */
+
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):
  * src [N,S,S,3] uint8 resident on the device; out [B,out_size,out_size,3] float32 with

@@ -406,3 +406,35 @@ def test_winograd_k4s2_matches_oracle(K, case):
     acc = dev(w.copy())
     K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1))
     assert relerr(acc, w.astype(np.float64) + dw_ref) <= 2e-5
+
+
+def test_filter_cache_reuse_and_invalidate(K):
+    """With the cache on, a second conv on the same filter skips the transform (same bits); an in-place change of the filter
+    followed by filter_cache_invalidate is honoured; results equal the uncached path bit for bit."""
+    rng = np.random.default_rng(5)
+    x = dev(rng.standard_normal((16, 8, 8, 512)).astype(np.float32))          # 3x3: enough tiles for the Winograd path
+    x4 = dev(rng.standard_normal((4, 8, 8, 256)).astype(np.float32))
+    w = dev((rng.standard_normal((3, 3, 512, 512)) / 68).astype(np.float32))
+    w4 = dev((rng.standard_normal((4, 4, 256, 256)) / 64).astype(np.float32))
+    d, ws = K.conv_desc(16, 8, 8, 512, 512, 3, 3, 1, 1, 'SAME')
+    d4, ws4 = K.conv_desc(4, 8, 8, 256, 256, 4, 4, 2, 2, 'SAME')
+    dy4 = dev(rng.standard_normal((4, 4, 4, 256)).astype(np.float32))
+    held0 = K.filter_cache_bytes()
+    plain = [K.conv_fwd(x, w, None, d, ws), K.conv_bwd_data(x, w, None, d, ws), K.conv_fwd(x4, w4, None, d4, ws4),
+             K.conv_bwd_data(dy4, w4, None, d4, ws4)]
+    prev = K.filter_cache(True)
+    try:
+        for rep in range(2):                                # second pass = cache hits
+            got = [K.conv_fwd(x, w, None, d, ws), K.conv_bwd_data(x, w, None, d, ws), K.conv_fwd(x4, w4, None, d4, ws4),
+                   K.conv_bwd_data(dy4, w4, None, d4, ws4)]
+            for a, b in zip(got, plain):
+                assert torch.equal(a, b)
+        # two 3x3 transforms (as-is and flipped), the 4x4 s2 forward and input-gradient transforms
+        assert K.filter_cache_bytes() - held0 in (0, 2 * 16 * 512 * 512 * 4 + (9 * 4 + 36) * 256 * 256 * 4)
+        assert K.filter_cache_bytes() >= 2 * 16 * 512 * 512 * 4 + (9 * 4 + 36) * 256 * 256 * 4
+        w.mul_(2.0)
+        K.filter_cache_invalidate(w)
+        assert torch.equal(K.conv_fwd(x, w, None, d, ws), plain[0] * 2)            # scaling by 2 is exact in fp32
+        assert torch.equal(K.conv_fwd(x4, w4, None, d4, ws4), plain[2])            # untouched filter: still served
+    finally:
+        K.filter_cache(prev)

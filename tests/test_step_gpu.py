@@ -351,3 +351,50 @@ def test_bf16_math_step_within_config3_tolerance(gpu, golden_step):
         assert cosine(m.g_arena, list(m.g_vars), 'g/grad/') >= 0.95
     finally:
         K.set_math('f32')
+
+
+def test_filter_cache_full_width_bit_identical(gpu):
+    """Transformed-filter cache (include/t2i_hip.h) at the benchmark's widths, where the Winograd paths are live: three
+    iterations with the cache on — eager, and replayed from one hipGraph — leave exactly the weights, Adam state and kt of
+    the run without it; the cache held buffers, and checkpoint-style loads behind the optimizer's back are honoured."""
+    from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    B = 8
+    cfg = _cfg(128, 1024, 128, 128, 128, B)
+    g = torch.Generator(device=gpu).manual_seed(11)
+    feeds = []
+    for _ in range(4):
+        feeds.append({'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+                      'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+                      'cond': torch.randn(B, 1024, generator=g, device=gpu), 'z': torch.randn(B, 128, generator=g, device=gpu),
+                      'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4,
+                      'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
+                      'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)})
+
+    def run(cache, graphs):
+        prev = K.filter_cache(cache)
+        try:
+            m = WGanCls(cfg, device=gpu, seed=3)
+            tr = WGanClsTrainer(None, m, None, cfg)
+            tr.iteration(1, feeds[0])
+            if graphs:
+                m.enable_graphs(feeds[0])
+            for i in range(2):
+                tr.iteration(2 + i, feeds[1 + i])
+            # a load behind the optimizer's back (ParamStore.load invalidates), then one more step
+            m.store.load({n: (v.detach() * 0.5).cpu().numpy() for n, v in m.store.vars.items() if n.endswith('conv2d_2/kernel')})
+            tr.iteration(4, feeds[3])
+            torch.cuda.synchronize()
+            held = K.filter_cache_bytes()
+            return ({n: v.detach().clone() for n, v in m.store.vars.items()}, m.D_optim.v.clone(), m.G_optim.m.clone(), float(m.kt)), held
+        finally:
+            K.filter_cache(prev)
+
+    (ref, _), (eager, held), (replay, _) = run(False, False), run(True, False), run(True, True)
+    assert held > 0                                         # the Winograd layers went through the cache
+    for other in (eager, replay):
+        assert other[3] == ref[3]
+        assert torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])
+        for n in ref[0]:
+            assert torch.equal(other[0][n], ref[0][n]), n

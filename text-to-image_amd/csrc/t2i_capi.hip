@@ -658,7 +658,14 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
                 float grad_scale, t2i_stream_t stream) {
   if (!w || !g || !m || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
   if (!(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
+  filter_cache_invalidate(w, (size_t)n * 4);          // transformed filters of this arena are stale from here on
   return check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
 }
+
+int t2i_filter_cache_enable(int on) { return filter_cache_enable(on); }
+
+void t2i_filter_cache_invalidate(const void* p, size_t bytes) { filter_cache_invalidate(p, bytes); }
+
+size_t t2i_filter_cache_bytes(void) { return filter_cache_bytes(); }
 
 }  // extern "C"

@@ -87,6 +87,9 @@ bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data);
 size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d);
 int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
                               hipStream_t stream);
+int filter_cache_enable(int on);
+void filter_cache_invalidate(const void* p, size_t bytes);
+size_t filter_cache_bytes();
 size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d);
 int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx, int act, float alpha,
                            void* ws, size_t ws_bytes, hipStream_t stream);

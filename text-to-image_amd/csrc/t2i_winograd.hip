@@ -13,9 +13,79 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "t2i_internal.h"
 
 namespace t2i {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Transformed-filter cache (opt-in, t2i_filter_cache_enable): U = G g G^T of a filter is the same for every conv that uses
+// it until the filter changes — the critic's filters are used by up to six convs per step.  Entries are keyed by (filter
+// pointer, transform kind, dims) and own their device buffer.  An entry is reusable only from the launch context that
+// filled it: eager launches reuse eager fills, launches captured into a graph reuse fills of the SAME capture (so every
+// graph contains all the transforms it depends on).  t2i_adam_tf drops the entries inside the arena it updates; any other
+// writer of filter memory must call t2i_filter_cache_invalidate (see include/t2i_hip.h).
+// ------------------------------------------------------------------------------------------------------------------
+struct FilterEntry {
+  const float* w; int kind, Cin, Cout; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
+};
+static std::mutex g_fc_mu;
+static std::vector<FilterEntry> g_fc;
+static int g_fc_on = 0;
+
+int filter_cache_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  const int prev = g_fc_on;
+  g_fc_on = on ? 1 : 0;
+  for (auto& e : g_fc) e.valid = false;
+  return prev;
+}
+
+void filter_cache_invalidate(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  const char* lo = reinterpret_cast<const char*>(p);
+  for (auto& e : g_fc) {
+    const char* q = reinterpret_cast<const char*>(e.w);
+    if (!p || (q >= lo && q < lo + bytes)) e.valid = false;
+  }
+}
+
+size_t filter_cache_bytes() {
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  size_t n = 0;
+  for (auto& e : g_fc) n += e.bytes;
+  return n;
+}
+
+// Returns the cache buffer for this filter's transform (and whether it has to be filled), or nullptr when the caller
+// should transform into its workspace as without the cache (cache off, first sight of a filter during capture, a second
+// stream, allocation failure).
+static float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill) {
+  *fill = true;
+  if (!g_fc_on) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const unsigned long long cap = st == hipStreamCaptureStatusActive ? id + 1 : 0;
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  FilterEntry* e = nullptr;
+  for (auto& x : g_fc)
+    if (x.w == w && x.kind == kind && x.Cin == Cin && x.Cout == Cout) { e = &x; break; }
+  if (!e) {
+    if (cap) return nullptr;                      // no allocation while a capture is open
+    float* U = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&U), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, U, bytes, 0ull, stream, false});
+    e = &g_fc.back();
+  }
+  if (e->bytes < bytes) return nullptr;
+  if (!cap && e->stream != stream) return nullptr;     // eager use from a second stream: no ordering with the fills / readers
+  if (e->valid && e->cap == cap) { *fill = false; return e->U; }
+  e->valid = true; e->cap = cap;
+  return e->U;
+}
 
 static inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -188,7 +258,10 @@ int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float
   float* V = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4));
   float* Mx = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4) + al256(16 * T * K * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
-  hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, bwd ? 1 : 0, U);
+  bool fill = true;
+  if (float* Uc = filter_cache_get(w, bwd ? 1 : 0, d.Cin, d.Cout, (size_t)16 * K * N * 4, stream, &fill)) U = Uc;
+  if (fill)
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, bwd ? 1 : 0, U);
   hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V);
   t2i_conv_desc gd = d;                // the 16 GEMMs as a batch of 1x1 convolutions over T "pixels" (fwd) / their input gradient (bwd)
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;   // Cin, Cout as in d
@@ -439,7 +512,10 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
   float* V = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4));
   float* Mx = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4) + al256(9 * T * K * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
-  hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  bool fill = true;
+  if (float* Uc = filter_cache_get(w, 2, d.Cin, d.Cout, (size_t)9 * 4 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;
+  if (fill)
+    hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
   hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.Cin = (int32_t)K; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
@@ -582,7 +658,10 @@ int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float*
   float* V = reinterpret_cast<float*>(base + al256((size_t)36 * d.Cin * d.Cout * 4));
   float* Mx = reinterpret_cast<float*>(base + al256((size_t)36 * d.Cin * d.Cout * 4) + al256(36 * T * d.Cout * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
-  hipLaunchKernelGGL(wino2b_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  bool fill = true;
+  if (float* Uc = filter_cache_get(w, 3, d.Cin, d.Cout, (size_t)36 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;
+  if (fill)
+    hipLaunchKernelGGL(wino2b_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
   hipLaunchKernelGGL(wino2b_input_kernel, dim3(wino_blocks(T * d.Cout)), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;

@@ -168,3 +168,5 @@ class DataParallel(object):
         """Make every rank start from rank `src`'s variables (weights, BN moving statistics)."""
         for v in store.vars.values():
             dist.broadcast(v.data, src=src, group=self.group)
+        from . import kernels as K
+        K.filter_cache_invalidate()

@@ -8,6 +8,8 @@ microseconds each and is bound by the host's launch rate, not by the GPU.  Repla
 launches (same kernels, same order)."""
 import torch
 
+from . import kernels as K
+
 
 class StepGraphs(object):
     def __init__(self, example_feed, keys):
@@ -36,4 +38,5 @@ class StepGraphs(object):
 
     def replay(self, name):
         self.graphs[name].replay()
+        K.filter_cache_invalidate()                  # a replayed optimizer step rewrote filters behind the host's back
         return self.outs[name]

@@ -563,6 +563,25 @@ def ca_kl_bwd(mean, log_sigma, eps, dcode, dkl):
     return dmean, dls
 
 
+def filter_cache(on):
+    """Opt into the transformed-filter cache of the Winograd conv paths (include/t2i_hip.h: contract).  Everything in this
+    package that writes filter memory outside t2i_adam_tf calls filter_cache_invalidate(): ParamStore.load, Saver.restore,
+    optim.Arena creation, dp.broadcast_variables, hipGraph replays.  Returns the previous state."""
+    return bool(lib.t2i_filter_cache_enable(1 if on else 0))
+
+
+def filter_cache_invalidate(t=None):
+    """Drop cached transforms of the filters inside tensor `t` (None: all)."""
+    if t is None:
+        lib.t2i_filter_cache_invalidate(None, 0)
+    elif t.is_cuda:
+        lib.t2i_filter_cache_invalidate(_ptr(t), t.numel() * t.element_size())
+
+
+def filter_cache_bytes():
+    return int(lib.t2i_filter_cache_bytes())
+
+
 def lerp_dev(a, b, t_dev, mode=0):
     """mode 0: (1-t)*a + t*b;  1: t*a;  2: (1-t)*a   with t a 1-element device tensor."""
     _chk(a, 'a')

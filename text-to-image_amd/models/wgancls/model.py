@@ -170,6 +170,7 @@ class WGanCls(object):
             if self.dp is not None:            # the exchange step runs between the two captured halves
                 self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
                 self._graphs['d_upd'].replay()
+            K.filter_cache_invalidate()        # the replay rewrote filters (and cached transforms) behind the host's back
         else:
             out = self._d_body(feed)
         self.global_step += 1
@@ -223,6 +224,7 @@ class WGanCls(object):
             if self.dp is not None:
                 self.dp.allreduce_arena(self.g_arena)
                 self._graphs['g_upd'].replay()
+            K.filter_cache_invalidate()
             return self._graphs['g_out']
         return self._g_body(feed)
 
@@ -247,6 +249,7 @@ class WGanCls(object):
             g['dupd_g'].replay()
             self.dp.allreduce_arena(self.g_arena)
             g['g_upd'].replay()
+        K.filter_cache_invalidate()
         self.global_step += 1
         return g['dg_out']
 

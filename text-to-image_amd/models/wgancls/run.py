@@ -28,6 +28,8 @@ def main(argv=None):
         os.makedirs(d, exist_ok=True)
     if cfg.EVAL.FLAG:
         raise NotImplementedError('EVAL mode (Inception score / FID) is outside the hot path; see DESIGN.md')
+    from t2i_amd import kernels as K
+    K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # weights change only through Adam / Saver here
     wgan = WGanCls(cfg)
     dataset = SyntheticTextDataset(cfg, wgan.device)
     trainer = WGanClsTrainer(sess=None, model=wgan, dataset=dataset, cfg=cfg)

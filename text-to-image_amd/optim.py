@@ -32,6 +32,7 @@ class Arena(object):
                 self.flat[o:o + k].copy_(v.reshape(-1))
                 v.data = self.flat[o:o + k].view(v.shape)
                 v.grad = self.grad[o:o + k].view(v.shape)
+        K.filter_cache_invalidate()                  # the variables moved (possibly onto recycled addresses)
 
     def zero_grad(self):
         self.grad.zero_()

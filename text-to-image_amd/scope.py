@@ -97,6 +97,8 @@ class VariableStore(object):
                 if tuple(t.shape) != tuple(self.vars[n].shape):
                     raise ValueError('%s: shape %s != %s' % (n, tuple(t.shape), tuple(self.vars[n].shape)))
                 self.vars[n].copy_(t.to(self.vars[n].device))
+        from . import kernels as K
+        K.filter_cache_invalidate()                  # filters changed behind the optimizer's back
 
     def state(self):
         return OrderedDict((n, v.detach().cpu().numpy().copy()) for n, v in self.vars.items())

@@ -60,6 +60,8 @@ class Saver(object):
             for k, get in self.extra.items():
                 if k in z.files:
                     get[1](z[k])
+        from .. import kernels as K
+        K.filter_cache_invalidate()
 
 
 def save(saver, sess, checkpoint_dir, step):
