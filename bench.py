@@ -82,7 +82,7 @@ def effective_cpus():
     return max(1, min(n, 64))
 
 
-def cpu_baseline_child(batch, budget_s=20.0):
+def cpu_baseline_child(batch, budget_s=15.0):
     """Runs in a child process: the oracle (torch-CPU fp32 restatement of the identical D+G iteration) on the host cores."""
     from oracle import torch_step as T
     threads = effective_cpus()
@@ -95,7 +95,7 @@ def cpu_baseline_child(batch, budget_s=20.0):
     tr.iteration(1, feed)                      # warm-up
     warm = time.time() - t0
     n, t0 = 0, time.time()
-    while n < 5 and (n == 0 or (time.time() - t0) * (n + 1) / n < budget_s):
+    while n < 12 and (n == 0 or (time.time() - t0) * (n + 1) / n < budget_s):     # ~10-15 s of CPU work on the GPU box's 16 cores
         tr.iteration(2 + n, feed)
         n += 1
         if n == 1 and warm > budget_s:
