@@ -197,19 +197,21 @@ def main():
     from t2i_amd import autograd as A
     if args.side_stream:
         A.enable_side_stream(True)
-    for i in range(args.warmup):
-        if use_graphs and i == min(2, args.warmup - 1):
-            model.enable_graphs(feed)          # the remaining warm-up and all timed steps are graph replays
-        trainer.iteration(1 + i, feed)
-    if use_graphs and model._graphs is None:
+    if use_graphs:
+        # set-up, before the W warm-up steps: eager iterations settle workspaces, kernel attributes, the filter cache's
+        # buffers and (N > 1) the communicator, then the iteration is captured; warm-up and timed steps are replays
+        for i in range(2):
+            trainer.iteration(1 + i, feed)
         model.enable_graphs(feed)
+    for i in range(args.warmup):
+        trainer.iteration(3 + i, feed)
     timer = ConvTimer()
     barrier()
     if args.instrument == 'inline':
         K.set_conv_timer(timer)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.iteration(1 + args.warmup + i, feed)
+        trainer.iteration(3 + args.warmup + i, feed)
     barrier()
     dt = time.perf_counter() - t0
     K.set_conv_timer(None)
@@ -220,7 +222,7 @@ def main():
         A.enable_side_stream(False)                            # ... and one stream, so durations are per kernel
         K.set_conv_timer(timer)
         for i in range(inst_steps):
-            trainer.iteration(1 + args.warmup + args.steps + i, feed)
+            trainer.iteration(3 + args.warmup + args.steps + i, feed)
         torch.cuda.synchronize()
         K.set_conv_timer(None)
         model._graphs = saved_graphs

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 import bench, t2i_amd
 from t2i_amd.dp import DataParallel
