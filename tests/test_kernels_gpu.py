@@ -438,3 +438,22 @@ def test_filter_cache_reuse_and_invalidate(K):
         assert torch.equal(K.conv_fwd(x4, w4, None, d4, ws4), plain[2])            # untouched filter: still served
     finally:
         K.filter_cache(prev)
+
+
+@pytest.mark.parametrize('C', [1, 3, 4, 5])
+def test_col_reduce_narrow_tensors(K, C):
+    """Column sums of [rows, C] for the 3-channel image layers (row-per-thread kernel for C <= 4, scalar path for C = 5):
+    sum, sum of squares and sum of products against float64, and the accumulate-into-sink form."""
+    rng = np.random.default_rng(C)
+    rows = 2 * 64 * 64 + 37
+    a = (rng.standard_normal((rows, C)) + 0.5).astype(np.float32)      # non-zero means: the sums are well conditioned
+    b = (rng.standard_normal((rows, C)) + 0.5).astype(np.float32)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    assert relerr(K.col_reduce(dev(a))[0], a64.sum(0)) <= 1e-5
+    s, ss = K.col_reduce(dev(a), None, True)
+    assert relerr(s, a64.sum(0)) <= 1e-5 and relerr(ss, (a64 * a64).sum(0)) <= 1e-5
+    s, sp = K.col_reduce(dev(a), dev(b), True)
+    assert relerr(s, a64.sum(0)) <= 1e-5 and relerr(sp, (a64 * b64).sum(0)) <= 1e-5
+    acc = dev(np.ones(C, np.float32))
+    K.col_reduce(dev(a), out=acc)
+    assert relerr(acc, 1.0 + a64.sum(0)) <= 1e-5

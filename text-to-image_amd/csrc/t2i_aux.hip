@@ -62,6 +62,41 @@ __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict
   }
 }
 
+// stage 1 for C <= 4 (bias gradients of the 3-channel image layers): with lane = column only C of 64 lanes would work,
+// so here a thread owns whole rows (consecutive threads, consecutive rows: contiguous 4*C-byte pieces) and the workgroup
+// joins its 256 partial sums by wave shuffles + LDS in a fixed order.  46.7 -> ~5 us on B*64*64 x 3.
+__global__ __launch_bounds__(256) void col_reduce_stage1_small(const float* __restrict__ a, const float* __restrict__ b,
+                                                               int64_t rows, int C, int64_t rows_per_chunk,
+                                                               float* __restrict__ part0, float* __restrict__ part1,
+                                                               bool want1) {
+  __shared__ float s0[4][4], s1[4][4];
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t rend = rbeg + rows_per_chunk;
+  if (rend > rows) rend = rows;
+  float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = rbeg + threadIdx.x; r < rend; r += 256) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) {
+        const float va = a[r * C + c];
+        acc0[c] += va;
+        if (want1) acc1[c] += va * (b ? b[r * C + c] : va);
+      }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v0 = wave_sum(acc0[c]), v1 = wave_sum(acc1[c]);
+    if (lane == 0) { s0[wave][c] = v0; s1[wave][c] = v1; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    part0[(size_t)blockIdx.y * C + c] = (s0[0][c] + s0[1][c]) + (s0[2][c] + s0[3][c]);
+    if (want1) part1[(size_t)blockIdx.y * C + c] = (s1[0][c] + s1[1][c]) + (s1[2][c] + s1[3][c]);
+  }
+}
+
 // stage 2: one block per 64 columns; 4 row lanes walk the partials (fixed order), LDS joins them
 __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
                                                          int nchunks, int C, float* __restrict__ out0,
@@ -217,8 +252,11 @@ hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C
                        out0, out1, accumulate);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
-                     out1 != nullptr);
+  if (C <= 4)
+    hipLaunchKernelGGL(col_reduce_stage1_small, dim3(1, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, out1 != nullptr);
+  else
+    hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
+                       out1 != nullptr);
   hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1, accumulate);
   return hipGetLastError();
 }
