@@ -705,6 +705,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Deep splits of small outputs (the critic's first-layer filter gradient: 48x128 outputs, 128-256 slabs): one thread per
+// output would walk hundreds of slabs in sequence (43 us, pure latency).  Here 16 slab lanes share an output: lane ty sums
+// slabs ty, ty+16, ... and the 16 partial sums are joined in lane order through LDS — still a fixed order.
+__global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(const float* __restrict__ slabs, int splitk,
+                                                                 size_t out_elems, const float* __restrict__ bias, int N,
+                                                                 int act, float alpha, float* __restrict__ out, int accumulate) {
+  __shared__ float4 red[16][16];
+  const size_t n4 = out_elems >> 2;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + tx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    for (int k = ty; k < splitk; k += 16) {
+      const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)k * out_elems)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n4) {
+    s = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = red[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    if (bias) {
+      int c = (int)((i * 4) % (size_t)N);
+      s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3];
+    }
+    s.x = apply_act(s.x, act, alpha); s.y = apply_act(s.y, act, alpha);
+    s.z = apply_act(s.z, act, alpha); s.w = apply_act(s.w, act, alpha);
+    if (accumulate) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slabs, int splitk,
                                                                    size_t out_elems, const float* __restrict__ bias,
                                                                    int N, int act, float alpha,
@@ -772,6 +809,11 @@ hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems
                                 float alpha, float* out, int accumulate, hipStream_t stream) {
   if ((out_elems & 3) == 0 && (N & 3) == 0) {
     size_t n4 = out_elems >> 2;
+    if (splitk >= 32 && n4 <= 65536) {           // few outputs, many slabs: parallelise over slabs too
+      hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, stream, slabs, splitk, out_elems,
+                         bias, N, act, alpha, out, accumulate);
+      return hipGetLastError();
+    }
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;

@@ -29,7 +29,7 @@ namespace t2i {
 // writer of filter memory must call t2i_filter_cache_invalidate (see include/t2i_hip.h).
 // ------------------------------------------------------------------------------------------------------------------
 struct FilterEntry {
-  const float* w; int kind, Cin, Cout; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
+  const float* w; int kind, Cin, Cout, dev; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
 };
 static std::mutex g_fc_mu;
 static std::vector<FilterEntry> g_fc;
@@ -69,15 +69,17 @@ static float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size
   unsigned long long id = 0;
   if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   const unsigned long long cap = st == hipStreamCaptureStatusActive ? id + 1 : 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(g_fc_mu);
   FilterEntry* e = nullptr;
   for (auto& x : g_fc)
-    if (x.w == w && x.kind == kind && x.Cin == Cin && x.Cout == Cout) { e = &x; break; }
+    if (x.w == w && x.kind == kind && x.Cin == Cin && x.Cout == Cout && x.dev == dev) { e = &x; break; }
   if (!e) {
     if (cap) return nullptr;                      // no allocation while a capture is open
     float* U = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&U), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, U, bytes, 0ull, stream, false});
+    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, dev, U, bytes, 0ull, stream, false});
     e = &g_fc.back();
   }
   if (e->bytes < bytes) return nullptr;
