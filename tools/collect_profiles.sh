@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -o r -- $BENCH --steps 5 --warmup 2 > "$OUT/ktrace.log" 2>&1
 cp "$(find "$OUT/ktrace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bench_s5w2.csv"
-python "$REPO/tools/prof_summary.py" "$OUT/ktrace" 7 45 > "$OUT/kernel_stats_summary.txt" 2>&1
+python "$REPO/tools/prof_summary.py" "$OUT/ktrace" 9 45 > "$OUT/kernel_stats_summary.txt" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
   tag=$(echo "$grp" | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$tag" -o r -- $BENCH --steps 3 --warmup 2 --no-graphs > "$OUT/pmc_$tag.log" 2>&1
