@@ -56,16 +56,21 @@ class ConvTimer(object):
     def __init__(self):
         self.records = []
 
-    def begin(self, flops):
+    def begin(self, flops, algo='implicit_gemm'):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        self.records.append((flops, s, e))
+        self.records.append((flops, s, e, algo))
         return e
 
     def summary(self):
-        tot_ms = sum(s.elapsed_time(e) for _, s, e in self.records)
-        tot_flop = sum(f for f, _, _ in self.records)
-        return dict(launches=len(self.records), ms=tot_ms, flop=tot_flop)
+        from t2i_amd import kernels as K
+        tot_ms = sum(s.elapsed_time(e) for _, s, e, _ in self.records)
+        tot_flop = sum(f for f, _, _, _ in self.records)
+        by_algo = {}
+        for f, s, e, a in self.records:      # per algorithm: calls, time, direct-convolution FLOPs, FLOPs issued to the matrix cores
+            r = by_algo.setdefault(a, [0, 0.0, 0.0, 0.0])
+            r[0] += 1; r[1] += s.elapsed_time(e); r[2] += f; r[3] += f * K.ALGO_MAC_RATIO[K.ALGO_NAMES.index(a)]
+        return dict(launches=len(self.records), ms=tot_ms, flop=tot_flop, by_algo=by_algo)
 
 
 def effective_cpus():
@@ -274,6 +279,11 @@ def main():
                 'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
                 'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
                 'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
+                # `achieved` counts direct-convolution FLOPs; the Winograd paths issue 1/2.25 resp. 9/16 of them
+                'executed_tflops': sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0,
+                'by_algorithm': {a: {'calls_per_step': r[0] / float(inst_steps), 'ms_per_step': r[1] / inst_steps,
+                                     'algorithmic_tflops': r[2] / (r[1] * 1e-3) / 1e12 if r[1] > 0 else 0.0}
+                                 for a, r in sorted(s['by_algo'].items())},
                 'device': info}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
             out['cpu_baseline'] = cpu_baseline()

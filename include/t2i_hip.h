@@ -192,6 +192,18 @@ int t2i_row_fma2(const float* a, const float* b, const float* alpha, const float
  * mode 0: out = (1-t)*a + t*b;  mode 1: out = t*a;  mode 2: out = (1-t)*a  (modes 1, 2 = the backward of mode 0). */
 int t2i_lerp_dev(const float* a, const float* b, const float* t_dev, int32_t mode, int64_t n, float* out, t2i_stream_t stream);
 
+/* Which algorithm the three conv entry points pick for this descriptor (which: 0 = t2i_conv2d_fwd, 1 = t2i_conv2d_bwd_data,
+ * 2 = t2i_conv2d_bwd_filter), assuming 16-byte aligned tensors.  For tests, benchmarks and roofline accounting: the
+ * Winograd paths execute 1/2.25 (F(2x2,3x3)) resp. 9/16 (F(2x2,2x2), 4x4 stride 2) of the direct convolution's
+ * multiply-adds.  Returns -1 for an invalid descriptor. */
+enum {
+  T2I_ALGO_IMPLICIT_GEMM = 0,        /* igemm_kernel on the direct convolution */
+  T2I_ALGO_WINOGRAD_F2X2_3X3 = 1,    /* 3x3 stride 1: transforms + 16 batched GEMMs */
+  T2I_ALGO_WINOGRAD_F2X2_2X2 = 2,    /* 4x4 stride 2: space-to-depth / per-phase F(2x2,2x2), 9 or 36 batched GEMMs */
+  T2I_ALGO_DIRECT_SMALL = 3          /* thin / tiny / head kernels of the 3-channel and 1-output layers */
+};
+int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which);
+
 /* ---- transformed-filter cache (optional) -------------------------------------------------------------------------
  * The Winograd paths of the three conv entry points transform the filter (U = G g G^T) on every call.  A training step
  * uses each critic filter in up to six convs between two optimizer updates; with the cache on, the transform is kept in

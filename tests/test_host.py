@@ -160,3 +160,30 @@ def test_committed_bench_line_has_the_contract_keys():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
+
+
+def test_conv_algorithm_choice_on_the_benchmark_layers():
+    """t2i_conv2d_algo (host logic only): which algorithm the three conv entry points take at the benchmark's layer shapes,
+    B = 64.  Pins the dispatch the roofline accounting and the Winograd parity tests rely on."""
+    import t2i_amd  # noqa: F401
+    from t2i_amd import kernels as K
+    G, W3, W2, S = 'implicit_gemm', 'winograd_f2x2_3x3', 'winograd_f2x2_2x2', 'direct_small'
+    want = {   # (H, W, Cin, Cout, k, stride, pad): (fwd, bwd_data, bwd_filter)
+        (64, 64, 3, 128, 4, 2, 'SAME'): (G, S, G),            # critic layer 1 / generator out_deconv (as its adjoint conv)
+        (32, 32, 128, 256, 4, 2, 'SAME'): (W2, G, W2),        # 128-channel side: per-phase transforms of dy cost more than they save
+        (16, 16, 256, 512, 4, 2, 'SAME'): (W2, W2, W2),
+        (8, 8, 512, 1024, 4, 2, 'SAME'): (W2, W2, W2),
+        (4, 4, 512, 1024, 3, 1, 'SAME'): (W3, W3, W3),
+        (4, 4, 1152, 1024, 3, 1, 'SAME'): (W3, W3, W3),
+        (8, 8, 512, 512, 3, 1, 'SAME'): (W3, W3, W3),
+        (16, 16, 256, 256, 3, 1, 'SAME'): (W3, W3, W3),
+        (32, 32, 128, 128, 3, 1, 'SAME'): (G, G, G),          # below 256 channels the transforms outweigh the saved multiplies
+        (4, 4, 1024, 256, 1, 1, 'SAME'): (G, G, G),
+        (64, 64, 3, 3, 3, 1, 'SAME'): (S, S, S),
+        (4, 4, 1024, 1, 4, 4, 'VALID'): (S, S, S),
+    }
+    for (H, W, Ci, Co, k, s, pad), algos in want.items():
+        d, _ = K.conv_desc(64, H, W, Ci, Co, k, k, s, s, pad)
+        assert tuple(K.conv_algo(d, m) for m in ('fwd', 'bwd_data', 'bwd_filter')) == algos, (H, W, Ci, Co, k, s)
+    d, _ = K.conv_desc(64, 8, 8, 512, 512, 3, 3, 1, 1, 'SAME', math=K.MATH_BF16)
+    assert K.conv_algo(d, 'fwd') == K.conv_algo(d, 'bwd_filter') == G      # bf16 math mode: no Winograd

@@ -342,8 +342,8 @@ def test_conv_epilogue_batch_norm_statistics(K):
         os.environ.pop('T2I_FORCE_SPLITK', None)
 
 
-@pytest.mark.parametrize('case', [(2, 4, 4, 256, 288, 'critic 4x4 map'), (3, 8, 8, 320, 256, 'generator 8x8'), (1, 16, 16, 256, 256, '16x16'),
-                                  (5, 4, 6, 512, 256, 'non-square')])
+@pytest.mark.parametrize('case', [(48, 4, 4, 512, 1024, 'critic 4x4 map'), (12, 8, 8, 512, 512, 'generator 8x8'), (13, 16, 16, 256, 256, '16x16'),
+                                  (16, 4, 6, 1152, 1024, 'non-square, 1152 = features ++ text channels')])
 def test_winograd_3x3_matches_oracle(K, case):
     """3x3 stride-1 SAME convs with >= 256 channels on small maps take the Winograd F(2x2,3x3) path (transforms + 16 batched
     GEMMs in one launch) in conv_fwd, conv_bwd_data and conv_bwd_filter.  Against the float64 direct oracle: 2e-5 of the output scale (the
@@ -356,6 +356,7 @@ def test_winograd_3x3_matches_oracle(K, case):
     w = (rng.standard_normal((3, 3, Ci, Co)) / np.sqrt(9 * Ci)).astype(np.float32)
     b = rng.standard_normal(Co).astype(np.float32)
     d, ws = K.conv_desc(B, H, W, Ci, Co, 3, 3, 1, 1, 'SAME')
+    assert [K.conv_algo(d, m) for m in ('fwd', 'bwd_data', 'bwd_filter')] == ['winograd_f2x2_3x3'] * 3     # this IS the path under test
     y_ref = O.conv2d(x, w, b, (1, 1), 'SAME')
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
@@ -386,6 +387,8 @@ def test_winograd_k4s2_matches_oracle(K, case):
     w = (rng.standard_normal((4, 4, Ci, Co)) / np.sqrt(16 * Ci)).astype(np.float32)
     b = rng.standard_normal(Co).astype(np.float32)
     d, ws = K.conv_desc(B, H, W, Ci, Co, 4, 4, 2, 2, 'SAME')
+    assert K.conv_algo(d, 'fwd') == K.conv_algo(d, 'bwd_filter') == 'winograd_f2x2_2x2'
+    assert K.conv_algo(d, 'bwd_data') == ('winograd_f2x2_2x2' if min(Ci, Co) >= 256 and Ci % 32 == 0 else 'implicit_gemm')
     y_ref = O.conv2d(x, w, b, (2, 2), 'SAME')
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
     assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
@@ -418,6 +421,8 @@ def test_filter_cache_reuse_and_invalidate(K):
     w4 = dev((rng.standard_normal((4, 4, 256, 256)) / 64).astype(np.float32))
     d, ws = K.conv_desc(16, 8, 8, 512, 512, 3, 3, 1, 1, 'SAME')
     d4, ws4 = K.conv_desc(4, 8, 8, 256, 256, 4, 4, 2, 2, 'SAME')
+    assert K.conv_algo(d, 'fwd') == K.conv_algo(d, 'bwd_data') == 'winograd_f2x2_3x3'
+    assert K.conv_algo(d4, 'fwd') == K.conv_algo(d4, 'bwd_data') == 'winograd_f2x2_2x2'
     dy4 = dev(rng.standard_normal((4, 4, 4, 256)).astype(np.float32))
     held0 = K.filter_cache_bytes()
     plain = [K.conv_fwd(x, w, None, d, ws), K.conv_bwd_data(x, w, None, d, ws), K.conv_fwd(x4, w4, None, d4, ws4),

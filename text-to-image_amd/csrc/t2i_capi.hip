@@ -662,6 +662,25 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
   return check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
 }
 
+int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
+  if (validate_desc(d) || which < 0 || which > 2) return -1;
+  const bool thin = !env_int("T2I_NO_THIN", 0);
+  if (which == 0) {
+    if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, false))) return T2I_ALGO_DIRECT_SMALL;
+    if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
+    if (winograd_k4s2_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
+  } else if (which == 1) {
+    if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, true) || thin_deconv_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
+    if (winograd_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
+    if (winograd_k4s2_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
+  } else {
+    if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
+    if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
+    if (winograd_k4s2_eligible(*d, false) && env_int("T2I_WINOGRAD_K4S2_BWDF", 1)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
+  }
+  return T2I_ALGO_IMPLICIT_GEMM;
+}
+
 int t2i_filter_cache_enable(int on) { return filter_cache_enable(on); }
 
 void t2i_filter_cache_invalidate(const void* p, size_t bytes) { filter_cache_invalidate(p, bytes); }

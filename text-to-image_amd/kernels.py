@@ -165,7 +165,7 @@ def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
-        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                  _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
         if ev is not None:
@@ -202,7 +202,7 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         nbytes = int(lib.t2i_conv2d_stats_bytes(ctypes.byref(d)))
         part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
         chunks = ctypes.c_int32(0)
-        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                        _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), wsp, wsn, _stream()),
               't2i_conv2d_fwd_stats')
@@ -220,7 +220,7 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dy.device)
     if _live(dy):
         wsp, wsn = _ws_args(dy, ws_bytes)
-        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_data')) if _TIMER[0] is not None else None
         check(lib.t2i_conv2d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w),
                                       _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, wsp,
                                       wsn, _stream()), 't2i_conv2d_bwd_data')
@@ -239,7 +239,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
     dw = out if out is not None else torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
-        ev = _TIMER[0].begin(conv_flops(d)) if _TIMER[0] is not None else None
+        ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_filter')) if _TIMER[0] is not None else None
         check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, wsp, wsn,
                                         _stream()),
               't2i_conv2d_bwd_filter')
@@ -561,6 +561,18 @@ def ca_kl_bwd(mean, log_sigma, eps, dcode, dkl):
                                 _ptr(_chk(dkl, 'dkl') if dkl is not None else None), mean.numel(), _ptr(dmean), _ptr(dls),
                                 _stream()), 't2i_ca_kl_bwd')
     return dmean, dls
+
+
+ALGO_NAMES = ('implicit_gemm', 'winograd_f2x2_3x3', 'winograd_f2x2_2x2', 'direct_small')
+ALGO_MAC_RATIO = (1.0, 1.0 / 2.25, 9.0 / 16.0, 1.0)       # executed / direct-convolution multiply-adds
+
+
+def conv_algo(d, which):
+    """Algorithm the library picks for descriptor `d`; which: 'fwd' | 'bwd_data' | 'bwd_filter'."""
+    a = int(lib.t2i_conv2d_algo(ctypes.byref(d), ('fwd', 'bwd_data', 'bwd_filter').index(which)))
+    if a < 0:
+        raise ValueError('invalid conv descriptor')
+    return ALGO_NAMES[a]
 
 
 def filter_cache(on):

@@ -51,8 +51,10 @@ def main():
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16'])
     a = ap.parse_args()
     K.set_math(a.math)
-    tot = {'fwd': [0, 0], 'bwd_data': [0, 0], 'bwd_filter': [0, 0]}
-    print('%-6s %5s %22s %10s | %8s %6s | %8s %6s | %8s %6s' % ('layer', 'B', 'shape', 'GFLOP', 'fwd us', 'TF/s', 'bwdD us', 'TF/s', 'bwdF us', 'TF/s'))
+    tot = {'fwd': [0, 0, 0], 'bwd_data': [0, 0, 0], 'bwd_filter': [0, 0, 0]}
+    # TF/s = direct-convolution FLOPs / time (what bench.py's roofline block counts); algo: G = implicit GEMM, W3 = Winograd
+    # F(2x2,3x3) (executes 1/2.25 of those FLOPs), W2 = Winograd F(2x2,2x2) on 4x4 stride 2 (9/16), S = small direct kernel
+    print('%-6s %5s %22s %10s | %8s %6s | %8s %6s | %8s %6s | %s' % ('layer', 'B', 'shape', 'GFLOP', 'fwd us', 'TF/s', 'bwdD us', 'TF/s', 'bwdF us', 'TF/s', 'algo f/d/w'))
     for name, H, W, Ci, Co, k, s, pad in LAYERS:
         if a.filter and a.filter not in name:
             continue
@@ -66,12 +68,17 @@ def main():
         t3 = timeit(lambda: K.conv_bwd_filter(x, dy, d, ws), a.reps)
         for key, t in (('fwd', t1), ('bwd_data', t2), ('bwd_filter', t3)):
             tot[key][0] += fl; tot[key][1] += t
-        print('%-6s %5d %22s %10.2f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f' % (
+        short = {'implicit_gemm': 'G', 'winograd_f2x2_3x3': 'W3', 'winograd_f2x2_2x2': 'W2', 'direct_small': 'S'}
+        algos = '/'.join(short[K.conv_algo(d, m)] for m in ('fwd', 'bwd_data', 'bwd_filter'))
+        for key in ('fwd', 'bwd_data', 'bwd_filter'):
+            tot[key][2] += fl * K.ALGO_MAC_RATIO[K.ALGO_NAMES.index(K.conv_algo(d, key))]
+        print('%-6s %5d %22s %10.2f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f | %s' % (
             name, B, '%dx%dx%d->%d k%ds%d' % (H, W, Ci, Co, k, s), fl / 1e9, t1 * 1e6, fl / t1 / 1e12, t2 * 1e6, fl / t2 / 1e12,
-            t3 * 1e6, fl / t3 / 1e12))
-    for key, (f, t) in tot.items():
+            t3 * 1e6, fl / t3 / 1e12, algos))
+    for key, (f, t, fx) in tot.items():
         if t:
-            print('TOTAL %-10s %8.2f GFLOP %8.1f us  %6.1f TF/s' % (key, f / 1e9, t * 1e6, f / t / 1e12))
+            print('TOTAL %-10s %8.2f GFLOP %8.1f us  %6.1f TF/s   (executed on the matrix cores: %.2f GFLOP, %.1f TF/s)' % (
+                key, f / 1e9, t * 1e6, f / t / 1e12, fx / 1e9, fx / t / 1e12))
 
 
 if __name__ == '__main__':
