@@ -228,7 +228,8 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
   if ((d.H & 1) || (d.W & 1) || (d.Cin % 32) || (d.Cout % 32)) return false;
   // pays when the GEMM work dominates the three transform passes: many channels on small maps
   const int cmin = d.Cin < d.Cout ? d.Cin : d.Cout;
-  if (cmin < wino_min_channels() || (int64_t)d.H * d.W > 256) return false;
+  static const int maxhw = getenv("T2I_WINOGRAD_MAXHW") ? atoi(getenv("T2I_WINOGRAD_MAXHW")) : 256;
+  if (cmin < wino_min_channels() || (int64_t)d.H * d.W > maxhw) return false;
   // ... and the 16 GEMMs are big enough to fill the chip after the fixed cost of the filter transform (measured: the
   // 4x4x256->512 critic layer at B=64, T*K*N = 3.4e7, loses 12%; 4x4x256->1024, 6.7e7, gains 10%)
   const int64_t T = (int64_t)d.B * (d.H / 2) * (d.W / 2);
