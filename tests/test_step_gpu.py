@@ -6,11 +6,14 @@
 Tolerances (fp32 vs float64 / fp32 oracle): loss scalars rel <= 1e-4 (they sum O(1e5) fp32 products through 12 layers
 and a double backward); gradients max|d|/max|ref| <= 1e-3 per tensor; post-Adam weights within 2*lr (Adam with beta1=0
 is sign-like at t=1)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cfg(z, e, c, gf, df, B):
@@ -398,3 +401,54 @@ def test_filter_cache_full_width_bit_identical(gpu):
         assert torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])
         for n in ref[0]:
             assert torch.equal(other[0][n], ref[0][n]), n
+
+
+_ALGO_CHILD = r'''
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+import bench, t2i_amd
+from t2i_amd import kernels as K
+from t2i_amd.models.wgancls.model import WGanCls
+dev = torch.device('cuda', 0)
+cfg = bench.make_cfg(16)
+m = WGanCls(cfg, device=dev, seed=5)
+feed = bench.synthetic_feed(cfg, dev, seed=9)
+d = m.d_losses(feed)
+out = {k: float(d[k]) for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2')}
+dg = m.d_arena.grad.clone()
+g = m.g_losses(feed)
+out['G_loss'] = float(g['G_loss'])
+torch.save({'d': dg.cpu(), 'g': m.g_arena.grad.cpu()}, sys.argv[2])
+descs = [K.conv_desc(48, 4, 4, 1152, 1024, 3, 3, 1, 1, 'SAME')[0], K.conv_desc(48, 16, 16, 256, 512, 4, 4, 2, 2, 'SAME')[0]]
+out['algos'] = [K.conv_algo(x, 'fwd') for x in descs]
+print(json.dumps(out))
+'''
+
+
+def test_winograd_and_direct_paths_agree_on_the_full_width_step(gpu, tmp_path):
+    """The same full-width critic + generator step (B=16, benchmark architecture, random init) computed twice in child
+    processes: with the library's default algorithm choice (Winograd on the many-channel 3x3 and 4x4-stride-2 layers) and
+    with T2I_WINOGRAD=0 T2I_WINOGRAD_K4S2=0 (implicit GEMM everywhere).  Two fp32 evaluation orders of the same
+    mathematics: losses agree to 1e-4 relative, the critic's gradient arena to 1e-2 and the generator's to 2e-3 of its
+    norm.  (Yardstick: at random init the 150x gradient penalty makes dD_loss/dw a sum of large cancelling terms, and even
+    torch-CPU fp32 sits ~2e-3 from float64 on some critic tensors — see test_full_width_step_vs_cpu_oracle, which holds
+    the float64 comparison; measured here: 2.9e-3 for the critic arena.)"""
+    import json
+    import subprocess
+    import sys
+    res = {}
+    for name, env in (('default', {}), ('direct', {'T2I_WINOGRAD': '0', 'T2I_WINOGRAD_K4S2': '0'})):
+        e = dict(os.environ); e.update(env)
+        dump = str(tmp_path / (name + '.pt'))
+        r = subprocess.run([sys.executable, '-c', _ALGO_CHILD, ROOT, dump], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1]
+        res[name] = (json.loads(line), torch.load(dump))
+    assert res['default'][0]['algos'] == ['winograd_f2x2_3x3', 'winograd_f2x2_2x2']
+    assert res['direct'][0]['algos'] == ['implicit_gemm', 'implicit_gemm']
+    for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'G_loss'):
+        a, b = res['default'][0][k], res['direct'][0][k]
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (k, a, b)
+    for k in ('d', 'g'):
+        a, b = res['default'][1][k].double(), res['direct'][1][k].double()
+        assert float((a - b).norm() / b.norm()) <= (1e-2 if k == 'd' else 2e-3), k
