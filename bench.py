@@ -175,10 +175,12 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('T2I_DIST_BACKEND', 'nccl')
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get('T2I_DIST_TIMEOUT_S', '600')))   # a stuck collective aborts the run instead of hanging it
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
         from t2i_amd.dp import DataParallel
         dp = DataParallel()
 
