@@ -241,7 +241,13 @@ def main():
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         if not torch.equal(lo, hi):
-            raise SystemExit('replicas diverged: %s vs %s' % (lo.tolist(), hi.tolist()))
+            names = list(model.store.vars.keys())       # which variables: per-variable checksums, min/max over ranks
+            per = torch.stack([model.store.vars[n].detach().double().sum() for n in names])
+            plo, phi = per.clone(), per.clone()
+            torch.distributed.all_reduce(plo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(phi, op=torch.distributed.ReduceOp.MAX)
+            bad = [names[i] for i in range(len(names)) if plo[i] != phi[i]]
+            raise SystemExit('replicas diverged: %s vs %s; variables that differ: %s' % (lo.tolist(), hi.tolist(), bad[:40]))
         if rank == 0:
             sys.stderr.write('[bench] replica sync check passed: %s\n' % sig.tolist())
     if use_dp:

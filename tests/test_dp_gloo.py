@@ -131,7 +131,8 @@ def _sinks_mode(dp, arena, params, data, rank, world):
     with pytest.raises(RuntimeError, match='structure changed'):
         for c in range(contrib[n] + 1):
             A._notify(params[n])
-    dp.allreduce_arena(arena)                                         # drain so both ranks stay in lockstep
+    with pytest.raises(RuntimeError, match='differ from the first armed step'):     # ... and the aborted backward is not
+        dp.allreduce_arena(arena)                                     # exchanged as if it were complete (both ranks alike)
     A.NOTIFY[0] = None
     A.SINKS.clear()
 

@@ -13,6 +13,8 @@ complete its all-reduce is issued on a side HIP stream while the main stream kee
 kernels.  xGMI is point-to-point (7 links x ~153 GB/s), ring all-reduce is per-link bound, so buckets are
 large (default 32 MB) — few, big collectives.  The sum is turned into a mean inside the Adam kernel (grad_scale).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,6 +30,8 @@ class DataParallel(object):
         self._arenas = {}
         self._by_ptr = {}
         self._side = None
+        # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
+        self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
 
     # ---- bucket plan ---------------------------------------------------------------------------------------------------
     def _plan(self, arena):
@@ -100,6 +104,8 @@ class DataParallel(object):
     def arm(self, arena):
         """Call right before backward: the hooks of this arena start counting."""
         st = self.attach(arena)
+        if not self.overlap:                 # exchange after the backward (allreduce_arena launches every bucket then)
+            return
         st['pending'] = [len(names) for _, _, names in st['buckets']]
         st['works'] = []
         st['seen'] = {}
@@ -138,6 +144,12 @@ class DataParallel(object):
         if st['armed']:
             if st['seen'] and st['expect'] is None:
                 st['expect'] = dict(st['seen'])    # contributions per sunk parameter, fixed by the model's structure
+            elif st['expect'] is not None and st['seen'] and st['seen'] != st['expect']:      # (a step without sunk gradients: nothing to compare)
+                names = {v.data_ptr(): n for n, v in arena.vars.items()}
+                diff = {names.get(p, hex(p)): (st['seen'].get(p, 0), st['expect'].get(p, 0))
+                        for p in set(st['seen']) | set(st['expect']) if st['seen'].get(p, 0) != st['expect'].get(p, 0)}
+                raise RuntimeError('data-parallel overlap: sunk gradient contributions (seen, learned) differ from the first '
+                                   'armed step for %s; a bucket may have been exchanged before it was complete' % diff)
             for bi in range(len(st['buckets'])):   # whatever hooks / notifications did not complete (unused parameters,
                 self._launch(st, bi)               # the learning step): launched now; _launch skips the ones in flight
         else:                                      # hooks were not armed: plain bucketed all-reduce after backward

@@ -290,6 +290,12 @@ class WGanCls(object):
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
                             'static': static, 'loaded': False}
             return
+        # Known limitation: after a capture, the eager schedule's EARLY bucket launches (issued from autograd's worker thread)
+        # were observed to start before the producing kernels had finished — one generator bucket came back different on two
+        # gloo ranks sharing a device (tools/preflight_2rank.sh); a host-side stream sync before the launch, or exchanging
+        # after the backward, removes it, and without a capture the same schedule stays in sync even under an artificial GPU
+        # backlog.  Root cause not established on the 1-GPU boxes, so from here on eager steps exchange after their backward.
+        self.dp.overlap = False
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         scale = 1.0 / self.dp.world
