@@ -11,6 +11,8 @@ Scheduling differences that do not change the mathematics: the t
 D(G), D(x), D(x_mismatch) run as ONE batched pass of 3B samples (the critic has no batch norm, samples are independent
 and weights shared, model.py:49-51), and the zero-valued branches of the double backward are never launched.
 """
+import os
+
 import torch
 
 from ... import autograd as A
@@ -295,7 +297,7 @@ class WGanCls(object):
         # gloo ranks sharing a device (tools/preflight_2rank.sh); a host-side stream sync before the launch, or exchanging
         # after the backward, removes it, and without a capture the same schedule stays in sync even under an artificial GPU
         # backlog.  Root cause not established on the 1-GPU boxes, so from here on eager steps exchange after their backward.
-        self.dp.overlap = False
+        self.dp.overlap = os.environ.get('T2I_DP_KEEP_OVERLAP') == '1'      # (diagnostics hook: keep the early launches)
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         scale = 1.0 / self.dp.world
