@@ -182,7 +182,7 @@ def main():
         else:
             dist.init_process_group(backend, timeout=tmo)
         from t2i_amd.dp import DataParallel
-        dp = DataParallel()
+        dp = DataParallel(bucket_bytes=int(os.environ.get('T2I_DP_BUCKET_MB', '32')) << 20)
 
     K.set_math(args.math)
     K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # transformed Winograd filters reused until Adam changes them
@@ -191,7 +191,14 @@ def main():
     if dp is not None:
         dp.broadcast_variables(model.store)
     trainer = WGanClsTrainer(None, model, None, cfg)
-    feed = synthetic_feed(cfg, device, seed=1 + rank)
+    # T2I_SAME_DATA=1 (diagnostics): every rank sees rank 0's batch and noise, so the averaged gradients equal the local ones
+    # and an N-rank run must end with EXACTLY the weights of a single process — a check of the exchange that, unlike the
+    # replica comparison, also catches buckets that are exchanged consistently but too early
+    same_data = os.environ.get('T2I_SAME_DATA') == '1'
+    feed = synthetic_feed(cfg, device, seed=1 + (0 if same_data else rank))
+    if same_data:
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed_all(1234)
 
     def barrier():
         if use_dp:
@@ -234,6 +241,11 @@ def main():
         K.set_conv_timer(None)
         model._graphs = saved_graphs
 
+    if same_data and rank == 0:
+        torch.cuda.synchronize()
+        sys.stderr.write('[bench] signature after %d iterations: %r\n' % (model.global_step, [
+            float(model.d_arena.flat.double().sum()), float(model.g_arena.flat.double().sum()), float(model.D_optim.v.double().sum()),
+            float(model.G_optim.v.double().sum()), float(model.kt)]))
     if use_dp and os.environ.get('T2I_CHECK_SYNC') == '1':      # replicas must still hold identical weights, Adam state and kt
         sig = torch.stack([model.d_arena.flat.double().sum(), model.g_arena.flat.double().sum(), model.D_optim.v.double().sum(),
                            model.kt.double()])

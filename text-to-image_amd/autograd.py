@@ -104,6 +104,10 @@ def _filter_grad(x, gpre, geom, w):
                 K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink)
             _notify(w)
             return None
+    if os.environ.get('T2I_DP_DEBUG') == '1' and NOTIFY[0] is not None:
+        import sys
+        sys.stderr.write('[ag] differentiable filter gradient: grad_enabled=%s sink=%s inputs_only=%s w.requires_grad=%s\n' % (
+            torch.is_grad_enabled(), sink_at(w.data_ptr()) is not None, _INPUTS_ONLY[0], w.requires_grad))
     return ConvBwdFilterFn.apply(x, gpre, geom)
 
 

@@ -7,8 +7,10 @@ replicas at local batch b behave as the reference at BATCH_SIZE = N*b with per-r
 Exchange step: the gradient arena (optim.Arena.grad, one flat buffer per optimizer) is cut into contiguous buckets in
 REVERSE creation order (the order backward produces them).  Finished parameters are counted — by a post-accumulate
 hook for gradients that go through autograd's AccumulateGrad, by autograd.NOTIFY for gradients that the kernels sum
-straight into the arena (gradient sinks: those never reach AccumulateGrad; how many contributions each parameter gets
-per backward is learned on the first armed step, which therefore exchanges after the backward).  When a bucket is
+straight into the arena (gradient sinks: no tensor gradient reaches AccumulateGrad for them — although the engine still
+VISITS a leaf named in backward(inputs=...) with an undefined gradient, so the hook only counts visits whose incoming
+gradient is defined; how many contributions each parameter gets per backward is learned on the first armed step, which
+therefore exchanges after the backward).  When a bucket is
 complete its all-reduce is issued on a side HIP stream while the main stream keeps running the remaining backward
 kernels.  xGMI is point-to-point (7 links x ~153 GB/s), ring all-reduce is per-link bound, so buckets are
 large (default 32 MB) — few, big collectives.  The sum is turned into a mean inside the Adam kernel (grad_scale).
@@ -57,12 +59,16 @@ class DataParallel(object):
         if key in self._arenas:
             return self._arenas[key]
         st = {'buckets': self._plan(arena), 'pending': None, 'works': [], 'armed': False, 'arena': arena,
-              'expect': None, 'seen': {}, 'owner_ptr': {}, 'launched': set()}
+              'expect': None, 'seen': {}, 'owner_ptr': {}, 'launched': set(), 'defined': set()}
         owner = {}
         for bi, (_, _, names) in enumerate(st['buckets']):
             for n in names:
                 owner[n] = bi
         for n, v in arena.vars.items():
+            # The engine visits a leaf named in backward(inputs=...) even when every path handed it an UNDEFINED gradient
+            # (all its contributions were summed into sinks): its hooks then fire with nothing accumulated.  The tensor
+            # pre-hook sees the incoming gradient and tells the post-accumulate hook whether anything real arrived.
+            v.register_hook(self._make_pre_hook(st, v.data_ptr()))
             v.register_post_accumulate_grad_hook(self._make_hook(st, owner[n]))
             st['owner_ptr'][v.data_ptr()] = owner[n]
             self._by_ptr[v.data_ptr()] = st
@@ -92,12 +98,27 @@ class DataParallel(object):
                                'on the first step (its bucket may already be in flight); the backward structure changed' %
                                (c, want))
 
+    def _make_pre_hook(self, st, ptr):
+        def pre(g):
+            if st['armed'] and g is not None:
+                st['defined'].add(ptr)
+            return g
+        return pre
+
     def _make_hook(self, st, bi):
-        def hook(_param):
+        def hook(param):
             if not st['armed']:
                 return
-            st['pending'][bi] -= 1
-            if st['pending'][bi] == 0:             # (sunk parameters do not count down on the learning step)
+            ptr = param.data_ptr()
+            if ptr not in st['defined']:
+                return                              # visited with an undefined gradient: nothing was accumulated
+            st['defined'].discard(ptr)
+            from . import autograd as A
+            if A.sink_at(ptr) is not None:          # a sunk parameter that ALSO received a tensor gradient: one more contribution
+                self.notify(ptr)
+                return
+            st['pending'][bi] -= 1                  # ordinary leaf: exactly one AccumulateGrad per backward
+            if st['pending'][bi] == 0:
                 self._launch(st, bi)
         return hook
 
@@ -110,11 +131,17 @@ class DataParallel(object):
         st['works'] = []
         st['seen'] = {}
         st['launched'] = set()
+        st['defined'] = set()
         st['armed'] = True
 
     def _launch(self, st, bi):
         start, end, _ = st['buckets'][bi]
         if bi in st['launched']:
+            return
+        if st['armed'] and os.environ.get('T2I_DP_SNAPSHOT') == '1' and not st.get('in_start'):
+            # diagnostics: instead of exchanging now, remember the bucket as it is at its "last contribution" ...
+            torch.cuda.synchronize()
+            st.setdefault('snap', {})[bi] = st['arena'].grad[start:end].clone()
             return
         st['launched'].add(bi)
         buf = st['arena'].grad[start:end]
@@ -141,6 +168,16 @@ class DataParallel(object):
         blocked).  Work enqueued on the calling stream between this and finish_allreduce overlaps the exchange — it must not
         touch the arena's gradients."""
         st = self.attach(arena)
+        if st.get('snap'):                      # ... and compare with what the backward finally left there
+            torch.cuda.synchronize()
+            for bi, snap in st['snap'].items():
+                b0, b1, names = st['buckets'][bi]
+                cur = arena.grad[b0:b1]
+                if not torch.equal(cur, snap):
+                    late = [n for n in names if not torch.equal(arena.grad_of(n).reshape(-1), snap[arena.offsets[n][0] - b0:arena.offsets[n][0] - b0 + arena.offsets[n][1]])]
+                    raise RuntimeError('bucket %d changed after its last announced contribution: %s' % (bi, late[:20]))
+            st['snap'] = {}
+        st['in_start'] = True
         if st['armed']:
             if st['seen'] and st['expect'] is None:
                 st['expect'] = dict(st['seen'])    # contributions per sunk parameter, fixed by the model's structure
@@ -157,6 +194,7 @@ class DataParallel(object):
             st['launched'] = set()
             for bi in range(len(st['buckets'])):
                 self._launch(st, bi)
+        st['in_start'] = False
         if extra is not None:
             if extra.is_cuda and self._side is not None:
                 self._side.wait_stream(torch.cuda.current_stream(extra.device))

@@ -23,6 +23,11 @@ from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_tra
                           reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
 
 
+# capture mode of the data-parallel graph segments: thread-local, because the process group's watchdog thread polls events
+# while the capture is open (T2I_DP_CAPTURE_MODE=global for diagnostics with a backend that has no such thread)
+_CAPTURE_MODE = os.environ.get('T2I_DP_CAPTURE_MODE', 'thread_local')
+
+
 class WGanCls(object):
     def __init__(self, cfg, build_model=True, device=None, seed=0, dp=None):
         """
@@ -292,32 +297,26 @@ class WGanCls(object):
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
                             'static': static, 'loaded': False}
             return
-        # Known limitation: after a capture, the eager schedule's EARLY bucket launches (issued from autograd's worker thread)
-        # were observed to start before the producing kernels had finished — one generator bucket came back different on two
-        # gloo ranks sharing a device (tools/preflight_2rank.sh); a host-side stream sync before the launch, or exchanging
-        # after the backward, removes it, and without a capture the same schedule stays in sync even under an artificial GPU
-        # backlog.  Root cause not established on the 1-GPU boxes, so from here on eager steps exchange after their backward.
-        self.dp.overlap = os.environ.get('T2I_DP_KEEP_OVERLAP') == '1'      # (diagnostics hook: keep the early launches)
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         scale = 1.0 / self.dp.world
         self._capturing = True
         try:
-            with torch.cuda.graph(gd, capture_error_mode='thread_local'):
+            with torch.cuda.graph(gd, capture_error_mode=_CAPTURE_MODE):
                 d_out = self.d_losses(static)
-            with torch.cuda.graph(gdu, pool=gd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(gdu, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._d_update(d_out, scale)
-            with torch.cuda.graph(gg, pool=gd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(gg, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 g_out = self.g_losses(static)
-            with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 self.G_optim.apply(grad_scale=scale)
             # dg_step: generator forward on its own (replayed while the critic's gradients are on the wire), then the critic's
             # update + the rest of the generator half in one launch; the autograd graph of the first capture is consumed by
             # the second (both allocate from the same private pool, replayed in capture order)
             ggf, gdug = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ggf, pool=gd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(ggf, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 fwd = self._g_forward(static)
-            with torch.cuda.graph(gdug, pool=gd.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(gdug, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._d_update(d_out, scale)
                 g_out2 = self.g_losses(static, fwd=fwd)
             del fwd

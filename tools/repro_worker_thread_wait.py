@@ -5,13 +5,17 @@ Single process, no torch.distributed.  A custom Function's backward (run by auto
 chain of kernels that finish a buffer on the current (null) stream, then makes a side stream wait for the current stream and
 copies the buffer to pinned host memory on the side stream — the pattern dp._launch uses for an early bucket.  The copy
 must see the final values.  Run before and after capturing an unrelated autograd backward into a hipGraph
-(thread-local capture mode), as WGanCls.enable_graphs does under data parallelism.  usage: repro_worker_thread_wait.py"""
+(thread-local capture mode), as WGanCls.enable_graphs does under data parallelism.  usage: repro_worker_thread_wait.py [hop]   (hop: the copy runs on a THIRD stream that waits for an event recorded
+on the empty side stream — the shape of a collective issued under `with torch.cuda.stream(side)`)"""
 import threading
 
 import torch
 
 dev = torch.device('cuda', 0)
+import sys
+HOP = len(sys.argv) > 1 and sys.argv[1] == 'hop'
 side = torch.cuda.Stream()
+third = torch.cuda.Stream(priority=-1)
 N = 1 << 24
 buf = torch.zeros(N, device=dev)
 host = torch.empty(N, pin_memory=True)
@@ -33,9 +37,16 @@ class Probe(torch.autograd.Function):
         buf.add_(t.sum() * 0 + 1.0)          # the "last gradient contribution": buf becomes all ones
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            host.copy_(buf, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record(side)
+        if HOP:                              # what a collective does: record on the (otherwise empty) side stream, copy on a third
+            ev2 = torch.cuda.Event(); ev2.record(side)
+            third.wait_event(ev2)
+            with torch.cuda.stream(third):
+                host.copy_(buf, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(third)
+        else:
+            with torch.cuda.stream(side):
+                host.copy_(buf, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(side)
         result['ev'] = ev
         result['thread'] = threading.current_thread().name
         result['stream'] = hex(cur.cuda_stream)
