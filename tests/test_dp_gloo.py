@@ -54,6 +54,12 @@ def _worker(rank, world, port, mode, q):
             use = names if mode != 'unused' else names[:-2]      # leave two parameters out of the graph
             return sum((params[n] * data[n]).sum() * (i + 1) for i, n in enumerate(use))
 
+        if mode == 'sinks_autograd':
+            _sinks_autograd_mode(dp, arena, params, data, rank, world)
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, 'ok'))
+            return
         if mode == 'sinks':
             _sinks_mode(dp, arena, params, data, rank, world)
             dist.barrier()
@@ -84,6 +90,64 @@ def _worker(rank, world, port, mode, q):
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, 'FAIL: %s\n%s' % (e, traceback.format_exc())))
+
+
+def _sinks_autograd_mode(dp, arena, params, data, rank, world):
+    """Sinks driven by REAL autograd: a Function whose backward sums the parameter gradient into the sink, announces it and
+    hands autograd `None` — run through backward(inputs=...), as the trainers do.  The engine still visits every listed leaf
+    (with an undefined gradient), which fires its post-accumulate hook: that visit must not count as a contribution, or a
+    bucket leaves when only half of its parameters are done (the bug this mode pins down).  p4 also gets a second, ordinary
+    tensor gradient."""
+    from t2i_amd import autograd as A
+    arena.enable_sinks()
+    names = list(params)
+
+    class SunkMul(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, dat):
+            ctx.save_for_backward(x, dat)
+            ctx.w_ref = w
+            return (x * (w.detach() * dat).sum())
+
+        @staticmethod
+        def backward(ctx, g):
+            x, dat = ctx.saved_tensors
+            A.sink_at(ctx.w_ref.data_ptr()).add_(((g * x).sum() * dat).reshape(-1))
+            A._notify(ctx.w_ref)
+            return g * 0, None, None
+
+    launches = []
+    orig_launch = dp._launch
+
+    def spy(st, bi):
+        if st['armed'] and st['expect'] is not None:                   # ... and only complete ones
+            ptr_bucket = st['owner_ptr']
+            assert all(st['seen'].get(p, 0) == c for p, c in st['expect'].items() if ptr_bucket[p] == bi), 'bucket %d left early' % bi
+        launches.append(bi)
+        return orig_launch(st, bi)
+    dp._launch = spy
+    x0 = torch.ones((), requires_grad=True)
+    for step in range(3):
+        arena.zero_grad()
+        dp.arm(arena)
+        launches.clear()
+        y = sum(SunkMul.apply(x0, params[n], data[n] * (step + 1)) for n in names)
+        y = y + (params['p4'] * data['p4']).sum() * 0.5                  # p4: one sunk + one ordinary tensor contribution
+        y.backward(inputs=list(params.values()) + [x0])
+        st = next(iter(dp._arenas.values()))
+        if step > 0:
+            assert launches, 'overlap path was not live'             # buckets left during the backward ...
+        scale = dp.allreduce_arena(arena)
+        assert scale == 1.0 / world
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {n: data[n] * (step + 1) + (data[n] * 0.5 if n == 'p4' else 0) for n in names})
+        for n in names:
+            want = sum(g[n] for g in gathered)
+            assert torch.allclose(arena.grad_of(n), want, atol=1e-4), (step, n, arena.grad_of(n).flatten()[:3], want.flatten()[:3])
+        assert st['seen'] == st['expect']
+    dp._launch = orig_launch
+    A.NOTIFY[0] = None
+    A.SINKS.clear()
 
 
 def _sinks_mode(dp, arena, params, data, rank, world):
@@ -137,7 +201,7 @@ def _sinks_mode(dp, arena, params, data, rank, world):
     A.SINKS.clear()
 
 
-@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks'])
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd'])
 def test_dp_allreduce_two_ranks(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
