@@ -138,12 +138,16 @@ class DataParallel(object):
         start, end, _ = st['buckets'][bi]
         if bi in st['launched']:
             return
+        st['launched'].add(bi)
         if st['armed'] and os.environ.get('T2I_DP_SNAPSHOT') == '1' and not st.get('in_start'):
             # diagnostics: instead of exchanging now, remember the bucket as it is at its "last contribution" ...
             torch.cuda.synchronize()
+            st['launched'].discard(bi)
             st.setdefault('snap', {})[bi] = st['arena'].grad[start:end].clone()
             return
-        st['launched'].add(bi)
+        self._launch_range(st, start, end)
+
+    def _launch_range(self, st, start, end):
         buf = st['arena'].grad[start:end]
         if buf.is_cuda:
             if self._side is None:
@@ -189,11 +193,10 @@ class DataParallel(object):
                                    'armed step for %s; a bucket may have been exchanged before it was complete' % diff)
             for bi in range(len(st['buckets'])):   # whatever hooks / notifications did not complete (unused parameters,
                 self._launch(st, bi)               # the learning step): launched now; _launch skips the ones in flight
-        else:                                      # hooks were not armed: plain bucketed all-reduce after backward
-            st['works'] = []
-            st['launched'] = set()
-            for bi in range(len(st['buckets'])):
-                self._launch(st, bi)
+        else:                                      # not armed (graph segments, exchange-after-backward): the gradients are
+            st['works'] = []                       # all final, so ONE collective over the whole arena — ring all-reduce is
+            st['launched'] = set(range(len(st['buckets'])))      # per-link bound, fewer and larger is better
+            self._launch_range(st, 0, arena.numel)
         st['in_start'] = False
         if extra is not None:
             if extra.is_cuda and self._side is not None:
