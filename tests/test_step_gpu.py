@@ -216,13 +216,15 @@ def test_full_width_step_vs_cpu_oracle(gpu):
     print('generator grads: worst max-norm error vs f64 %.2e (torch-CPU fp32: %.2e) at %s' % worst)
 
 
-def test_graph_replay_matches_eager(gpu, golden_step):
+@pytest.mark.parametrize('n_critic', [1, 2])
+def test_graph_replay_matches_eager(gpu, golden_step, n_critic):
     """d_step/g_step captured into hipGraphs and replayed == the eager launches, bit for bit, over 3 iterations
     (same kernels, same order; only the launch mechanism differs)."""
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
     gs = golden_step
     cfg = _cfg(8, 32, 16, 8, 8, 4)
+    cfg.TRAIN.N_CRITIC = n_critic        # 2: critic-only iterations in between (d_step's own graph) next to the merged D+G launch
     params = {k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')}
     feeds = []
     g = torch.Generator(device=gpu).manual_seed(5)

@@ -90,7 +90,11 @@ class WGanCls(object):
         key = (tuple(t.shape), float(value), t.device)
         c = self._consts.get(key)
         if c is None:
-            c = self._consts[key] = torch.full(tuple(t.shape), float(value), dtype=torch.float32, device=t.device)
+            c = torch.full(tuple(t.shape), float(value), dtype=torch.float32, device=t.device)
+            # a tensor first created while a graph is being captured lives in that graph's pool and is filled by a node of
+            # THAT graph only: caching it would hand other graphs (and eager steps) memory nobody ever filled for them
+            if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._consts[key] = c
         return c
 
     def _ones_like(self, t):
