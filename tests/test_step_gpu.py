@@ -251,7 +251,8 @@ def test_graph_replay_matches_eager(gpu, golden_step, n_critic):
         assert torch.equal(s0[n], s1[n]), n
 
 
-def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
+@pytest.mark.parametrize('n_critic', [1, 2])
+def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step, n_critic):
     """Three launch schedules of the same iteration give the same bits: (a) one stream; (b) sunk filter gradients on the
     second HIP stream (autograd.SIDE); (c) = (b) under dp.DataParallel with an RCCL communicator of world size 1, where
     the gradient buckets are all-reduced on the communication stream as autograd.NOTIFY completes them (first step learns
@@ -265,10 +266,11 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
     gs = golden_step
     cfg = _cfg(8, 32, 16, 8, 8, 4)
+    cfg.TRAIN.N_CRITIC = n_critic        # 2: critic-only iterations (the d_step segments) around one D+G iteration
     params = {k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')}
     feeds = []
     g = torch.Generator(device=gpu).manual_seed(6)
-    for _ in range(3):
+    for _ in range(4):
         f = _feed(gs, gpu)
         f['x'] = torch.rand(f['x'].shape, generator=g, device=gpu) * 2 - 1
         f['z'] = torch.randn(f['z'].shape, generator=g, device=gpu)
@@ -281,7 +283,7 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step):
             m.store.load(params)
             tr = WGanClsTrainer(None, m, None, cfg)
             outs = []
-            for i in range(3):
+            for i in range(4):
                 if graphs and i == 1:                # [losses+backward] | eager all-reduce | [Adam] graph segments
                     m.enable_graphs(feeds[0])
                 outs.append(tr.iteration(1 + i, feeds[i]))
