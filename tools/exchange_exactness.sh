@@ -12,3 +12,8 @@ env T2I_SAME_DATA=1 timeout 300 python bench.py --instrument off --no-cpu-baseli
 run2 "T2I_DP_GRAPHS=0" "--warmup 3 --steps 2"
 run2 "T2I_DP_GRAPHS=0 T2I_DP_NO_OVERLAP=1" "--warmup 3 --steps 2"
 run2 "" "--warmup 1 --steps 2"
+# the same with critic-only iterations in between (N_CRITIC = 2: d_step's own graph segments next to the merged D+G ones)
+export T2I_N_CRITIC=2
+env T2I_SAME_DATA=1 timeout 300 python bench.py --no-graphs --instrument off --no-cpu-baseline --warmup 4 --steps 2 2>&1 >/dev/null | grep signature | sed 's/^/N_CRITIC=2, 1 process eager:   /'
+run2 "T2I_DP_GRAPHS=0" "--warmup 4 --steps 2"
+run2 "" "--warmup 2 --steps 2"
