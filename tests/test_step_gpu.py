@@ -216,8 +216,8 @@ def test_full_width_step_vs_cpu_oracle(gpu):
     print('generator grads: worst max-norm error vs f64 %.2e (torch-CPU fp32: %.2e) at %s' % worst)
 
 
-@pytest.mark.parametrize('n_critic', [1, 2])
-def test_graph_replay_matches_eager(gpu, golden_step, n_critic):
+@pytest.mark.parametrize('n_critic,noise_in_feed', [(1, True), (2, True), (1, False), (2, False)])
+def test_graph_replay_matches_eager(gpu, golden_step, n_critic, noise_in_feed):
     """d_step/g_step captured into hipGraphs and replayed == the eager launches, bit for bit, over 3 iterations
     (same kernels, same order; only the launch mechanism differs)."""
     from t2i_amd.models.wgancls.model import WGanCls
@@ -232,9 +232,12 @@ def test_graph_replay_matches_eager(gpu, golden_step, n_critic):
         f = _feed(gs, gpu)
         f['x'] = torch.rand(f['x'].shape, generator=g, device=gpu) * 2 - 1
         f['z'] = torch.randn(f['z'].shape, generator=g, device=gpu)
+        if not noise_in_feed:                # the model draws the conditioning-augmentation noise itself, as the reference does:
+            del f['ca_noise_d'], f['ca_noise_g']   # replays must re-draw it, in the eager step's order
         feeds.append(f)
     states = []
     for use_graphs in (False, True):
+        torch.manual_seed(77); torch.cuda.manual_seed_all(77)
         m = WGanCls(cfg, device=gpu)
         m.store.load(params)
         tr = WGanClsTrainer(None, m, None, cfg)
@@ -456,3 +459,27 @@ def test_winograd_and_direct_paths_agree_on_the_full_width_step(gpu, tmp_path):
     for k in ('d', 'g'):
         a, b = res['default'][1][k].double(), res['direct'][1][k].double()
         assert float((a - b).norm() / b.norm()) <= (1e-2 if k == 'd' else 2e-3), k
+
+
+def test_trainer_train_with_graphs_matches_eager(gpu):
+    """WGanClsTrainer.train(graphs=True) on the synthetic dataset (fresh batches, z, epsilon and conditioning noise every
+    iteration) ends with exactly the state of the eager loop: the capture happens after the first generator step, inputs are
+    copied into the static buffers and the noise is re-drawn in the eager order."""
+    from t2i_amd.data import SyntheticTextDataset
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    cfg = _cfg(8, 32, 16, 8, 8, 4)
+    cfg.TRAIN.N_CRITIC = 2
+    states = []
+    for graphs in (False, True):
+        torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+        m = WGanCls(cfg, device=gpu, seed=1)
+        ds = SyntheticTextDataset(cfg, device=gpu, seed=3, num_examples=64)
+        tr = WGanClsTrainer(None, m, ds, cfg)
+        tr.train(max_steps=8, log=lambda s: None, graphs=graphs)
+        torch.cuda.synchronize()
+        assert (m._graphs is not None) == graphs
+        states.append(({n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt)))
+    assert states[0][1] == states[1][1]
+    for n in states[0][0]:
+        assert torch.equal(states[0][0][n], states[1][0][n]), n

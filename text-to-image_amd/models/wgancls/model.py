@@ -175,7 +175,7 @@ class WGanCls(object):
     def d_step(self, feed):
         self.D_optim.prepare(float(feed['learning_rate_d']))
         if self._graphs is not None:
-            self._load_static(feed)
+            self._load_static(feed, noise=('ca_noise_d',))
             self._graphs['d'].replay()
             out = self._graphs['d_out']
             if self.dp is not None:            # the exchange step runs between the two captured halves
@@ -229,7 +229,9 @@ class WGanCls(object):
         self.G_optim.prepare(float(feed['learning_rate_g']))
         if self._graphs is not None:
             if not self._graphs['loaded']:
-                self._load_static(feed)
+                self._load_static(feed, noise=('ca_noise_g',))
+            elif feed.get('ca_noise_g') is None:       # inputs were loaded by d_step on this feed: only the G step's own draw is due
+                torch.nn.init.trunc_normal_(self._graphs['static']['ca_noise_g'], mean=0.0, std=1.0, a=-2.0, b=2.0)
             self._graphs['loaded'] = False
             self._graphs['g'].replay()
             if self.dp is not None:
@@ -267,10 +269,18 @@ class WGanCls(object):
     # ---- hipGraph capture of the two halves of the iteration ---------------------------------------------------------------
     _STATIC_KEYS = ('x', 'x_mismatch', 'cond', 'z', 'epsilon', 'ca_noise_d', 'ca_noise_g')
 
-    def _load_static(self, feed):
+    def _load_static(self, feed, noise=('ca_noise_d', 'ca_noise_g')):
+        """Copy this step's inputs into the captured graphs' static buffers.  Conditioning-augmentation noise the feed does
+        not carry is RE-DRAWN in place, in the order the eager step would draw it (`noise`: which of the two draws this
+        step makes) — the reference resamples tf.truncated_normal on every run (model.py:119)."""
         for k, buf in self._graphs['static'].items():
-            src = feed[k]
-            if src.data_ptr() != buf.data_ptr():
+            src = feed.get(k)
+            if src is None:
+                if k not in ('ca_noise_d', 'ca_noise_g'):
+                    raise KeyError('feed lacks %r, which the captured graphs read' % k)
+                if k in noise:
+                    torch.nn.init.trunc_normal_(buf, mean=0.0, std=1.0, a=-2.0, b=2.0)
+            elif src.data_ptr() != buf.data_ptr():
                 buf.copy_(src.reshape(buf.shape))
         self._graphs['loaded'] = True
 
@@ -284,9 +294,8 @@ class WGanCls(object):
         ever captured."""
         static = {k: feed[k].clone() for k in self._STATIC_KEYS if feed.get(k) is not None}
         for k in ('ca_noise_d', 'ca_noise_g'):
-            if k not in static:   # fixed-shape device draw, refreshed by the caller if wanted
-                static[k] = torch.nn.init.trunc_normal_(
-                    torch.empty(feed['cond'].shape[0], self.compressed_embed_dim, device=self.device), 0.0, 1.0, -2.0, 2.0)
+            if k not in static:   # re-drawn in place before every replay (_load_static); nothing is drawn here, so the
+                static[k] = torch.zeros(feed['cond'].shape[0], self.compressed_embed_dim, device=self.device)   # RNG stream stays the eager one
         torch.cuda.synchronize(self.device)
         gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.dp is None:

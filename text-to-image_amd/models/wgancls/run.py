@@ -19,6 +19,7 @@ def main(argv=None):
                     help='Relative path to the config of the model')
     ap.add_argument('--steps', type=int, default=None, help='override TRAIN.MAX_STEPS')
     ap.add_argument('--batch', type=int, default=None, help='override TRAIN.BATCH_SIZE')
+    ap.add_argument('--graphs', type=int, default=1, help='1: replay the iteration from hipGraphs once it has run eagerly (default)')
     args = ap.parse_args(argv)
     print(args.cfg)
     cfg = config_from_yaml(args.cfg)
@@ -33,7 +34,7 @@ def main(argv=None):
     wgan = WGanCls(cfg)
     dataset = SyntheticTextDataset(cfg, wgan.device)
     trainer = WGanClsTrainer(sess=None, model=wgan, dataset=dataset, cfg=cfg)
-    trainer.train(max_steps=args.steps)
+    trainer.train(max_steps=args.steps, graphs=bool(args.graphs))
 
 
 if __name__ == '__main__':

@@ -65,11 +65,13 @@ class WGanClsTrainer(object):
         return Saver(m.store, {'D_optim': m.D_optim, 'G_optim': m.G_optim}, {'kt': (lambda: m.kt.detach().cpu().numpy(), set_kt)},
                      max_to_keep=int(getattr(self.cfg.TRAIN, 'CHECKPOINTS_TO_KEEP', 5)))
 
-    def train(self, max_steps=None, start_point=None, log=None, side_effects=False):
+    def train(self, max_steps=None, start_point=None, log=None, side_effects=False, graphs=False):
         """reference trainer.py:49-126.  With side_effects=True the periodic work around the hot path is on as in the
         reference: resume from the latest checkpoint in cfg.CHECKPOINT_DIR, captions of the fixed sample batch, a PNG grid
         of `sampler` outputs every TRAIN.SAMPLE_PERIOD iterations, a checkpoint when idx % 500 == 2.  TF summaries are
-        replaced by the scalar log line (every SUMMARY_PERIOD iterations); the scalars are also returned per iteration."""
+        replaced by the scalar log line (every SUMMARY_PERIOD iterations); the scalars are also returned per iteration.
+        graphs=True: once a critic step and a generator step have run eagerly, the iteration is captured into hipGraphs and
+        replayed (bit-identical to the eager launches, including the order of the conditioning-noise draws)."""
         from ...utils.saver import load, save
         from ...utils.utils import get_balanced_factorization, save_captions, save_images
         log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
@@ -87,8 +89,13 @@ class WGanClsTrainer(object):
             log(' [*] Load SUCCESS' if could_load else ' [!] Load failed...')
         start_point = start_point or 0
         t0 = time.time()
+        seen_g = False
         for idx in range(start_point + 1, end):
-            out = self.iteration(idx)
+            feed = self.make_feed(idx)
+            out = self.iteration(idx, feed)
+            seen_g = seen_g or 'g' in out
+            if graphs and seen_g and m._graphs is None:
+                m.enable_graphs(feed)
             if idx % self.cfg.TRAIN.SUMMARY_PERIOD == 0:
                 d, g = out['d'], out.get('g', {})
                 log('[%6d] D_loss %.4f G_loss %.4f wdist %.4f wdist2 %.4f gp %.4f gp2 %.4f kt %.4f (%.1fs)' % (
