@@ -139,8 +139,35 @@ def _deconv_k4s2(x, w, b):
     return F.conv_transpose2d(x, w.permute(3, 2, 0, 1), b, stride=2, padding=1)
 
 
-def _lrelu(x):
-    return F.leaky_relu(x, 0.2)
+class MaskTape(object):
+    """Pins the branch every lrelu / relu takes.  A piecewise-linear net evaluated in two arithmetics (fp32 MFMA chains on
+    the GPU, float64 here) agrees to rounding EXCEPT at units whose pre-activation lies within rounding distance of the
+    kink: there the two sides pick different slopes and that unit's gradient differs by O(itself).  To compare gradients at
+    the tolerance SURVEY.md §8(c) states (1e-4) the parity tests record the branch decisions of one side (`record`) and
+    replay them on the other (`masks`): both then differentiate the SAME piecewise-linear function; a replayed unit whose
+    own pre-activation has the other sign is within rounding distance of zero, so values move by rounding only.
+    masks / record: lists of bool tensors in call order (NCHW for feature maps, [B, C] for dense layers)."""
+
+    def __init__(self, masks=None):
+        self.masks, self.record, self.i = masks, [], 0
+
+    def act(self, x, slope):
+        if self.masks is None:
+            m = x > 0
+        else:
+            m = self.masks[self.i]
+            assert m.shape == x.shape, ('mask %d' % self.i, tuple(m.shape), tuple(x.shape))
+        self.i += 1
+        self.record.append(m)
+        return x * torch.where(m, torch.ones((), dtype=x.dtype), torch.full((), slope, dtype=x.dtype))
+
+
+def _lrelu(x, tape=None):
+    return F.leaky_relu(x, 0.2) if tape is None else tape.act(x, 0.2)
+
+
+def _relu(x, tape=None):
+    return F.relu(x) if tape is None else tape.act(x, 0.0)
 
 
 def _bn(P, name, x, train, stats_out, eps=1e-5):
@@ -158,13 +185,14 @@ def _bn(P, name, x, train, stats_out, eps=1e-5):
     return (x - mean.view(shape)) / torch.sqrt(var.view(shape) + eps) * gamma.view(shape) + beta.view(shape)
 
 
-def generator(P, cfg, z, embed, ca_noise, train=True, stats_out=None):
+def generator(P, cfg, z, embed, ca_noise, train=True, stats_out=None, tape=None, aux=None):
     """-> (img NHWC in [-1,1], mean, log_sigma).  ca_noise: explicit truncated-normal draw [B,compressed]
-    (the reference resamples in-graph, model.py:119) or None for cond_noise=False."""
+    (the reference resamples in-graph, model.py:119) or None for cond_noise=False.  tape: optional MaskTape;
+    aux: optional dict that receives 'logits_absmax', the scale of the pre-tanh output (the tests' yardstick for G)."""
     g = cfg.gf
     B = z.shape[0]
-    mean = _lrelu(embed @ P['g_net/dense/kernel'] + P['g_net/dense/bias'])
-    log_sigma = _lrelu(embed @ P['g_net/dense_1/kernel'] + P['g_net/dense_1/bias'])
+    mean = _lrelu(embed @ P['g_net/dense/kernel'] + P['g_net/dense/bias'], tape)
+    log_sigma = _lrelu(embed @ P['g_net/dense_1/kernel'] + P['g_net/dense_1/bias'], tape)
     c = mean + torch.exp(log_sigma) * ca_noise if ca_noise is not None else mean
     h = torch.cat([z, c], 1) @ P['g_net/dense_2/kernel'] + P['g_net/dense_2/bias']
     h = _bn(P, 'g_net/BatchNorm', h, train, stats_out)
@@ -181,36 +209,38 @@ def generator(P, cfg, z, embed, ca_noise, train=True, stats_out=None):
     def bn(i, x):
         return _bn(P, 'g_net/BatchNorm_%d' % i, x, train, stats_out)
 
-    r = F.relu(bn(1, cv(0, h0, 'VALID')))
-    r = F.relu(bn(2, cv(1, r)))
+    r = _relu(bn(1, cv(0, h0, 'VALID')), tape)
+    r = _relu(bn(2, cv(1, r)), tape)
     r = bn(3, cv(2, r))
-    h1 = F.relu(h0 + r)
+    h1 = _relu(h0 + r, tape)
     h2 = bn(4, cv(3, dc(0, h1)))
-    r = F.relu(bn(5, cv(4, h2, 'VALID')))
-    r = F.relu(bn(6, cv(5, r)))
+    r = _relu(bn(5, cv(4, h2, 'VALID')), tape)
+    r = _relu(bn(6, cv(5, r)), tape)
     r = bn(7, cv(6, r))
-    h3 = F.relu(h2 + r)
-    h4 = F.relu(bn(8, cv(7, dc(1, h3))))
-    h5 = F.relu(bn(9, cv(8, dc(2, h4))))
+    h3 = _relu(h2 + r, tape)
+    h4 = _relu(bn(8, cv(7, dc(1, h3))), tape)
+    h5 = _relu(bn(9, cv(8, dc(2, h4))), tape)
     logits = cv(9, dc(3, h5))
+    if aux is not None:
+        aux['logits_absmax'] = float(logits.detach().abs().max())
     return torch.tanh(logits).permute(0, 2, 3, 1), mean, log_sigma
 
 
-def discriminator(P, cfg, img_nhwc, embed):
-    """-> logit [B,1,1,1].  No batch norm: samples are independent."""
+def discriminator(P, cfg, img_nhwc, embed, tape=None):
+    """-> logit [B,1,1,1].  No batch norm: samples are independent.  tape: optional MaskTape."""
     x = img_nhwc.permute(0, 3, 1, 2)
 
     def cv(i, x, s, pad='SAME'):
         n = 'd_net/Conv%s' % ('' if i == 0 else '_%d' % i)
         return _conv(x, P[n + '/weights'], P[n + '/biases'], s, pad)
 
-    h0 = _lrelu(cv(0, x, 2)); h1 = _lrelu(cv(1, h0, 2)); h2 = _lrelu(cv(2, h1, 2)); h3 = cv(3, h2, 2)
-    r = _lrelu(cv(4, h3, 1, 'valid')); r = _lrelu(cv(5, r, 1)); r = cv(6, r, 1)
-    h4 = _lrelu(h3 + r)
-    e = _lrelu(embed @ P['d_net/dense/kernel'] + P['d_net/dense/bias'])
+    h0 = _lrelu(cv(0, x, 2), tape); h1 = _lrelu(cv(1, h0, 2), tape); h2 = _lrelu(cv(2, h1, 2), tape); h3 = cv(3, h2, 2)
+    r = _lrelu(cv(4, h3, 1, 'valid'), tape); r = _lrelu(cv(5, r, 1), tape); r = cv(6, r, 1)
+    h4 = _lrelu(h3 + r, tape)
+    e = _lrelu(embed @ P['d_net/dense/kernel'] + P['d_net/dense/bias'], tape)
     e = e[:, :, None, None].expand(-1, -1, 4, 4)
-    h5 = _lrelu(cv(7, torch.cat([h4, e], 1), 1, 'same'))
-    h6 = _lrelu(cv(8, h5, 1, 'valid'))
+    h5 = _lrelu(cv(7, torch.cat([h4, e], 1), 1, 'same'), tape)
+    h6 = _lrelu(cv(8, h5, 1, 'valid'), tape)
     return cv(9, h6, 4, 'valid')
 
 
@@ -222,23 +252,31 @@ def _gp(grad):
 # ----------------------------------------------------------------------------------------------
 # the two halves of one iteration
 # ----------------------------------------------------------------------------------------------
-def d_step(P, cfg, feed, kt):
+def _tapes(masks, keys):
+    """masks: None or {pass name: list of bool tensors} -> {pass name: MaskTape or None}"""
+    return {k: (MaskTape(masks[k]) if masks is not None else None) for k in keys}
+
+
+def d_step(P, cfg, feed, kt, masks=None):
     """Critic half (reference trainer.py:97; model.py:48-55,79-100).  All losses / gradients are taken at the
     pre-update values.  feed: x, x_mismatch [B,64,64,C] NHWC; cond [B,E]; z [B,Z]; eps [B,1,1,1]; ca_noise_d.
+    masks: optional activation branches to replay, {'G','Dg','Dx','Dxmi','Dxh': [bool tensors]} (MaskTape).
     -> dict(scalars..., grads={name: tensor for d vars}, kt_grad, kt_new)"""
     names = trainable(P, 'd_net')
     Q = dict(P)
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
+    tp = _tapes(masks, ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh'))
     with torch.no_grad():
-        G, _, _ = generator(P, cfg, feed['z'], feed['cond'], feed['ca_noise_d'], train=True)
+        aux = {}
+        G, _, _ = generator(P, cfg, feed['z'], feed['cond'], feed['ca_noise_d'], train=True, tape=tp['G'], aux=aux)
     x, xm, cond = feed['x'], feed['x_mismatch'], feed['cond']
-    Dg = discriminator(Q, cfg, G, cond)
-    Dx = discriminator(Q, cfg, x, cond)
-    Dxmi = discriminator(Q, cfg, xm, cond)
+    Dg = discriminator(Q, cfg, G, cond, tp['Dg'])
+    Dx = discriminator(Q, cfg, x, cond, tp['Dx'])
+    Dxmi = discriminator(Q, cfg, xm, cond, tp['Dxmi'])
     x_hat = (feed['eps'] * G + (1.0 - feed['eps']) * x).requires_grad_(True)
     cond_inp = (cond + 0.0).requires_grad_(True)
-    Dxh = discriminator(Q, cfg, x_hat, cond_inp)
+    Dxh = discriminator(Q, cfg, x_hat, cond_inp, tp['Dxh'])
     gx, gc = torch.autograd.grad(Dxh.sum(), [x_hat, cond_inp], create_graph=True)
     real_gp, real_gp2 = _gp(gx), _gp(gc)
     loss_real, loss_fake, loss_mis = Dx.mean(), Dg.mean(), Dxmi.mean()
@@ -254,25 +292,30 @@ def d_step(P, cfg, feed, kt):
                 real_gp2=f(real_gp2), reg_loss=f((Dxmi ** 2).mean()), balance_loss=balance,
                 kt_grad=kt_grad, kt_new=kt - cfg.kt_lr * kt_grad,
                 grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)),
-                G=G.detach(), Dx_hat=Dxh.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
+                G=G.detach(), G_logits_absmax=aux['logits_absmax'], Dx_hat=Dxh.detach(), grad_x_hat=gx.detach(),
+                grad_cond=gc.detach())
 
 
-def g_step(P, cfg, feed):
-    """Generator half (reference trainer.py:100-102; model.py:87,92,102-106).  -> dict(G_loss, kl, grads, bn_stats)."""
+def g_step(P, cfg, feed, masks=None):
+    """Generator half (reference trainer.py:100-102; model.py:87,92,102-106).  masks: {'G','Dg': [...]} (MaskTape).
+    -> dict(G_loss, kl, grads, bn_stats)."""
     names = trainable(P, 'g_net')
     Q = dict(P)
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
     stats = {}
-    G, mean, log_sigma = generator(Q, cfg, feed['z'], feed['cond'], feed['ca_noise_g'], train=True, stats_out=stats)
-    Dg = discriminator(Q, cfg, G, feed['cond'])
+    tp = _tapes(masks, ('G', 'Dg'))
+    aux = {}
+    G, mean, log_sigma = generator(Q, cfg, feed['z'], feed['cond'], feed['ca_noise_g'], train=True, stats_out=stats,
+                                   tape=tp['G'], aux=aux)
+    Dg = discriminator(Q, cfg, G, feed['cond'], tp['Dg'])
     kl = torch.mean(-log_sigma + 0.5 * (-1.0 + torch.exp(2.0 * log_sigma) + mean ** 2))
     G_loss = -Dg.mean() + cfg.kl_coeff * kl
     grads = torch.autograd.grad(G_loss, [Q[n] for n in names])
     f = lambda t: float(t.detach())
     return dict(G_loss=f(G_loss), G_kl_loss=f(kl), D_loss_fake=f(Dg.mean()),
                 grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), bn_stats=stats,
-                G=G.detach())
+                G=G.detach(), G_logits_absmax=aux['logits_absmax'])
 
 
 class AdamTF(object):

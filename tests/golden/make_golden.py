@@ -109,7 +109,7 @@ def make_step():
     kt = 0.7
     d = T.d_step(P, cfg, feed, kt)
     for k_, v in d.items():
-        if isinstance(v, float):
+        if isinstance(v, float) and k_ != 'G_logits_absmax':      # (a test yardstick added after the fixture was cut)
             out['d/' + k_] = np.array(v)
     for n, v in d['grads'].items():
         out['d/grad/' + n] = v.numpy()

@@ -177,3 +177,35 @@ def test_golden_step_is_nontrivial(golden_step):
     k = 'd_net/Conv_3/weights'
     delta = golden_step['after/' + k] - golden_step['param/' + k].astype(np.float64)
     assert np.all(np.abs(delta) <= 1.0001e-4)
+
+
+def test_mask_tape_replay_is_identity_and_pins_branches():
+    """MaskTape (used by the B=64 GPU parity test): replaying a run's own branches reproduces it exactly; replaying a
+    branch set with one unit forced onto the other slope changes that run's gradients (the tape really decides)."""
+    cfg = T.Cfg(z_dim=8, embed_dim=32, compressed=16, gf=8, df=8, batch=2)
+    P = {n: v.double() for n, v in T.init_variables(cfg, seed=3).items()}
+    feed = {k: v.double() for k, v in T.synthetic_feed(cfg, seed=4).items()}
+    own = {k: T.MaskTape() for k in ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh')}
+    with torch.no_grad():
+        G, _, _ = T.generator(P, cfg, feed['z'], feed['cond'], feed['ca_noise_d'], train=True, tape=own['G'])
+        T.discriminator(P, cfg, G, feed['cond'], own['Dg']); T.discriminator(P, cfg, feed['x'], feed['cond'], own['Dx'])
+        T.discriminator(P, cfg, feed['x_mismatch'], feed['cond'], own['Dxmi'])
+        T.discriminator(P, cfg, feed['eps'] * G + (1.0 - feed['eps']) * feed['x'], feed['cond'], own['Dxh'])
+    masks = {k: [m.clone() for m in t.record] for k, t in own.items()}
+    assert [len(masks[k]) for k in ('G', 'Dg', 'Dxh')] == [10, 9, 9]
+    free, pinned = T.d_step(P, cfg, feed, 0.7), T.d_step(P, cfg, feed, 0.7, masks=masks)
+    assert abs(free['D_loss'] - pinned['D_loss']) <= 1e-12 * abs(free['D_loss'])
+    for n in free['grads']:          # x * slope(mask) vs F.leaky_relu: the same function, evaluated in a slightly different order
+        assert torch.allclose(free['grads'][n], pinned['grads'][n], rtol=1e-10, atol=1e-12), n
+    masks['Dxh'][1][:] = ~masks['Dxh'][1]            # force a whole layer of the x_hat pass onto the other slope
+    forced = T.d_step(P, cfg, feed, 0.7, masks=masks)
+    assert forced['real_gp'] != free['real_gp']
+    gfree = T.g_step(P, cfg, feed)
+    own = {k: T.MaskTape() for k in ('G', 'Dg')}
+    with torch.no_grad():
+        G, _, _ = T.generator(P, cfg, feed['z'], feed['cond'], feed['ca_noise_g'], train=True, tape=own['G'])
+        T.discriminator(P, cfg, G, feed['cond'], own['Dg'])
+    gpin = T.g_step(P, cfg, feed, masks={k: t.record for k, t in own.items()})
+    assert abs(gfree['G_loss'] - gpin['G_loss']) <= 1e-12 * abs(gfree['G_loss'])
+    for n in gfree['grads']:
+        assert torch.allclose(gfree['grads'][n], gpin['grads'][n], rtol=1e-10, atol=1e-12), n

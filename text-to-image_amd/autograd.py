@@ -376,13 +376,17 @@ class BatchNormTrainFn(Function):
             if ctx.act != K.ACT_NONE:
                 gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
             sum_dy, sum_dy_x = K.col_reduce(gy, x, True)
-        gsink, bsink = _sink_of(ctx.gamma_ref), _sink_of(ctx.beta_ref)
+        # gamma / beta that do not require a gradient (a critic with batch norm run under store.frozen() in the generator
+        # step: detached views that share the real parameters' addresses) must neither reach the sinks nor be announced
+        want_g, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gsink = _sink_of(ctx.gamma_ref) if want_g else None
+        bsink = _sink_of(ctx.beta_ref) if want_b else None
         if gsink is not None and bsink is not None:
             dx, _, _ = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=gsink, dbeta_out=bsink)
             _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
             return dx, None, None, None, None, None, None, None, None
         dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None, None
 
 
 class GpSlopesFn(Function):

@@ -63,16 +63,28 @@ def _stream():
 WS_LANE = [0]
 _WS = {}
 _WS_MIN = 64 << 20
+_WS_CAPTURED = set()     # lanes whose CURRENT buffer has been handed to a kernel inside a graph capture
+_WS_RETIRED = []         # outgrown buffers that captured graphs still point at: kept alive for the life of the process
 
 
 def workspace(device, nbytes):
+    """The lane's scratch buffer, grown on demand.  A hipGraph captured while a buffer was current has that buffer's
+    address baked into its kernel arguments, so once a capture has used a buffer it is never freed: a later eager call
+    that needs more (the sampler at SAMPLE_NUM > BATCH_SIZE, a bigger batch) gets a NEW buffer and the old one is retired
+    but kept alive — replays keep writing into memory they still own."""
     key = (device.type, device.index, WS_LANE[0])
     buf = _WS.get(key)
+    capturing = torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
     if buf is None or buf.numel() < nbytes:
-        if torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError('workspace would grow during graph capture; run warm-up iterations first')
+        if buf is not None and key in _WS_CAPTURED:
+            _WS_RETIRED.append(buf)
+            _WS_CAPTURED.discard(key)
         buf = torch.empty(max(int(nbytes), _WS_MIN), dtype=torch.uint8, device=device)
         _WS[key] = buf
+    if capturing:
+        _WS_CAPTURED.add(key)
     return buf
 
 

@@ -56,13 +56,17 @@ class WGanClsTrainer(object):
 
     def make_saver(self):
         """tf.train.Saver(max_to_keep=CHECKPOINTS_TO_KEEP) (reference trainer.py:51): every variable under its TF name, the
-        two optimizers' Adam slots and step counts, and the kt balance scalar."""
+        two optimizers' Adam slots and step counts, the kt balance scalar and global_step (model.py:28)."""
         from ...utils.saver import Saver
         m = self.model
 
         def set_kt(v):
             m.kt.fill_(float(v))
-        return Saver(m.store, {'D_optim': m.D_optim, 'G_optim': m.G_optim}, {'kt': (lambda: m.kt.detach().cpu().numpy(), set_kt)},
+
+        def set_step(v):
+            m.global_step = int(v)
+        return Saver(m.store, {'D_optim': m.D_optim, 'G_optim': m.G_optim},
+                     {'kt': (lambda: m.kt.detach().cpu().numpy(), set_kt), 'global_step': (lambda: m.global_step, set_step)},
                      max_to_keep=int(getattr(self.cfg.TRAIN, 'CHECKPOINTS_TO_KEEP', 5)))
 
     def train(self, max_steps=None, start_point=None, log=None, side_effects=False, graphs=False):

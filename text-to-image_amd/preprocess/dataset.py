@@ -173,38 +173,50 @@ class Dataset(object):
         return {class_id: idx for idx, class_id in enumerate(np.unique(self._class_id))}
 
 
+def _unpickle(path, **kw):
+    with open(path, 'rb') as f:
+        return pickle.load(f, **kw)
+
+
 class TextDataset(object):
-    """reference preprocess/dataset.py:229-283: locates `<orig>images.pickle`, `char-CNN-RNN-embeddings.pickle`,
-    `filenames.pickle`, `class_info.pickle` under a split directory and builds a Dataset from them."""
+    """The on-disk side of the pipeline (role of reference preprocess/dataset.py:229-283): a dataset directory holds one
+    sub-directory per split (`train`, `test`), each with four pickles —
+
+        <orig>images.pickle              joblib dump, uint8 [N, orig, orig, 3]; orig = FINAL_SIZE_TO_ORIG[size] (76 for 64x64)
+        char-CNN-RNN-embeddings.pickle   [N, captions per image, D] float (Python-2 pickle: bytes encoding)
+        filenames.pickle                 N relative image names (caption files are found through them)
+        class_info.pickle                N class ids, 1-based on disk, 0-based in memory
+
+    `get_data(split_dir)` reads them and returns a `Dataset` whose image store and embeddings are resident on the device;
+    the caller assigns the result to `.train` / `.test` (reference models/wgancls/run.py:33-40)."""
+
+    EMBEDDINGS = 'char-CNN-RNN-embeddings.pickle'
+    FILENAMES = 'filenames.pickle'
+    CLASSES = 'class_info.pickle'
 
     def __init__(self, workdir, size, device=None):
-        self.size = size
         if size not in FINAL_SIZE_TO_ORIG:
             raise RuntimeError('Size {} not supported'.format(size))
-        self.image_filename = '/{}images.pickle'.format(FINAL_SIZE_TO_ORIG[size])
+        self.workdir, self.size, self.device = workdir, size, device
         self.image_shape = [size, size, 3]
-        self.image_dim = self.image_shape[0] * self.image_shape[1] * 3
-        self.embedding_shape = None
-        self._train = None
-        self._test = None
-        self.workdir = workdir
-        self.device = device
-        self._dataset_name = os.path.basename(os.path.normpath(workdir))
-        self.embedding_filename = '/char-CNN-RNN-embeddings.pickle'
+        self.image_dim = size * size * 3
+        self.image_filename = '/%dimages.pickle' % FINAL_SIZE_TO_ORIG[size]      # leading '/' like the reference attribute
+        self.embedding_filename = '/' + self.EMBEDDINGS
+        self.embedding_shape = None            # [D], known once a split has been read
+        self.train = None
+        self.test = None
 
-    train = property(lambda self: self._train, lambda self, v: setattr(self, '_train', v))
-    test = property(lambda self: self._test, lambda self, v: setattr(self, '_test', v))
-    name = property(lambda self: self._dataset_name)
+    @property
+    def name(self):
+        return os.path.basename(os.path.normpath(self.workdir))
 
     def get_data(self, pickle_path, aug_flag=True):
         import joblib
-        images = np.array(joblib.load(pickle_path + self.image_filename))
-        with open(pickle_path + self.embedding_filename, 'rb') as f:
-            embeddings = np.array(pickle.load(f, encoding='bytes'))
-            self.embedding_shape = [embeddings.shape[-1]]
-        with open(pickle_path + '/filenames.pickle', 'rb') as f:
-            list_filenames = pickle.load(f)
-        with open(pickle_path + '/class_info.pickle', 'rb') as f:
-            class_id = np.array(pickle.load(f, encoding='bytes')) - 1        # classes [1,102] -> [0,101]
-        return Dataset(images, self.image_shape[0], embeddings, list_filenames, self.workdir, class_id, aug_flag, class_id,
-                       device=self.device)
+        split = pickle_path.rstrip('/')
+        images = np.asarray(joblib.load(split + self.image_filename))
+        embeddings = np.asarray(_unpickle(os.path.join(split, self.EMBEDDINGS), encoding='bytes'))
+        self.embedding_shape = [int(embeddings.shape[-1])]
+        filenames = _unpickle(os.path.join(split, self.FILENAMES))
+        class_id = np.asarray(_unpickle(os.path.join(split, self.CLASSES), encoding='bytes')) - 1
+        return Dataset(images, self.size, embeddings=embeddings, filenames=filenames, workdir=self.workdir, labels=class_id,
+                       aug_flag=aug_flag, class_id=class_id, device=self.device)

@@ -3,8 +3,8 @@
 On-disk format: one `<prefix>-<step>.npz` per checkpoint holding every variable of the store under its TF name
 (`d_net/Conv_3/weights`, `g_net/BatchNorm_4/moving_mean`, ... — conv kernels HWIO, deconv [kh,kw,Cout,Cin], dense
 [in,out], i.e. exactly the key space and layouts of the reference's TF checkpoints, so arrays dumped from a real TF run
-load unchanged), plus optimizer slots under `<opt>/<name>/Adam` and `/Adam_1` and the scalars `kt`, `global_step` and
-`<opt>/t`; and a `checkpoint` text file naming the latest one (what tf.train.get_checkpoint_state reads).  `load`
+load unchanged), plus optimizer slots under `<opt>/<name>/Adam` and `/Adam_1`, the step counts `<opt>/t` and whatever
+scalars the trainer registers through `extra` (wgancls: `kt` and `global_step`); and a `checkpoint` text file naming the latest one (what tf.train.get_checkpoint_state reads).  `load`
 returns (found, counter) with the counter parsed from the file name like the reference does."""
 import os
 import re
@@ -64,20 +64,41 @@ class Saver(object):
         K.filter_cache_invalidate()
 
 
+_CKPT_RE = re.compile(r'^model-(\d+)\.npz$')
+
+
+def _existing(checkpoint_dir):
+    """Checkpoints already in the directory, oldest step first (what max_to_keep prunes against after a resume)."""
+    found = []
+    if os.path.isdir(checkpoint_dir):
+        for f in os.listdir(checkpoint_dir):
+            m = _CKPT_RE.match(f)
+            if m:
+                found.append((int(m.group(1)), os.path.join(checkpoint_dir, f)))
+    return [p for _, p in sorted(found)]
+
+
 def save(saver, sess, checkpoint_dir, step):
-    """reference utils/saver.py:6-10 (sess is unused: there is no TF session)."""
+    """reference utils/saver.py:6-10 (sess is unused: there is no TF session).  The archive is written to a temporary
+    name and renamed into place, so a crash mid-save never leaves a truncated newest checkpoint; the `checkpoint` state
+    file is updated only after the archive exists."""
     if not os.path.exists(checkpoint_dir):
         os.makedirs(checkpoint_dir)
     name = 'model-%d.npz' % step
     path = os.path.join(checkpoint_dir, name)
-    np.savez(path, **saver.state())
-    saver._kept.append(path)
+    tmp = path + '.tmp'
+    with open(tmp, 'wb') as f:
+        np.savez(f, **saver.state())
+    os.replace(tmp, path)
+    saver._kept = [p for p in _existing(checkpoint_dir) if p != path] + [path]
     while len(saver._kept) > saver.max_to_keep:
         old = saver._kept.pop(0)
         if os.path.exists(old):
             os.remove(old)
-    with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
+    state_tmp = os.path.join(checkpoint_dir, 'checkpoint.tmp')
+    with open(state_tmp, 'w') as f:
         f.write('model_checkpoint_path: "%s"\n' % name)
+    os.replace(state_tmp, os.path.join(checkpoint_dir, 'checkpoint'))
     return path
 
 
@@ -90,6 +111,7 @@ def load(saver, sess, checkpoint_dir):
         if m and os.path.exists(os.path.join(checkpoint_dir, m.group(1))):
             ckpt_name = os.path.basename(m.group(1))
             saver.restore(os.path.join(checkpoint_dir, ckpt_name))
+            saver._kept = _existing(checkpoint_dir)          # pruning continues across the resume
             counter = int(next(re.finditer(r'(\d+)(?!.*\d)', ckpt_name)).group(0))
             print(' [*] Success to read {}'.format(ckpt_name))
             return True, counter

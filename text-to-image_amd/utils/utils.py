@@ -3,28 +3,27 @@ trainers call around the sampler (`save_images(samples, get_balanced_factorizati
 Host-side NumPy like the reference; `merge`, `inverse_transform` and `get_balanced_factorization` are pinned against the
 reference's own outputs (tests/golden/reference_utils.npz).  PNG encoding uses Pillow (the reference's scipy.misc.imsave
 is gone from SciPy): bytescale to uint8 exactly as imsave did for float input (min -> 0, max -> 255)."""
+import math
 import os
 
 import numpy as np
 
 
 def merge(images, size):
-    """[n,h,w,c] -> one [size[0]*h, size[1]*w(,c)] float64 grid, row-major (utils.py:30-49)."""
+    """Tile n images [n,h,w,c] into one (rows, cols) = `size` grid, filled row by row; cells past n stay zero.
+    -> float64 [rows*h, cols*w, c] for c in (3, 4), [rows*h, cols*w] for c == 1 (role of reference utils/utils.py:30-49;
+    done as one reshape/transpose of a zero-padded stack instead of a per-image paste loop)."""
     images = np.asarray(images)
-    h, w = images.shape[1], images.shape[2]
-    if images.shape[3] in (3, 4):
-        img = np.zeros((h * size[0], w * size[1], images.shape[3]))
-        for idx, image in enumerate(images):
-            i, j = idx % size[1], idx // size[1]
-            img[j * h:j * h + h, i * w:i * w + w, :] = image
-        return img
-    if images.shape[3] == 1:
-        img = np.zeros((h * size[0], w * size[1]))
-        for idx, image in enumerate(images):
-            i, j = idx % size[1], idx // size[1]
-            img[j * h:j * h + h, i * w:i * w + w] = image[:, :, 0]
-        return img
-    raise ValueError('in merge(x,size) x parameter must have dimensions: HxW or HxWx3 or HxWx4')
+    n, h, w, c = images.shape
+    rows, cols = int(size[0]), int(size[1])
+    if c not in (1, 3, 4):
+        raise ValueError('merge: images must have 1, 3 or 4 channels, got an array of shape %s' % (images.shape,))
+    if n > rows * cols:
+        raise ValueError('merge: %d images do not fit a %d x %d grid' % (n, rows, cols))
+    cells = np.zeros((rows * cols, h, w, c))
+    cells[:n] = images
+    grid = cells.reshape(rows, cols, h, w, c).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, c)
+    return grid[:, :, 0] if c == 1 else grid
 
 
 def inverse_transform(images):
@@ -32,16 +31,13 @@ def inverse_transform(images):
 
 
 def get_balanced_factorization(x):
-    """x = a*b with a <= b as close as possible (utils.py:82-93)."""
-    if x <= 0:
-        raise ValueError('Argument must be a strictly positive number but it is %d' % x)
-    a = int(np.sqrt(x))
-    if a ** 2 == x:
-        return a, a
-    for a in range(a, 0, -1):
-        if x % a == 0:
-            return a, x // a
-    raise ValueError('Error finding the balanced factorization of %d' % x)
+    """(a, b) with a * b == x, a <= b and a as large as possible: the most square grid for x sample images (role of
+    reference utils/utils.py:82-93)."""
+    x = int(x)
+    if x < 1:
+        raise ValueError('get_balanced_factorization needs a positive integer, got %d' % x)
+    a = max(d for d in range(1, math.isqrt(x) + 1) if x % d == 0)
+    return a, x // a
 
 
 def _bytescale(img):
@@ -70,13 +66,9 @@ def save_images(images, size, image_path):
 
 
 def save_captions(directory, captions):
-    """utils.py:96-109"""
-    if not os.path.exists(directory):
-        os.makedirs(directory)
-    filepath = os.path.join(directory, 'captions.txt')
-    if os.path.exists(filepath):
-        os.remove(filepath)
-    with open(filepath, 'w+') as f:
-        f.write('Captions of the sampled x:\n')
-        for idx, caption in enumerate(captions):
-            f.write('{}: {}\n'.format(idx + 1, caption[0]))
+    """Write `<directory>/captions.txt`: a header line, then "<1-based index>: <first caption of the sample>" per sampled
+    image; an existing file is replaced (role of reference utils/utils.py:96-109)."""
+    os.makedirs(directory, exist_ok=True)
+    lines = ['Captions of the sampled x:'] + ['%d: %s' % (i, cap[0]) for i, cap in enumerate(captions, 1)]
+    with open(os.path.join(directory, 'captions.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
