@@ -8,12 +8,16 @@
  * Conventions (all entry points):
  *   - extern "C"; return 0 on success, a negative T2I_ERR_* otherwise; never throw.  t2i_last_error() gives the
  *     thread-local message of the last failure.
- *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees tensors.
- *     Scratch comes from the caller's workspace (size from the matching *_workspace_bytes query; 256-byte aligned).
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees device memory.
+ *     Scratch comes from the caller's workspace (size from the matching *_workspace_bytes query; 256-byte aligned); the
+ *     optional transformed-filter cache lives in an arena the caller attaches (t2i_filter_cache_attach).
  *   - tensors are dense NHWC fp32 ("[B,H,W,C]", C fastest); conv filters are TF "HWIO" [KH,KW,Cin,Cout];
  *     dense kernels are [in,out].  No tensor may exceed 2^30-16 elements (4 GiB: buffer addressing).
  *   - every call is asynchronous on the given hipStream_t (void* here so the header needs no HIP include) and is
- *     safe to capture into a hipGraph: no allocation, no synchronisation, no host-visible state.
+ *     safe to capture into a hipGraph: no allocation, no synchronisation.  Host-side state is limited to (a) the tuning
+ *     switches, read from the T2I_* environment once at first use and changed afterwards only through t2i_tuning_set, and
+ *     (b) the bookkeeping (not the storage) of the filter cache, mutex-guarded; the planner never consults the environment
+ *     at call time, so equal descriptors take equal paths for the life of the process.
  */
 #ifndef T2I_HIP_H
 #define T2I_HIP_H
@@ -53,10 +57,18 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 2 (v2: t2i_conv_desc.math) */
+int t2i_version(void);            /* ABI version, currently 3 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+                                   * t2i_tuning_set, t2i_kt_sgd) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
+
+/* Tuning / diagnostic switch `key` := value (tests, sweeps: tools/sweep_conv.py).  Keys and their T2I_* environment
+ * defaults: force_tile (T2I_FORCE_TILE: 22, 21, 12, 11 = 128x128 ... 64x64; 0 = planner), force_splitk, debug_plan, group_n,
+ * no_ut, no_thin, winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc,
+ * winograd_k4s2_bwdf, adam_blocks, max_chain (longest unsplit fp32 reduction chain, default 8192), split_cost.
+ * Not a hot-path call; changes apply to launches planned afterwards (workspace queries included). */
+int t2i_tuning_set(const char* key, double value);
 
 /* ---- convolution family: reference utils/ops.py:58-63 (conv2d) and :66-71 (conv2d_transpose) ------------------ */
 size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fwd / bwd_data / bwd_filter */
@@ -172,6 +184,13 @@ int t2i_ca_kl_bwd(const float* mean, const float* log_sigma, const float* eps, c
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
                 float beta2, float eps, float grad_scale, t2i_stream_t stream);
 
+/* kt <- kt - lr * 2 (kt*wd2 - wd) * wd2, the SGD step on balance_loss = (kt*wdist2 - wdist)^2 (reference
+ * models/wgancls/model.py:85,100: GradientDescentOptimizer(0.001) minimising balance_loss over kt).  wdist_sums = device
+ * [2] holding wdist and wdist2 SUMMED over the data-parallel ranks (each rank's value being its batch mean) and
+ * scale = 1/ranks, so that wd, wd2 are the global-batch means (the loss is quadratic in them: averaging per-rank
+ * gradients would not be its gradient).  Single rank: the two means and scale = 1. */
+int t2i_kt_sgd(float* kt, const float* wdist_sums, float scale, float lr, t2i_stream_t stream);
+
 /* ---- PGGAN operators: reference utils/ops.py:74-81 (layer_norm), :100-101 (pool), :109-111 (upscale) ------------ */
 /* y[b,h,w,:] = scale * sum of the 2x2 window of x [B,H,W,C] (H, W even) -> [B,H/2,W/2,C].  scale = 1/4 is
  * ops.pool(x, 2) (AVG, SAME, even extents); scale = 1 is the backward of t2i_upscale2. */
@@ -207,16 +226,21 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which);
 /* ---- transformed-filter cache (optional) -------------------------------------------------------------------------
  * The Winograd paths of the three conv entry points transform the filter (U = G g G^T) on every call.  A training step
  * uses each critic filter in up to six convs between two optimizer updates; with the cache on, the transform is kept in
- * a library-owned device buffer keyed by (filter pointer, transform kind, Cin, Cout) and reused until the filter changes.
+ * a slot of a CALLER-OWNED arena, keyed by (filter pointer, transform kind, Cin, Cout), and reused until the filter changes.
+ * t2i_filter_cache_attach(buf, bytes) hands the library that arena (device memory, 16-byte aligned, on the device the
+ * convs run on); slots are carved from it in order and never moved; when it is full, further filters are simply
+ * transformed per call.  attach(NULL, 0) detaches (all entries dropped); the caller frees the arena only after that and
+ * after every graph captured with the cache on has been destroyed.  The wgancls step at the reference's widths needs 0.65 GB.
  * CONTRACT when enabled: filter memory may be modified only by t2i_adam_tf (which drops the entries of the arena it
  * updates) or must be followed by t2i_filter_cache_invalidate(ptr, bytes) (ptr NULL = everything) — this includes
  * initialisation, checkpoint loads, broadcasts, and replaying a captured graph that contains t2i_adam_tf from a process
  * that also issues eager convs.  Launches captured into a hipGraph reuse only transforms filled in the same capture, so a
- * graph always contains every transform it depends on; buffers are allocated on eager calls only (run the step once
- * before capturing).  Results are bit-identical with and without the cache.  Off by default; returns the previous state. */
+ * graph always contains every transform it depends on.  Results are bit-identical with and without the cache.  Off by
+ * default; t2i_filter_cache_enable returns the previous state. */
+int t2i_filter_cache_attach(void* buf, size_t bytes);
 int t2i_filter_cache_enable(int on);
 void t2i_filter_cache_invalidate(const void* ptr, size_t bytes);
-size_t t2i_filter_cache_bytes(void);            /* device memory currently held by the cache */
+size_t t2i_filter_cache_bytes(void);            /* bytes of the attached arena handed out so far */
 
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):

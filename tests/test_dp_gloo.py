@@ -54,6 +54,24 @@ def _worker(rank, world, port, mode, q):
             use = names if mode != 'unused' else names[:-2]      # leave two parameters out of the graph
             return sum((params[n] * data[n]).sum() * (i + 1) for i, n in enumerate(use))
 
+        if mode == 'kt':
+            # the kt step under data parallelism (model.py _d_update): ranks exchange their batch means (wdist, wdist2) as
+            # `extra`, and the gradient of balance_loss = (kt*wd2 - wd)^2 is evaluated on the GLOBAL means — which differs
+            # from the average of the per-rank gradients whenever the ranks see different data
+            per_rank = [(0.25, 0.03), (0.10, -0.02)]
+            wd = torch.tensor(per_rank[rank], dtype=torch.float32)
+            arena.zero_grad()
+            scale = dp.allreduce_arena(arena, extra=wd)
+            kt = 0.7
+            g_wd, g_wd2 = float(wd[0]) * scale, float(wd[1]) * scale
+            assert abs(g_wd - 0.175) < 1e-7 and abs(g_wd2 - 0.005) < 1e-7
+            grad_global = 2.0 * (kt * g_wd2 - g_wd) * g_wd2
+            grad_avg = sum(2.0 * (kt * b - a) * b for a, b in per_rank) / world
+            assert abs(grad_global - (-0.001715)) < 1e-6 and abs(grad_global - grad_avg) > 1e-3
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, 'ok'))
+            return
         if mode == 'sinks_autograd':
             _sinks_autograd_mode(dp, arena, params, data, rank, world)
             dist.barrier()
@@ -201,7 +219,7 @@ def _sinks_mode(dp, arena, params, data, rank, world):
     A.SINKS.clear()
 
 
-@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd'])
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd', 'kt'])
 def test_dp_allreduce_two_ranks(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -268,18 +268,24 @@ def _bf16_round(a):
 @pytest.mark.parametrize('tile', [22, 21, 12, 11])
 @pytest.mark.parametrize('splitk', [1, 3])
 @pytest.mark.parametrize('math', ['f32', 'bf16'])
-def test_every_tile_and_split_config(K, monkeypatch, tile, splitk, math):
+def test_every_tile_and_split_config(K, tile, splitk, math):
     """The planner picks tile shape / split-K per launch; here every combination is forced (tuning hooks
-    T2I_FORCE_TILE / T2I_FORCE_SPLITK, direct thin kernels off) on shapes with ragged M, N and K.
+    t2i_tuning_set force_tile / force_splitk, direct thin kernels off) on shapes with ragged M, N and K.
     math='bf16' (t2i_conv_desc.math = T2I_MATH_BF16, BASELINE config 3): the kernel rounds both operands to bf16 and
     accumulates their exact products in fp32, so against the float64 oracle evaluated ON THE ROUNDED OPERANDS it must
     meet the same tolerance as the fp32 path; the raw fp32 inputs are what is handed to the kernel."""
     from oracle import np_ops as O
     rnd = _bf16_round if math == 'bf16' else (lambda a: a)
     mcode = K.MATH_BF16 if math == 'bf16' else K.MATH_F32
-    monkeypatch.setenv('T2I_FORCE_TILE', str(tile))
-    monkeypatch.setenv('T2I_FORCE_SPLITK', str(splitk))
-    monkeypatch.setenv('T2I_NO_THIN', '1')
+    K.tuning_set('force_tile', tile); K.tuning_set('force_splitk', splitk); K.tuning_set('no_thin', 1)
+    try:
+        _every_tile_body(K, tile, splitk, math, rnd, mcode)
+    finally:
+        K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0); K.tuning_set('no_thin', 0)
+
+
+def _every_tile_body(K, tile, splitk, math, rnd, mcode):
+    from oracle import np_ops as O
     # the last three shapes have 32-multiple channels and Wo | 32: they take the tap-uniform (fwd / bwd_data) and
     # pixel-walk (bwd_filter) address paths; every other combination goes through the generic decode
     for case in [(3, 16, 16, 40, 72, 4, 4, 2, 'SAME'), (2, 32, 32, 3, 128, 4, 4, 2, 'SAME'), (5, 4, 4, 136, 200, 3, 3, 1, 'SAME'),
@@ -314,7 +320,7 @@ def test_conv_epilogue_batch_norm_statistics(K):
                        (11, (5, 4, 4, 64, 40, 3, 3, 1, 'SAME')), (0, (64, 8, 8, 128, 128, 3, 3, 1, 'SAME'))):
         B, H, W, Ci, Co, KH, KW, s, pad = case
         if tile:
-            os.environ['T2I_FORCE_TILE'] = str(tile); os.environ['T2I_FORCE_SPLITK'] = '1'
+            K.tuning_set('force_tile', tile); K.tuning_set('force_splitk', 1)
         try:
             x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
             w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
@@ -332,14 +338,14 @@ def test_conv_epilogue_batch_norm_statistics(K):
                 assert tile == 0                                        # only the planner's own choice may decline (split-K)
             assert relerr(y, K.conv_fwd(dev(x), dev(w), dev(b), d, 256 << 20).double().cpu().numpy()) == 0.0
         finally:
-            os.environ.pop('T2I_FORCE_TILE', None); os.environ.pop('T2I_FORCE_SPLITK', None)
-    os.environ['T2I_FORCE_SPLITK'] = '3'
+            K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0)
+    K.tuning_set('force_splitk', 3)
     try:
         d, ws = K.conv_desc(2, 4, 4, 512, 256, 3, 3, 1, 1, 'SAME')
         y = K.conv_fwd_stats(dev(rng.standard_normal((2, 4, 4, 512)).astype(np.float32)), dev(rng.standard_normal((3, 3, 512, 256)).astype(np.float32)), None, d, 256 << 20)
         assert K.take_stats(y) is None
     finally:
-        os.environ.pop('T2I_FORCE_SPLITK', None)
+        K.tuning_set('force_splitk', 0)
 
 
 @pytest.mark.parametrize('case', [(48, 4, 4, 512, 1024, 'critic 4x4 map'), (12, 8, 8, 512, 512, 'generator 8x8'), (13, 16, 16, 256, 256, '16x16'),
@@ -462,3 +468,19 @@ def test_col_reduce_narrow_tensors(K, C):
     acc = dev(np.ones(C, np.float32))
     K.col_reduce(dev(a), out=acc)
     assert relerr(acc, 1.0 + a64.sum(0)) <= 1e-5
+
+
+def test_kt_sgd_matches_formula_and_is_rank_count_invariant(K):
+    """t2i_kt_sgd: kt -= lr * 2 (kt*wd2 - wd) wd2 on the (rank-summed) batch means (reference models/wgancls/model.py:85,100).
+    Against float64: 1e-6 relative.  N identical ranks (sums = N * means, scale = 1/N, N a power of two) give the single-rank
+    bits: the exactness harness of the data-parallel exchange (tests/test_dp_exactness_gpu.py) relies on it."""
+    wd, wd2, kt0, lr = 0.2522463, 0.03209869, 0.7, 1e-3
+    outs = []
+    for n in (1, 2, 4, 8):
+        kt = torch.tensor(kt0, dtype=torch.float32, device='cuda')
+        sums = torch.tensor([wd, wd2], dtype=torch.float32, device='cuda') * n
+        K.kt_sgd(kt, sums, 1.0 / n, lr)
+        outs.append(float(kt))
+    want = kt0 - lr * 2.0 * (kt0 * wd2 - wd) * wd2
+    assert abs(outs[0] - want) <= 1e-6 * abs(want)
+    assert all(o == outs[0] for o in outs), outs

@@ -49,7 +49,10 @@ SIGNATURES = {
     't2i_ca_kl_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     't2i_lerp_dev': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
     't2i_conv2d_algo': (ctypes.c_int, [_p, _i32]),
+    't2i_filter_cache_attach': (ctypes.c_int, [_p, _sz]),
     't2i_filter_cache_enable': (ctypes.c_int, [ctypes.c_int]),
+    't2i_tuning_set': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_double]),
+    't2i_kt_sgd': (ctypes.c_int, [_p, _p, _f, _f, _p]),
     't2i_filter_cache_invalidate': (None, [_p, ctypes.c_size_t]),
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),

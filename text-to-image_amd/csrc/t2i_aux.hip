@@ -688,11 +688,29 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
 
 hipError_t adam_tf_launch(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_dev,
                           float b1, float b2, float eps, float gscale, hipStream_t stream) {
-  static const int adam_cap = getenv("T2I_ADAM_BLOCKS") ? atoi(getenv("T2I_ADAM_BLOCKS")) : 2048;
+  const int adam_cap = tuning().adam_blocks;
   size_t nb = ((((size_t)n + 3) >> 2) + 255) / 256;
   if (nb > (size_t)adam_cap) nb = adam_cap;
   hipLaunchKernelGGL(adam_tf_kernel, dim3((int)nb), dim3(256), 0, stream, w, g, m, v, (size_t)n,
                      lr_t, lr_dev, b1, b2, eps, gscale);
+  return hipGetLastError();
+}
+
+// kt <- kt - lr * d(balance_loss)/d(kt) with balance_loss = (kt*wdist2 - wdist)^2 (reference models/wgancls/model.py:85,100:
+// GradientDescentOptimizer(0.001) on kt).  wdist / wdist2 arrive as SUMS over the data-parallel ranks of the per-rank batch
+// means (scale = 1/ranks turns them into the global-batch means: the balance loss is quadratic in them, so averaging
+// per-rank gradients would not be the gradient of the global loss).  One thread; no fma contraction, so that one rank
+// (sum == value, scale == 1) and N identical ranks agree bit for bit.
+__global__ void kt_sgd_kernel(float* __restrict__ kt, const float* __restrict__ sums, float scale, float lr) {
+#pragma clang fp contract(off)
+  const float wd = sums[0] * scale, wd2 = sums[1] * scale;
+  const float k = *kt;
+  const float grad = 2.f * (k * wd2 - wd) * wd2;
+  *kt = k - lr * grad;
+}
+
+hipError_t kt_sgd_launch(float* kt, const float* sums, float scale, float lr, hipStream_t stream) {
+  hipLaunchKernelGGL(kt_sgd_kernel, dim3(1), dim3(1), 0, stream, kt, sums, scale, lr);
   return hipGetLastError();
 }
 

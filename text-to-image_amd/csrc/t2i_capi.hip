@@ -49,6 +49,7 @@ hipError_t lerp_dev_launch(const float*, const float*, const float*, int, size_t
 hipError_t col_reduce_partials_launch(const float*, const float*, int, int, float*, float*, int, hipStream_t);
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
+hipError_t kt_sgd_launch(float*, const float*, float, float, hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
                                  void*, hipStream_t);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
@@ -103,6 +104,33 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+static Tuning& tuning_mut() {
+  static Tuning t = [] {
+    Tuning v;
+    v.force_tile = env_int("T2I_FORCE_TILE", 0);            // e.g. 22, 12, 21, 11 (tuning hooks)
+    v.force_splitk = env_int("T2I_FORCE_SPLITK", 0);
+    v.debug_plan = env_int("T2I_DEBUG_PLAN", 0);
+    v.group_n = env_int("T2I_GROUP_N", 8);
+    v.no_ut = env_int("T2I_NO_UT", 0);
+    v.no_thin = env_int("T2I_NO_THIN", 0);
+    v.winograd = env_int("T2I_WINOGRAD", 1);
+    v.winograd_minc = env_int("T2I_WINOGRAD_MINC", 256);
+    v.winograd_maxhw = env_int("T2I_WINOGRAD_MAXHW", 256);
+    v.winograd_k4s2 = env_int("T2I_WINOGRAD_K4S2", 1);
+    v.winograd_k4s2_minc = env_int("T2I_WINOGRAD_K4S2_MINC", 128);
+    v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 256);
+    v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
+    v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
+    v.max_chain = env_int("T2I_MAX_CHAIN", 8192);           // longest unsplit reduction on the 128x128 tile (see make_plan)
+    const char* sc = getenv("T2I_SPLIT_COST");
+    v.split_cost = (sc && *sc) ? atof(sc) : 4.0;            // us per extra launch
+    return v;
+  }();
+  return t;
+}
+
+const Tuning& tuning() { return tuning_mut(); }
+
 // Tile / split-K choice by a makespan model.  Measured on MI355X: a balanced launch of this kernel sustains ~72% of
 // the fp32 matrix peak, but launches whose workgroup count is not a multiple of the 256 CUs lose up to 45% to the
 // last partial round (each CU works through its workgroups at a fixed MFMA rate; co-resident workgroups time-share).
@@ -132,8 +160,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
   if (maxsplit > split_cap) maxsplit = split_cap;
-  const int ft = env_int("T2I_FORCE_TILE", 0);   // e.g. 22, 12, 21, 11 (tuning hooks)
-  const int fs = env_int("T2I_FORCE_SPLITK", 0);
+  const int ft = tuning().force_tile;
+  const int fs = tuning().force_splitk;
   Plan best;
   double best_t = 1e300;
   for (int c = 0; c < 4; ++c) {
@@ -154,12 +182,17 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       const int64_t per = (ktiles + sk - 1) / sk;
       const int64_t sk_eff = (ktiles + per - 1) / per;
       if (sk_eff != sk) continue;                       // same plan as a smaller sk
+      // fp32 accuracy: the MFMA accumulates an output element's K products as ONE sequential fmaf chain, whose rounding
+      // error grows ~sqrt(K).  Chains are kept <= max_chain products by splitting K: the slabs are then joined by
+      // splitk_reduce in a fixed order (a K-chunked partial sum; a second accumulator set inside the kernel would cost the
+      // 128x128 tile its second resident workgroup: 228 of 256 registers are taken).
+      if (!math && !batched && per * 32 > tuning().max_chain && sk < maxsplit && !fs) continue;
       const int64_t blocks = tiles * sk_eff;
       const int64_t rounds = (blocks + 255) / 256;
       const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
       double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * share_eff[resident]);
-      static const double split_cost = getenv("T2I_SPLIT_COST") ? atof(getenv("T2I_SPLIT_COST")) : 4.0;   // us per extra launch
+      const double split_cost = tuning().split_cost;
       if (sk_eff > 1) t += (math ? 2.0 : split_cost) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
       if (t < best_t) {
         best_t = t;
@@ -170,7 +203,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       }
     }
   }
-  if (env_int("T2I_DEBUG_PLAN", 0))
+  if (tuning().debug_plan)
     fprintf(stderr, "[t2i plan] M=%lld N=%lld K=%lld phases=%d -> tile %dx%d splitk=%d (k/split=%d) model %.1f us\n",
             (long long)M, (long long)N, (long long)K, nphase, 64 * best.wmt, 64 * best.wnt, best.splitk, best.k_per_split, best_t);
   return best;
@@ -225,7 +258,7 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
     else *stats_chunks = pl.tiles_m;
   }
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
-  { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+  { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
   p.out_elems = out_elems;
   if (pl.splitk > 1) {
@@ -238,7 +271,7 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
   } else {
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = accumulate;
   }
-  if (env_int("T2I_NO_UT", 0) && var == 2) var = 1;
+  if (tuning().no_ut && var == 2) var = 1;
   int rc = check(igemm_launch(mode, p, pl.wmt, pl.wnt, var, stream), what);
   if (rc != T2I_OK) return rc;
   if (pl.splitk > 1)
@@ -266,7 +299,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
     p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
     Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
-    { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+    { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
     p.splitk = 1; p.k_per_split = pl.k_per_split;
     p.out_elems = (size_t)p.M * p.N;
     p.c = c; p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
@@ -288,7 +321,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
   p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
   Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
-  { const int g = env_int("T2I_GROUP_N", 8); p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+  { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
   p.splitk = 1; p.k_per_split = pl.k_per_split;
   p.out_elems = (size_t)p.M * p.N;
   p.c = c; p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
@@ -303,7 +336,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 2; }
+int t2i_version(void) { return 3; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -369,7 +402,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
   if (stats_chunks) *stats_chunks = 0;
-  if (!env_int("T2I_NO_THIN", 0)) {
+  if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
     if (tiny_conv_eligible(*d, false))
@@ -398,7 +431,7 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
-  if (!env_int("T2I_NO_THIN", 0)) {
+  if (!tuning().no_thin) {
     if (head_conv_eligible(*d) && !bias && act == T2I_ACT_NONE)
       return check(head_bwd_data_launch(*d, dy, w, dx, (hipStream_t)stream), "t2i_conv2d_bwd_data(head)");
     if (tiny_conv_eligible(*d, true))
@@ -429,7 +462,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
-  if (!env_int("T2I_NO_THIN", 0)) {
+  if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
     if (tiny_bwdw_eligible(*d)) {
@@ -440,7 +473,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
-  if (winograd_k4s2_eligible(*d, false) && env_int("T2I_WINOGRAD_K4S2_BWDF", 1) && aligned16(x) && aligned16(dy) && aligned16(dw))
+  if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
@@ -662,9 +695,30 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
   return check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
 }
 
+int t2i_tuning_set(const char* key, double value) {
+  if (!key) { set_error("t2i_tuning_set: null key"); return T2I_ERR_INVALID; }
+  Tuning& t = tuning_mut();
+  struct { const char* name; int* field; } ints[] = {
+      {"force_tile", &t.force_tile}, {"force_splitk", &t.force_splitk}, {"debug_plan", &t.debug_plan}, {"group_n", &t.group_n},
+      {"no_ut", &t.no_ut}, {"no_thin", &t.no_thin}, {"winograd", &t.winograd}, {"winograd_minc", &t.winograd_minc},
+      {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
+      {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
+      {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}};
+  for (auto& e : ints)
+    if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
+  if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }
+  set_error("t2i_tuning_set: unknown key '%s'", key);
+  return T2I_ERR_INVALID;
+}
+
+int t2i_kt_sgd(float* kt, const float* wdist_sums, float scale, float lr, t2i_stream_t stream) {
+  if (!kt || !wdist_sums) { set_error("t2i_kt_sgd: bad argument"); return T2I_ERR_INVALID; }
+  return check(kt_sgd_launch(kt, wdist_sums, scale, lr, (hipStream_t)stream), "t2i_kt_sgd");
+}
+
 int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
   if (validate_desc(d) || which < 0 || which > 2) return -1;
-  const bool thin = !env_int("T2I_NO_THIN", 0);
+  const bool thin = !tuning().no_thin;
   if (which == 0) {
     if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, false))) return T2I_ALGO_DIRECT_SMALL;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
@@ -676,9 +730,14 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
   } else {
     if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
-    if (winograd_k4s2_eligible(*d, false) && env_int("T2I_WINOGRAD_K4S2_BWDF", 1)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
+    if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf) return T2I_ALGO_WINOGRAD_F2X2_2X2;
   }
   return T2I_ALGO_IMPLICIT_GEMM;
+}
+
+int t2i_filter_cache_attach(void* buf, size_t bytes) {
+  if ((buf == nullptr) != (bytes == 0) || !aligned16(buf)) { set_error("t2i_filter_cache_attach: need a 16-byte aligned buffer and its size, or (NULL, 0)"); return T2I_ERR_INVALID; }
+  return filter_cache_attach(buf, bytes);
 }
 
 int t2i_filter_cache_enable(int on) { return filter_cache_enable(on); }

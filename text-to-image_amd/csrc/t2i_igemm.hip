@@ -142,6 +142,23 @@ __device__ __forceinline__ void bT_offset(const IgemmParams& p, const PhaseInfo&
   off = ((kh * p.d.KW + kw) * p.d.Cin + n) * p.d.Cout + co;
 }
 
+// phase[idx] of the kernel's (only) argument, fetched from the kernel-argument segment in the constant address space
+__device__ __forceinline__ PhaseInfo load_phase(int idx) {
+  PhaseInfo r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char* KernArg;
+  typedef const __attribute__((address_space(4))) int32_t* Words;
+  const Words src = (Words)((KernArg)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(IgemmParams, phase) + (size_t)idx * sizeof(PhaseInfo));
+  int32_t* dst = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(PhaseInfo) / 4); ++i) dst[i] = src[i];
+#else
+  (void)idx;
+  r = PhaseInfo();
+#endif
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // VAR: 0 = scalar gathers (channels not a multiple of 4); 1 = 16-byte gathers, per-element tap decode;
 //      2 = 16-byte gathers with a TAP-UNIFORM K-tile (gathered channels % 32 == 0): one K-tile never straddles a filter
@@ -192,7 +209,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int bm = tile_m * BM;
   const int bn = tile_n * BN;
   const int split = blockIdx.y;
-  const PhaseInfo& pi = p.phase[(MODE == MODE_BWD_DATA && p.nbatch <= 1) ? blockIdx.z : 0];     // batched launches: one phase
+  // The stride phase of this workgroup, read from the kernel-argument segment through an explicit constant-address-space
+  // pointer (scalar loads with a uniform dynamic offset).  Indexing the by-value argument itself, `p.phase[blockIdx.z]`,
+  // made hipcc copy the whole struct to scratch in the scalar-gather variant (private_segment 1680 B in igemm<1,2,2,0,0>).
+  const PhaseInfo pi = load_phase((MODE == MODE_BWD_DATA && p.nbatch <= 1) ? blockIdx.z : 0);     // batched launches: one phase
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
   const int kbeg = split * p.k_per_split;
   const int kend = min(Kdim, kbeg + p.k_per_split);
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   float4 areg[A_LD], breg[B_LD];
 
-  auto load_tile = [&](int t) {   // tiles past the end read as zeros (k >= kend), so the loop needs no tail branch
+  auto load_tile = [&](int t) __attribute__((always_inline)) {   // tiles past the end read as zeros (k >= kend), so the loop needs no tail branch
     const int k0 = kbeg + t * BK;
     // ---------------- A ----------------
     if (A_KINNER && UT) {
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     float* as = As + buf * S::A_ELEMS;
     float* bs = Bs + buf * S::B_ELEMS;
     if (BF) {
@@ -474,13 +494,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   if constexpr (BF) {
     // ---- bf16 main loop: 2 MFMA k-steps of 16 per K-tile; the loop is bound by the fp32 operand fetch, not by the MFMAs
     // (8 per wave-tile, 32 cycles each), so the schedule is the plain one: fragments of tile t -> registers, tile t+1
     // registers -> the other LDS buffer, loads of tile t+2, MFMAs, one barrier.
     struct FragH { bf16x8 a[WMT][2]; bf16x8 b[WNT][2]; };
-    auto read_h = [&](FragH& f, const float* as, const float* bs) {
+    auto read_h = [&](FragH& f, const float* as, const float* bs) __attribute__((always_inline)) {
       const unsigned* au = reinterpret_cast<const unsigned*>(as);
       const unsigned* bu = reinterpret_cast<const unsigned*>(bs);
 #pragma unroll
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // fragments of one 8-k chunk: 4 MFMA steps x (WMT + WNT) operands
   struct Frag { float a[WMT][4]; float b[WNT][4]; };
 
-  auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) {
+  auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
       const int row = wm * 32 * WMT + i * 32 + l31;
@@ -542,7 +561,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto mma_frag = [&](const Frag& f) {
+  auto mma_frag = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // sched_barrier(0) pins this order; left alone hipcc sinks every ds_read next to its MFMAs (fewer live registers)
   // and the LDS latency lands between MFMA groups — ~20% of the matrix pipe idle.
   Frag fa0, fa1, fb0, fb1;
-  auto k_tile = [&](int t, Frag& c0, Frag& c1, Frag& n0, Frag& n1) {
+  auto k_tile = [&](int t, Frag& c0, Frag& c1, Frag& n0, Frag& n1) __attribute__((always_inline)) {
     const float* as = As + (t & 1) * S::A_ELEMS;
     const float* bs = Bs + (t & 1) * S::B_ELEMS;
     const float* an = As + ((t + 1) & 1) * S::A_ELEMS;

@@ -88,6 +88,7 @@ size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d);
 int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
                               hipStream_t stream);
 int filter_cache_enable(int on);
+int filter_cache_attach(void* buf, size_t bytes);
 void filter_cache_invalidate(const void* p, size_t bytes);
 size_t filter_cache_bytes();
 size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d);
@@ -107,6 +108,16 @@ hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems
                                 float alpha, float* out, int accumulate, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// Tuning / diagnostic switches, read from the T2I_* environment ONCE (first use) so that the planner never depends on the
+// environment at call time: two calls with the same descriptor always take the same path within a process.
+struct Tuning {
+  int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
+  int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
+  int adam_blocks, max_chain;
+  double split_cost;
+};
+const Tuning& tuning();
 
 }  // namespace t2i
 #endif

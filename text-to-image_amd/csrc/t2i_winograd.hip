@@ -21,19 +21,30 @@
 namespace t2i {
 
 // ------------------------------------------------------------------------------------------------------------------
-// Transformed-filter cache (opt-in, t2i_filter_cache_enable): U = G g G^T of a filter is the same for every conv that uses
-// it until the filter changes — the critic's filters are used by up to six convs per step.  Entries are keyed by (filter
-// pointer, transform kind, dims) and own their device buffer.  An entry is reusable only from the launch context that
+// Transformed-filter cache (opt-in, t2i_filter_cache_attach + t2i_filter_cache_enable): U = G g G^T of a filter is the same
+// for every conv that uses it until the filter changes — the critic's filters are used by up to six convs per step.  Entries
+// are keyed by (filter pointer, transform kind, dims); their storage is carved out of a CALLER-OWNED arena.  An entry is reusable only from the launch context that
 // filled it: eager launches reuse eager fills, launches captured into a graph reuse fills of the SAME capture (so every
 // graph contains all the transforms it depends on).  t2i_adam_tf drops the entries inside the arena it updates; any other
 // writer of filter memory must call t2i_filter_cache_invalidate (see include/t2i_hip.h).
 // ------------------------------------------------------------------------------------------------------------------
 struct FilterEntry {
-  const float* w; int kind, Cin, Cout, dev; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
+  const float* w; int kind, Cin, Cout; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
 };
 static std::mutex g_fc_mu;
 static std::vector<FilterEntry> g_fc;
 static int g_fc_on = 0;
+static char* g_fc_buf = nullptr;      // caller-owned arena (t2i_filter_cache_attach); entries are carved from it in order
+static size_t g_fc_cap = 0, g_fc_used = 0;
+
+int filter_cache_attach(void* buf, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  g_fc.clear();                       // entries of the previous arena point into memory the caller may now free
+  g_fc_buf = reinterpret_cast<char*>(buf);
+  g_fc_cap = bytes;
+  g_fc_used = 0;
+  return T2I_OK;
+}
 
 int filter_cache_enable(int on) {
   std::lock_guard<std::mutex> lk(g_fc_mu);
@@ -54,14 +65,12 @@ void filter_cache_invalidate(const void* p, size_t bytes) {
 
 size_t filter_cache_bytes() {
   std::lock_guard<std::mutex> lk(g_fc_mu);
-  size_t n = 0;
-  for (auto& e : g_fc) n += e.bytes;
-  return n;
+  return g_fc_used;
 }
 
-// Returns the cache buffer for this filter's transform (and whether it has to be filled), or nullptr when the caller
-// should transform into its workspace as without the cache (cache off, first sight of a filter during capture, a second
-// stream, allocation failure).
+// Returns the cache slot for this filter's transform (and whether it has to be filled), or nullptr when the caller
+// should transform into its workspace as without the cache (cache off, no arena attached or arena full, a second stream).
+// The library allocates nothing: slots are carved out of the caller's arena, never moved, and live until the next attach.
 static float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill) {
   *fill = true;
   if (!g_fc_on) return nullptr;
@@ -69,17 +78,17 @@ static float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size
   unsigned long long id = 0;
   if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   const unsigned long long cap = st == hipStreamCaptureStatusActive ? id + 1 : 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(g_fc_mu);
+  if (!g_fc_buf) return nullptr;
   FilterEntry* e = nullptr;
   for (auto& x : g_fc)
-    if (x.w == w && x.kind == kind && x.Cin == Cin && x.Cout == Cout && x.dev == dev) { e = &x; break; }
+    if (x.w == w && x.kind == kind && x.Cin == Cin && x.Cout == Cout) { e = &x; break; }
   if (!e) {
-    if (cap) return nullptr;                      // no allocation while a capture is open
-    float* U = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&U), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, dev, U, bytes, 0ull, stream, false});
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (g_fc_used + need > g_fc_cap) return nullptr;          // arena full: this filter is transformed per call
+    float* U = reinterpret_cast<float*>(g_fc_buf + g_fc_used);
+    g_fc_used += need;
+    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, U, bytes, 0ull, stream, false});
     e = &g_fc.back();
   }
   if (e->bytes < bytes) return nullptr;
@@ -216,19 +225,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
-static int wino_min_channels() {
-  static const int v = getenv("T2I_WINOGRAD_MINC") ? atoi(getenv("T2I_WINOGRAD_MINC")) : 256;
-  return v;
-}
+static int wino_min_channels() { return tuning().winograd_minc; }
 
 bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
-  static const int on = getenv("T2I_WINOGRAD") ? atoi(getenv("T2I_WINOGRAD")) : 1;
-  if (!on || d.math != T2I_MATH_F32) return false;     // bf16 math: the direct kernel is operand-stream bound, 16 GEMMs would stream 4x more
+  if (!tuning().winograd || d.math != T2I_MATH_F32) return false;     // bf16 math: the direct kernel is operand-stream bound, 16 GEMMs would stream 4x more
   if (!(d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.pad_t == 1 && d.pad_l == 1 && d.Ho == d.H && d.Wo == d.W)) return false;
   if ((d.H & 1) || (d.W & 1) || (d.Cin % 32) || (d.Cout % 32)) return false;
   // pays when the GEMM work dominates the three transform passes: many channels on small maps
   const int cmin = d.Cin < d.Cout ? d.Cin : d.Cout;
-  static const int maxhw = getenv("T2I_WINOGRAD_MAXHW") ? atoi(getenv("T2I_WINOGRAD_MAXHW")) : 256;
+  const int maxhw = tuning().winograd_maxhw;
   if (cmin < wino_min_channels() || (int64_t)d.H * d.W > maxhw) return false;
   // ... and the 16 GEMMs are big enough to fill the chip after the fixed cost of the filter transform (measured: the
   // 4x4x256->512 critic layer at B=64, T*K*N = 3.4e7, loses 12%; 4x4x256->1024, 6.7e7, gains 10%)
@@ -485,15 +490,14 @@ __global__ __launch_bounds__(256) void wino2_output_kernel(const float* __restri
 }
 
 bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data) {
-  static const int on = getenv("T2I_WINOGRAD_K4S2") ? atoi(getenv("T2I_WINOGRAD_K4S2")) : 1;
-  static const int minc = getenv("T2I_WINOGRAD_K4S2_MINC") ? atoi(getenv("T2I_WINOGRAD_K4S2_MINC")) : 128;
-  if (!on || d.math != T2I_MATH_F32) return false;
+  const int minc = tuning().winograd_k4s2_minc;
+  if (!tuning().winograd_k4s2 || d.math != T2I_MATH_F32) return false;
   if (!(d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1)) return false;
   if ((d.H & 3) || (d.W & 3) || d.Ho * 2 != d.H || d.Wo * 2 != d.W) return false;          // 2x2 output tiles, no ragged edge
   if (bwd_data ? ((d.Cout % 32) || (d.Cin % 32)) : ((d.Cin % 8) || (d.Cout % 32))) return false;
   // the input-gradient form transforms dy once per output phase (9x its bytes through the workspace): it only pays
   // from 256 channels up (32x32x128->256 measured 13 % slower, 16x16x256->512 11 % faster than the direct GEMM)
-  static const int minc_bwd = getenv("T2I_WINOGRAD_K4S2_BWD_MINC") ? atoi(getenv("T2I_WINOGRAD_K4S2_BWD_MINC")) : 256;
+  const int minc_bwd = tuning().winograd_k4s2_bwd_minc;
   const int m = bwd_data ? minc_bwd : minc;
   return d.Cin >= m && d.Cout >= m;
 }

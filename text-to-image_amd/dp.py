@@ -2,7 +2,10 @@
 
 The reference is single-device; replicas are new functionality: every rank holds identical weights,
 kt and Adam state, sees its own slice of the global batch, and gradients are averaged before the optimizer — so N
-replicas at local batch b behave as the reference at BATCH_SIZE = N*b with per-replica batch-norm statistics.
+replicas at local batch b behave as the reference at BATCH_SIZE = N*b with per-replica batch-norm statistics.  The kt
+step is not a gradient average: balance_loss = (kt*wdist2 - wdist)^2 is quadratic in two batch means, so the ranks
+exchange those means (summed next to the arena as `extra`) and each evaluates the gradient of the GLOBAL-batch loss
+(t2i_kt_sgd); tests/test_dp_gloo.py checks it on distinct per-rank data.
 
 Exchange step: the gradient arena (optim.Arena.grad, one flat buffer per optimizer) is cut into contiguous buckets in
 REVERSE creation order (the order backward produces them).  Finished parameters are counted — by a post-accumulate

@@ -587,11 +587,37 @@ def conv_algo(d, which):
     return ALGO_NAMES[a]
 
 
-def filter_cache(on):
-    """Opt into the transformed-filter cache of the Winograd conv paths (include/t2i_hip.h: contract).  Everything in this
-    package that writes filter memory outside t2i_adam_tf calls filter_cache_invalidate(): ParamStore.load, Saver.restore,
-    optim.Arena creation, dp.broadcast_variables, hipGraph replays.  Returns the previous state."""
+_FC_ARENA = [None]
+
+
+def filter_cache(on, device=None):
+    """Opt into the transformed-filter cache of the Winograd conv paths (include/t2i_hip.h: contract).  The library owns no
+    device memory: the first call allocates the arena the transforms live in (T2I_FILTER_CACHE_MB, default 1024; the
+    wgancls step needs 650 MB) and attaches it.  Everything in this package that writes filter memory outside t2i_adam_tf
+    calls filter_cache_invalidate(): ParamStore.load, Saver.restore, optim.Arena creation, dp.broadcast_variables, hipGraph
+    replays.  Returns the previous state."""
+    if on and _FC_ARENA[0] is None and torch.cuda.is_available():
+        import os
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        buf = torch.empty(int(os.environ.get('T2I_FILTER_CACHE_MB', '1024')) << 20, dtype=torch.uint8, device=dev)
+        check(lib.t2i_filter_cache_attach(_ptr(buf), buf.numel()), 't2i_filter_cache_attach')
+        _FC_ARENA[0] = buf           # kept for the life of the process: captured graphs point into it
     return bool(lib.t2i_filter_cache_enable(1 if on else 0))
+
+
+def tuning_set(key, value):
+    """Planner / diagnostic switch (include/t2i_hip.h t2i_tuning_set); drops cached descriptors, whose workspace sizes
+    were computed under the old setting."""
+    check(lib.t2i_tuning_set(key.encode(), float(value)), 't2i_tuning_set')
+    _DESC_CACHE.clear()
+
+
+def kt_sgd(kt, wdist_sums, scale, lr):
+    """kt -= lr * d balance_loss / d kt from the (rank-summed) batch means wdist, wdist2; in place on the device scalar."""
+    _chk(wdist_sums, 'wdist_sums')
+    assert wdist_sums.numel() == 2 and kt.numel() == 1
+    if _live(wdist_sums):
+        check(lib.t2i_kt_sgd(_ptr(kt), _ptr(wdist_sums), scale, lr, _stream()), 't2i_kt_sgd')
 
 
 def filter_cache_invalidate(t=None):

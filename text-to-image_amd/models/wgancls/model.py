@@ -154,21 +154,25 @@ class WGanCls(object):
                                 inputs=list(self.d_vars.values()))
         A.side_join()                          # filter gradients issued on the side stream are in the arena
         out = {k: scal[i] for i, k in enumerate(K.D_HEAD_KEYS)}
+        # (wdist, wdist2): what the kt step needs.  Under data parallelism these two batch means are summed over the ranks
+        # next to the gradient arena (balance_loss is quadratic in them, so the per-rank kt gradients must not be averaged);
+        # a private copy, because the exchange works in place and the logged scalars should stay this rank's own
+        i0 = K.D_HEAD_KEYS.index('wdist')
+        out['wd_sums'] = scal[i0:i0 + 2].clone() if self.dp is not None else scal[i0:i0 + 2]
         out.update(G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
         return out
 
     def _d_update(self, out, scale):
-        """Adam on the critic arena + the kt step; `scale` turns rank-summed gradients into the mean."""
+        """Adam on the critic arena + the kt step; `scale` turns rank-summed gradients (and batch means) into the mean."""
         self.D_optim.apply(grad_scale=scale)
-        with torch.no_grad():
-            self.kt -= (self.kt_lr * scale) * out['kt_grad']          # GradientDescentOptimizer(0.001) on balance_loss
+        K.kt_sgd(self.kt, out['wd_sums'], scale, self.kt_lr)          # GradientDescentOptimizer(0.001) on balance_loss (model.py:100)
 
     def _d_body(self, feed):
         """Device work of the critic step (graph-capturable): losses, backward, [all-reduce], Adam, kt."""
         out = self.d_losses(feed)
         scale = 1.0
         if self.dp is not None:
-            scale = self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
+            scale = self.dp.allreduce_arena(self.d_arena, extra=out['wd_sums'])
         self._d_update(out, scale)
         return out
 
@@ -179,7 +183,7 @@ class WGanCls(object):
             self._graphs['d'].replay()
             out = self._graphs['d_out']
             if self.dp is not None:            # the exchange step runs between the two captured halves
-                self.dp.allreduce_arena(self.d_arena, extra=out['kt_grad'])
+                self.dp.allreduce_arena(self.d_arena, extra=out['wd_sums'])
                 self._graphs['d_upd'].replay()
             K.filter_cache_invalidate()        # the replay rewrote filters (and cached transforms) behind the host's back
         else:
@@ -256,7 +260,7 @@ class WGanCls(object):
             g['dg'].replay()
         else:
             g['d'].replay()
-            self.dp.start_allreduce(self.d_arena, extra=g['d_out']['kt_grad'])
+            self.dp.start_allreduce(self.d_arena, extra=g['d_out']['wd_sums'])
             g['g_fwd'].replay()                    # generator forward overlaps the critic's gradient exchange
             self.dp.finish_allreduce(self.d_arena)
             g['dupd_g'].replay()

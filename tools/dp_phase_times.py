@@ -35,7 +35,7 @@ g = m._graphs
 if not use_dp:
     steps = [('d graph', lambda: g['d'].replay()), ('g graph', lambda: g['g'].replay())]
 else:
-  steps = [('d graph', lambda: g['d'].replay()), ('d exchange', lambda: dp.allreduce_arena(m.d_arena, extra=g['d_out']['kt_grad'])),
+  steps = [('d graph', lambda: g['d'].replay()), ('d exchange', lambda: dp.allreduce_arena(m.d_arena, extra=g['d_out']['wd_sums'])),
            ('d update', lambda: g['d_upd'].replay()), ('g graph', lambda: g['g'].replay()),
            ('g exchange', lambda: dp.allreduce_arena(m.g_arena)), ('g update', lambda: g['g_upd'].replay())]
 gpu = {n: 0.0 for n, _ in steps}

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Tile / split-K sweep of the implicit-GEMM kernel through the T2I_FORCE_TILE / T2I_FORCE_SPLITK tuning hooks."""
+"""Tile / split-K sweep of the implicit-GEMM kernel through the t2i_tuning_set force_tile / force_splitk hooks."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import t2i_amd  # noqa: E402,F401
-from t2i_amd import kernels as K  # noqa: E402
+from t2i_amd import kernels as K
+from t2i_amd._lib import lib  # noqa: E402
 from tools.bench_conv import LAYERS, timeit  # noqa: E402
 
 WANT = [('D2', 64), ('D3', 64), ('D4', 64), ('D7', 64), ('D10', 64), ('G5c', 64), ('G8c', 64), ('G4c', 64), ('D4', 192),
@@ -27,12 +28,12 @@ for name, B in WANT:
     fns = {'fwd': lambda: K.conv_fwd(x, w, None, d, big), 'bwdD': lambda: K.conv_bwd_data(dy, w, None, d, big),
            'bwdF': lambda: K.conv_bwd_filter(x, dy, d, big)}
     for mode, fn in fns.items():
-        os.environ.pop('T2I_FORCE_TILE', None); os.environ.pop('T2I_FORCE_SPLITK', None)
+        lib.t2i_tuning_set(b'force_tile', 0.0); lib.t2i_tuning_set(b'force_splitk', 0.0)
         t0 = timeit(fn, 10)
         res = []
         for tile in (22, 21, 12, 11):
             for sk in (1, 2, 3, 4, 6, 8):
-                os.environ['T2I_FORCE_TILE'] = str(tile); os.environ['T2I_FORCE_SPLITK'] = str(sk)
+                lib.t2i_tuning_set(b'force_tile', float(tile)); lib.t2i_tuning_set(b'force_splitk', float(sk))
                 try:
                     res.append((timeit(fn, 10), tile, sk))
                 except Exception as e:
