@@ -89,9 +89,10 @@ def effective_cpus():
     return max(1, min(n, 64))
 
 
-def cpu_baseline_child(batch, budget_s=15.0):
+def cpu_baseline_child(batch, budget_s=None):
     """Runs in a child process: the oracle (torch-CPU fp32 restatement of the identical D+G iteration) on the host cores."""
     from oracle import torch_step as T
+    budget_s = budget_s if budget_s is not None else (15.0 if batch <= 16 else 18.0)
     threads = effective_cpus()
     torch.set_num_threads(threads)
     cfg = T.Cfg(batch=batch)
@@ -109,8 +110,9 @@ def cpu_baseline_child(batch, budget_s=15.0):
             break
     dt = (time.time() - t0) / n
     print(json.dumps({'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-                      'sample': '%d timed iteration(s) after 1 warm-up of the same fp32 D+G step at B=%d (BASELINE.json '
-                                'configs[0], the reference\'s CPU-runnable case), torch-CPU oracle' % (n, batch),
+                      'sample': '%d timed iteration(s) after 1 warm-up of the same fp32 D+G step at B=%d (%s), torch-CPU oracle' % (
+                          n, batch, 'BASELINE.json configs[0], the reference\'s CPU-runnable case' if batch == 16 else
+                          'the batch the metric is quoted on'),
                       'ms_per_step': dt * 1e3}))
 
 
@@ -128,6 +130,58 @@ def cpu_baseline(batch=16, timeout_s=180):
                 'sample': 'not measured: %s' % type(e).__name__}
 
 
+def _signature(model):
+    return [model.d_arena.flat.clone(), model.g_arena.flat.clone(), model.D_optim.v.clone(), model.G_optim.v.clone(), model.kt.clone()]
+
+
+def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch):
+    """Self-check of the N-rank exchange before anything is timed (first contact with a multi-GPU node must diagnose itself):
+    every rank runs 4 iterations on IDENTICAL data, once as a single replica (no communicator) and once through the
+    data-parallel schedule that will be timed (2 eager iterations that learn the bucket counts, then the captured segments).
+    Averaging N identical gradients returns the gradient, so the two runs must agree: exactly for N = 2 (x + x and its
+    halving are exact in fp32), and to rounding for N > 2 (a ring sums 3x, 5x, ... which need not be representable) — there
+    the bound is Adam's own: no weight may differ by more than the 4 steps could move it, and all but 0.1 % must agree to
+    5 % of one step.  A bucket that is exchanged too early, twice, or not at all fails both by orders of magnitude."""
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    feed = synthetic_feed(cfg, device, seed=977)            # the same batch and noise on every rank
+    lr = float(cfg.TRAIN.D_LR)
+    sigs, losses = [], []
+    for dp in (None, make_dp()):
+        model = WGanCls(cfg, device=device, seed=0, dp=dp)
+        if dp is not None:
+            dp.broadcast_variables(model.store)
+        trainer = WGanClsTrainer(None, model, None, cfg)
+        for i in range(2):
+            out = trainer.iteration(1 + i, feed)
+        if dp is not None and use_graphs:
+            model.enable_graphs(feed)
+        for i in range(2):
+            out = trainer.iteration(3 + i, feed)
+        torch.cuda.synchronize()
+        sigs.append(_signature(model))
+        losses.append((float(out['d']['D_loss']), float(out['g']['G_loss'])))
+        del trainer, model
+    one, many = sigs
+    report = {'ranks': world, 'iterations': 4, 'exact': all(torch.equal(a, b) for a, b in zip(one, many))}
+    worst, loose = 0.0, 0.0
+    for a, b in zip(one[:2], many[:2]):                     # the two weight arenas
+        d = (a - b).abs()
+        worst = max(worst, float(d.max()) / lr)
+        loose = max(loose, float((d > 0.05 * lr).float().mean()))
+    report.update(max_weight_diff_in_steps=worst, frac_weights_off_by_5pct_of_a_step=loose,
+                  kt_diff=abs(float(one[4]) - float(many[4])), loss_single=losses[0], loss_dp=losses[1])
+    ok = report['exact'] if world == 2 else (worst <= 4 * 2.0 * 1.001 and loose <= 1e-3 and report['kt_diff'] <= 1e-5 * max(abs(float(one[4])), 1.0))
+    report['ok'] = bool(ok)
+    flag = torch.tensor([0 if ok else 1], device=device)
+    torch.distributed.all_reduce(flag)
+    if int(flag) != 0:
+        raise SystemExit('[bench] DATA-PARALLEL PREFLIGHT FAILED on rank %d of %d: the %d-rank run on identical data does not '
+                         'reproduce the single-replica run (%s).  The gradient exchange is broken on this node: not timing it.  '
+                         '(T2I_PREFLIGHT=0 skips this check; T2I_DP_GRAPHS=0 selects the eager overlap schedule.)' % (rank, world, world, report))
+    return report
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -143,6 +197,8 @@ def main():
                          "operands, fp32 accumulation and fp32 tensors) -- reported with dtype 'bf16', never the default")
     ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
                     help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='timed regions of --steps iterations each, every one bracketed by barrier + synchronize; the MEDIAN is reported')
     ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -189,6 +245,14 @@ def main():
     K.set_math(args.math)
     K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # transformed Winograd filters reused until Adam changes them
     cfg = make_cfg(args.batch)
+    use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
+    preflight = None
+    if world > 1 and os.environ.get('T2I_PREFLIGHT', '1') != '0':
+        from t2i_amd.dp import DataParallel as _DP
+        preflight = dp_preflight(cfg, device, lambda: _DP(bucket_bytes=int(os.environ.get('T2I_DP_BUCKET_MB', '32')) << 20),
+                                 use_graphs, rank, world, args.batch)
+        if rank == 0:
+            sys.stderr.write('[bench] data-parallel preflight passed: %r\n' % (preflight,))
     model = WGanCls(cfg, device=device, seed=0, dp=dp)
     if dp is not None:
         dp.broadcast_variables(model.store)
@@ -209,7 +273,6 @@ def main():
 
     # N > 1: each half of the iteration is cut at its exchange step ([losses+backward] | all-reduce | [Adam]); the collectives
     # themselves are never captured.  T2I_DP_GRAPHS=0 keeps the data-parallel step eager (bucketed overlap, dp.py).
-    use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
     from t2i_amd import autograd as A
     if args.side_stream:
         A.enable_side_stream(True)
@@ -222,15 +285,25 @@ def main():
     for i in range(args.warmup):
         trainer.iteration(3 + i, feed)
     timer = ConvTimer()
-    barrier()
-    if args.instrument == 'inline':
-        K.set_conv_timer(timer)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        trainer.iteration(3 + args.warmup + i, feed)
-    barrier()
-    dt = time.perf_counter() - t0
-    K.set_conv_timer(None)
+    regions = []                                # --repeats timed regions of exactly --steps iterations each
+    it = 3 + args.warmup
+    for r in range(max(1, args.repeats)):
+        barrier()
+        if args.instrument == 'inline' and r == 0:
+            K.set_conv_timer(timer)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.iteration(it, feed)
+            it += 1
+        barrier()
+        dt_r = time.perf_counter() - t0
+        K.set_conv_timer(None)
+        if use_dp:                              # the region's time is the slowest rank's
+            t = torch.tensor([dt_r], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_r = float(t)
+        regions.append(dt_r)
+    dt = sorted(regions)[len(regions) // 2]     # median region
     inst_steps = args.steps
     if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
         inst_steps = min(args.steps, 3)
@@ -238,7 +311,7 @@ def main():
         A.enable_side_stream(False)                            # ... and one stream, so durations are per kernel
         K.set_conv_timer(timer)
         for i in range(inst_steps):
-            trainer.iteration(3 + args.warmup + args.steps + i, feed)
+            trainer.iteration(it + i, feed)
         torch.cuda.synchronize()
         K.set_conv_timer(None)
         model._graphs = saved_graphs
@@ -264,10 +337,6 @@ def main():
             raise SystemExit('replicas diverged: %s vs %s; variables that differ: %s' % (lo.tolist(), hi.tolist(), bad[:40]))
         if rank == 0:
             sys.stderr.write('[bench] replica sync check passed: %s\n' % sig.tolist())
-    if use_dp:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
 
@@ -279,36 +348,57 @@ def main():
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                       'launch': ('hipGraph replay (%s)' % ('4 graphs + 2 eager all-reduces/iteration, critic exchange overlapped with the generator forward' if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
-           'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12}
+           'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12,
+           'timing': {'regions': len(regions), 'steps_per_region': args.steps, 'statistic': 'median over regions (max over ranks per region)',
+                      'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
+    if preflight is not None:
+        out['dp_preflight'] = preflight
     if rank == 0:
         if args.instrument != 'off':
             s = timer.summary()
             info = K.device_info(local_rank)
             achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
-            traffic, traffic_src = None, None
             peak = FP32_MATRIX_PEAK_TFLOPS if args.math == 'f32' else BF16_MATRIX_PEAK_TFLOPS
-            try:
-                if args.math != 'f32':
-                    raise KeyError('the PMC passes were taken in f32 mode')   # HBM-side bytes per launch measured by rocprofv3 PMC passes over this same command (tools/pmc_summary.py)
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_igemm.json')))
-                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_pmc_igemm.json (FETCH_SIZE x2 + WRITE_SIZE)'
-            except Exception:
-                pass
+            # HBM-side bytes per launch and MFMA pipe utilisation come from rocprofv3 PMC passes over this same command
+            # (separate --pmc runs, tools/pmc_summary.py), NOT from this run: they are labelled "from_profile", carry the
+            # profile's own launch count, and are dropped when that count is not this run's (another planner / algorithm mix)
+            traffic, mfma_util, prof = None, None, None
+            launches_per_step = s['launches'] / float(inst_steps)
+            # the profile counts igemm_kernel dispatches; every conv entry-point call launches exactly one, except the small direct kernels
+            igemm_per_step = launches_per_step - (s['by_algo'].get('direct_small', [0])[0] / float(inst_steps))
+            for cand in ('r02_pmc_igemm%s.json' % ('' if args.math == 'f32' else '_bf16'), 'r01_pmc_igemm.json'):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
+                except Exception:
+                    continue
+                if pmc.get('math', 'f32') != args.math:
+                    continue
+                prof = {'source': 'from_profile', 'file': 'profiles/' + cand, 'counters': 'FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES',
+                        'profile_igemm_launches_per_step': pmc.get('launches_per_iteration'), 'run_igemm_launches_per_step': igemm_per_step}
+                same = pmc.get('launches_per_iteration') is not None and abs(pmc['launches_per_iteration'] - igemm_per_step) <= 0.02 * igemm_per_step
+                prof['counts_agree'] = bool(same)
+                if same:
+                    traffic, mfma_util = pmc.get('traffic_bytes_per_launch'), pmc.get('mfma_util')
+                break
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src,
+                'frac': achieved / peak, 'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
                 'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
-                'launches_per_step': s['launches'] / float(inst_steps), 'igemm_ms_per_step': s['ms'] / inst_steps,
+                'launches_per_step': launches_per_step, 'igemm_ms_per_step': s['ms'] / inst_steps,
                 'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
                 # `achieved` counts direct-convolution FLOPs; the Winograd paths issue 1/2.25 resp. 9/16 of them
                 'executed_tflops': sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0,
+                'executed_frac': (sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 / peak) if s['ms'] > 0 else 0.0,
+                'note': 'frac counts direct-convolution FLOPs (Winograd issues 1/2.25 resp. 9/16 of them): read it together with '
+                        'executed_frac (multiply-adds actually issued to the matrix cores / peak) and mfma_util (PMC)',
                 'by_algorithm': {a: {'calls_per_step': r[0] / float(inst_steps), 'ms_per_step': r[1] / inst_steps,
                                      'algorithmic_tflops': r[2] / (r[1] * 1e-3) / 1e12 if r[1] > 0 else 0.0}
                                  for a, r in sorted(s['by_algo'].items())},
                 'device': info}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(16)              # BASELINE configs[0]
+            out['cpu_baseline_b64'] = cpu_baseline(64)          # and the batch the metric is quoted on
     if use_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

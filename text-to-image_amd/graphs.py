@@ -24,12 +24,14 @@ class StepGraphs(object):
             if v is not None and v is not buf:
                 buf.copy_(v, non_blocking=True)
 
-    def capture(self, name, body):
-        """body(static_feed) -> anything holding device tensors (kept alive and returned by replay)."""
+    def capture(self, name, body, capture_error_mode='global'):
+        """body(static_feed) -> anything holding device tensors (kept alive and returned by replay).
+        capture_error_mode='thread_local' when another thread touches the HIP runtime during the capture (the process
+        group's watchdog under data parallelism)."""
         dev = next(iter(self.static.values())).device
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool):
+        with torch.cuda.graph(g, pool=self._pool, capture_error_mode=capture_error_mode):
             out = body(self.static)
         if self._pool is None:
             self._pool = g.pool()

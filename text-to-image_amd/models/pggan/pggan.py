@@ -30,7 +30,7 @@ from ...utils.ops import concat_tile, conv2d, fc, layer_norm, lerp, lrelu_act, p
 class PGGAN(object):
     def __init__(self, batch_size, steps, check_dir_write, check_dir_read, dataset, sample_path, log_dir, stage, trans,
                  build_model=True, device=None, seed=0, store=None, fmap_base=1024, fmap_max=512, z_dim=128, embed_dim=1024,
-                 compr_embed_dim=128):
+                 compr_embed_dim=128, dp=None):
         self.batch_size, self.steps = batch_size, steps
         self.check_dir_write, self.check_dir_read = check_dir_write, check_dir_read
         self.dataset, self.sample_path, self.log_dir = dataset, sample_path, log_dir
@@ -47,7 +47,11 @@ class PGGAN(object):
         self.alpha_tra = 0.0                      # tf.Variable(0.0, trainable=False, name='alpha_tra')
         self._alpha_dev = torch.zeros(1, device=self.device)      # ... kept in device memory: graph-replayable fade-in
         self._graphs = None
-        self.dp = None
+        # data parallelism (BASELINE config 5 "DP=8"; the reference is single-device): an optional dp.DataParallel — replicas
+        # at local batch `batch_size`, critic and generator gradients all-reduced over RCCL, bucketed and overlapped with the
+        # backward when eager, exchanged between captured graph segments under replay (same contract as models/wgancls)
+        self.dp = dp
+        self._capturing = False
         if build_model:
             self.build_model()
             self.define_losses()
@@ -117,6 +121,8 @@ class PGGAN(object):
         wdist, wdist2 = D_loss_real - D_loss_fake, D_loss_real - D_loss_mismatch
         D_loss = -wdist - wdist2 + self.gp_coeff * (real_gp + real_gp2)
         self.d_arena.zero_grad()
+        if self.dp is not None and not self._capturing:
+            self.dp.arm(self.d_arena)           # bucketed all-reduce overlaps the rest of this backward
         D_loss.backward(inputs=list(self.d_vars.values()))
         A.side_join()
         return dict(D_loss=D_loss.detach(), wdist=wdist.detach(), wdist2=wdist2.detach(), real_gp=real_gp.detach(),
@@ -131,6 +137,8 @@ class PGGAN(object):
         G_kl_loss = self.kl_std_normal_loss(mean, log_sigma)
         G_loss = -Dg_logit.mean() + self.kl_coeff * G_kl_loss
         self.g_arena.zero_grad()
+        if self.dp is not None and not self._capturing:
+            self.dp.arm(self.g_arena)
         G_loss.backward(inputs=list(self.g_vars.values()))
         A.side_join()
         return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
@@ -141,12 +149,14 @@ class PGGAN(object):
 
     def _d_body(self, feed):
         d = self.d_losses(feed)
-        self.D_optimizer.apply()
+        scale = self.dp.allreduce_arena(self.d_arena) if self.dp is not None else 1.0
+        self.D_optimizer.apply(grad_scale=scale)
         return d
 
     def _g_body(self, feed):
         g = self.g_losses(feed)
-        self.G_optimizer.apply()
+        scale = self.dp.allreduce_arena(self.g_arena) if self.dp is not None else 1.0
+        self.G_optimizer.apply(grad_scale=scale)
         return g
 
     def enable_graphs(self, feed):
@@ -162,8 +172,21 @@ class PGGAN(object):
         self._graphs = StepGraphs(feed, ('x', 'x_mismatch', 'cond', 'z', 'eps_graph', 'ca_noise_d', 'ca_noise_g'))
         self._redraw(feed)
         self._graphs.load(feed)
-        self._graphs.capture('d', self._d_body)
-        self._graphs.capture('g', self._g_body)
+        if self.dp is None:
+            self._graphs.capture('d', self._d_body)
+            self._graphs.capture('g', self._g_body)
+            return
+        # data parallelism: each half is cut at its exchange step — [losses + backward] | all-reduce (eager, never captured)
+        # | [Adam]; thread-local capture mode because the process group's watchdog thread polls events meanwhile
+        scale = 1.0 / self.dp.world
+        self._capturing = True
+        try:
+            self._graphs.capture('d', self.d_losses, capture_error_mode='thread_local')
+            self._graphs.capture('d_upd', lambda f: self.D_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local')
+            self._graphs.capture('g', self.g_losses, capture_error_mode='thread_local')
+            self._graphs.capture('g_upd', lambda f: self.G_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local')
+        finally:
+            self._capturing = False
 
     def _redraw(self, feed):
         st = self._graphs.static
@@ -181,8 +204,15 @@ class PGGAN(object):
             self._graphs.load(feed)
             self.D_optimizer.prepare(self.adam_lr)
             d = self._graphs.replay('d')
+            if self.dp is not None:
+                self.dp.allreduce_arena(self.d_arena)
+                self._graphs.replay('d_upd')
             self.G_optimizer.prepare(self.adam_lr)
-            return {'d': d, 'g': self._graphs.replay('g')}
+            g = self._graphs.replay('g')
+            if self.dp is not None:
+                self.dp.allreduce_arena(self.g_arena)
+                self._graphs.replay('g_upd')
+            return {'d': d, 'g': g}
         self.D_optimizer.prepare(self.adam_lr)
         d = self._d_body(feed)
         self.G_optimizer.prepare(self.adam_lr)

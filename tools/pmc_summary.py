@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc runs of bench.py (one pass per counter group, as MI355X_MICROARCH.md prescribes) for the
-implicit-GEMM kernel class.  usage: pmc_summary.py FETCH_DIR WRITE_DIR MFMA_DIR ITERS OUT.json"""
+implicit-GEMM kernel class.  usage: pmc_summary.py FETCH_DIR WRITE_DIR MFMA_DIR ITERS OUT.json [f32|bf16]"""
 import collections
 import csv
 import glob
@@ -32,7 +32,7 @@ fetch_b = fetch['FETCH_SIZE'] * 1024 * 2
 write_b = write['WRITE_SIZE'] * 1024
 cycles = mfma['GRBM_GUI_ACTIVE'] / 8.0                    # summed over the 8 XCDs
 out = {
-    'kernel': 't2i::igemm_kernel<*>', 'iterations_profiled': iters, 'launches_per_iteration': nm / iters,
+    'kernel': 't2i::igemm_kernel<*>', 'math': (sys.argv[6] if len(sys.argv) > 6 else 'f32'), 'iterations_profiled': iters, 'launches_per_iteration': nm / iters,
     'hbm_side_read_bytes_per_launch': fetch_b / nf, 'hbm_side_write_bytes_per_launch': write_b / nw,
     'traffic_bytes_per_launch': fetch_b / nf + write_b / nw,
     'traffic_bytes_per_iteration': (fetch_b + write_b) / iters,
