@@ -49,10 +49,13 @@ typedef struct t2i_conv_desc {
   int32_t Ho, Wo, Cout;  /* output [B,Ho,Wo,Cout] */
   int32_t KH, KW, SH, SW;
   int32_t pad_t, pad_l;  /* TF SAME puts the odd pixel bottom/right, so only top/left are needed */
-  int32_t math;          /* T2I_MATH_F32 (0): exact fp32 matrix pipe.  T2I_MATH_BF16 (1): operands rounded to bf16 (RNE)
-                          * inside the kernel, v_mfma_*_bf16 with fp32 accumulation; tensors in memory stay fp32
-                          * (BASELINE config 3).  The direct kernels for thin layers (Cin or Cout <= 4, the logit
-                          * head) compute in fp32 in both modes. */
+  int32_t math;          /* T2I_MATH_F32 (0): exact fp32 matrix pipe.  T2I_MATH_BF16 (1): operands rounded to bf16 (RNE),
+                          * v_mfma_*_bf16 with fp32 accumulation; the tensors at this interface stay fp32 (BASELINE
+                          * config 3).  Where the gathered tensor has a multiple of 64 channels the forward conv and the
+                          * input gradient first stage bf16 copies of their operands (activation: workspace; filter:
+                          * workspace or the filter cache) and run a GEMM whose operands are bf16 in memory; elsewhere
+                          * the rounding happens on the way into LDS.  Same arithmetic either way.  The direct kernels for
+                          * thin layers (Cin or Cout <= 4, the logit head) compute in fp32 in both modes. */
 } t2i_conv_desc;
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
@@ -79,13 +82,14 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
                    float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* t2i_conv2d_fwd that also hands the batch norm behind it its statistics: if the launch takes the unsplit path,
- * *chunks = number of M-tiles and stats = [2][chunks][Cout] per-tile column sums of y and of y*y (finish with
- * t2i_col_reduce_partials(stats, stats + chunks*Cout, chunks, Cout, sum, sumsq, ...)); otherwise *chunks = 0 and the
- * caller reduces y itself (t2i_col_reduce).  stats must hold t2i_conv2d_stats_bytes(d). */
+ * *chunks = number of M-tiles, *tile_rows = their height and stats = [2][chunks][Cout]: per tile the column sums of y and
+ * the second moment of y ABOUT THE TILE'S OWN MEAN (finish with t2i_bn_stats_tiles(stats, stats + chunks*Cout, chunks,
+ * tile_rows, B*Ho*Wo, Cout, sum, m2, ...)); otherwise *chunks = 0 and the caller computes the statistics itself
+ * (t2i_bn_stats).  stats must hold t2i_conv2d_stats_bytes(d). */
 size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d);
 int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, void* ws, size_t ws_bytes,
-                         t2i_stream_t stream);
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, void* ws,
+                         size_t ws_bytes, t2i_stream_t stream);
 
 /* dx = conv^T(dy, w) (+ bias over Cin if non-NULL, then act).  This IS ops.conv2d_transpose (utils/ops.py:66-71):
  * TF stores the deconv filter as [KH,KW,Cout_deconv,Cin_deconv], i.e. the HWIO filter of the adjoint conv, so the
@@ -100,25 +104,34 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
 
 /* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);
-/* out0[c] = sum_r a[r,c];  out1[c] = sum_r a[r,c]*b[r,c]  (b == NULL -> a*a; out1 == NULL -> skipped).
- * bias gradients (db = colsum(dy)), BN moments (sum, sum of squares) and BN backward (sum dy, sum dy*x). */
-int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, int accumulate,
-                   void* ws, size_t ws_bytes, t2i_stream_t stream); /* accumulate != 0: out += (sums into a gradient arena) */
+/* out0[c] = sum_r a[r,c];  out1[c] = sum_r a[r,c]*(b[r,c] - center[c])  (b == NULL -> a*a; center == NULL -> 0;
+ * out1 == NULL -> skipped).  Bias gradients (db = colsum(dy)) and the batch-norm backward sums (sum dy, sum dy*(x - mean):
+ * centred inside the reduction — sum(dy*x) - mean*sum(dy) would cancel). */
+int t2i_col_reduce(const float* a, const float* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
+                   int accumulate, void* ws, size_t ws_bytes, t2i_stream_t stream); /* accumulate != 0: out += (gradient arena) */
 
 /* ---- batch norm, training mode: reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm fused, scale=True) --- */
 /* Second stage alone: out0[c] = sum_k part0[k*C + c] (k < chunks, fixed order), same for part1/out1 when given. */
 int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chunks, int32_t C, float* out0, float* out1,
                             int accumulate, t2i_stream_t stream);
-/* From sum/sumsq over n rows: mean, rstd = 1/sqrt(var_biased+eps); scale = gamma*rstd, shift = beta-mean*scale;
- * and, if moving_mean != NULL, moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
-int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, const float* gamma,
+/* Batch statistics of x [rows, C], numerically stable: sum[c] = sum_r x[r,c] and m2[c] = sum_r (x[r,c] - mean[c])^2, from
+ * per-chunk moments about a sample of the chunk merged with Chan's update — NOT from sum(x^2) - sum(x)^2/n, which loses the
+ * variance to cancellation when |mean| >> std (a rank-2 batch norm over a batch of 2; deep batch-normed stacks at batch 2).
+ * Workspace as t2i_col_reduce.  t2i_bn_stats_tiles: the same from the per-tile partials of t2i_conv2d_fwd_stats. */
+int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2, void* ws, size_t ws_bytes, t2i_stream_t stream);
+int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,
+                       float* sum, float* m2, t2i_stream_t stream);
+/* From sum and the centred second moment m2 over n rows: mean, rstd = 1/sqrt(m2/n + eps) (biased variance);
+ * scale = gamma*rstd, shift = beta-mean*scale; and, if moving_mean != NULL,
+ * moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
+int t2i_bn_finalize(const float* sum, const float* m2, int64_t n, int32_t C, const float* gamma,
                     const float* beta, float eps, float decay, float* mean, float* rstd, float* scale, float* shift,
                     float* moving_mean, float* moving_var, t2i_stream_t stream);
 /* y = act(x*scale[c] + shift[c])  (normalise + affine + activation in one pass; also eval-mode BN). */
 int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act,
                  float alpha, float* y, t2i_stream_t stream);
-/* dx = gamma*rstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n), xhat = (x-mean)*rstd.  sum_dy_x = sum dy*x (raw x);
- * the kernel converts to the centred form.  Also emits dgamma, dbeta. */
+/* dx = gamma*rstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n), xhat = (x-mean)*rstd, sum_dy_xhat = rstd * sum_dy_x with
+ * sum_dy_x = sum dy*(x - mean) (t2i_col_reduce / t2i_act_bwd_colsum with center = mean).  Also emits dgamma, dbeta. */
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma,
                float* dbeta, int accumulate /* dgamma/dbeta += */, void* ws /* >= 3*C floats */, size_t ws_bytes,
@@ -130,11 +143,11 @@ int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_s
 /* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream);
 /* Fused activation backward + column sums: dx = dy * act'(y), colsum[c] = sum_r dx[r,c] and, if x2 != NULL,
- * colsum_x2[c] = sum_r dx[r,c]*x2[r,c], in ONE pass over a [rows, C] view (C % 4 == 0, 16-byte aligned).  Serves the
- * bias gradient of a conv layer and the two reductions of the batch-norm backward.  accumulate: sums are added to the
- * outputs.  Workspace as t2i_col_reduce. */
-int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, int64_t rows, int32_t C, int act, float alpha,
-                       float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+ * colsum_x2[c] = sum_r dx[r,c]*(x2[r,c] - center[c]) (center NULL = 0), in ONE pass over a [rows, C] view (C % 4 == 0,
+ * 16-byte aligned).  Serves the bias gradient of a conv layer and the two reductions of the batch-norm backward (x2 = the
+ * layer input, center = its batch mean).  accumulate: sums are added to the outputs.  Workspace as t2i_col_reduce. */
+int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
+                       float alpha, float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
                        t2i_stream_t stream);
 /* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
@@ -219,7 +232,9 @@ enum {
   T2I_ALGO_IMPLICIT_GEMM = 0,        /* igemm_kernel on the direct convolution */
   T2I_ALGO_WINOGRAD_F2X2_3X3 = 1,    /* 3x3 stride 1: transforms + 16 batched GEMMs */
   T2I_ALGO_WINOGRAD_F2X2_2X2 = 2,    /* 4x4 stride 2: space-to-depth / per-phase F(2x2,2x2), 9 or 36 batched GEMMs */
-  T2I_ALGO_DIRECT_SMALL = 3          /* thin / tiny / head kernels of the 3-channel and 1-output layers */
+  T2I_ALGO_DIRECT_SMALL = 3,         /* thin / tiny / head kernels of the 3-channel and 1-output layers */
+  T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS = 4 /* math = BF16, gathered channels % 64 == 0 (fwd, bwd_data): the gathered tensor and
+                                      * the filter are first copied to bf16 (workspace / filter cache), then igemm_h_kernel */
 };
 int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which);
 

@@ -54,13 +54,12 @@ class Vars(_Vars):
         return act(y) if act else y
 
 
-def _lrelu(x):
-    return F.leaky_relu(x, 0.2)
+from .torch_step import lrelu as _lrelu, relu as _relu, tape_section  # noqa: E402  (honour an installed SectionTape)
 
 
 def _to_rgb(V, scope, x, stage, cfg):
     V.enter('%s/rgb_stage_%d' % (scope, stage))
-    x = F.relu(V.conv(x, 9, 2, 1, 'SAME', 'he'))
+    x = _relu(V.conv(x, 9, 2, 1, 'SAME', 'he'))
     return V.conv(x, cfg.channels, 1, 1, 'SAME', 'he')
 
 
@@ -78,8 +77,8 @@ def generator(V, cfg, z, cond, stages, t, alpha, noise):
     x = V.dense(torch.cat([z, code], 1), 4 * 4 * cfg.nf(0), 'he')
     x = V.ln(x)
     x = x.reshape(-1, 4, 4, cfg.nf(0)).permute(0, 3, 1, 2)
-    x = V.ln(V.conv(x, cfg.nf(0), 3, 1, 'SAME', 'he'), F.relu)
-    x = V.ln(V.conv(x, cfg.nf(0), 3, 1, 'SAME', 'he'), F.relu)
+    x = V.ln(V.conv(x, cfg.nf(0), 3, 1, 'SAME', 'he'), _relu)
+    x = V.ln(V.conv(x, cfg.nf(0), 3, 1, 'SAME', 'he'), _relu)
     x_iden = None
     for i in range(1, stages):
         if i == stages - 1 and t:
@@ -87,8 +86,8 @@ def generator(V, cfg, z, cond, stages, t, alpha, noise):
             x_iden = F.interpolate(x_iden, scale_factor=2, mode='nearest')
         V.enter('g_net/conv_stage_%d' % i)
         x = F.interpolate(x, scale_factor=2, mode='nearest')
-        x = V.ln(V.conv(x, cfg.nf(i), 3, 1, 'SAME', 'he'), F.relu)
-        x = V.ln(V.conv(x, cfg.nf(i), 3, 1, 'SAME', 'he'), F.relu)
+        x = V.ln(V.conv(x, cfg.nf(i), 3, 1, 'SAME', 'he'), _relu)
+        x = V.ln(V.conv(x, cfg.nf(i), 3, 1, 'SAME', 'he'), _relu)
     x = _to_rgb(V, 'g_net', x, stages - 1, cfg)
     if t:
         x = (1.0 - alpha) * x_iden + alpha * x
@@ -137,14 +136,20 @@ def d_step(P, cfg, feed, stages, t, alpha):
     Q = dict(P)
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
-    with torch.no_grad():
+    with torch.no_grad(), tape_section('G'):
         G, _, _ = generator(Vars(P), cfg, feed['z'], feed['cond'], stages, t, alpha, feed['ca_noise_d'])
     D = lambda img, c: discriminator(Vars(Q), cfg, img, c, stages, t, alpha)
-    Dg, Dx, Dxmi = D(G, feed['cond']), D(feed['x'], feed['cond']), D(feed['x_mismatch'], feed['cond'])
+    with tape_section('Dg'):
+        Dg = D(G, feed['cond'])
+    with tape_section('Dx'):
+        Dx = D(feed['x'], feed['cond'])
+    with tape_section('Dxmi'):
+        Dxmi = D(feed['x_mismatch'], feed['cond'])
     eps = feed['eps'].reshape(-1, 1, 1, 1)
     x_hat = (eps * G + (1.0 - eps) * feed['x']).detach().requires_grad_(True)
     cond_inp = feed['cond'].detach().clone().requires_grad_(True)
-    Dx_hat = D(x_hat, cond_inp)
+    with tape_section('Dxh'):
+        Dx_hat = D(x_hat, cond_inp)
     gx, gc = torch.autograd.grad(Dx_hat.sum(), [x_hat, cond_inp], create_graph=True)
     real_gp, real_gp2 = _gp(gx), _gp(gc)
     wdist, wdist2 = Dx.mean() - Dg.mean(), Dx.mean() - Dxmi.mean()
@@ -160,8 +165,10 @@ def g_step(P, cfg, feed, stages, t, alpha):
     Q = dict(P)
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
-    G, mean, log_sigma = generator(Vars(Q), cfg, feed['z'], feed['cond'], stages, t, alpha, feed['ca_noise_g'])
-    Dg = discriminator(Vars(Q), cfg, G, feed['cond'], stages, t, alpha)
+    with tape_section('G'):
+        G, mean, log_sigma = generator(Vars(Q), cfg, feed['z'], feed['cond'], stages, t, alpha, feed['ca_noise_g'])
+    with tape_section('Dg'):
+        Dg = discriminator(Vars(Q), cfg, G, feed['cond'], stages, t, alpha)
     G_kl = kl_loss(mean, log_sigma)
     G_loss = -Dg.mean() + cfg.kl_coeff * G_kl
     grads = torch.autograd.grad(G_loss, [Q[n] for n in names])

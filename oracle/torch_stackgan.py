@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import np_ops
 from .torch_step import AdamTF, _bn, _conv, _deconv_k4s2, trainable  # noqa: F401
+from .torch_step import lrelu as _lrelu, relu as _relu, tape_section  # activations that honour an installed SectionTape
 
 
 class Cfg(object):
@@ -101,10 +102,6 @@ class Vars(object):
         return _bn(self.P, n, x, train, stats)
 
 
-def _lrelu(x):
-    return F.leaky_relu(x, 0.2)
-
-
 def _ca(V, embed, noise):
     """generate_conditionals + sample_normal_conditional (stageI/model.py:59-75)."""
     mean = _lrelu(V.dense(embed, V.cfg.compressed, 'n02'))
@@ -129,13 +126,13 @@ def stage1_generator(V, cfg, z, embed, noise, train=True, stats=None):
     h = V.bn(h, train, stats)
     h0 = h.reshape(B, 4, 4, g * 8).permute(0, 3, 1, 2)
     bn = lambda x: V.bn(x, train, stats)
-    r = F.relu(bn(V.conv(h0, g * 2, 1, 1, 'VALID'))); r = F.relu(bn(V.conv(r, g * 2, 3))); r = bn(V.conv(r, g * 8, 3))
-    h1 = F.relu(h0 + r)
+    r = _relu(bn(V.conv(h0, g * 2, 1, 1, 'VALID'))); r = _relu(bn(V.conv(r, g * 2, 3))); r = bn(V.conv(r, g * 8, 3))
+    h1 = _relu(h0 + r)
     h2 = bn(V.conv(V.deconv(h1, g * 4), g * 4, 3))
-    r = F.relu(bn(V.conv(h2, g, 1, 1, 'VALID'))); r = F.relu(bn(V.conv(r, g, 3))); r = bn(V.conv(r, g * 4, 3))
-    h3 = F.relu(h2 + r)
-    h4 = F.relu(bn(V.conv(V.deconv(h3, g * 2), g * 2, 3)))
-    h5 = F.relu(bn(V.conv(V.deconv(h4, g), g, 3)))
+    r = _relu(bn(V.conv(h2, g, 1, 1, 'VALID'))); r = _relu(bn(V.conv(r, g, 3))); r = bn(V.conv(r, g * 4, 3))
+    h3 = _relu(h2 + r)
+    h4 = _relu(bn(V.conv(V.deconv(h3, g * 2), g * 2, 3)))
+    h5 = _relu(bn(V.conv(V.deconv(h4, g), g, 3)))
     out = torch.tanh(V.conv(V.deconv(h5, cfg.channels), cfg.channels, 3))
     return out.permute(0, 2, 3, 1), mean, log_sigma
 
@@ -166,18 +163,18 @@ def stage2_generator(V, cfg, img64_nhwc, embed, noise, train=True, stats=None):
     g = cfg.gf
     bn = lambda t: V.bn(t, train, stats)
     x = img64_nhwc.permute(0, 3, 1, 2)
-    e0 = F.relu(V.conv(x, g, 3, 1, 'SAME', 'he'))
-    e1 = F.relu(bn(V.conv(e0, g * 2, 4, 2, 'SAME', 'he')))
-    enc = F.relu(bn(V.conv(e1, g * 4, 4, 2, 'SAME', 'he')))                       # [B, 4g, 16, 16]
+    e0 = _relu(V.conv(x, g, 3, 1, 'SAME', 'he'))
+    e1 = _relu(bn(V.conv(e0, g * 2, 4, 2, 'SAME', 'he')))
+    enc = _relu(bn(V.conv(e1, g * 4, 4, 2, 'SAME', 'he')))                       # [B, 4g, 16, 16]
     code, mean, log_sigma = _ca(V, embed, noise)
     tile = code[:, :, None, None].expand(-1, -1, 16, 16)
-    h = F.relu(bn(V.conv(torch.cat([enc, tile], 1), g * 4, 3, 1, 'SAME', 'he')))
+    h = _relu(bn(V.conv(torch.cat([enc, tile], 1), g * 4, 3, 1, 'SAME', 'he')))
     for _ in range(4):                                                             # generator_residual_layer: k4 s1 SAME
-        r = F.relu(bn(V.conv(h, g * 4, 4, 1, 'SAME', 'he')))
+        r = _relu(bn(V.conv(h, g * 4, 4, 1, 'SAME', 'he')))
         r = bn(V.conv(r, g * 4, 4, 1, 'SAME', 'he'))
-        h = F.relu(h + r)
+        h = _relu(h + r)
     for f in (g * 2, g, g // 2, g // 4):                                           # generator_upsample
-        h = F.relu(bn(V.conv(V.deconv(h, f, 'n02'), f, 3, 1, 'SAME', 'he')))
+        h = _relu(bn(V.conv(V.deconv(h, f, 'n02'), f, 3, 1, 'SAME', 'he')))
     out = torch.tanh(V.conv(h, cfg.channels, 3, 1, 'SAME', 'he'))
     return out.permute(0, 2, 3, 1), mean, log_sigma
 
@@ -234,11 +231,14 @@ def d_step(P, cfg, feed, stage=1, cfg1=None):
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
     gstats, dstats = {}, [{}, {}, {}]
-    with torch.no_grad():
+    with torch.no_grad(), tape_section('G'):
         G, _, _ = _gen(P, cfg, cfg1, stage, feed, 'ca_noise_d', gstats)
-    lf = _disc(Q, cfg, stage, G, feed['cond'], dstats[0])
-    lm = _disc(Q, cfg, stage, feed['x'], feed['cond'], dstats[1])
-    lw = _disc(Q, cfg, stage, feed['x_mismatch'], feed['cond'], dstats[2])
+    with tape_section('Dfake'):
+        lf = _disc(Q, cfg, stage, G, feed['cond'], dstats[0])
+    with tape_section('Dmatch'):
+        lm = _disc(Q, cfg, stage, feed['x'], feed['cond'], dstats[1])
+    with tape_section('Dmis'):
+        lw = _disc(Q, cfg, stage, feed['x_mismatch'], feed['cond'], dstats[2])
     fake, match, mism = sigmoid_ce(lf, 0.0), sigmoid_ce(lm, cfg.real_label), sigmoid_ce(lw, 0.0)
     D_loss = match + cfg.alpha * mism + (1.0 - cfg.alpha) * fake
     grads = torch.autograd.grad(D_loss, [Q[n] for n in names])
@@ -254,14 +254,18 @@ def g_step(P, cfg, feed, stage=1, cfg1=None):
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
     gstats, dstats = {}, [{}, {}, {}]
-    G, mean, log_sigma = _gen(Q, cfg, cfg1, stage, feed, 'ca_noise_g', gstats)
-    lf = _disc(Q, cfg, stage, G, feed['cond'], dstats[0])
+    with tape_section('G'):
+        G, mean, log_sigma = _gen(Q, cfg, cfg1, stage, feed, 'ca_noise_g', gstats)
+    with tape_section('Dfake'):
+        lf = _disc(Q, cfg, stage, G, feed['cond'], dstats[0])
     G_gan, G_kl = sigmoid_ce(lf, 1.0), kl_loss(mean, log_sigma)
     G_loss = G_gan + cfg.kl * G_kl
     grads = torch.autograd.grad(G_loss, [Q[n] for n in names])
     with torch.no_grad():     # G_optim sits under ALL update ops: the two real critic passes run for their moving averages
-        _disc(P, cfg, stage, feed['x'], feed['cond'], dstats[1])
-        _disc(P, cfg, stage, feed['x_mismatch'], feed['cond'], dstats[2])
+        with tape_section('Dmatch'):
+            _disc(P, cfg, stage, feed['x'], feed['cond'], dstats[1])
+        with tape_section('Dmis'):
+            _disc(P, cfg, stage, feed['x_mismatch'], feed['cond'], dstats[2])
     f = lambda t: float(t.detach())
     return dict(G_loss=f(G_loss), G_gan_loss=f(G_gan), G_kl_loss=f(G_kl), G=G.detach(),
                 grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), g_stats=gstats, d_stats=dstats)

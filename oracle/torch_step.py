@@ -170,6 +170,68 @@ def _relu(x, tape=None):
     return F.relu(x) if tape is None else tape.act(x, 0.0)
 
 
+class SectionTape(object):
+    """MaskTape for the other oracles (torch_stackgan, torch_pggan, torch_gancls), installed globally with `use_tape` instead
+    of being threaded through every call: activations are grouped into named sections, one per network pass
+    (`tape_section('G')`, `'Dfake'`, ...), so that the GPU side — which may batch several passes into one — can be matched
+    section by section.  masks: {section: [bool tensors in call order]} to replay, or None to record (`.record`)."""
+
+    def __init__(self, masks=None):
+        self.masks, self.record, self.sec, self.pos = masks, OrderedDict(), None, {}
+
+    def act(self, x, slope):
+        i = self.pos.get(self.sec, 0)
+        self.pos[self.sec] = i + 1
+        if self.masks is None:
+            m = x > 0
+        else:
+            m = self.masks[self.sec][i]
+            assert m.shape == x.shape, (self.sec, i, tuple(m.shape), tuple(x.shape))
+        self.record.setdefault(self.sec, []).append(m)
+        return x * torch.where(m, torch.ones((), dtype=x.dtype), torch.full((), slope, dtype=x.dtype))
+
+
+TAPE = [None]
+
+
+class use_tape(object):
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.prev, TAPE[0] = TAPE[0], self.tape
+        return self.tape
+
+    def __exit__(self, *a):
+        TAPE[0] = self.prev
+
+
+class tape_section(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        t = TAPE[0]
+        if t is not None:
+            self.prev, t.sec = t.sec, self.name
+
+    def __exit__(self, *a):
+        t = TAPE[0]
+        if t is not None:
+            t.sec = self.prev
+
+
+def lrelu(x):
+    """leaky relu (0.2) that honours the globally installed SectionTape"""
+    t = TAPE[0]
+    return F.leaky_relu(x, 0.2) if t is None else t.act(x, 0.2)
+
+
+def relu(x):
+    t = TAPE[0]
+    return F.relu(x) if t is None else t.act(x, 0.0)
+
+
 def _bn(P, name, x, train, stats_out, eps=1e-5):
     gamma, beta = P[name + '/gamma'], P[name + '/beta']
     dims = (0,) if x.dim() == 2 else (0, 2, 3)

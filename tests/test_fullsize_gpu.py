@@ -1,0 +1,169 @@
+"""Full-size parity of the "next" rows against the float64 oracles, mask-pinned like
+tests/test_step_b64_gpu.py: StackGAN Stage-II at its real 256x256 resolution and full width (GF=128, DF=64, critic up to
+2048 channels), and a PGGAN transition stage at 64x64 (stage 5: the first stage with 256-channel layers next to the 512 ones).
+Tolerances are SURVEY 8(c)'s: loss scalars 1e-5 relative, gradients max|d|/max|ref| <= 1e-4 per tensor; where a tensor's
+exact gradient is zero (biases in front of a batch norm) the bound is absolute.  Batch sizes are the smallest that keep the
+float64 oracle at ~30 s (2 and 4); the tiny-width golden steps (tests/test_stackgan.py, tests/test_pggan.py) stay as the
+committed-fixture checks."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from branches import flips, record_branches, split_sections
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr(got, ref, scale=None):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().double().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    s = float(np.abs(ref).max()) if scale is None else scale
+    return float(np.abs(got - ref).max() / max(s, 1e-30))
+
+
+class Checker(object):
+    def __init__(self):
+        self.bad = []
+
+    def __call__(self, name, err, tol):
+        print('  %-44s %.2e  (tol %.0e)%s' % (name, err, tol, '' if err <= tol else '   <-- FAIL'))
+        if not err <= tol:
+            self.bad.append((name, err, tol))
+
+    def grads(self, arena, names, ref):
+        for n in names:
+            r = ref[n]
+            if float(r.abs().max()) < 1e-9:
+                self('grad ' + n + ' (exact zero: abs)', float(arena.grad_of(n).abs().max()), 1e-4)
+            else:
+                self('grad ' + n, relerr(arena.grad_of(n), r), 1e-4)
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import t2i_amd  # noqa: F401
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    return torch.device('cuda')
+
+
+def test_stackgan_stage2_full_size(gpu):
+    from oracle import torch_stackgan as SG, torch_step as T
+    from t2i_amd.models.stackgan.stageI.model import ConditionalGan as StageI
+    from t2i_amd.models.stackgan.stageII.model import ConditionalGan as StageII
+    from t2i_amd.models.stackgan.stageII.trainer import ConditionalGanTrainer
+    from t2i_amd.utils.config import config_from_yaml
+    B = 2
+    base = os.path.join(ROOT, 'text-to-image_amd', 'models', 'stackgan')
+    c1 = config_from_yaml(os.path.join(base, 'stageI', 'cfg', 'flowers.yml')); c1.TRAIN.BATCH_SIZE = B
+    c2 = config_from_yaml(os.path.join(base, 'stageII', 'cfg', 'flowers.yml')); c2.TRAIN.BATCH_SIZE = B
+    o1, o2 = SG.Cfg(batch=B), SG.Cfg(out_size=256, real_label=0.95, batch=B)
+    P = OrderedDict((n, v.float().double()) for n, v in SG.init_variables(o2, 2, o1, seed=0).items())      # fp32-representable
+    feed = {k: v.float().double() for k, v in SG.synthetic_feed(o2, 2, o1, seed=1).items()}
+    m = StageII(StageI(c1, build_model=False, device=gpu), c2)
+    m.store.load({n: v.numpy() for n, v in P.items()})
+    assert m.output_size == 256 and [n for n in m.store.vars] == list(P)
+    f = {k: v.float().to(gpu) for k, v in feed.items()}
+    hf = {'inputs': f['x'], 'wrong_inputs': f['x_mismatch'], 'phi_inputs': f['cond'], 'z': f['z']}
+    hf.update({k: v for k, v in f.items() if k.startswith('ca_noise')})
+    moving0 = {n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n}
+    tr = ConditionalGanTrainer(None, m, None, c2)
+    plan = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
+    chk = Checker()
+    # ---- critic step
+    rec = []
+    with record_branches(rec):
+        d = tr.d_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        SG.d_step(P, o2, feed, 2, o1)
+    masks = split_sections(rec, own.record, plan)
+    fl, units = flips(own.record, masks)
+    print('Stage-II critic step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        ref = SG.d_step(P, o2, feed, 2, o1)
+    for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
+        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 1e-5)
+    chk('G (256x256 image)', relerr(d['G'], ref['G']), 1e-5)
+    chk.grads(m.d_arena, m.d_vars, ref['grads'])
+    with torch.no_grad():                      # undo the moving-average side effect of the probe pass
+        for n, v in moving0.items():
+            m.store.vars[n].copy_(v)
+    # ---- generator step
+    rec = []
+    with record_branches(rec):
+        g = tr.g_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        SG.g_step(P, o2, feed, 2, o1)
+    masks = split_sections(rec, own.record, plan)
+    fl, units = flips(own.record, masks)
+    print('Stage-II generator step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        gref = SG.g_step(P, o2, feed, 2, o1)
+    for k in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
+        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 1e-5)
+    chk.grads(m.g_arena, m.g_vars, gref['grads'])
+    assert not chk.bad, chk.bad
+
+
+@pytest.mark.parametrize('stage', [5])
+def test_pggan_transition_stage_full_width(gpu, stage):
+    from oracle import torch_pggan as PG, torch_step as T
+    from t2i_amd.models.pggan.pggan import PGGAN
+    B, alpha = 4, 0.3
+    cfg = PG.Cfg(batch=B)
+    P = OrderedDict((n, v.float().double()) for n, v in PG.init_variables(cfg, stage, True, seed=0).items())
+    feed = {k: v.float().double() for k, v in PG.synthetic_feed(cfg, stage, seed=1).items()}
+    m = PGGAN(B, 100, None, None, None, None, None, stage, True, device=gpu)
+    m.store.load({n: v.numpy() for n, v in P.items()})
+    m.set_alpha(alpha)
+    f = {k: v.float().to(gpu) for k, v in feed.items()}
+    hf = {'x': f['x'], 'x_mismatch': f['x_mismatch'], 'cond': f['cond'], 'z': f['z'], 'eps_graph': f['eps'].reshape(-1),
+          'ca_noise_d': f['ca_noise_d'], 'ca_noise_g': f['ca_noise_g']}
+    chk = Checker()
+    rec = []
+    with record_branches(rec):
+        d = m.d_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        PG.d_step(P, cfg, feed, stage, True, alpha)
+    masks = split_sections(rec, own.record, [('G',), ('Dg', 'Dx', 'Dxmi'), ('Dxh',)])
+    fl, units = flips(own.record, masks)
+    print('PGGAN stage %dt critic step: %d of %d branches differ (%.2e)' % (stage, fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        ref = PG.d_step(P, cfg, feed, stage, True, alpha)
+    for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
+        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 1e-5)
+    chk('G (%dx%d image)' % (m.output_size, m.output_size), relerr(d['G'], ref['G']), 1e-5)
+    chk('D(x_hat)', relerr(d['Dx_hat_logit'], ref['Dx_hat']), 1e-5)
+    chk.grads(m.d_arena, m.d_vars, ref['grads'])
+    rec = []
+    with record_branches(rec):
+        g = m.g_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        PG.g_step(P, cfg, feed, stage, True, alpha)
+    masks = split_sections(rec, own.record, [('G',), ('Dg',)])
+    fl, units = flips(own.record, masks)
+    print('PGGAN stage %dt generator step: %d of %d branches differ (%.2e)' % (stage, fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        gref = PG.g_step(P, cfg, feed, stage, True, alpha)
+    for k in ('G_loss', 'G_kl_loss'):
+        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 1e-5)
+    chk.grads(m.g_arena, m.g_vars, gref['grads'])
+    assert not chk.bad, chk.bad

@@ -80,7 +80,7 @@ def test_batch_norm_golden(K, golden_ops, tag):
     x, gamma, beta, dy = dev(g('x')), dev(g('gamma')), dev(g('beta')), dev(g('dy'))
     C = x.shape[-1]
     n = x.numel() // C
-    s, ss = K.col_reduce(x, None, True)
+    s, ss = K.bn_stats(x)                       # (sum, centred second moment)
     mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
     mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, 1e-5, 0.9, mm, mv)
     y = K.bn_apply(x, scale, shift)
@@ -88,7 +88,7 @@ def test_batch_norm_golden(K, golden_ops, tag):
     assert relerr(mean, g('mean')) <= FWD_TOL
     assert relerr(1.0 / rstd ** 2 - 1e-5, g('var')) <= 1e-4
     assert relerr(mm, g('moving_mean')) <= FWD_TOL and relerr(mv, g('moving_var')) <= 1e-5
-    sdy, sdyx = K.col_reduce(dy, x, True)
+    sdy, sdyx = K.col_reduce(dy, x, True, center=mean)      # sum dy, sum dy * (x - mean)
     dx, dgamma, dbeta = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx)
     assert relerr(dx, g('dx')) <= GRAD_TOL
     assert relerr(dgamma, g('dgamma')) <= GRAD_TOL and relerr(dbeta, g('dbeta')) <= GRAD_TOL
@@ -333,7 +333,8 @@ def test_conv_epilogue_batch_norm_statistics(K):
             if got is not None:
                 scale = float((ref * ref).sum(0).sqrt().max())                 # column sums of +-values: compare on the scale of |y|
                 assert float((got[0].double().cpu() - ref.sum(0).cpu()).abs().max()) <= 1e-5 * scale * np.sqrt(ref.shape[0])
-                assert relerr(got[1], (ref * ref).sum(0).cpu().numpy()) <= 1e-5
+                m2 = ((ref - ref.mean(0, keepdim=True)) ** 2).sum(0)            # centred second moment, merged over tiles by Chan's update
+                assert relerr(got[1], m2.cpu().numpy()) <= 1e-5
             else:
                 assert tile == 0                                        # only the planner's own choice may decline (split-K)
             assert relerr(y, K.conv_fwd(dev(x), dev(w), dev(b), d, 256 << 20).double().cpu().numpy()) == 0.0
@@ -484,3 +485,59 @@ def test_kt_sgd_matches_formula_and_is_rank_count_invariant(K):
     want = kt0 - lr * 2.0 * (kt0 * wd2 - wd) * wd2
     assert abs(outs[0] - want) <= 1e-6 * abs(want)
     assert all(o == outs[0] for o in outs), outs
+
+
+@pytest.mark.parametrize('case', [(3, 16, 16, 64, 72, 4, 4, 2, 'SAME'), (5, 4, 4, 192, 200, 3, 3, 1, 'SAME'), (2, 8, 8, 128, 96, 1, 1, 1, 'VALID'),
+                                  (7, 4, 4, 1152, 136, 3, 3, 1, 'SAME'), (2, 32, 32, 64, 64, 4, 4, 2, 'SAME'), (5, 16, 8, 64, 128, 4, 4, 1, 'SAME'),
+                                  (64, 1, 1, 1024, 128, 1, 1, 1, 'VALID')])
+def test_bf16_operand_gemm_matches_rounded_oracle(K, case):
+    """math = bf16 on layers whose gathered tensor has a multiple of 64 channels: the activation and the filter are staged
+    as bf16 copies and multiplied by igemm_h_kernel (bf16 operands in memory, BK = 64).  Same arithmetic as the first bf16
+    mode — operands rounded to bf16 (RNE), exact products, fp32 accumulation — so against the float64 oracle evaluated on
+    the ROUNDED operands it meets the fp32 tolerances, for the forward conv (+ bias + lrelu) and, where the output
+    channels are a multiple of 64 too, the input gradient; unsplit and with a forced split-K (slabs + fixed-order reduce)."""
+    from oracle import np_ops as O
+    B, H, W, Ci, Co, KH, KW, s, pad = case
+    rng = np.random.default_rng(B * 100 + Ci)
+    x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+    w = (rng.standard_normal((KH, KW, Ci, Co)) / np.sqrt(KH * KW * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    d, _ = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad, math=K.MATH_BF16)
+    assert K.conv_algo(d, 'fwd') == 'implicit_gemm_bf16_operands'
+    ws = 256 << 20
+    y_ref = O.conv2d(_bf16_round(x), _bf16_round(w), b, (s, s), pad)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    for splitk in (0, 3):
+        K.tuning_set('force_splitk', splitk)
+        try:
+            assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= FWD_TOL, (case, splitk)
+            if Co % 64 == 0:
+                assert K.conv_algo(d, 'bwd_data') == 'implicit_gemm_bf16_operands'
+                assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws),
+                              O.conv2d_bwd_data(_bf16_round(dy), _bf16_round(w), x.shape, (s, s), pad)) <= GRAD_TOL, (case, splitk)
+        finally:
+            K.tuning_set('force_splitk', 0)
+
+
+@pytest.mark.parametrize('rows,C,offset', [(2, 16384, 300.0), (32, 512, 1000.0), (64 * 16, 256, 50.0), (192 * 32 * 32, 128, 20.0), (7, 3, 100.0)])
+def test_bn_stats_are_stable_against_a_large_mean(K, rows, C, offset):
+    """t2i_bn_stats: (sum, sum (x - mean)^2) by shifted per-chunk moments + Chan merging.  x = offset + unit noise: the
+    two-moment formula sum(x^2)/n - mean^2 that round 1 used loses (offset/std)^2 * 2^-24 of the variance (offset 1000, std 1:
+    6 % relative error — and a rank-2 batch norm over a batch of 2 is the extreme case); the stable form must give the
+    variance to 1e-5 and the normalised output of batch norm to 1e-5 * the offset's own representation error."""
+    rng = np.random.default_rng(rows + C)
+    x = (offset + rng.standard_normal((rows, C))).astype(np.float32)
+    xd = x.astype(np.float64)
+    s, m2 = K.bn_stats(dev(x))
+    var_ref = ((xd - xd.mean(0)) ** 2).sum(0)
+    assert relerr(s, xd.sum(0)) <= 1e-6
+    assert float(np.abs(m2.double().cpu().numpy() - var_ref).max() / var_ref.max()) <= 1e-5
+    naive = (x.astype(np.float32) ** 2).sum(0, dtype=np.float32) - (x.sum(0, dtype=np.float32) ** 2) / np.float32(rows)
+    if offset >= 300.0 and rows > 2:
+        assert float(np.abs(naive - var_ref).max() / var_ref.max()) > 1e-3          # the formula this replaces really is that bad
+    # backward sums, centred inside the reduction
+    dy = rng.standard_normal((rows, C)).astype(np.float32)
+    mean = torch.tensor(xd.mean(0), dtype=torch.float32, device='cuda')
+    sdy, sdyxc = K.col_reduce(dev(dy), dev(x), True, center=mean)
+    ref = (dy.astype(np.float64) * (xd - mean.double().cpu().numpy())).sum(0)
+    assert float(np.abs(sdyxc.double().cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-4

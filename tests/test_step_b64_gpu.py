@@ -20,7 +20,6 @@ above all) are small differences of large numbers.  Their error bound is relativ
 (oracle.torch_step.d_step_term_scales: max_i |coef_i| max|d term_i / d theta|), which is what 1e-4 of fp32 arithmetic can
 promise; the test prints both ratios and asserts the plain one wherever no cancellation is involved.
 """
-import contextlib
 import os
 
 import numpy as np
@@ -31,32 +30,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@contextlib.contextmanager
-def record_branches(out):
-    """Tap every fused lrelu / relu of the HIP path: appends (output > 0) of each activation, in launch order, to `out`.
-    The wrappers in t2i_amd.kernels are looked up by module attribute at call time, so patching them here is enough."""
-    from t2i_amd import kernels as K
-    saved = {}
-
-    def wrap(name, act_pos):
-        fn = getattr(K, name)
-        saved[name] = fn
-
-        def tapped(*a, **kw):
-            y = fn(*a, **kw)
-            act = a[act_pos] if len(a) > act_pos else kw.get('act', K.ACT_NONE)
-            if act in (K.ACT_LRELU, K.ACT_RELU):
-                out.append((y > 0).cpu())
-            return y
-        setattr(K, name, tapped)
-
-    try:
-        wrap('conv_fwd', 5); wrap('conv_fwd_stats', 5); wrap('conv_bwd_data', 5)
-        wrap('bn_apply', 3); wrap('add_act', 2)
-        yield out
-    finally:
-        for n, fn in saved.items():
-            setattr(K, n, fn)
+from branches import record_branches  # noqa: E402
 
 
 def _to_oracle_layout(m):

@@ -27,13 +27,15 @@ SIGNATURES = {
     't2i_conv2d_bwd_data': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, _p]),
     't2i_conv2d_bwd_filter': (ctypes.c_int, [_dp, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_col_reduce_workspace_bytes': (_sz, [_i64, _i32]),
-    't2i_col_reduce': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_col_reduce': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_bn_stats': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
+    't2i_bn_stats_tiles': (ctypes.c_int, [_p, _p, _i32, _i32, _i64, _i32, _p, _p, _p]),
     't2i_bn_finalize': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p]),
     't2i_bn_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p]),
     't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
-    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
     't2i_axpby': (ctypes.c_int, [_p, _f, _p, _f, _i64, _p, _p]),
     't2i_interp': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
@@ -56,7 +58,8 @@ SIGNATURES = {
     't2i_filter_cache_invalidate': (None, [_p, ctypes.c_size_t]),
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),
-    't2i_conv2d_fwd_stats': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, ctypes.POINTER(ctypes.c_int32), _p, _sz, _p]),
+    't2i_conv2d_fwd_stats': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, ctypes.POINTER(ctypes.c_int32),
+                                            ctypes.POINTER(ctypes.c_int32), _p, _sz, _p]),
     't2i_col_reduce_partials': (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, ctypes.c_int, _p]),
     't2i_pool2_sum': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
     't2i_upscale2': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),

@@ -353,7 +353,7 @@ class BatchNormTrainFn(Function):
         C = x.shape[-1]
         n = x.numel() // C
         hit = K.take_stats(x)                     # left by the producing conv's epilogue (ops.conv2d(..., stats=True))
-        s, ss = hit if hit is not None else K.col_reduce(x, None, True)
+        s, ss = hit if hit is not None else K.bn_stats(x)     # (sum, sum (x - mean)^2): stable moments, not sum x^2
         mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean, moving_var)
         y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
@@ -371,11 +371,11 @@ class BatchNormTrainFn(Function):
         x, gamma, mean, rstd, y = ctx.saved_tensors
         gy = _c(gy)
         if ctx.act != K.ACT_NONE and gy.shape[-1] % 4 == 0:
-            gy, sum_dy, sum_dy_x = K.act_bwd_colsum(gy, y, ctx.act, ctx.alpha, x2=x)    # mask + both reductions, one pass
+            gy, sum_dy, sum_dy_x = K.act_bwd_colsum(gy, y, ctx.act, ctx.alpha, x2=x, center=mean)    # mask + both reductions, one pass
         else:
             if ctx.act != K.ACT_NONE:
                 gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
-            sum_dy, sum_dy_x = K.col_reduce(gy, x, True)
+            sum_dy, sum_dy_x = K.col_reduce(gy, x, True, center=mean)     # sum dy, sum dy * (x - mean)
         # gamma / beta that do not require a gradient (a critic with batch norm run under store.frozen() in the generator
         # step: detached views that share the real parameters' addresses) must neither reach the sinks nor be announced
         want_g, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]

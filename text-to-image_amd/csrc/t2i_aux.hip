@@ -35,10 +35,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------
 // column reduction, stage 1: grid (col tiles of 64, row chunks); block (64 cols, 4 row lanes)
 // ---------------------------------------------------------------------------------------------------------------
+// Two refinements shared by the stage-1 kernels (both exist for batch norm, see bn_stats_* below):
+//   shift   (second moment of a itself): every value is taken relative to the chunk's first row, s[c] = a[rbeg, c], i.e. the
+//           partials are sum(a - s) and sum((a - s)^2) — the raw sums sum(a), sum(a^2) lose var = E[a^2] - E[a]^2 to
+//           cancellation as soon as |mean| >> std (worst with few rows: a rank-2 batch norm over a batch of 2);
+//   center  (second factor b): the partial is sum(a * (b - center[c])): the batch-norm backward needs sum(dy * (x - mean)),
+//           and forming it as sum(dy*x) - mean*sum(dy) cancels the same way.
 __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t rows, int C, int64_t rows_per_chunk,
                                                          float* __restrict__ part0, float* __restrict__ part1,
-                                                         bool want1) {
+                                                         bool want1, int shift, const float* __restrict__ center) {
   __shared__ float s0[4][64], s1[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -47,10 +53,12 @@ __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict
   if (rend > rows) rend = rows;
   float acc0 = 0.f, acc1 = 0.f;
   if (c < C) {
+    const float sh = shift ? a[rbeg * C + c] : 0.f;
+    const float ce = center ? center[c] : 0.f;
     for (int64_t r = rbeg + ty; r < rend; r += 4) {
-      float va = a[r * C + c];
+      float va = a[r * C + c] - sh;
       acc0 += va;
-      if (want1) acc1 += va * (b ? b[r * C + c] : va);
+      if (want1) acc1 += va * (b ? b[r * C + c] - ce : va);
     }
   }
   s0[ty][tx] = acc0;
@@ -68,19 +76,23 @@ __global__ __launch_bounds__(256) void col_reduce_stage1(const float* __restrict
 __global__ __launch_bounds__(256) void col_reduce_stage1_small(const float* __restrict__ a, const float* __restrict__ b,
                                                                int64_t rows, int C, int64_t rows_per_chunk,
                                                                float* __restrict__ part0, float* __restrict__ part1,
-                                                               bool want1) {
+                                                               bool want1, int shift, const float* __restrict__ center) {
   __shared__ float s0[4][4], s1[4][4];
   const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t rend = rbeg + rows_per_chunk;
   if (rend > rows) rend = rows;
   float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+  float sh[4] = {0.f, 0.f, 0.f, 0.f}, ce[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C) { if (shift) sh[c] = a[rbeg * C + c]; if (center) ce[c] = center[c]; }
   for (int64_t r = rbeg + threadIdx.x; r < rend; r += 256) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < C) {
-        const float va = a[r * C + c];
+        const float va = a[r * C + c] - sh[c];
         acc0[c] += va;
-        if (want1) acc1[c] += va * (b ? b[r * C + c] : va);
+        if (want1) acc1[c] += va * (b ? b[r * C + c] - ce[c] : va);
       }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,7 +142,8 @@ __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict
 template <bool WANT1, bool HAS_B>
 __global__ __launch_bounds__(256) void col_reduce_stage1_v4(const float* __restrict__ a, const float* __restrict__ b,
                                                             int64_t rows, int C, int64_t rows_per_chunk,
-                                                            float* __restrict__ part0, float* __restrict__ part1) {
+                                                            float* __restrict__ part0, float* __restrict__ part1, int shift,
+                                                            const float* __restrict__ center) {
   __shared__ float4 red[16][16];
   __shared__ float4 red1[WANT1 ? 16 : 1][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -140,12 +153,16 @@ __global__ __launch_bounds__(256) void col_reduce_stage1_v4(const float* __restr
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
+    const float4 sh = shift ? *reinterpret_cast<const float4*>(a + rbeg * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ce = (HAS_B && center) ? *reinterpret_cast<const float4*>(center + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+      float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+      v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       if (WANT1) {
-        const float4 w = HAS_B ? *reinterpret_cast<const float4*>(b + r * C + c) : v;
+        float4 w = v;
+        if (HAS_B) { w = *reinterpret_cast<const float4*>(b + r * C + c); w.x -= ce.x; w.y -= ce.y; w.z -= ce.z; w.w -= ce.w; }
         acc1.x += v.x * w.x; acc1.y += v.y * w.y; acc1.z += v.z * w.z; acc1.w += v.w * w.w;
       }
     }
@@ -233,38 +250,127 @@ size_t col_reduce_ws(int64_t rows, int C) {
   return (size_t)nc * C * 2 * sizeof(float);
 }
 
-hipError_t col_reduce_launch(const float* a, const float* b, int64_t rows, int C, float* out0, float* out1, int accumulate,
-                             void* ws, hipStream_t stream) {
+// stage 1 of a column reduction into the workspace partials; shared by col_reduce_launch and bn_stats_launch
+static void col_reduce_stage1_launch(const float* a, const float* b, int64_t rows, int C, bool want1, int shift, const float* center,
+                                     int ct, int nc, int64_t rpc, float* part0, float* part1, hipStream_t stream) {
+  const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(part0) |
+                                     reinterpret_cast<uintptr_t>(center)) & 15) == 0;
+  if (v4) {
+    if (!want1)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
+    else if (b)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
+    else
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
+  } else if (C <= 4) {
+    hipLaunchKernelGGL(col_reduce_stage1_small, dim3(1, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, want1, shift, center);
+  } else {
+    hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, want1, shift, center);
+  }
+}
+
+hipError_t col_reduce_launch(const float* a, const float* b, const float* center, int64_t rows, int C, float* out0, float* out1,
+                             int accumulate, void* ws, hipStream_t stream) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
-  const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
-                                     reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
-  if (v4) {
-    if (out1 == nullptr)
-      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
-    else if (b)
-      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
-    else
-      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1);
+  col_reduce_stage1_launch(a, b, rows, C, out1 != nullptr, 0, center, ct, nc, rpc, part0, part1, stream);
+  const bool v4 = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
+  if (v4)
     hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part0, (const float*)(out1 ? part1 : nullptr), nc, C,
                        out0, out1, accumulate);
-    return hipGetLastError();
-  }
-  if (C <= 4)
-    hipLaunchKernelGGL(col_reduce_stage1_small, dim3(1, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, out1 != nullptr);
   else
-    hipLaunchKernelGGL(col_reduce_stage1, dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1,
-                       out1 != nullptr);
-  hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1, accumulate);
+    hipLaunchKernelGGL(col_reduce_stage2, dim3(ct), dim3(256), 0, stream, part0, part1, nc, C, out0, out1, accumulate);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batch-norm statistics, numerically stable: (sum, M2 = sum (x - mean)^2) per column.
+//   stage 1 (col_reduce_stage1*, shift = 1): per row chunk k the sums S1 = sum(x - s_k), S2 = sum((x - s_k)^2) about the
+//            chunk's first row s_k = x[rbeg_k, c];
+//   stage 2: chunk k becomes the aggregate (n_k, mean_k = s_k + S1/n_k, M2_k = S2 - S1^2/n_k) — the subtraction is
+//            harmless because s_k is one of the chunk's own samples — and aggregates are merged pairwise with Chan's
+//            update (n, mean, M2) + (n', mean', M2') -> M2 + M2' + (mean' - mean)^2 n n'/(n + n'), in a fixed order.
+//   TILES = true: the per-tile partials of a conv epilogue instead (t2i_conv2d_fwd_stats): part0 = the tile's column sums,
+//            part1 = its M2 about the tile's own mean, n_k = rows of tile k.
+// The two-moment formula var = sum(x^2)/n - mean^2 (round 1) is exact in real arithmetic but loses mean^2/var digits in
+// fp32: a rank-2 batch norm over a batch of 2 whose two values differ by 1e-3 of their size comes out with a 40 % wrong
+// variance, and the StackGAN Stage-II image (batch 2, ~40 batch-normed layers) sat 1e-3 from float64 for this reason alone.
+// ---------------------------------------------------------------------------------------------------------------
+struct Agg { float n, mean, m2; };
+
+__device__ __forceinline__ Agg agg_merge(Agg a, Agg b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  Agg r;
+  r.n = a.n + b.n;
+  const float delta = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + delta * f;
+  r.m2 = a.m2 + b.m2 + delta * delta * a.n * f;
+  return r;
+}
+
+template <bool TILES>
+__global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                       const float* __restrict__ x, int nchunks, int64_t rows, int64_t rows_per_chunk,
+                                                       int C, float* __restrict__ sum, float* __restrict__ m2) {
+  __shared__ float sn[4][64], sm[4][64], sq[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  Agg a = {0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int k = ty; k < nchunks; k += 4) {
+      const int64_t rbeg = (int64_t)k * rows_per_chunk;
+      int64_t rend = rbeg + rows_per_chunk;
+      if (rend > rows) rend = rows;
+      Agg b;
+      b.n = (float)(rend - rbeg);
+      const float p0 = part0[(size_t)k * C + c], p1 = part1[(size_t)k * C + c];
+      if (TILES) {
+        b.mean = p0 / b.n;
+        b.m2 = p1;
+      } else {
+        const float d = p0 / b.n;
+        b.mean = x[rbeg * C + c] + d;
+        b.m2 = fmaxf(p1 - p0 * d, 0.f);
+      }
+      a = agg_merge(a, b);
+    }
+  }
+  sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    Agg r = {sn[0][tx], sm[0][tx], sq[0][tx]};
+#pragma unroll
+    for (int k = 1; k < 4; ++k) r = agg_merge(r, Agg{sn[k][tx], sm[k][tx], sq[k][tx]});
+    sum[c] = r.mean * r.n;
+    m2[c] = r.m2;
+  }
+}
+
+hipError_t bn_stats_launch(const float* x, int64_t rows, int C, float* sum, float* m2, void* ws, hipStream_t stream) {
+  int ct, nc; int64_t rpc;
+  col_reduce_plan(rows, C, &ct, &nc, &rpc);
+  float* part0 = reinterpret_cast<float*>(ws);
+  float* part1 = part0 + (size_t)nc * C;
+  col_reduce_stage1_launch(x, nullptr, rows, C, true, 1, nullptr, ct, nc, rpc, part0, part1, stream);
+  hipLaunchKernelGGL(bn_stats_stage2<false>, dim3(ct), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2);
+  return hipGetLastError();
+}
+
+hipError_t bn_stats_tiles_launch(const float* part_sum, const float* part_m2, int chunks, int tile_rows, int64_t rows, int C, float* sum,
+                                 float* m2, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_stats_stage2<true>, dim3((C + 63) / 64), dim3(256), 0, stream, part_sum, part_m2, (const float*)nullptr, chunks,
+                     rows, (int64_t)tile_rows, C, sum, m2);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // batch norm
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float n, int C,
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ m2, float n, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float decay, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mmean,
@@ -272,8 +378,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float mu = sum[c] / n;
-  float var = sumsq[c] / n - mu * mu;   // biased batch variance
-  if (var < 0.f) var = 0.f;
+  const float var = fmaxf(m2[c], 0.f) / n;   // biased batch variance from the CENTERED second moment (bn_stats_*)
   const float rs = rsqrtf(var + eps);
   mean[c] = mu;
   rstd[c] = rs;
@@ -321,7 +426,7 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float mu = mean[c], rs = rstd[c], g = gamma[c], sdy = sum_dy[c];
-  const float sdyxh = rs * (sum_dy_x[c] - mu * sdy);
+  const float sdyxh = rs * sum_dy_x[c];          // sum_dy_x = sum dy * (x - mean): centered by the reduction that produced it
   dgamma[c] = accumulate ? dgamma[c] + sdyxh : sdyxh;
   dbeta[c] = accumulate ? dbeta[c] + sdy : sdy;
   const float grs = g * rs;
@@ -445,8 +550,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 // read the same tensor; one pass instead of two (float4 per lane, 16 lanes = 64 columns, 16 row lanes per workgroup).
 template <bool SECOND>   // SECOND: also part1[c] = sum_r dx[r,c] * x2[r,c]  (batch-norm backward needs sum dy and sum dy*x)
 __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ x2, int64_t rows, int C,
-                                                             int64_t rows_per_chunk, int act, float alpha,
+                                                             const float* __restrict__ x2, const float* __restrict__ center,
+                                                             int64_t rows, int C, int64_t rows_per_chunk, int act, float alpha,
                                                              float* __restrict__ dx, float* __restrict__ part,
                                                              float* __restrict__ part1) {
   __shared__ float4 red[16][16];
@@ -458,6 +563,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
+    const float4 ce = (SECOND && center) ? *reinterpret_cast<const float4*>(center + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
       const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
@@ -469,7 +575,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
       if (SECOND) {
         const float4 v = *reinterpret_cast<const float4*>(x2 + r * C + c);
-        acc1.x += d.x * v.x; acc1.y += d.y * v.y; acc1.z += d.z * v.z; acc1.w += d.w * v.w;
+        acc1.x += d.x * (v.x - ce.x); acc1.y += d.y * (v.y - ce.y); acc1.z += d.z * (v.z - ce.z); acc1.w += d.w * (v.w - ce.w);
       }
     }
   }
@@ -490,18 +596,18 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
   }
 }
 
-hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x2, int64_t rows, int C, int act, float alpha,
-                                 float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream) {
+hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int C, int act,
+                                 float alpha, float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
   float* part1 = part + (size_t)nc * C;
   const bool second = x2 != nullptr && sum1 != nullptr;
   if (second)
-    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, rows, C, rpc, act, alpha,
+    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
                        dx, part, part1);
   else
-    hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, rows, C, rpc, act, alpha,
+    hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
                        dx, part, part1);
   hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
                      sum0, second ? sum1 : (float*)nullptr, accumulate);

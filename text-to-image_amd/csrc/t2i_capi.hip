@@ -23,7 +23,9 @@ void set_error(const char* fmt, ...) {
 
 // launchers implemented in t2i_aux.hip
 size_t col_reduce_ws(int64_t rows, int C);
-hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
+hipError_t col_reduce_launch(const float*, const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
+hipError_t bn_stats_launch(const float*, int64_t, int, float*, float*, void*, hipStream_t);
+hipError_t bn_stats_tiles_launch(const float*, const float*, int, int, int64_t, int, float*, float*, hipStream_t);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t);
@@ -50,8 +52,8 @@ hipError_t col_reduce_partials_launch(const float*, const float*, int, int, floa
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t kt_sgd_launch(float*, const float*, float, float, hipStream_t);
-hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, float*, float*, int,
-                                 void*, hipStream_t);
+hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, const float*, int64_t, int, int, float, float*, float*,
+                                 float*, int, void*, hipStream_t);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -121,6 +123,7 @@ static Tuning& tuning_mut() {
     v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 256);
     v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
     v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
+    v.bf16_operands = env_int("T2I_BF16_OPERANDS", 1);     // bf16 math: stage bf16 operand copies (t2i_igemm_h.hip) where eligible
     v.max_chain = env_int("T2I_MAX_CHAIN", 8192);           // longest unsplit reduction on the 128x128 tile (see make_plan)
     const char* sc = getenv("T2I_SPLIT_COST");
     v.split_cost = (sc && *sc) ? atof(sc) : 4.0;            // us per extra launch
@@ -139,7 +142,8 @@ const Tuning& tuning() { return tuning_mut(); }
 // bf16 math: the MFMAs are 16x faster but the operands are still fetched as fp32, so the kernel is bound by the L2 -> LDS
 // operand stream (measured ~16 TB/s chip-wide on 128x128 tiles): bytes per FLOP scale with 1/tile edge, which is what
 // rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
-static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false) {
+static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false,
+                      int bk = 32) {
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
   // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
@@ -156,7 +160,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   const double* share_eff = math ? share_eff_bf16 : share_eff_f32;
   const double unit_us = math ? 0.135 : 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
   const double overhead_tiles = math ? 8.0 : 3.0;   // prologue + epilogue of a workgroup, in K-tile steps
-  const int64_t ktiles = (K + 31) / 32;
+  const int64_t ktiles = (K + bk - 1) / bk;        // K-tiles of the kernel that will run (32; 64 for the bf16-operand kernel)
+  const double tile_w = bk / 32.0;                 // ... in units of the 32-wide tile-step the cost constants are quoted for
   int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
   if (maxsplit > split_cap) maxsplit = split_cap;
@@ -186,18 +191,18 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       // error grows ~sqrt(K).  Chains are kept <= max_chain products by splitting K: the slabs are then joined by
       // splitk_reduce in a fixed order (a K-chunked partial sum; a second accumulator set inside the kernel would cost the
       // 128x128 tile its second resident workgroup: 228 of 256 registers are taken).
-      if (!math && !batched && per * 32 > tuning().max_chain && sk < maxsplit && !fs) continue;
+      if (!math && !batched && per * bk > tuning().max_chain && sk < maxsplit && !fs) continue;
       const int64_t blocks = tiles * sk_eff;
       const int64_t rounds = (blocks + 255) / 256;
       const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
-      double t = (double)rounds * ((double)per + overhead_tiles) * (wmt * wnt) * unit_us /
+      double t = (double)rounds * ((double)per * tile_w + overhead_tiles) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * share_eff[resident]);
       const double split_cost = tuning().split_cost;
       if (sk_eff > 1) t += (math ? 2.0 : split_cost) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
       if (t < best_t) {
         best_t = t;
         best.wmt = wmt; best.wnt = wnt;
-        best.splitk = (int)sk_eff; best.k_per_split = (int)(per * 32);
+        best.splitk = (int)sk_eff; best.k_per_split = (int)(per * bk);
         best.tiles_m = (int)tm; best.tiles_n = (int)tn;
         best.ws_bytes = sk_eff > 1 ? (size_t)sk_eff * out_elems * sizeof(float) : 0;
       }
@@ -277,6 +282,83 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
   if (pl.splitk > 1)
     rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(ws), pl.splitk, out_elems, bias, p.N, act, alpha, out,
                                     accumulate, stream), what);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 math with bf16 operands in memory (t2i_igemm_h.hip): forward conv and input gradient / transposed conv whose
+// gathered tensor has a multiple of 64 channels.  Workspace = [bf16 copy of the gathered tensor][bf16 filter image,
+// unless the filter cache holds it][split-K slabs].
+// ------------------------------------------------------------------------------------------------------------------
+static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static bool h_eligible(const t2i_conv_desc& d, bool bwd_data) {
+  const int C = bwd_data ? d.Cout : d.Cin;
+  return d.math == T2I_MATH_BF16 && tuning().bf16_operands && C >= 64 && (C % 64) == 0;
+}
+
+static void h_problem(IgemmParams& p, const t2i_conv_desc* d, int mode, size_t* n_in, size_t* out_elems) {
+  fill_common(p, d);
+  if (mode == MODE_FWD) {
+    p.M = d->B * d->Ho * d->Wo; p.N = d->Cout; p.K = d->KH * d->KW * d->Cin;
+    p.div_c.set(d->Cin);
+    *n_in = (size_t)d->B * d->H * d->W * d->Cin;
+    *out_elems = (size_t)p.M * p.N;
+  } else {
+    p.K = fill_phases(p);
+    p.M = d->B * p.hqwq; p.N = d->Cin;
+    p.div_c.set(d->Cout);
+    *n_in = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+    *out_elems = (size_t)d->B * d->H * d->W * d->Cin;
+  }
+}
+
+static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
+  IgemmParams p;
+  size_t n_in, out_elems;
+  h_problem(p, d, mode, &n_in, &out_elems);
+  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64);
+  return al256c(n_in * 2) + al256c((size_t)d->KH * d->KW * d->Cin * d->Cout * 2) + pl.ws_bytes;
+}
+
+static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const float* w, const float* bias, float* out, int act,
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+  IgemmParams p;
+  size_t n_in, out_elems;
+  h_problem(p, d, mode, &n_in, &out_elems);
+  const size_t nw = (size_t)d->KH * d->KW * d->Cin * d->Cout;
+  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64);
+  const size_t off_w = al256c(n_in * 2), off_s = off_w + al256c(nw * 2), need = off_s + pl.ws_bytes;
+  if (!ws || ws_bytes < need || !aligned16(ws)) {
+    set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, need);
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  int rc = check(cast_bf16_launch(in, n_in, base, stream), what);
+  if (rc != T2I_OK) return rc;
+  bool fill = true;
+  void* wh = filter_cache_get(w, mode == MODE_FWD ? 4 : 5, d->Cin, d->Cout, nw * 2, stream, &fill);
+  if (!wh) { wh = base + off_w; fill = true; }
+  if (fill) {
+    rc = check(wcast_launch(w, d->KH * d->KW, d->Cin, d->Cout, mode == MODE_FWD ? 1 : 0, wh, stream), what);
+    if (rc != T2I_OK) return rc;
+  }
+  p.a = reinterpret_cast<const float*>(base); p.b = reinterpret_cast<const float*>(wh);
+  p.a_bytes = (uint32_t)(n_in * 2); p.b_bytes = (uint32_t)(nw * 2);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
+  p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
+  p.out_elems = out_elems;
+  if (pl.splitk > 1) {
+    p.c = reinterpret_cast<float*>(base + off_s);
+    p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
+  } else {
+    p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = 0;
+  }
+  rc = check(igemm_h_launch(mode, p, pl.wmt, pl.wnt, stream), what);
+  if (rc != T2I_OK) return rc;
+  if (pl.splitk > 1)
+    rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(base + off_s), pl.splitk, out_elems, bias, p.N, act, alpha, out, 0, stream), what);
   return rc;
 }
 
@@ -362,6 +444,8 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (b > need) need = b;
   b = make_plan((int64_t)d->KH * d->KW * d->Cin, d->Cout, (int64_t)d->B * d->Ho * d->Wo, 1, nw, split_cap_for(MODE_BWD_FILTER), d->math).ws_bytes;
   if (b > need) need = b;
+  if (h_eligible(*d, false) && conv_h_ws(d, MODE_FWD) > need) need = conv_h_ws(d, MODE_FWD);
+  if (h_eligible(*d, true) && conv_h_ws(d, MODE_BWD_DATA) > need) need = conv_h_ws(d, MODE_BWD_DATA);
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
@@ -387,12 +471,15 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
 }
 
 int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, void* ws, size_t ws_bytes,
-                         t2i_stream_t stream) {
-  if (!stats || !chunks || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, void* ws,
+                         size_t ws_bytes, t2i_stream_t stream) {
+  if (!stats || !chunks || !tile_rows || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
   int c = 0;
   const int rc = conv2d_fwd_impl(d, x, w, bias, y, act, alpha, stats, &c, ws, ws_bytes, stream);
   *chunks = c;
+  // the M-tile height of the launch that produced the partials: tiles are 128 or 64 rows, and c = ceil(M / height)
+  const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+  *tile_rows = (c > 0 && (M + 127) / 128 == c) ? 128 : 64;
   return rc;
 }
 
@@ -412,6 +499,8 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
     return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  if (h_eligible(*d, false) && aligned16(x) && aligned16(w))
+    return conv_h(MODE_FWD, d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -443,6 +532,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
     return winograd_conv(*d, true, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (winograd_k4s2_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
     return winograd_k4s2_bwd_data(*d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  if (h_eligible(*d, true) && aligned16(dy) && aligned16(w))
+    return conv_h(MODE_BWD_DATA, d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
@@ -499,11 +590,27 @@ size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C) {
   return col_reduce_ws(rows, C);
 }
 
-int t2i_col_reduce(const float* a, const float* b, int64_t rows, int32_t C, float* out0, float* out1, int accumulate,
-                   void* ws, size_t ws_bytes, t2i_stream_t stream) {
-  if (!a || !out0 || rows <= 0 || C <= 0) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
+int t2i_col_reduce(const float* a, const float* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
+                   int accumulate, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  if (!a || !out0 || rows <= 0 || C <= 0 || (center && !b)) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_col_reduce: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(col_reduce_launch(a, b, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_col_reduce");
+  return check(col_reduce_launch(a, b, center, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_col_reduce");
+}
+
+int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  if (!x || !sum || !m2 || rows <= 0 || C <= 0) { set_error("t2i_bn_stats: bad argument"); return T2I_ERR_INVALID; }
+  if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_bn_stats: workspace too small"); return T2I_ERR_WORKSPACE; }
+  return check(bn_stats_launch(x, rows, C, sum, m2, ws, (hipStream_t)stream), "t2i_bn_stats");
+}
+
+int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,
+                       float* sum, float* m2, t2i_stream_t stream) {
+  if (!part_sum || !part_m2 || !sum || !m2 || chunks <= 0 || tile_rows <= 0 || rows <= 0 || C <= 0 ||
+      (int64_t)chunks * tile_rows < rows || (int64_t)(chunks - 1) * tile_rows >= rows) {
+    set_error("t2i_bn_stats_tiles: bad argument");
+    return T2I_ERR_INVALID;
+  }
+  return check(bn_stats_tiles_launch(part_sum, part_m2, chunks, tile_rows, rows, C, sum, m2, (hipStream_t)stream), "t2i_bn_stats_tiles");
 }
 
 int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chunks, int32_t C, float* out0, float* out1,
@@ -559,14 +666,15 @@ int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_s
 int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream) {
   return ew_call(1, dy, y, n, act, alpha, 0.f, dx, stream, "t2i_act_bwd", true);
 }
-int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, int64_t rows, int32_t C, int act, float alpha,
-                       float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
+                       float alpha, float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
                        t2i_stream_t stream) {
+  if (center && (!x2 || !aligned16(center))) { set_error("t2i_act_bwd_colsum: center needs x2 and 16-byte alignment"); return T2I_ERR_INVALID; }
   if ((x2 == nullptr) != (colsum_x2 == nullptr) || (x2 && !aligned16(x2))) { set_error("t2i_act_bwd_colsum: x2 / colsum_x2 must come together, 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
   if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(act_bwd_colsum_launch(dy, y, x2, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
+  return check(act_bwd_colsum_launch(dy, y, x2, center, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
                                      (hipStream_t)stream), "t2i_act_bwd_colsum");
 }
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
@@ -703,7 +811,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"no_ut", &t.no_ut}, {"no_thin", &t.no_thin}, {"winograd", &t.winograd}, {"winograd_minc", &t.winograd_minc},
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
-      {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}};
+      {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }
@@ -721,10 +829,12 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
   const bool thin = !tuning().no_thin;
   if (which == 0) {
     if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, false))) return T2I_ALGO_DIRECT_SMALL;
+    if (h_eligible(*d, false)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
   } else if (which == 1) {
     if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, true) || thin_deconv_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
+    if (h_eligible(*d, true)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;
     if (winograd_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
   } else {

@@ -633,9 +633,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   float* out = p.c + bz * p.batch_c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
   const bool fused = (p.splitk == 1);
   const bool want_stats = MODE == MODE_FWD && fused && p.stats != nullptr;
-  float cs[WNT], cq[WNT];      // this lane's column partials over its rows (batch-norm statistics of the layer output)
+  float cs[WNT];               // this lane's column sums over its rows (batch-norm statistics of the layer output)
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+  for (int j = 0; j < WNT; ++j) cs[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < WMT; ++i) {
 #pragma unroll
@@ -666,33 +666,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             if (p.accumulate) v += out[rowoff + n];
           }
           out[rowoff + n] = v;
-          if (want_stats) { cs[j] += v; cq[j] += v * v; }
+          if (want_stats) cs[j] += v;
         }
       }
     }
   }
-  // ---- fused batch-norm statistics: the tile's column sums of y and y^2 (the conv that feeds a batch norm hands it the
-  // partials, so the normalisation needs no extra pass over the tensor to find its mean and variance).  Lane l and l^32
-  // hold the same column; the two waves stacked along M meet in LDS; one float per column and M-tile goes to memory and
-  // a short fixed-order reduction over the M-tiles finishes the job (col_reduce_stage2).
+  // ---- fused batch-norm statistics (the conv that feeds a batch norm hands it the partials, so the normalisation needs no
+  // extra pass over the tensor): per column the tile's SUM and its second moment ABOUT THE TILE'S OWN MEAN, M2 = sum (y - m)^2.
+  // Two passes over the accumulators, which are still in registers: sums first (lane l and l^32 hold the same column; the two
+  // waves stacked along M meet in LDS), then the centred squares.  The batch norm merges the tiles with Chan's update
+  // (t2i_bn_stats_tiles); raw sums of squares would lose var = E[y^2] - E[y]^2 to cancellation when |mean| >> std.
   if (want_stats) {
     __syncthreads();                                   // every wave is done with the operand tiles in LDS
-    float* red = smem;                                 // [2 (wm)][2 (sum, sumsq)][BN]
+    float* red = smem;                                 // [2 (wm)][BN] sums, then [2 (wm)][BN] centred squares
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
       const float s0 = cs[j] + __shfl_xor(cs[j], 32, 64);
-      const float q0 = cq[j] + __shfl_xor(cq[j], 32, 64);
-      if (lh == 0) {
-        const int col = wn * 32 * WNT + j * 32 + l31;
-        red[(wm * 2 + 0) * BN + col] = s0;
-        red[(wm * 2 + 1) * BN + col] = q0;
-      }
+      if (lh == 0) red[wm * BN + wn * 32 * WNT + j * 32 + l31] = s0;
     }
+    __syncthreads();
+    const float rows_tile = (float)min(BM, p.M - bm);
+    float cq[WNT];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = wn * 32 * WNT + j * 32 + l31;
+      const int n = bn + col;
+      const float mean = (red[col] + red[BN + col]) / rows_tile;
+      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const float dlt = apply_act(acc[i][j][e] + bv, p.act, p.alpha) - mean;
+          q += (m < p.M) ? dlt * dlt : 0.f;
+        }
+      cq[j] = q + __shfl_xor(q, 32, 64);
+    }
+    __syncthreads();                                   // the sums have been read by everyone
+    float tsum = 0.f;
+    if (tid < BN) tsum = red[tid] + red[BN + tid];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+      if (lh == 0) red[wm * BN + wn * 32 * WNT + j * 32 + l31] = cq[j];
     __syncthreads();
     if (tid < BN && bn + tid < p.N) {
       const size_t tm = (size_t)tile_m;
-      p.stats[tm * p.N + bn + tid] = red[0 * BN + tid] + red[2 * BN + tid];
-      p.stats[((size_t)tiles_m + tm) * p.N + bn + tid] = red[1 * BN + tid] + red[3 * BN + tid];
+      p.stats[tm * p.N + bn + tid] = tsum;
+      p.stats[((size_t)tiles_m + tm) * p.N + bn + tid] = red[tid] + red[BN + tid];
     }
   }
 }

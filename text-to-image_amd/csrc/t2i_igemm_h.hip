@@ -1,0 +1,350 @@
+// t2i_igemm_h.hip — implicit-GEMM convolution on the bf16 matrix pipe with bf16 OPERANDS IN MEMORY (gfx950 only).
+//
+// BASELINE config 3 ("bf16 MFMA, fp32 accumulate / master").  The first bf16 mode (igemm_kernel<..., MATH=1>) fetched fp32
+// operands and rounded them on their way into LDS: it was bound by the fp32 L2 -> LDS stream, twice the bytes the MFMA
+// needs, plus a v_cvt per element pair (0.086 of the bf16 peak).  Here the operands are bf16 in memory:
+//   * activations: a bf16 copy of the gathered tensor (x for the forward conv, dy for the input gradient / transposed
+//     conv), same NHWC layout, written by cast_bf16_kernel into the caller's workspace right before the GEMM (one
+//     HBM-bound pass: 6 bytes per element against the >= 2*Cout*taps FLOPs it feeds);
+//   * filters: a bf16 copy laid out K-INNER for the GEMM that uses it — [tap][Cout][Cin] for the forward conv (the
+//     per-tap transpose of HWIO), [tap][Cin][Cout] (= HWIO itself) for the input gradient — produced by wcast_kernel and
+//     kept in the transformed-filter cache until the optimizer changes the filter.
+// Both operands are then K-inner: a thread moves 16 bytes (8 consecutive k of one row) from global memory to LDS with
+// no arithmetic at all, and every MFMA operand is one ds_read_b128.
+//   tile    128x128 (4 waves 2x2, 2x2 accumulators of 32x32 each) or 64x64; BK = 64 (4 MFMA steps of k = 16)
+//   LDS     [rows][64 bf16 + 16 B pad]: row stride 36 dwords, conflict-free for the 16-lane groups of ds_read_b128
+//   loop    tile t in LDS, tile t+1 in registers, tile t+2 in flight; one barrier per K-tile (512 MFMA cycles per wave)
+//   K-tiles never straddle a filter tap (gathered channels % 64 == 0): (kh, kw, c0) are decoded once per tile on the scalar
+//   unit; padding taps / ragged rows / split-K tails read zeros through the buffer-load range check.
+// Results are those of the first bf16 mode bit for bit in exact arithmetic terms: both round the same fp32 values to bf16
+// with RNE and accumulate exact products in fp32; only the summation order inside a K-tile differs (k = 64 per barrier
+// instead of 32).  Outputs, bias, activation, split-K slabs and the accumulate-into-arena epilogue are fp32 as before.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HBK = 64;                 // K-tile in elements
+constexpr int HROW = 36;                // LDS row stride in dwords (64 bf16 = 32 dwords + 4 pad)
+constexpr unsigned HOOB = 0xFFFFFFF0u;  // byte offset beyond every legal buffer: the load returns 0
+
+__device__ __forceinline__ unsigned pk2(float lo, float hi) {      // v_cvt_pk_bf16_f32, round to nearest even
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// staging kernels
+// ------------------------------------------------------------------------------------------------------------------
+// y[i] = bf16(x[i]), n % 8 == 0, both 16-byte aligned: two 16-byte loads -> one 16-byte store per thread and step
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, size_t n8, uint4* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    y[i] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+  }
+}
+
+// filter copies.  w is HWIO [T][Ci][Co] fp32.
+//   transpose = 0: out[T][Ci][Co] bf16 (plain cast: the K-inner image of the input-gradient GEMM, rows n = ci, k = co)
+//   transpose = 1: out[T][Co][Ci] bf16 (per-tap transpose: the K-inner image of the forward GEMM, rows n = co, k = ci)
+// One workgroup = a 32 (ci) x 32 (co) block of one tap through an LDS tile.
+__global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ w, int Ci, int Co, int transpose,
+                                                    __bf16* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const float* src = w + (size_t)t * Ci * Co;
+  __bf16* dst = out + (size_t)t * Ci * Co;
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + tx;
+    tile[j][tx] = (ci < Ci && co < Co) ? src[(size_t)ci * Co + co] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    if (transpose) {
+      const int co = co0 + j, ci = ci0 + tx;
+      if (co < Co && ci < Ci) dst[(size_t)co * Ci + ci] = (__bf16)tile[tx][j];
+    } else {
+      const int ci = ci0 + j, co = co0 + tx;
+      if (ci < Ci && co < Co) dst[(size_t)ci * Co + co] = (__bf16)tile[j][tx];
+    }
+  }
+}
+
+hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream) {
+  const size_t n8 = n >> 3;
+  size_t blocks = (n8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n8, reinterpret_cast<uint4*>(y));
+  return hipGetLastError();
+}
+
+hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream) {
+  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, taps);
+  hipLaunchKernelGGL(wcast_kernel, grid, dim3(256), 0, stream, w, Ci, Co, transpose, reinterpret_cast<__bf16*>(out));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ PhaseInfo load_phase_h(int idx) {
+  PhaseInfo r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char* KernArg;
+  typedef const __attribute__((address_space(4))) int32_t* Words;
+  const Words src = (Words)((KernArg)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(IgemmParams, phase) + (size_t)idx * sizeof(PhaseInfo));
+  int32_t* dst = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(PhaseInfo) / 4); ++i) dst[i] = src[i];
+#else
+  (void)idx;
+  r = PhaseInfo();
+#endif
+  return r;
+}
+
+template <int WMT, int WNT>
+struct SmemH {
+  static constexpr int BM = 64 * WMT, BN = 64 * WNT;
+  static constexpr int A_DW = BM * HROW, B_DW = BN * HROW;      // dwords per buffer
+  static constexpr int BYTES = 2 * (A_DW + B_DW) * 4;
+};
+
+// MODE_FWD:      y [M = B*Ho*Wo, N = Cout]  = im2col(x_h)[M, K = KH*KW*Cin] * w_h[tap][n = co][k = ci]
+// MODE_BWD_DATA: dx[M = B*Hq*Wq, N = Cin]   = gather(dy_h)[M, K = taps*Cout] * w_h[tap][n = ci][k = co]   (grid.z = phase)
+template <int MODE, int WMT, int WNT>
+__global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
+  using S = SmemH<WMT, WNT>;
+  constexpr int BM = S::BM, BN = S::BN;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
+  unsigned* As = smem_h;
+  unsigned* Bs = smem_h + 2 * S::A_DW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // block -> tile: XCD-contiguous runs of tile ids, grouped rasterisation (as igemm_kernel)
+  const int tiles_m = p.tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    const int g = p.group_n;
+    const int per_group = g * tiles_m;
+    const int grp = bid / per_group;
+    const int r = bid - grp * per_group;
+    const int n0 = grp * g;
+    const int width = min(g, p.tiles_n - n0);
+    tile_m = r / width;
+    tile_n = n0 + (r - tile_m * width);
+  }
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int split = blockIdx.y;
+  const PhaseInfo pi = load_phase_h(MODE == MODE_BWD_DATA ? blockIdx.z : 0);
+  const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(Kdim, kbeg + p.k_per_split);
+  const int ntiles = (kend - kbeg + HBK - 1) / HBK;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), (short)0, (int)p.b_bytes, 0x00020000);
+
+  // ---- loader state: thread -> (16-byte piece kp = tid & 7 of the 128-byte K-tile row, rows (tid >> 3) + 32 i) ------------
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;
+  const int kp = tid & 7, r0 = tid >> 3;
+  const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;          // channels of the gathered tensor = k extent of one tap
+  const int Wsrc = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+  const unsigned Hs = (MODE == MODE_FWD) ? p.d.H : p.d.Ho, Ws = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+  int a_rowoff[A_LD], a_h0[A_LD], a_w0[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = bm + r0 + 32 * i;
+    bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int base, h0, w0;
+    if (MODE == MODE_FWD) {
+      const int b = p.div_howo.div(mm);
+      const int rem = mm - b * p.howo;
+      const int oh = p.div_wo.div(rem);
+      const int ow = rem - oh * p.d.Wo;
+      base = b * p.d.H * p.d.W;
+      h0 = oh * p.d.SH - p.d.pad_t;
+      w0 = ow * p.d.SW - p.d.pad_l;
+    } else {
+      const int b = p.div_hqwq.div(mm);
+      const int rem = mm - b * p.hqwq;
+      const int ihq = p.div_wq.div(rem);
+      const int iwq = rem - ihq * p.Wq;
+      base = b * p.d.Ho * p.d.Wo;
+      h0 = ihq + pi.oh_off;
+      w0 = iwq + pi.ow_off;
+      ok = ok && (ihq * p.d.SH + pi.ph < p.d.H) && (iwq * p.d.SW + pi.pw < p.d.W);
+    }
+    a_ok[i] = ok; a_h0[i] = h0; a_w0[i] = w0;
+    a_rowoff[i] = (base + h0 * Wsrc + w0) * Csrc + kp * 8;
+  }
+  int b_rowoff[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int n = bn + r0 + 32 * i;
+    b_ok[i] = n < p.N;
+    b_rowoff[i] = n * Csrc + kp * 8;                   // both filter images are [tap][N][Csrc]
+  }
+
+  u32x4 areg[A_LD], breg[B_LD];
+
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const int k0 = kbeg + t * HBK;
+    const int tap = p.div_c.div(k0);                   // wave-uniform
+    const int c0 = k0 - tap * Csrc;
+    const bool kok = (k0 + kp * 8) < kend;
+    int dh, dw, wtap;
+    if (MODE == MODE_FWD) {
+      dh = p.div_kw.div(tap);
+      dw = tap - dh * p.d.KW;
+      wtap = tap;
+    } else {
+      const int jh = pi.div_ntw.div(tap);
+      const int jw = tap - jh * pi.ntw;
+      dh = -jh; dw = -jw;
+      wtap = (pi.kh0 + jh * p.d.SH) * p.d.KW + (pi.kw0 + jw * p.d.SW);
+    }
+    const int sa = (dh * Wsrc + dw) * Csrc + c0;
+    const int sb = wtap * p.N * Csrc + c0;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const bool ok = a_ok[i] & kok & ((unsigned)(a_h0[i] + dh) < Hs) & ((unsigned)(a_w0[i] + dw) < Ws);
+      areg[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (unsigned)(a_rowoff[i] + sa) * 2u : HOOB, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      breg[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, (b_ok[i] & kok) ? (unsigned)(b_rowoff[i] + sb) * 2u : HOOB, 0, 0);
+  };
+
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    unsigned* as = As + buf * S::A_DW;
+    unsigned* bs = Bs + buf * S::B_DW;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4*>(&as[(r0 + 32 * i) * HROW + kp * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) *reinterpret_cast<u32x4*>(&bs[(r0 + 32 * i) * HROW + kp * 4]) = breg[i];
+  };
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  load_tile(1);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned* as = As + (t & 1) * S::A_DW;
+    const unsigned* bs = Bs + (t & 1) * S::B_DW;
+    bf16x8 fa[WMT][4], fb[WNT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+        fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[(wm * 32 * WMT + i * 32 + l31) * HROW + s * 8 + lh * 4]));
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+        fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[(wn * 32 * WNT + i * 32 + l31) * HROW + s * 8 + lh * 4]));
+    }
+    store_tile((t + 1) & 1);          // tile t+1 (registers) -> the other buffer; every wave finished reading it before the
+    load_tile(t + 2);                 // barrier that ended iteration t-1
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int n = 0; n < WNT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue (fp32 output; same conventions as igemm_kernel) ----------------------------------------------------------
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  const bool fused = (p.splitk == 1);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      bool mok = m < p.M;
+      int rowoff;
+      if (MODE == MODE_BWD_DATA) {
+        const int mm = mok ? m : 0;
+        const int b = p.div_hqwq.div(mm);
+        const int rem = mm - b * p.hqwq;
+        const int ihq = p.div_wq.div(rem);
+        const int iwq = rem - ihq * p.Wq;
+        const int ih = ihq * p.d.SH + pi.ph, iw = iwq * p.d.SW + pi.pw;
+        mok = mok && ih < p.d.H && iw < p.d.W;
+        rowoff = ((b * p.d.H + ih) * p.d.W + iw) * p.N;
+      } else {
+        rowoff = m * p.N;
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int n = bn + wn * 32 * WNT + j * 32 + l31;
+        if (mok && n < p.N) {
+          float v = acc[i][j][e];
+          if (fused) {
+            if (p.bias) v += p.bias[n];
+            v = apply_act(v, p.act, p.alpha);
+            if (p.accumulate) v += out[rowoff + n];
+          }
+          out[rowoff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int WMT, int WNT>
+static hipError_t launch_h(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+  using S = SmemH<WMT, WNT>;
+  auto k = igemm_h_kernel<MODE, WMT, WNT>;
+  static bool attr_done = false;   // benign race: idempotent
+  if (!attr_done && S::BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), S::BYTES, stream, p);
+  return hipGetLastError();
+}
+
+// tiles: (wmt, wnt) in {(2,2), (2,1), (1,2), (1,1)}
+hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream) {
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
+#define T2I_H(M_, a, b) if (mode == M_ && wmt == a && wnt == b) return launch_h<M_, a, b>(p, grid, stream);
+  T2I_H(MODE_FWD, 2, 2) T2I_H(MODE_FWD, 2, 1) T2I_H(MODE_FWD, 1, 2) T2I_H(MODE_FWD, 1, 1)
+  T2I_H(MODE_BWD_DATA, 2, 2) T2I_H(MODE_BWD_DATA, 2, 1) T2I_H(MODE_BWD_DATA, 1, 2) T2I_H(MODE_BWD_DATA, 1, 1)
+#undef T2I_H
+  return hipErrorInvalidValue;
+}
+
+}  // namespace t2i

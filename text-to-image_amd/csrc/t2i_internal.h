@@ -104,6 +104,12 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
                      hipStream_t stream, const char* what);
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);
+// bf16 operands in memory (t2i_igemm_h.hip): staging kernels + the GEMM
+hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
+hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream);
+hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream);
+// slot of the caller-owned filter-cache arena for (filter, kind) — nullptr when the cache cannot serve it (t2i_winograd.hip)
+float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
                                 float alpha, float* out, int accumulate, hipStream_t stream);
 
@@ -114,7 +120,7 @@ void set_error(const char* fmt, ...);
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain;
+  int adam_blocks, max_chain, bf16_operands;
   double split_cost;
 };
 const Tuning& tuning();

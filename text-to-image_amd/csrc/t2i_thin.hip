@@ -291,7 +291,7 @@ hipError_t head_bwd_filter_launch(const t2i_conv_desc& d, const float* x, const 
 namespace t2i {
 
 size_t col_reduce_ws(int64_t rows, int C);
-hipError_t col_reduce_launch(const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
+hipError_t col_reduce_launch(const float*, const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------------------------
 // tiny filter gradient (Cin, Cout <= 3, k <= 3: the generator's 3 -> 3 output conv): 81 sums over B*H*W pixels.
@@ -377,7 +377,7 @@ hipError_t tiny_bwdw_launch(const t2i_conv_desc& d, const float* x, const float*
   float* part = reinterpret_cast<float*>(ws);
   char* ws2 = reinterpret_cast<char*>(ws) + (((size_t)nb * C * sizeof(float) + 255) & ~(size_t)255);
   hipLaunchKernelGGL((tiny_bwdw_kernel<3, 3>), dim3(nb), dim3(256), 0, stream, x, dy, part, d);
-  return col_reduce_launch(part, nullptr, nb, C, dw, nullptr, accumulate, ws2, stream);
+  return col_reduce_launch(part, nullptr, nullptr, nb, C, dw, nullptr, accumulate, ws2, stream);
 }
 
 }  // namespace t2i

@@ -71,7 +71,7 @@ size_t filter_cache_bytes() {
 // Returns the cache slot for this filter's transform (and whether it has to be filled), or nullptr when the caller
 // should transform into its workspace as without the cache (cache off, no arena attached or arena full, a second stream).
 // The library allocates nothing: slots are carved out of the caller's arena, never moved, and live until the next attach.
-static float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill) {
+float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill) {
   *fill = true;
   if (!g_fc_on) return nullptr;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -191,17 +191,31 @@ _STATS = {}
 
 
 def take_stats(x):
-    """(column sums, column sums of squares) of `x` if the conv that produced it left its epilogue partials, else None."""
+    """(column sums, centred second moments sum (x - mean)^2) of `x` if the conv that produced it left its epilogue
+    partials (per-tile sums and second moments about each tile's mean, merged here with Chan's update), else None."""
     hit = _STATS.pop(x.data_ptr(), None)
     if hit is None:
         return None
-    part, chunks, shape = hit
+    part, chunks, tile_rows, shape = hit
     if tuple(x.shape) != shape:
         return None
     C = x.shape[-1]
     s0 = torch.empty(C, dtype=torch.float32, device=x.device); s1 = torch.empty_like(s0)
-    check(lib.t2i_col_reduce_partials(_ptr(part), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks, C, _ptr(s0), _ptr(s1), 0,
-                                      _stream()), 't2i_col_reduce_partials')
+    check(lib.t2i_bn_stats_tiles(_ptr(part), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks, tile_rows, x.numel() // C, C,
+                                 _ptr(s0), _ptr(s1), _stream()), 't2i_bn_stats_tiles')
+    return s0, s1
+
+
+def bn_stats(x):
+    """x viewed as [rows, C] -> (sum over rows, sum over rows of (x - mean)^2), numerically stable (t2i_bn_stats)."""
+    _chk(x, 'x')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    s0 = torch.empty(C, dtype=torch.float32, device=x.device); s1 = torch.empty_like(s0)
+    if _live(x):
+        need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
+        wsp, wsn = _ws_args(x, need)
+        check(lib.t2i_bn_stats(_ptr(x), rows, C, _ptr(s0), _ptr(s1), wsp, wsn, _stream()), 't2i_bn_stats')
     return s0, s1
 
 
@@ -213,17 +227,17 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         wsp, wsn = _ws_args(x, ws_bytes)
         nbytes = int(lib.t2i_conv2d_stats_bytes(ctypes.byref(d)))
         part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-        chunks = ctypes.c_int32(0)
+        chunks, tile_rows = ctypes.c_int32(0), ctypes.c_int32(0)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
-                                       _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), wsp, wsn, _stream()),
-              't2i_conv2d_fwd_stats')
+                                       _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), ctypes.byref(tile_rows), wsp, wsn,
+                                       _stream()), 't2i_conv2d_fwd_stats')
         if ev is not None:
             ev.record()
         if chunks.value > 0:
             if len(_STATS) > 64:
                 _STATS.clear()
-            _STATS[y.data_ptr()] = (part, int(chunks.value), tuple(y.shape))
+            _STATS[y.data_ptr()] = (part, int(chunks.value), int(tile_rows.value), tuple(y.shape))
     return y
 
 
@@ -260,8 +274,8 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
     return dw
 
 
-def col_reduce(a, b=None, want_second=False, out=None):
-    """a viewed as [rows, C] (C = last dim).  -> (colsum(a), colsum(a*b or a*a) or None).
+def col_reduce(a, b=None, want_second=False, out=None, center=None):
+    """a viewed as [rows, C] (C = last dim).  -> (colsum(a), colsum(a*(b - center) or a*a) or None).
     out: an existing [C] buffer to ACCUMULATE colsum(a) into (a bias slot of the gradient arena)."""
     _chk(a, 'a')
     C = a.shape[-1]
@@ -276,12 +290,13 @@ def col_reduce(a, b=None, want_second=False, out=None):
     if _live(a):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(a, need)
-        check(lib.t2i_col_reduce(_ptr(a), _ptr(b), rows, C, _ptr(out0), _ptr(out1), 1 if out is not None else 0, wsp, wsn,
-                                 _stream()), 't2i_col_reduce')
+        check(lib.t2i_col_reduce(_ptr(a), _ptr(b), _ptr(_chk(center, 'center') if center is not None else None), rows, C, _ptr(out0),
+                                 _ptr(out1), 1 if out is not None else 0, wsp, wsn, _stream()), 't2i_col_reduce')
     return out0, out1
 
 
 def bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean=None, moving_var=None):
+    """s = column sums, ss = CENTRED second moments sum (x - mean)^2 (bn_stats / take_stats)."""
     C = s.numel()
     mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=s.device) for _ in range(4))
     if _live(s):
@@ -302,7 +317,8 @@ def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
 
 
 def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=None, dbeta_out=None):
-    """dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into instead of fresh tensors."""
+    """sum_dy_x = colsum(dy * (x - mean)) (col_reduce / act_bwd_colsum with center=mean).
+    dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into instead of fresh tensors."""
     _chk(dy, 'dy'); _chk(x, 'x')
     C = x.shape[-1]
     dx = torch.empty_like(x)
@@ -334,9 +350,9 @@ def act_bwd(dy, y, act, alpha=0.2):
     return dx
 
 
-def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None):
-    """-> (dx = dy*act'(y), colsum(dx)[, colsum(dx*x2)]) in one pass: a conv layer's activation backward + bias gradient,
-    or (with x2) the masked gradient and both reductions of the batch-norm backward.
+def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
+    """-> (dx = dy*act'(y), colsum(dx)[, colsum(dx*(x2 - center))]) in one pass: a conv layer's activation backward + bias
+    gradient, or (with x2 = layer input, center = its batch mean) the masked gradient and both reductions of the batch-norm backward.
     out: gradient-arena slot to ACCUMULATE colsum(dx) into (then the second return value is `out`)."""
     _chk(dy, 'dy'); _chk(y, 'y')
     C = dy.shape[-1]
@@ -350,7 +366,8 @@ def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None):
     if _live(dy):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(dy, need)
-        check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), rows, C, act, alpha, _ptr(dx), _ptr(s), _ptr(s2),
+        check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), _ptr(_chk(center, 'center') if center is not None else None), rows, C,
+                                     act, alpha, _ptr(dx), _ptr(s), _ptr(s2),
                                      1 if out is not None else 0, wsp, wsn, _stream()), 't2i_act_bwd_colsum')
     return (dx, s) if x2 is None else (dx, s, s2)
 
@@ -575,8 +592,8 @@ def ca_kl_bwd(mean, log_sigma, eps, dcode, dkl):
     return dmean, dls
 
 
-ALGO_NAMES = ('implicit_gemm', 'winograd_f2x2_3x3', 'winograd_f2x2_2x2', 'direct_small')
-ALGO_MAC_RATIO = (1.0, 1.0 / 2.25, 9.0 / 16.0, 1.0)       # executed / direct-convolution multiply-adds
+ALGO_NAMES = ('implicit_gemm', 'winograd_f2x2_3x3', 'winograd_f2x2_2x2', 'direct_small', 'implicit_gemm_bf16_operands')
+ALGO_MAC_RATIO = (1.0, 1.0 / 2.25, 9.0 / 16.0, 1.0, 1.0)       # executed / direct-convolution multiply-adds
 
 
 def conv_algo(d, which):
