@@ -38,7 +38,8 @@ def _worker(rank, world, port, mode, q):
         shapes = [(5, 7), (3,), (4, 4, 2, 6), (9,), (1001,), (2, 3)]
         params = OrderedDict(('p%d' % i, torch.randn(s).requires_grad_(True)) for i, s in enumerate(shapes))
         arena = optim.Arena(params)
-        dp = DataParallel(bucket_bytes=400)        # tiny buckets -> several of them, exercised in reverse order
+        # 'bf16': buckets are exchanged as bf16 and written back into the fp32 arena (BASELINE config 3)
+        dp = DataParallel(bucket_bytes=400, grad_dtype='bf16' if mode == 'bf16' else 'f32')        # tiny buckets -> several of them, exercised in reverse order
         plan = dp._plan(arena)
         # buckets tile the arena exactly once, last-created parameters first
         covered = sorted((s, e) for s, e, _ in plan)
@@ -85,7 +86,7 @@ def _worker(rank, world, port, mode, q):
             q.put((rank, 'ok'))
             return
         arena.zero_grad()
-        if mode in ('hooks', 'unused'):
+        if mode in ('hooks', 'unused', 'bf16'):
             dp.arm(arena)                           # overlap path: hooks launch buckets as they complete
         loss_fn().backward(inputs=list(params.values()))
         extra = torch.tensor(float(rank + 1))
@@ -99,7 +100,12 @@ def _worker(rank, world, port, mode, q):
         dist.all_gather_object(gathered, {n: v.clone() for n, v in local.items()})
         for n in params:
             want = sum(g[n] for g in gathered)
-            assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n
+            if mode == 'bf16':     # each rank's contribution was rounded to bf16 (2^-9 relative) before the sum, which is again bf16
+                want = sum(g[n].bfloat16() for g in gathered).float()
+                assert torch.allclose(arena.grad_of(n), want, rtol=2e-2, atol=1e-2), n
+                assert arena.grad_of(n).dtype == torch.float32
+            else:
+                assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n
             assert params[n].grad.data_ptr() == arena.grad_of(n).data_ptr()     # still views of the arena
         dp.broadcast_variables(type('S', (), {'vars': params})())
         dist.barrier()
@@ -219,7 +225,7 @@ def _sinks_mode(dp, arena, params, data, rank, world):
     A.SINKS.clear()
 
 
-@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd', 'kt'])
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd', 'kt', 'bf16'])
 def test_dp_allreduce_two_ranks(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -25,7 +25,10 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, bucket_bytes=32 << 20, process_group=None, grad_dtype='f32'):
+        """grad_dtype: 'f32' (exchange the fp32 arena in place) or 'bf16' (BASELINE config 3: a bucket is rounded to bf16
+        into a staging buffer, all-reduced in bf16 — half the bytes on every xGMI link — and written back into the fp32
+        arena on arrival; the optimizer and its moments stay fp32)."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed must be initialised (init_process_group) before DataParallel')
         self.group = process_group
@@ -35,6 +38,10 @@ class DataParallel(object):
         self._arenas = {}
         self._by_ptr = {}
         self._side = None
+        if grad_dtype not in ('f32', 'bf16'):
+            raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (grad_dtype,))
+        self.grad_dtype = grad_dtype
+        self._stage = {}                      # id(arena) -> bf16 staging buffer of the arena's size
         # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
         self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
 
@@ -152,6 +159,12 @@ class DataParallel(object):
 
     def _launch_range(self, st, start, end):
         buf = st['arena'].grad[start:end]
+        stage = None
+        if self.grad_dtype == 'bf16':
+            full = self._stage.get(id(st['arena']))
+            if full is None:
+                full = self._stage[id(st['arena'])] = torch.empty(st['arena'].numel, dtype=torch.bfloat16, device=buf.device)
+            stage = full[start:end]
         if buf.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=buf.device)
@@ -160,9 +173,19 @@ class DataParallel(object):
             if A.SIDE.stream is not None:                                   # ... including the filter-gradient stream's
                 self._side.wait_stream(A.SIDE.stream)
             with torch.cuda.stream(self._side):
-                st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
+                if stage is None:
+                    st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:                # fp32 -> bf16 (RNE), exchange, bf16 -> fp32, all ordered on the communication stream
+                    stage.copy_(buf)
+                    w = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    w.wait()
+                    buf.copy_(stage)
+        elif stage is None:
             st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            stage.copy_(buf)
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(stage)
 
     def allreduce_arena(self, arena, extra=None):
         """Finish the exchange for `arena` (launch whatever the hooks did not, wait) and return the factor that turns the
