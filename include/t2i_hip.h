@@ -121,6 +121,13 @@ int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chun
 int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2, void* ws, size_t ws_bytes, t2i_stream_t stream);
 int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,
                        float* sum, float* m2, t2i_stream_t stream);
+/* Statistics AND the finalize step in one chain (stage 1 + one stage-2 launch): exactly one of x (the tensor, [rows, C];
+ * workspace as t2i_col_reduce) or the tile partials of t2i_conv2d_fwd_stats (part_sum / part_m2 / chunks / tile_rows).
+ * Outputs as t2i_bn_finalize.  What the training-mode batch norm of utils/ops.py:7-29 launches in front of t2i_bn_apply. */
+int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
+                           int32_t C, const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd,
+                           float* scale, float* shift, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes,
+                           t2i_stream_t stream);
 /* From sum and the centred second moment m2 over n rows: mean, rstd = 1/sqrt(m2/n + eps) (biased variance);
  * scale = gamma*rstd, shift = beta-mean*scale; and, if moving_mean != NULL,
  * moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
@@ -136,6 +143,14 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
                const float* sum_dy, const float* sum_dy_x, int64_t rows, int32_t C, float* dx, float* dgamma,
                float* dbeta, int accumulate /* dgamma/dbeta += */, void* ws /* >= 3*C floats */, size_t ws_bytes,
                t2i_stream_t stream);
+
+/* The whole training-mode batch-norm backward in three launches: [g = dy*act'(y) and the reductions sum g, sum g*(x - mean),
+ * stage 1] -> [stage 2 + dgamma/dbeta + the coefficients of dx] -> [dx = k_dy*g + k_x*x + k_0].  y == NULL: no activation
+ * behind the batch norm (g = dy, gmask unused).  gmask: caller's [rows, C] buffer for g.  C % 4 == 0, 16-byte alignment. */
+size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C);
+int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
+                     int32_t C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     size_t ws_bytes, t2i_stream_t stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------------- */
 /* y = act(x) */

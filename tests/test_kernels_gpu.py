@@ -92,6 +92,22 @@ def test_batch_norm_golden(K, golden_ops, tag):
     dx, dgamma, dbeta = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx)
     assert relerr(dx, g('dx')) <= GRAD_TOL
     assert relerr(dgamma, g('dgamma')) <= GRAD_TOL and relerr(dbeta, g('dbeta')) <= GRAD_TOL
+    # the fused chains the batch norm Function launches: statistics + finalize in one, backward in three launches
+    mm2, mv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    mean2, rstd2, scale2, shift2 = K.bn_train_stats(x, gamma, beta, 1e-5, 0.9, mm2, mv2)
+    for a, b_ in ((mean2, mean), (rstd2, rstd), (scale2, scale), (shift2, shift), (mm2, mm), (mv2, mv)):
+        assert torch.equal(a, b_)
+    if C % 4 == 0:
+        dx2, dgamma2, dbeta2 = K.bn_bwd_fused(dy, None, x, mean, rstd, gamma, K.ACT_NONE)
+        assert torch.equal(dx2, dx) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+        yr = K.bn_apply(x, scale, shift, K.ACT_RELU)                      # with an activation behind the batch norm
+        gm = K.act_bwd(dy, yr, K.ACT_RELU)
+        s1, s2 = K.col_reduce(gm, x, True, center=mean)
+        want = K.bn_bwd(gm, x, mean, rstd, gamma, s1, s2)
+        acc_g, acc_b = torch.full((C,), 0.5, device='cuda'), torch.full((C,), -0.25, device='cuda')
+        got = K.bn_bwd_fused(dy, yr, x, mean, rstd, gamma, K.ACT_RELU, dgamma_out=acc_g, dbeta_out=acc_b)
+        assert torch.equal(got[0], want[0])
+        assert relerr(acc_g, (want[1] + 0.5).double().cpu().numpy()) <= 1e-6 and relerr(acc_b, (want[2] - 0.25).double().cpu().numpy()) <= 1e-6
 
 
 def test_adam_golden(K, golden_ops):
@@ -541,3 +557,26 @@ def test_bn_stats_are_stable_against_a_large_mean(K, rows, C, offset):
     sdy, sdyxc = K.col_reduce(dev(dy), dev(x), True, center=mean)
     ref = (dy.astype(np.float64) * (xd - mean.double().cpu().numpy())).sum(0)
     assert float(np.abs(sdyxc.double().cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-4
+
+
+@pytest.mark.parametrize('B,H', [(2, 64), (3, 16), (64, 64)])
+def test_stem_conv_forward(K, B, H):
+    """The critic's first layer (3 -> 128 channels, k4 s2 SAME) on its dedicated kernel: image rows staged in LDS, no K loop,
+    8*3 MFMA steps per 32 output channels; vs the float64 oracle at the forward tolerance, with bias + lrelu fused."""
+    from oracle import np_ops as O
+    rng = np.random.default_rng(B + H)
+    x = rng.uniform(-1, 1, (B, H, H, 3)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, 3, 128)) / np.sqrt(48)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    d, ws = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+    assert K.conv_algo(d, 'fwd') == 'direct_small'
+    y = K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2)
+    if B <= 3:
+        assert relerr(y, O.lrelu(O.conv2d(x, w, b, (2, 2), 'SAME'))) <= FWD_TOL
+    K.tuning_set('no_thin', 1)               # the general implicit-GEMM path computes the same thing
+    try:
+        d2, ws2 = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+        y2 = K.conv_fwd(dev(x), dev(w), dev(b), d2, max(ws2, 64 << 20), K.ACT_LRELU, 0.2)
+    finally:
+        K.tuning_set('no_thin', 0)
+    assert relerr(y, y2.double().cpu().numpy()) <= 2e-6

@@ -67,12 +67,18 @@ def test_tiny_step_matches_golden(gpu, golden_step):
         assert abs(float(d[k]) - ref) <= 1e-4 * max(abs(ref), 1.0), (k, float(d[k]), ref)
     for n in m.d_vars:
         _check_grad(m.d_arena.grad_of(n), gs['d/grad/' + n], n)
+    print('tiny wgancls: worst critic gradient error %.2e; losses %s' % (
+        max(relerr(m.d_arena.grad_of(n), gs['d/grad/' + n], floor=1e-30) for n in m.d_vars if np.abs(gs['d/grad/' + n]).max() >= 1e-9),
+        {k: '%.1e' % (abs(float(d[k]) - float(gs['d/' + k])) / max(abs(float(gs['d/' + k])), 1.0)) for k in ('D_loss', 'wdist', 'real_gp', 'real_gp2')}))
     g = m.g_losses(feed)
     assert abs(float(g['G_loss']) - float(gs['g/G_loss'])) <= 1e-4 * max(abs(float(gs['g/G_loss'])), 1.0)
     assert abs(float(g['G_kl_loss']) - float(gs['g/G_kl_loss'])) <= 1e-4 * max(abs(float(gs['g/G_kl_loss'])), 1.0)
     assert relerr(g['G'], gs['g/G']) <= 1e-4
     for n in m.g_vars:
         _check_grad(m.g_arena.grad_of(n), gs['g/grad/' + n], n)
+    print('tiny wgancls: worst generator gradient error %.2e; G_loss %.1e G %.1e' % (
+        max(relerr(m.g_arena.grad_of(n), gs['g/grad/' + n], floor=1e-30) for n in m.g_vars if np.abs(gs['g/grad/' + n]).max() >= 1e-9),
+        abs(float(g['G_loss']) - float(gs['g/G_loss'])) / max(abs(float(gs['g/G_loss'])), 1.0), relerr(g['G'], gs['g/G'])))
 
 
 def _check_grad(got, ref, name, tol=1e-3):

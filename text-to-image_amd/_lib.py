@@ -30,6 +30,9 @@ SIGNATURES = {
     't2i_col_reduce': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_bn_stats': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
     't2i_bn_stats_tiles': (ctypes.c_int, [_p, _p, _i32, _i32, _i64, _i32, _p, _p, _p]),
+    't2i_bn_train_fwd_stats': (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    't2i_bn_bwd_fused_workspace_bytes': (_sz, [_i64, _i32]),
+    't2i_bn_bwd_fused': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_bn_finalize': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p]),
     't2i_bn_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),

@@ -352,9 +352,9 @@ class BatchNormTrainFn(Function):
         x = _c(x)
         C = x.shape[-1]
         n = x.numel() // C
-        hit = K.take_stats(x)                     # left by the producing conv's epilogue (ops.conv2d(..., stats=True))
-        s, ss = hit if hit is not None else K.bn_stats(x)     # (sum, sum (x - mean)^2): stable moments, not sum x^2
-        mean, rstd, scale, shift = K.bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean, moving_var)
+        # statistics (the producing conv's epilogue partials when ops.conv2d(..., stats=True) left any, else a pass over x;
+        # numerically stable either way) and the finalize step in one chain of launches
+        mean, rstd, scale, shift = K.bn_train_stats(x, gamma, beta, eps, decay, moving_mean, moving_var)
         y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
         ctx.act, ctx.alpha = act, alpha
@@ -370,9 +370,8 @@ class BatchNormTrainFn(Function):
             return (None,) * 9
         x, gamma, mean, rstd, y = ctx.saved_tensors
         gy = _c(gy)
-        if ctx.act != K.ACT_NONE and gy.shape[-1] % 4 == 0:
-            gy, sum_dy, sum_dy_x = K.act_bwd_colsum(gy, y, ctx.act, ctx.alpha, x2=x, center=mean)    # mask + both reductions, one pass
-        else:
+        fused = gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x, mean))
+        if not fused:
             if ctx.act != K.ACT_NONE:
                 gy = K.act_bwd(gy, y, ctx.act, ctx.alpha)
             sum_dy, sum_dy_x = K.col_reduce(gy, x, True, center=mean)     # sum dy, sum dy * (x - mean)
@@ -381,11 +380,16 @@ class BatchNormTrainFn(Function):
         want_g, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gsink = _sink_of(ctx.gamma_ref) if want_g else None
         bsink = _sink_of(ctx.beta_ref) if want_b else None
-        if gsink is not None and bsink is not None:
-            dx, _, _ = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=gsink, dbeta_out=bsink)
+        sunk = gsink is not None and bsink is not None
+        if fused:            # [act backward + both reductions] -> [second stage + coefficients] -> [dx]: three launches
+            dx, dgamma, dbeta = K.bn_bwd_fused(gy, y if ctx.act != K.ACT_NONE else None, x, mean, rstd, gamma, ctx.act, ctx.alpha,
+                                               dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
+        else:
+            dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=gsink if sunk else None,
+                                         dbeta_out=bsink if sunk else None)
+        if sunk:
             _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
             return dx, None, None, None, None, None, None, None, None
-        dx, dgamma, dbeta = K.bn_bwd(gy, x, mean, rstd, gamma, sum_dy, sum_dy_x)
         return dx, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None, None
 
 

@@ -300,6 +300,28 @@ hipError_t col_reduce_launch(const float* a, const float* b, const float* center
 // ---------------------------------------------------------------------------------------------------------------
 struct Agg { float n, mean, m2; };
 
+// Optional tail of the statistics' second stage: what bn_finalize_kernel does, done by the thread that already holds the
+// column's (n, mean, M2) — one launch less per batch norm (20 per wgancls iteration).  gamma == nullptr: not requested.
+struct BnFin {
+  const float* gamma; const float* beta; float eps, decay;
+  float* mean; float* rstd; float* scale; float* shift; float* mmean; float* mvar;
+};
+
+__device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float mu, float m2) {
+  const float var = fmaxf(m2, 0.f) / n;                      // biased batch variance
+  const float rs = rsqrtf(var + f.eps);
+  f.mean[c] = mu;
+  f.rstd[c] = rs;
+  const float sc = f.gamma[c] * rs;
+  f.scale[c] = sc;
+  f.shift[c] = f.beta[c] - mu * sc;
+  if (f.mmean) {                                             // TF fused BN: the moving variance takes the UNBIASED estimate
+    const float unb = var * (n / fmaxf(n - 1.f, 1.f));
+    f.mmean[c] = f.decay * f.mmean[c] + (1.f - f.decay) * mu;
+    f.mvar[c] = f.decay * f.mvar[c] + (1.f - f.decay) * unb;
+  }
+}
+
 __device__ __forceinline__ Agg agg_merge(Agg a, Agg b) {
   if (b.n == 0.f) return a;
   if (a.n == 0.f) return b;
@@ -315,7 +337,7 @@ __device__ __forceinline__ Agg agg_merge(Agg a, Agg b) {
 template <bool TILES>
 __global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__ part0, const float* __restrict__ part1,
                                                        const float* __restrict__ x, int nchunks, int64_t rows, int64_t rows_per_chunk,
-                                                       int C, float* __restrict__ sum, float* __restrict__ m2) {
+                                                       int C, float* __restrict__ sum, float* __restrict__ m2, BnFin fin) {
   __shared__ float sn[4][64], sm[4][64], sq[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -345,8 +367,8 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__
     Agg r = {sn[0][tx], sm[0][tx], sq[0][tx]};
 #pragma unroll
     for (int k = 1; k < 4; ++k) r = agg_merge(r, Agg{sn[k][tx], sm[k][tx], sq[k][tx]});
-    sum[c] = r.mean * r.n;
-    m2[c] = r.m2;
+    if (sum) { sum[c] = r.mean * r.n; m2[c] = r.m2; }
+    if (fin.gamma) bn_fin_col(fin, c, r.n, r.mean, r.m2);
   }
 }
 
@@ -371,7 +393,8 @@ __device__ __forceinline__ Agg4 agg4_merge(const Agg4& a, const Agg4& b) {
 template <bool TILES>
 __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restrict__ part0, const float* __restrict__ part1,
                                                           const float* __restrict__ x, int nchunks, int64_t rows,
-                                                          int64_t rows_per_chunk, int C, float* __restrict__ sum, float* __restrict__ m2) {
+                                                          int64_t rows_per_chunk, int C, float* __restrict__ sum, float* __restrict__ m2,
+                                                          BnFin fin) {
   __shared__ float sn[16][16];
   __shared__ float4 sm[16][16], sq[16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -412,36 +435,53 @@ __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restric
       b.n = sn[k][tx]; b.mean = sm[k][tx]; b.m2 = sq[k][tx];
       r = agg4_merge(r, b);
     }
-    const float so[4] = {r.mean.x * r.n, r.mean.y * r.n, r.mean.z * r.n, r.mean.w * r.n};
+    const float mu[4] = {r.mean.x, r.mean.y, r.mean.z, r.mean.w};
     const float mo[4] = {r.m2.x, r.m2.y, r.m2.z, r.m2.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sum[c + e] = so[e]; m2[c + e] = mo[e]; }
+    for (int e = 0; e < 4; ++e) {
+      if (sum) { sum[c + e] = mu[e] * r.n; m2[c + e] = mo[e]; }
+      if (fin.gamma) bn_fin_col(fin, c + e, r.n, mu[e], mo[e]);
+    }
   }
 }
 
 template <bool TILES>
 static void bn_stats_stage2_launch(const float* part0, const float* part1, const float* x, int nc, int64_t rows, int64_t rpc, int C,
-                                   float* sum, float* m2, hipStream_t stream) {
+                                   float* sum, float* m2, const BnFin& fin, hipStream_t stream) {
   const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(part0) | reinterpret_cast<uintptr_t>(part1) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   if (v4)
-    hipLaunchKernelGGL(bn_stats_stage2_v4<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2);
+    hipLaunchKernelGGL(bn_stats_stage2_v4<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
   else
-    hipLaunchKernelGGL(bn_stats_stage2<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2);
+    hipLaunchKernelGGL(bn_stats_stage2<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
 }
 
-hipError_t bn_stats_launch(const float* x, int64_t rows, int C, float* sum, float* m2, void* ws, hipStream_t stream) {
+static BnFin make_fin(const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd, float* scale, float* shift,
+                      float* mm, float* mv) {
+  BnFin f;
+  f.gamma = gamma; f.beta = beta; f.eps = eps; f.decay = decay;
+  f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift; f.mmean = mm; f.mvar = mv;
+  return f;
+}
+
+// gamma == nullptr: statistics only (sum, m2); else the batch norm's mean / rstd / scale / shift (+ moving averages) as well
+hipError_t bn_stats_launch(const float* x, int64_t rows, int C, float* sum, float* m2, const float* gamma, const float* beta, float eps,
+                           float decay, float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, void* ws,
+                           hipStream_t stream) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
   col_reduce_stage1_launch(x, nullptr, rows, C, true, 1, nullptr, ct, nc, rpc, part0, part1, stream);
-  bn_stats_stage2_launch<false>(part0, part1, x, nc, rows, rpc, C, sum, m2, stream);
+  bn_stats_stage2_launch<false>(part0, part1, x, nc, rows, rpc, C, sum, m2, make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv),
+                                stream);
   return hipGetLastError();
 }
 
 hipError_t bn_stats_tiles_launch(const float* part_sum, const float* part_m2, int chunks, int tile_rows, int64_t rows, int C, float* sum,
-                                 float* m2, hipStream_t stream) {
-  bn_stats_stage2_launch<true>(part_sum, part_m2, (const float*)nullptr, chunks, rows, (int64_t)tile_rows, C, sum, m2, stream);
+                                 float* m2, const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd,
+                                 float* scale, float* shift, float* mm, float* mv, hipStream_t stream) {
+  bn_stats_stage2_launch<true>(part_sum, part_m2, (const float*)nullptr, chunks, rows, (int64_t)tile_rows, C, sum, m2,
+                               make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv), stream);
   return hipGetLastError();
 }
 
@@ -513,6 +553,52 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* 
   k_0[c] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
 }
 
+// second stage of the two backward reductions (sum dy, sum dy*(x - mean)) fused with bn_bwd_coef_kernel: the thread that
+// finishes a column's sums turns them into dgamma, dbeta and the three coefficients of dx = k_dy*dy + k_x*x + k_0
+__global__ __launch_bounds__(256) void bn_bwd_stage2_coef_v4(const float* __restrict__ part0, const float* __restrict__ part1, int nchunks,
+                                                             int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, float n, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ k_dy, float* __restrict__ k_x,
+                                                             float* __restrict__ k_0, int accumulate) {
+  __shared__ float4 red[16][16], red1[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    for (int k = ty; k < nchunks; k += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c);
+      const float4 w = *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c);
+      a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+      a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+    }
+  }
+  red[ty][tx] = a0;
+  red1[ty][tx] = a1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float4 s0 = red[0][tx], s1 = red1[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][tx], w = red1[k][tx];
+      s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+      s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+    }
+    const float sd[4] = {s0.x, s0.y, s0.z, s0.w}, sx[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cc = c + e;
+      const float mu = mean[cc], rs = rstd[cc], g = gamma[cc], sdy = sd[e];
+      const float sdyxh = rs * sx[e];
+      dgamma[cc] = accumulate ? dgamma[cc] + sdyxh : sdyxh;
+      dbeta[cc] = accumulate ? dbeta[cc] + sdy : sdy;
+      const float grs = g * rs;
+      k_dy[cc] = grs;
+      k_x[cc] = -grs * rs * sdyxh / n;
+      k_0[cc] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
+    }
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ k_dy, const float* __restrict__ k_x,
@@ -582,6 +668,13 @@ hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, con
                        C, dx);
   return hipGetLastError();
 }
+
+// Whole batch-norm backward in three launches (C % 4 == 0, 16-byte aligned): [activation backward + the two reductions,
+// stage 1] -> [stage 2 + coefficients] -> [dx].  y == nullptr: no activation in front (gy is used as it is).  gmask: the
+// masked gradient dy*act'(y), written by stage 1 and read by the last launch (caller's buffer, may alias nothing else).
+hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               int64_t rows, int C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta,
+                               int accumulate, void* ws, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // elementwise (float4 body + scalar tail handled by the same kernel)
@@ -689,6 +782,30 @@ hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x
                        dx, part, part1);
   hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
                      sum0, second ? sum1 : (float*)nullptr, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               int64_t rows, int C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta,
+                               int accumulate, void* ws, hipStream_t stream) {
+  int ct, nc; int64_t rpc;
+  col_reduce_plan(rows, C, &ct, &nc, &rpc);
+  float* part = reinterpret_cast<float*>(ws);
+  float* part1 = part + (size_t)nc * C;
+  float* coef = part1 + (size_t)nc * C;              // 3*C floats behind the partials
+  const float* g = dy;
+  if (y) {
+    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha, gmask, part,
+                       part1);
+    g = gmask;
+  } else {
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean);
+  }
+  float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
+  hipLaunchKernelGGL(bn_bwd_stage2_coef_v4, dim3(ct), dim3(256), 0, stream, part, part1, nc, C, mean, rstd, gamma, (float)rows, dgamma, dbeta,
+                     k_dy, k_x, k_0, accumulate);
+  const size_t n = (size_t)rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx);
   return hipGetLastError();
 }
 

@@ -24,8 +24,12 @@ void set_error(const char* fmt, ...) {
 // launchers implemented in t2i_aux.hip
 size_t col_reduce_ws(int64_t rows, int C);
 hipError_t col_reduce_launch(const float*, const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
-hipError_t bn_stats_launch(const float*, int64_t, int, float*, float*, void*, hipStream_t);
-hipError_t bn_stats_tiles_launch(const float*, const float*, int, int, int64_t, int, float*, float*, hipStream_t);
+hipError_t bn_stats_launch(const float*, int64_t, int, float*, float*, const float*, const float*, float, float, float*, float*, float*,
+                           float*, float*, float*, void*, hipStream_t);
+hipError_t bn_stats_tiles_launch(const float*, const float*, int, int, int64_t, int, float*, float*, const float*, const float*, float, float,
+                                 float*, float*, float*, float*, float*, float*, hipStream_t);
+hipError_t bn_bwd_fused_launch(const float*, const float*, const float*, const float*, const float*, const float*, int64_t, int, int, float,
+                               float*, float*, float*, float*, int, void*, hipStream_t);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t);
@@ -64,6 +68,8 @@ bool head_conv_eligible(const t2i_conv_desc& d);
 hipError_t head_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
 hipError_t head_bwd_data_launch(const t2i_conv_desc&, const float*, const float*, float*, hipStream_t);
 hipError_t head_bwd_filter_launch(const t2i_conv_desc&, const float*, const float*, float*, int, hipStream_t);
+bool stem_fwd_eligible(const t2i_conv_desc& d);
+hipError_t stem_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
 bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
 hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
 
@@ -494,6 +500,8 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
     if (tiny_conv_eligible(*d, false))
       return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
+    if (stem_fwd_eligible(*d) && aligned16(w))
+      return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(stem)");
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
@@ -600,7 +608,47 @@ int t2i_col_reduce(const float* a, const float* b, const float* center, int64_t 
 int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!x || !sum || !m2 || rows <= 0 || C <= 0) { set_error("t2i_bn_stats: bad argument"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_bn_stats: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(bn_stats_launch(x, rows, C, sum, m2, ws, (hipStream_t)stream), "t2i_bn_stats");
+  return check(bn_stats_launch(x, rows, C, sum, m2, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws,
+                               (hipStream_t)stream), "t2i_bn_stats");
+}
+
+int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
+                           int32_t C, const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd,
+                           float* scale, float* shift, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes,
+                           t2i_stream_t stream) {
+  if (!gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || ((moving_mean == nullptr) != (moving_var == nullptr)) ||
+      ((x == nullptr) == (part_sum == nullptr)) || (part_sum && (!part_m2 || chunks <= 0 || tile_rows <= 0))) {
+    set_error("t2i_bn_train_fwd_stats: bad argument (exactly one of x / tile partials)");
+    return T2I_ERR_INVALID;
+  }
+  if (x) {
+    if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_bn_train_fwd_stats: workspace too small"); return T2I_ERR_WORKSPACE; }
+    return check(bn_stats_launch(x, rows, C, nullptr, nullptr, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, ws,
+                                 (hipStream_t)stream), "t2i_bn_train_fwd_stats");
+  }
+  return check(bn_stats_tiles_launch(part_sum, part_m2, chunks, tile_rows, rows, C, nullptr, nullptr, gamma, beta, eps, decay, mean, rstd, scale,
+                                     shift, moving_mean, moving_var, (hipStream_t)stream), "t2i_bn_train_fwd_stats");
+}
+
+size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return col_reduce_ws(rows, C) + (size_t)3 * C * sizeof(float);
+}
+
+int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
+                     int32_t C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     size_t ws_bytes, t2i_stream_t stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || (y && !gmask)) {
+    set_error("t2i_bn_bwd_fused: bad argument (C % 4 == 0 required; gmask needed with an activation)");
+    return T2I_ERR_INVALID;
+  }
+  if (!(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(mean) && (!y || (aligned16(y) && aligned16(gmask))))) {
+    set_error("t2i_bn_bwd_fused: tensors must be 16-byte aligned");
+    return T2I_ERR_INVALID;
+  }
+  if (!ws || ws_bytes < t2i_bn_bwd_fused_workspace_bytes(rows, C) || !aligned16(ws)) { set_error("t2i_bn_bwd_fused: workspace too small"); return T2I_ERR_WORKSPACE; }
+  return check(bn_bwd_fused_launch(dy, y, x, mean, rstd, gamma, rows, C, act, alpha, gmask, dx, dgamma, dbeta, accumulate ? 1 : 0, ws,
+                                   (hipStream_t)stream), "t2i_bn_bwd_fused");
 }
 
 int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,
@@ -610,7 +658,8 @@ int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chun
     set_error("t2i_bn_stats_tiles: bad argument");
     return T2I_ERR_INVALID;
   }
-  return check(bn_stats_tiles_launch(part_sum, part_m2, chunks, tile_rows, rows, C, sum, m2, (hipStream_t)stream), "t2i_bn_stats_tiles");
+  return check(bn_stats_tiles_launch(part_sum, part_m2, chunks, tile_rows, rows, C, sum, m2, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream), "t2i_bn_stats_tiles");
 }
 
 int t2i_col_reduce_partials(const float* part0, const float* part1, int32_t chunks, int32_t C, float* out0, float* out1,
@@ -828,7 +877,7 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
   if (validate_desc(d) || which < 0 || which > 2) return -1;
   const bool thin = !tuning().no_thin;
   if (which == 0) {
-    if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, false))) return T2I_ALGO_DIRECT_SMALL;
+    if (thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, false) || stem_fwd_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
     if (h_eligible(*d, false)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_2X2;

@@ -284,6 +284,96 @@ hipError_t head_bwd_filter_launch(const t2i_conv_desc& d, const float* x, const 
 
 }  // namespace t2i
 
+// ------------------------------------------------------------------------------------------------------------------
+// First critic layer (and the input gradient of the generator's last deconv): y = act(conv_k4s2(x[B,H,W,CI<=4], w) + b)
+// with Cout a multiple of 32.  As an implicit GEMM its K is 16*CI = 48: the general kernel spends its time in prologue
+// and in 12 scalar gathers per float4 (28 us at B = 64 for 36.7 MB of traffic).  Here one workgroup owns 4 output rows of
+// one image (4 x 32 pixels = a 128-row GEMM tile) and there is no K loop at all:
+//   * the 10 input rows it needs (+ one zero pixel left and right) go to LDS with coalesced loads, the whole filter
+//     [16*CI][Cout] next to them;
+//   * wave w = output row, lane = output column: the MFMA A operand of step k = (kh, kw, ci) is one ds_read_b32 at
+//     row 2w + kh, pixel 2 ow + kw (stride 6 floats across lanes: conflict free), the B operand a row of the filter;
+//   * 8*CI MFMA steps (v_mfma_f32_32x32x2_f32) per 32 output channels, bias + activation in registers, 128-byte stores.
+// The 3-channel ends of the nets are HBM-bound: this moves them from ~1.3 TB/s towards the stream rate.
+// ------------------------------------------------------------------------------------------------------------------
+namespace t2i {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int CI, int NB>      // NB = Cout / 32 accumulator blocks per wave (4 for the critic's 128 channels)
+__global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                            int act, float alpha) {
+  constexpr int K = 16 * CI, Co = 32 * NB;
+  extern __shared__ __attribute__((aligned(16))) float lds_stem[];
+  const int Wo = W >> 1, Ho = H >> 1;
+  const int RL = (W + 2) * CI;                 // padded row length in floats
+  float* xs = lds_stem;                        // [10][RL]
+  float* ws = lds_stem + 10 * RL;              // [K][Co]
+  const int tiles_w = Wo >> 5;                 // 32 output columns per tile
+  const int b = blockIdx.z, oh0 = blockIdx.y * 4, ow0 = blockIdx.x * 32;
+  (void)tiles_w;
+  // ---- stage input rows 2*oh0-1 .. 2*oh0+8, columns 2*ow0-1 .. 2*ow0+64, zero outside the image ---------------------------
+  const int cols = 66 * CI;                    // 32 output columns need 66 input pixels
+  for (int i = threadIdx.x; i < 10 * cols; i += 256) {
+    const int r = i / cols, j = i - r * cols;
+    const int px = j / CI, ci = j - px * CI;
+    const int ih = 2 * oh0 - 1 + r, iw = 2 * ow0 - 1 + px;
+    float v = 0.f;
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((size_t)(b * H + ih) * W + iw) * CI + ci];
+    xs[r * cols + j] = v;
+  }
+  for (int i = threadIdx.x; i < K * Co / 4; i += 256) reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16_t acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  // k = (kh*4 + kw)*CI + ci; MFMA step s consumes k = 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+#pragma unroll
+  for (int s2 = 0; s2 < K / 2; ++s2) {
+    const int k = 2 * s2 + lh;
+    const int tap = k / CI, ci = k - tap * CI;
+    const int kh = tap >> 2, kw = tap & 3;
+    const float a = xs[(2 * wave + kh) * cols + (2 * l31 + kw) * CI + ci];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ws[k * Co + j * 32 + l31], acc[j], 0, 0, 0);
+  }
+  // ---- epilogue: C/D layout col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*lh (output column) -------------------------
+  const int oh = oh0 + wave;
+  if (oh < Ho) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float bv = bias ? bias[j * 32 + l31] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ow = ow0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (ow < Wo) y[((size_t)(b * Ho + oh) * Wo + ow) * Co + j * 32 + l31] = apply_act(acc[j][e] + bv, act, alpha);
+      }
+    }
+  }
+}
+
+bool stem_fwd_eligible(const t2i_conv_desc& d) {
+  return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin == 3 && d.Cout == 128 &&
+         (d.H & 1) == 0 && (d.W & 1) == 0 && d.Ho * 2 == d.H && d.Wo * 2 == d.W && d.math == T2I_MATH_F32;
+}
+
+hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                           hipStream_t stream) {
+  const size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * 128) * sizeof(float);
+  auto k = stem_k4s2_fwd_kernel<3, 4>;
+  dim3 grid((d.Wo + 31) / 32, (d.Ho + 3) / 4, d.B);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, x, w, bias, y, d.H, d.W, act, alpha);
+  return hipGetLastError();
+}
+
+}  // namespace t2i
+
 // Measured and dropped (round 1): direct VALU kernels for the Cin = 3 k4 s2 forward / filter gradient (critic layer 1).
 // Three variants (LDS-broadcast patch, multi-row, SGPR patch via s_load) all ran 34-38 us at B = 64 against 31 us for the
 // igemm path: 48 dependent scalar-fp32 FMAs per output sit at the non-packed VALU rate (~10 us) and the per-pixel

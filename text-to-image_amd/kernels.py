@@ -206,6 +206,50 @@ def take_stats(x):
     return s0, s1
 
 
+def bn_train_stats(x, gamma, beta, eps, decay, moving_mean=None, moving_var=None):
+    """Batch statistics of x (view [rows, C]) and the batch norm's finalize step in one chain -> (mean, rstd, scale, shift);
+    moving averages updated in place when given.  Uses the producing conv's epilogue partials when it left any (take_stats)."""
+    _chk(x, 'x')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(4))
+    if _live(x):
+        hit = _STATS.pop(x.data_ptr(), None)
+        if hit is not None and tuple(x.shape) != hit[3]:
+            hit = None
+        if hit is not None:
+            part, chunks, tile_rows, _ = hit
+            check(lib.t2i_bn_train_fwd_stats(None, _ptr(part), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks, tile_rows, rows, C,
+                                             _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift),
+                                             _ptr(moving_mean), _ptr(moving_var), None, 0, _stream()), 't2i_bn_train_fwd_stats')
+        else:
+            wsp, wsn = _ws_args(x, int(lib.t2i_col_reduce_workspace_bytes(rows, C)))
+            check(lib.t2i_bn_train_fwd_stats(_ptr(x), None, None, 0, 0, rows, C, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(mean),
+                                             _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(moving_mean), _ptr(moving_var), wsp, wsn, _stream()),
+                  't2i_bn_train_fwd_stats')
+    return mean, rstd, scale, shift
+
+
+def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, dbeta_out=None):
+    """Training-mode batch-norm backward in three launches (C % 4 == 0).  y: the activation output behind the batch norm or
+    None.  -> (dx, dgamma, dbeta); dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into."""
+    _chk(dy, 'dy'); _chk(x, 'x')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    gmask = torch.empty_like(x) if y is not None else None
+    acc = dgamma_out is not None
+    assert acc == (dbeta_out is not None)
+    dgamma = dgamma_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, int(lib.t2i_bn_bwd_fused_workspace_bytes(rows, C)))
+        check(lib.t2i_bn_bwd_fused(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
+                                   rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
+                                   _stream()), 't2i_bn_bwd_fused')
+    return dx, dgamma, dbeta
+
+
 def bn_stats(x):
     """x viewed as [rows, C] -> (sum over rows, sum over rows of (x - mean)^2), numerically stable (t2i_bn_stats)."""
     _chk(x, 'x')
