@@ -307,14 +307,11 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
   constexpr int K = 16 * CI, Co = 32 * NB;
   extern __shared__ __attribute__((aligned(16))) float lds_stem[];
   const int Wo = W >> 1, Ho = H >> 1;
-  const int RL = (W + 2) * CI;                 // padded row length in floats
-  float* xs = lds_stem;                        // [10][RL]
-  float* ws = lds_stem + 10 * RL;              // [K][Co]
-  const int tiles_w = Wo >> 5;                 // 32 output columns per tile
+  constexpr int cols = 66 * CI;                // 32 output columns need 66 input pixels (one of padding left and right)
+  float* xs = lds_stem;                        // [10][cols]
+  float* ws = lds_stem + 10 * cols;            // [K][Co]
   const int b = blockIdx.z, oh0 = blockIdx.y * 4, ow0 = blockIdx.x * 32;
-  (void)tiles_w;
   // ---- stage input rows 2*oh0-1 .. 2*oh0+8, columns 2*ow0-1 .. 2*ow0+64, zero outside the image ---------------------------
-  const int cols = 66 * CI;                    // 32 output columns need 66 input pixels
   for (int i = threadIdx.x; i < 10 * cols; i += 256) {
     const int r = i / cols, j = i - r * cols;
     const int px = j / CI, ci = j - px * CI;

@@ -1,12 +1,14 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh).
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh [round]).
 # Kernel trace and each PMC group are separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
-# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/r01/.
+# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r02);
+# copy what should be judged into profiles/ with the round prefix.
 set -u
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-OUT="$REPO/gpurun_out/r01"; rm -rf "$OUT"; mkdir -p "$OUT"
+ROUND="${1:-r02}"
+OUT="$REPO/gpurun_out/$ROUND"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off"
+BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off --repeats 1"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -o r -- $BENCH --steps 5 --warmup 2 > "$OUT/ktrace.log" 2>&1
 cp "$(find "$OUT/ktrace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bench_s5w2.csv"
 python "$REPO/tools/prof_summary.py" "$OUT/ktrace" 9 45 > "$OUT/kernel_stats_summary.txt" 2>&1
@@ -14,7 +16,16 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   tag=$(echo "$grp" | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$tag" -o r -- $BENCH --steps 3 --warmup 2 --no-graphs > "$OUT/pmc_$tag.log" 2>&1
 done
-python "$REPO/tools/pmc_summary.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES" 5 "$OUT/pmc_igemm.json" > "$OUT/pmc_summary.log" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES" 5 "$OUT/pmc_igemm.json" f32 > "$OUT/pmc_summary.log" 2>&1
+# the same for config 3 (bf16 math): kernel trace + PMC passes
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace_bf16" -o r -- $BENCH --math bf16 --steps 5 --warmup 2 > "$OUT/ktrace_bf16.log" 2>&1
+python "$REPO/tools/prof_summary.py" "$OUT/ktrace_bf16" 9 45 > "$OUT/kernel_stats_summary_bf16.txt" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+  tag=$(echo "$grp" | cut -d' ' -f1)
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmcb_$tag" -o r -- $BENCH --math bf16 --steps 3 --warmup 2 --no-graphs > "$OUT/pmcb_$tag.log" 2>&1
+done
+python "$REPO/tools/pmc_summary.py" "$OUT/pmcb_FETCH_SIZE" "$OUT/pmcb_WRITE_SIZE" "$OUT/pmcb_SQ_VALU_MFMA_BUSY_CYCLES" 5 "$OUT/pmc_igemm_bf16.json" bf16 > "$OUT/pmc_summary_bf16.log" 2>&1
+rm -rf "$OUT/ktrace_bf16" "$OUT/pmcb_FETCH_SIZE" "$OUT/pmcb_WRITE_SIZE" "$OUT/pmcb_SQ_VALU_MFMA_BUSY_CYCLES"
 cd "$REPO"
 timeout 300 python tools/bench_conv.py --batch 64 > "$OUT/conv_microbench_B64.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 192 --filter D > "$OUT/conv_microbench_B192.txt" 2>&1

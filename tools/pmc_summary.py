@@ -13,7 +13,7 @@ def agg(d):
     tot = collections.defaultdict(float)
     seen, dur = set(), 0
     for r in csv.DictReader(open(f)):
-        if 'igemm_kernel' not in r['Kernel_Name']:
+        if 'igemm_kernel' not in r['Kernel_Name'] and 'igemm_h_kernel' not in r['Kernel_Name']:
             continue
         tot[r['Counter_Name']] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
