@@ -531,6 +531,14 @@ def test_bf16_operand_gemm_matches_rounded_oracle(K, case):
                 assert K.conv_algo(d, 'bwd_data') == 'implicit_gemm_bf16_operands'
                 assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws),
                               O.conv2d_bwd_data(_bf16_round(dy), _bf16_round(w), x.shape, (s, s), pad)) <= GRAD_TOL, (case, splitk)
+            if d.Wo % 4 == 0:          # filter gradient: both operands staged as bf16 and transposed in registers by the loaders
+                assert K.conv_algo(d, 'bwd_filter') == 'implicit_gemm_bf16_operands'
+                dw_ref = O.conv2d_bwd_filter(_bf16_round(x), _bf16_round(dy), w.shape, (s, s), pad)
+                assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= GRAD_TOL, (case, splitk)
+                base = rng.standard_normal(w.shape).astype(np.float32)
+                acc = dev(base)
+                K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc)                      # accumulate into an arena slot
+                assert relerr(acc, base + dw_ref) <= GRAD_TOL, (case, splitk)
         finally:
             K.tuning_set('force_splitk', 0)
 

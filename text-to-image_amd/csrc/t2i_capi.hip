@@ -149,7 +149,7 @@ const Tuning& tuning() { return tuning_mut(); }
 // operand stream (measured ~16 TB/s chip-wide on 128x128 tiles): bytes per FLOP scale with 1/tile edge, which is what
 // rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
 static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false,
-                      int bk = 32) {
+                      int bk = 32, int m_unit = 0) {      // m_unit > 0: the M tile must divide it (tiles that stay inside one filter tap)
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
   // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
@@ -177,6 +177,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   double best_t = 1e300;
   for (int c = 0; c < 4; ++c) {
     const int wmt = cand[c][0], wnt = cand[c][1];
+    if (m_unit > 0 && (m_unit % (64 * wmt)) != 0) continue;
     if (ft) { if (ft != wmt * 10 + wnt) continue; }
     else if (batched && !math) {
       // batched (Winograd) GEMMs: K = channels only, 9-36 GEMMs per launch -> short K loops, many workgroups; 64x64 tiles
@@ -368,6 +369,58 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const float
   return rc;
 }
 
+// filter gradient with bf16 operand copies: workspace = [x_h][dy_h][split-K slabs]
+static bool h_filter_eligible(const t2i_conv_desc& d) {
+  return d.math == T2I_MATH_BF16 && tuning().bf16_operands && d.Cin >= 64 && (d.Cin % 64) == 0 && (d.Cout % 8) == 0 && (d.Wo % 4) == 0 &&
+         (!tuning().force_tile || (d.Cin % (64 * (tuning().force_tile / 10))) == 0);
+}
+
+static Plan h_filter_plan(const t2i_conv_desc* d) {
+  const int64_t M = (int64_t)d->KH * d->KW * d->Cin, N = d->Cout, K = (int64_t)d->B * d->Ho * d->Wo;
+  return make_plan(M, N, K, 1, (size_t)(M * N), split_cap_for(MODE_BWD_FILTER), 1, false, 64, d->Cin);
+}
+
+static size_t conv_h_filter_ws(const t2i_conv_desc* d) {
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+  return al256c(nx * 2) + al256c(ny * 2) + h_filter_plan(d).ws_bytes;
+}
+
+static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  const char* what = "t2i_conv2d_bwd_filter(bf16 operands)";
+  IgemmParams p;
+  fill_common(p, d);
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+  p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
+  p.div_c.set(d->Cin);
+  const size_t out_elems = (size_t)p.M * p.N;
+  const Plan pl = h_filter_plan(d);
+  const size_t off_y = al256c(nx * 2), off_s = off_y + al256c(ny * 2), need = off_s + pl.ws_bytes;
+  if (!ws || ws_bytes < need || !aligned16(ws)) {
+    set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, need);
+    return T2I_ERR_WORKSPACE;
+  }
+  char* base = reinterpret_cast<char*>(ws);
+  int rc = check(cast_bf16_launch(x, nx, base, stream), what);
+  if (rc != T2I_OK) return rc;
+  rc = check(cast_bf16_launch(dy, ny, base + off_y, stream), what);
+  if (rc != T2I_OK) return rc;
+  p.a = reinterpret_cast<const float*>(base); p.b = reinterpret_cast<const float*>(base + off_y);
+  p.a_bytes = (uint32_t)(nx * 2); p.b_bytes = (uint32_t)(ny * 2);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.group_n = 1;
+  p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
+  p.out_elems = out_elems;
+  p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f;
+  if (pl.splitk > 1) { p.c = reinterpret_cast<float*>(base + off_s); p.accumulate = 0; }
+  else { p.c = dw; p.accumulate = accumulate; }
+  rc = check(igemm_h_filter_launch(p, pl.wmt, pl.wnt, stream), what);
+  if (rc != T2I_OK) return rc;
+  if (pl.splitk > 1)
+    rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(base + off_s), pl.splitk, out_elems, nullptr, p.N, T2I_ACT_NONE, 0.f, dw,
+                                    accumulate, stream), what);
+  return rc;
+}
+
 // nbatch independent GEMMs of one shape in one launch (Winograd's 16 tile positions), as 1x1 convolutions over T "pixels":
 //   fwd: c[T, Cout] = a[T, Cin] * b[Cin, Cout]        (MODE_FWD,      b row-major [K][N])
 //   bwd: c[T, Cin]  = a[T, Cout] * b[Cin, Cout]^T     (MODE_BWD_DATA, b read as its K-inner image [n][k])
@@ -452,6 +505,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (b > need) need = b;
   if (h_eligible(*d, false) && conv_h_ws(d, MODE_FWD) > need) need = conv_h_ws(d, MODE_FWD);
   if (h_eligible(*d, true) && conv_h_ws(d, MODE_BWD_DATA) > need) need = conv_h_ws(d, MODE_BWD_DATA);
+  if (h_filter_eligible(*d) && conv_h_filter_ws(d) > need) need = conv_h_filter_ws(d);
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
@@ -574,6 +628,8 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
     return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+  if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
+    return conv_h_filter(d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;
@@ -890,6 +946,7 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
     if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf) return T2I_ALGO_WINOGRAD_F2X2_2X2;
+    if (h_filter_eligible(*d)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;
   }
   return T2I_ALGO_IMPLICIT_GEMM;
 }

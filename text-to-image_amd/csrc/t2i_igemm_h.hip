@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "t2i_internal.h"
 
 namespace t2i {
@@ -321,6 +323,180 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient with bf16 operands in memory:
+//   dw[M = KH*KW*Cin, N = Cout] = sum over k = (b, oh, ow) of  x_h[b, oh*SH-pad_t+kh, ow*SW-pad_l+kw, ci] * dy_h[b, oh, ow, co]
+// Both operands are "N-inner" in memory (channels contiguous, the reduction index k is the pixel), while the MFMA wants 8
+// consecutive k per lane: the loaders transpose in registers.  A thread fetches, for ONE group of 8 channels, KPT
+// consecutive pixels of one output row (16 bytes each), regroups the 16-bit halves with v_perm_b32 into per-channel runs
+// of KPT consecutive k, and writes each run to its channel's LDS row (ds_write_b64 / b32).  The M tile lies inside one
+// filter tap (Cin % BM == 0), so (kh, kw, ci0) are tile constants and a K-tile is 64 consecutive output pixels.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned perm_lo(unsigned k0, unsigned k1) { return __builtin_amdgcn_perm(k1, k0, 0x05040100u); }   // (k0.lo, k1.lo)
+__device__ __forceinline__ unsigned perm_hi(unsigned k0, unsigned k1) { return __builtin_amdgcn_perm(k1, k0, 0x07060302u); }   // (k0.hi, k1.hi)
+
+template <int WMT, int WNT>
+__global__ __launch_bounds__(256) void igemm_h_filter_kernel(IgemmParams p) {
+  using S = SmemH<WMT, WNT>;
+  constexpr int BM = S::BM, BN = S::BN;
+  constexpr int A_G = BM / 8, B_G = BN / 8;            // groups of 8 channels per tile row block
+  constexpr int A_KL = 256 / A_G, B_KL = 256 / B_G;    // threads along k
+  constexpr int A_KPT = HBK / A_KL, B_KPT = HBK / B_KL;   // consecutive pixels per thread: 4 (128-wide) or 2 (64-wide)
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
+  unsigned* As = smem_h;
+  unsigned* Bs = smem_h + 2 * S::A_DW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int ntiles = (kend - kbeg + HBK - 1) / HBK;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), (short)0, (int)p.b_bytes, 0x00020000);
+
+  // tile constants: the filter tap and first input channel of this M tile
+  const int tap = p.div_c.div(bm);
+  const int ci0 = bm - tap * p.d.Cin;
+  const int kh = p.div_kw.div(tap), kw = tap - kh * p.d.KW;
+  const int a_g = tid % A_G, a_kl = tid / A_G;
+  const int b_g = tid % B_G, b_kl = tid / B_G;
+  const bool b_nok = (bn + b_g * 8) < p.N;
+
+  u32x4 areg[A_KPT], breg[B_KPT];
+
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    {
+      const int k = kbeg + t * HBK + a_kl * A_KPT;          // A_KPT | 4 | Wo: the thread's pixels share one output row
+      const bool kok = k < kend;
+      const int kk = kok ? k : 0;
+      const int b = p.div_howo.div(kk);
+      const int rem = kk - b * p.howo;
+      const int oh = p.div_wo.div(rem);
+      const int ow = rem - oh * p.d.Wo;
+      const int ih = oh * p.d.SH - p.d.pad_t + kh;
+      const bool rok = kok & ((unsigned)ih < (unsigned)p.d.H);
+      const int rowbase = (b * p.d.H + ih) * p.d.W;
+#pragma unroll
+      for (int i = 0; i < A_KPT; ++i) {
+        const int iw = (ow + i) * p.d.SW - p.d.pad_l + kw;
+        const bool ok = rok & ((unsigned)iw < (unsigned)p.d.W);
+        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? (unsigned)((rowbase + iw) * p.d.Cin + ci0 + a_g * 8) * 2u : HOOB, 0, 0);
+      }
+    }
+    {
+      const int k = kbeg + t * HBK + b_kl * B_KPT;          // dy pixels are the reduction index itself: consecutive in memory
+      const bool ok = b_nok & (k < kend);
+#pragma unroll
+      for (int i = 0; i < B_KPT; ++i)
+        breg[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? (unsigned)((k + i) * p.N + bn + b_g * 8) * 2u : HOOB, 0, 0);
+    }
+  };
+
+  // regs[i] = 8 channels of pixel i  ->  per channel j a run of KPT consecutive k, written to LDS row (g*8 + j)
+  auto store_one = [&](unsigned* dst_base, const u32x4* regs, int g, int kl, auto kpt_tag) __attribute__((always_inline)) {
+    constexpr int KPT = decltype(kpt_tag)::value;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {                      // channel pair (2jp, 2jp+1) = dword jp of every load
+      unsigned* row_lo = dst_base + (g * 8 + 2 * jp) * HROW + (kl * KPT) / 2;
+      unsigned* row_hi = row_lo + HROW;
+      if constexpr (KPT == 4) {
+        *reinterpret_cast<uint2*>(row_lo) = make_uint2(perm_lo(regs[0][jp], regs[1][jp]), perm_lo(regs[2][jp], regs[3][jp]));
+        *reinterpret_cast<uint2*>(row_hi) = make_uint2(perm_hi(regs[0][jp], regs[1][jp]), perm_hi(regs[2][jp], regs[3][jp]));
+      } else {
+        *row_lo = perm_lo(regs[0][jp], regs[1][jp]);
+        *row_hi = perm_hi(regs[0][jp], regs[1][jp]);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    store_one(As + buf * S::A_DW, areg, a_g, a_kl, std::integral_constant<int, A_KPT>());
+    store_one(Bs + buf * S::B_DW, breg, b_g, b_kl, std::integral_constant<int, B_KPT>());
+  };
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  load_tile(1);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned* as = As + (t & 1) * S::A_DW;
+    const unsigned* bs = Bs + (t & 1) * S::B_DW;
+    bf16x8 fa[WMT][4], fb[WNT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+        fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[(wm * 32 * WMT + i * 32 + l31) * HROW + s * 8 + lh * 4]));
+#pragma unroll
+      for (int i = 0; i < WNT; ++i)
+        fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[(wn * 32 * WNT + i * 32 + l31) * HROW + s * 8 + lh * 4]));
+    }
+    store_tile((t + 1) & 1);
+    load_tile(t + 2);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int n = 0; n < WNT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+    __syncthreads();
+  }
+
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  const bool fused = (p.splitk == 1);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int n = bn + wn * 32 * WNT + j * 32 + l31;
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][e];
+          if (fused && p.accumulate) v += out[(size_t)m * p.N + n];
+          out[(size_t)m * p.N + n] = v;
+        }
+      }
+    }
+}
+
+template <int WMT, int WNT>
+static hipError_t launch_hf(const IgemmParams& p, hipStream_t stream) {
+  using S = SmemH<WMT, WNT>;
+  auto k = igemm_h_filter_kernel<WMT, WNT>;
+  static bool attr_done = false;
+  if (!attr_done && S::BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n, p.splitk), dim3(256), S::BYTES, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStream_t stream) {
+  if (wmt == 2 && wnt == 2) return launch_hf<2, 2>(p, stream);
+  if (wmt == 2 && wnt == 1) return launch_hf<2, 1>(p, stream);
+  if (wmt == 1 && wnt == 2) return launch_hf<1, 2>(p, stream);
+  if (wmt == 1 && wnt == 1) return launch_hf<1, 1>(p, stream);
+  return hipErrorInvalidValue;
 }
 
 template <int MODE, int WMT, int WNT>

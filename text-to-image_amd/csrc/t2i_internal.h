@@ -106,6 +106,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream);
 // bf16 operands in memory (t2i_igemm_h.hip): staging kernels + the GEMM
 hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
+hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
 hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream);
 hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream);
 // slot of the caller-owned filter-cache arena for (filter, kind) — nullptr when the cache cannot serve it (t2i_winograd.hip)

@@ -312,15 +312,34 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
   float* ws = lds_stem + 10 * cols;            // [K][Co]
   const int b = blockIdx.z, oh0 = blockIdx.y * 4, ow0 = blockIdx.x * 32;
   // ---- stage input rows 2*oh0-1 .. 2*oh0+8, columns 2*ow0-1 .. 2*ow0+64, zero outside the image ---------------------------
-  for (int i = threadIdx.x; i < 10 * cols; i += 256) {
+  // (all loads are issued before the first LDS store: a load -> store loop serialises ~14 global round trips per workgroup)
+  constexpr int XN = (10 * cols + 255) / 256, WN = (K * Co / 4 + 255) / 256;
+  float xv[XN];
+  float4 wv[WN];
+#pragma unroll
+  for (int u = 0; u < XN; ++u) {
+    const int i = threadIdx.x + 256 * u;
     const int r = i / cols, j = i - r * cols;
     const int px = j / CI, ci = j - px * CI;
     const int ih = 2 * oh0 - 1 + r, iw = 2 * ow0 - 1 + px;
-    float v = 0.f;
-    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((size_t)(b * H + ih) * W + iw) * CI + ci];
-    xs[r * cols + j] = v;
+    const bool ok = i < 10 * cols && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    xv[u] = ok ? x[((size_t)(b * H + ih) * W + iw) * CI + ci] : 0.f;
   }
-  for (int i = threadIdx.x; i < K * Co / 4; i += 256) reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(w)[i];
+#pragma unroll
+  for (int u = 0; u < WN; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    wv[u] = i < K * Co / 4 ? reinterpret_cast<const float4*>(w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < XN; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < 10 * cols) xs[i] = xv[u];
+  }
+#pragma unroll
+  for (int u = 0; u < WN; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < K * Co / 4) reinterpret_cast<float4*>(ws)[i] = wv[u];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
