@@ -366,8 +366,13 @@ __global__ __launch_bounds__(256) void igemm_h_filter_kernel(IgemmParams p) {
   const int tap = p.div_c.div(bm);
   const int ci0 = bm - tap * p.d.Cin;
   const int kh = p.div_kw.div(tap), kw = tap - kh * p.d.KW;
-  const int a_g = tid % A_G, a_kl = tid / A_G;
-  const int b_g = tid % B_G, b_kl = tid / B_G;
+  // thread -> (channel group g, k lane kl).  A wave holds ALL k lanes and 64/KL adjacent groups: its transposing LDS stores
+  // (rows 8 apart = 32 banks apart at the 36-dword row stride) then spread over all banks through the k offset — with the
+  // groups fastest over lanes instead (fully coalesced 256-byte global reads) the same stores were 8-way bank conflicted and
+  // the kernel was bound by LDS writes; a wave's global reads are still whole 64-byte (128-wide tile) / 32-byte segments.
+  constexpr int A_GL = 64 / A_KL, B_GL = 64 / B_KL;
+  const int a_g = (lane % A_GL) + wave * A_GL, a_kl = lane / A_GL;
+  const int b_g = (lane % B_GL) + wave * B_GL, b_kl = lane / B_GL;
   const bool b_nok = (bn + b_g * 8) < p.N;
 
   u32x4 areg[A_KPT], breg[B_KPT];

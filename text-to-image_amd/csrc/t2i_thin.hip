@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
 
 bool stem_fwd_eligible(const t2i_conv_desc& d) {
   return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin == 3 && d.Cout == 128 &&
-         (d.H & 1) == 0 && (d.W & 1) == 0 && d.Ho * 2 == d.H && d.Wo * 2 == d.W && d.math == T2I_MATH_F32;
+         (d.H & 1) == 0 && (d.W & 1) == 0 && d.Ho * 2 == d.H && d.Wo * 2 == d.W;   // fp32 arithmetic in both math modes, like the other thin kernels
 }
 
 hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,

@@ -68,7 +68,7 @@ def main():
         t3 = timeit(lambda: K.conv_bwd_filter(x, dy, d, ws), a.reps)
         for key, t in (('fwd', t1), ('bwd_data', t2), ('bwd_filter', t3)):
             tot[key][0] += fl; tot[key][1] += t
-        short = {'implicit_gemm': 'G', 'winograd_f2x2_3x3': 'W3', 'winograd_f2x2_2x2': 'W2', 'direct_small': 'S'}
+        short = {'implicit_gemm': 'G', 'winograd_f2x2_3x3': 'W3', 'winograd_f2x2_2x2': 'W2', 'direct_small': 'S', 'implicit_gemm_bf16_operands': 'H'}
         algos = '/'.join(short[K.conv_algo(d, m)] for m in ('fwd', 'bwd_data', 'bwd_filter'))
         for key in ('fwd', 'bwd_data', 'bwd_filter'):
             tot[key][2] += fl * K.ALGO_MAC_RATIO[K.ALGO_NAMES.index(K.conv_algo(d, key))]
