@@ -98,8 +98,8 @@ def relerr(got, ref, floor=1e-30):
 @pytest.mark.gpu
 @pytest.mark.parametrize('stage', [1, 2])
 def test_stackgan_tiny_iteration_matches_golden(stage):
-    """Stage-I: losses rel <= 1e-4, gradients max-norm <= 2e-3 per tensor (exact-zero ones: abs <= 1e-4); Stage-II (much
-    deeper, tolerances in the body): 1e-3 / 2e-2.  Then one full trainer
+    """Stage-I: losses rel <= 1e-5, gradients max-norm <= 1e-4 per tensor (exact-zero ones: abs <= 1e-4) — SURVEY 8(c)'s
+    tolerances; Stage-II (much deeper, tolerances and measurements in the body): 1e-4 / 5e-4 / 1e-3.  Then one full trainer
     iteration at epoch 150 (lr = D_LR / 2): Adam(beta1=.5) step and every batch-norm moving average — including, for
     Stage-II, those of the frozen Stage-I generator that runs inside the graph in training mode."""
     if not torch.cuda.is_available():
@@ -118,10 +118,12 @@ def test_stackgan_tiny_iteration_matches_golden(stage):
     Trainer = T1 if stage == 1 else T2
     tr = Trainer(None, m, None, m.cfg)
     d = tr.d_losses(feed)
-    # Stage-II stacks ~45 conv + batch-norm layers whose statistics are taken over as few as 32 values (B=2, 4x4 maps,
-    # kernels widened 12x): fp32 rounding reaches the logits at ~1e-3, so its scalar tolerance is 1e-3 instead of 1e-4
-    # (torch-CPU fp32 is at 4e-5 on the same tensors: the ~35x ratio is the sequential fp32 MFMA accumulation)
-    ltol, gtol, itol, mtol = (1e-4, 2e-3, 1e-3, 5e-4) if stage == 1 else (1e-3, 2e-2, 5e-3, 5e-3)
+    # Stage-II stacks ~45 conv + batch-norm layers whose statistics are taken over as few as 32 values (B=2, 4x4 maps).
+    # Round 1 needed 1e-3 / 2e-2 / 8e-2 here and blamed the sequential fp32 MFMA accumulation; the cause was the batch-norm
+    # variance formed as sum(x^2)/n - mean^2.  With stable statistics (un-pinned comparison, measured):
+    # Stage-I losses 2.4e-7, gradients 4.6e-6, image 3.4e-6; Stage-II losses 1.2e-5, critic gradients 3.2e-5, generator
+    # gradients 1.0e-4, image 6.9e-5.
+    ltol, gtol, itol, mtol = (1e-5, 1e-4, 1e-4, 5e-4) if stage == 1 else (1e-4, 5e-4, 5e-4, 5e-3)
     for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
         print('stage %d %s rel err %.2e (tol %.0e)' % (stage, k, abs(float(d[k]) - float(gs['d/' + k])) / max(abs(float(gs['d/' + k])), 1.0), ltol))
         assert abs(float(d[k]) - float(gs['d/' + k])) <= ltol * max(abs(float(gs['d/' + k])), 1.0), (k, float(d[k]), float(gs['d/' + k]))
@@ -149,10 +151,8 @@ def test_stackgan_tiny_iteration_matches_golden(stage):
         assert abs(float(g[k]) - float(gs['g/' + k])) <= ltol * max(abs(float(gs['g/' + k])), 1.0), k
     print('stage %d image err %.2e (tol %.0e)' % (stage, relerr(g['G'][:, ::4, ::4, :], gs['g/G_sample']), itol))
     assert relerr(g['G'][:, ::4, ::4, :], gs['g/G_sample']) <= itol
-    # Stage-II generator gradients come back through the 25-layer critic AND ~40 generator layers: the fp32 forward noise
-    # (1.5e-3 at the image) flips a few relu/lrelu masks per layer; measured 1.3e-2 relative L2 overall (cosine 0.99991),
-    # worst tensor 4e-2 — a wrong kernel gives O(1)
-    check(m.g_arena, m.g_vars, 'g/grad/', None if stage == 1 else 8e-2)
+    # Stage-II generator gradients come back through the 25-layer critic AND ~40 generator layers (measured 1.0e-4 worst)
+    check(m.g_arena, m.g_vars, 'g/grad/', None if stage == 1 else 1e-3)
     # full iteration from the initial state
     m.store.load(params)
     tr = Trainer(None, m, None, m.cfg)

@@ -3,9 +3,10 @@
   * tiny model (GF=DF=8, B=4): every loss scalar, every gradient of both steps, kt', first Adam step and BN moving
     statistics against the committed float64 golden step (tests/golden/step_tiny.npz);
   * full-width model at B=8: losses and gradients against the torch-CPU fp32 oracle run on the same seeded inputs.
-Tolerances (fp32 vs float64 / fp32 oracle): loss scalars rel <= 1e-4 (they sum O(1e5) fp32 products through 12 layers
-and a double backward); gradients max|d|/max|ref| <= 1e-3 per tensor; post-Adam weights within 2*lr (Adam with beta1=0
-is sign-like at t=1)."""
+Tolerances for the tiny golden step = SURVEY.md 8(c)'s: forward tensors 1e-5, loss scalars rel <= 1e-5, gradients
+max|d|/max|ref| <= 1e-4 per tensor (measured after the batch-norm statistics were made stable: 5.5e-6 / 1.2e-6 / 5.5e-6);
+post-Adam weights within 2*lr (Adam with beta1=0 is sign-like at t=1).  The metric's own size (B = 64) is
+tests/test_step_b64_gpu.py."""
 import os
 
 import numpy as np
@@ -57,23 +58,23 @@ def test_tiny_step_matches_golden(gpu, golden_step):
     feed = _feed(gs, gpu)
     d = m.d_losses(feed)
     torch.cuda.synchronize()
-    assert relerr(d['G'], gs['d/G']) <= 1e-4
-    assert relerr(d['Dx_hat_logit'], gs['d/Dx_hat']) <= 1e-4
+    assert relerr(d['G'], gs['d/G']) <= 1e-5
+    assert relerr(d['Dx_hat_logit'], gs['d/Dx_hat']) <= 1e-5
     assert relerr(d['grad_x_hat'], gs['d/grad_x_hat']) <= 1e-4
     assert relerr(d['grad_cond'], gs['d/grad_cond']) <= 1e-4
     for k in ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2',
               'reg_loss', 'balance_loss', 'kt_grad'):
         ref = float(gs['d/' + k])
-        assert abs(float(d[k]) - ref) <= 1e-4 * max(abs(ref), 1.0), (k, float(d[k]), ref)
+        assert abs(float(d[k]) - ref) <= 1e-5 * max(abs(ref), 1.0), (k, float(d[k]), ref)
     for n in m.d_vars:
         _check_grad(m.d_arena.grad_of(n), gs['d/grad/' + n], n)
     print('tiny wgancls: worst critic gradient error %.2e; losses %s' % (
         max(relerr(m.d_arena.grad_of(n), gs['d/grad/' + n], floor=1e-30) for n in m.d_vars if np.abs(gs['d/grad/' + n]).max() >= 1e-9),
         {k: '%.1e' % (abs(float(d[k]) - float(gs['d/' + k])) / max(abs(float(gs['d/' + k])), 1.0)) for k in ('D_loss', 'wdist', 'real_gp', 'real_gp2')}))
     g = m.g_losses(feed)
-    assert abs(float(g['G_loss']) - float(gs['g/G_loss'])) <= 1e-4 * max(abs(float(gs['g/G_loss'])), 1.0)
-    assert abs(float(g['G_kl_loss']) - float(gs['g/G_kl_loss'])) <= 1e-4 * max(abs(float(gs['g/G_kl_loss'])), 1.0)
-    assert relerr(g['G'], gs['g/G']) <= 1e-4
+    assert abs(float(g['G_loss']) - float(gs['g/G_loss'])) <= 1e-5 * max(abs(float(gs['g/G_loss'])), 1.0)
+    assert abs(float(g['G_kl_loss']) - float(gs['g/G_kl_loss'])) <= 1e-5 * max(abs(float(gs['g/G_kl_loss'])), 1.0)
+    assert relerr(g['G'], gs['g/G']) <= 1e-5
     for n in m.g_vars:
         _check_grad(m.g_arena.grad_of(n), gs['g/grad/' + n], n)
     print('tiny wgancls: worst generator gradient error %.2e; G_loss %.1e G %.1e' % (
@@ -81,7 +82,7 @@ def test_tiny_step_matches_golden(gpu, golden_step):
         abs(float(g['G_loss']) - float(gs['g/G_loss'])) / max(abs(float(gs['g/G_loss'])), 1.0), relerr(g['G'], gs['g/G'])))
 
 
-def _check_grad(got, ref, name, tol=1e-3):
+def _check_grad(got, ref, name, tol=1e-4):
     """Per-tensor max-norm check.  Tensors whose exact gradient is zero (a bias in front of a batch norm; the logit
     bias, whose +1/-1 terms cancel) only carry fp32 rounding residue: bound it absolutely instead."""
     ref = np.asarray(ref, np.float64)
