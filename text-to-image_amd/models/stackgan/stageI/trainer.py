@@ -55,7 +55,7 @@ class ConditionalGanTrainer(object):
         D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
         D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
         m.d_arena.zero_grad()
-        if m.dp is not None:
+        if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.d_arena)
         D_loss.backward(inputs=list(m.d_vars.values()))
         A.side_join()
@@ -78,7 +78,7 @@ class ConditionalGanTrainer(object):
         G_kl_loss = self.kl_loss(mean, log_sigma)
         G_loss = G_gan_loss + self.kl_coeff * G_kl_loss
         m.g_arena.zero_grad()
-        if m.dp is not None:
+        if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.g_arena)
         G_loss.backward(inputs=list(m.g_vars.values()))
         A.side_join()
@@ -102,13 +102,12 @@ class ConditionalGanTrainer(object):
     NOISE_KEYS = ('ca_noise_d', 'ca_noise_g')
 
     def enable_graphs(self, feed):
-        """Capture the two halves into hipGraphs and replay them from then on (single GPU).  Call after at least one eager
-        iteration with the same shapes.  The conditioning-augmentation noise lives in static buffers that are re-drawn
-        before every replay (the reference draws it inside the graph on every run)."""
+        """Capture the two halves into hipGraphs and replay them from then on.  Call after at least one eager iteration with
+        the same shapes.  The conditioning-augmentation noise lives in static buffers that are re-drawn before every replay
+        (the reference draws it inside the graph on every run).  With data parallelism each half is cut at its exchange
+        step — [losses + backward] | all-reduce of the gradient arena, issued eagerly | [Adam] — as in models/wgancls."""
         from ....graphs import StepGraphs
         m = self.model
-        if m.dp is not None:
-            raise RuntimeError('graph capture with data parallelism is not supported yet')
         feed = dict(feed)
         for k in self.NOISE_KEYS:
             if feed.get(k) is None:
@@ -116,8 +115,19 @@ class ConditionalGanTrainer(object):
         self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z') + tuple(self.NOISE_KEYS))
         self._draw_noise(feed)
         self._graphs.load(feed)
-        self._graphs.capture('d', self._d_body)
-        self._graphs.capture('g', self._g_body)
+        if m.dp is None:
+            self._graphs.capture('d', self._d_body)
+            self._graphs.capture('g', self._g_body)
+            return
+        scale = 1.0 / m.dp.world
+        self._capturing = True
+        try:
+            self._graphs.capture('d', self.d_losses, capture_error_mode='thread_local')
+            self._graphs.capture('d_upd', lambda f: self.D_optim.apply(grad_scale=scale), capture_error_mode='thread_local')
+            self._graphs.capture('g', self.g_losses, capture_error_mode='thread_local')
+            self._graphs.capture('g_upd', lambda f: self.G_optim.apply(grad_scale=scale), capture_error_mode='thread_local')
+        finally:
+            self._capturing = False
 
     def _noise_dim(self, key):
         return self.model.compressed_embed_dim
@@ -133,10 +143,17 @@ class ConditionalGanTrainer(object):
         if graphs is not None:
             self._draw_noise(feed)
             graphs.load(feed)
+            dp = self.model.dp
             self.D_optim.prepare(lr)
             d = graphs.replay('d')
+            if dp is not None:
+                dp.allreduce_arena(self.model.d_arena)
+                graphs.replay('d_upd')
             self.G_optim.prepare(lr)
             g = graphs.replay('g')
+            if dp is not None:
+                dp.allreduce_arena(self.model.g_arena)
+                graphs.replay('g_upd')
             return {'d': d, 'g': g}
         self.D_optim.prepare(lr)
         d = self._d_body(feed)
