@@ -60,8 +60,8 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 3 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
-                                   * t2i_tuning_set, t2i_kt_sgd) */
+int t2i_version(void);            /* ABI version, currently 4 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+                                   * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
@@ -69,7 +69,7 @@ int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arc
 /* Tuning / diagnostic switch `key` := value (tests, sweeps: tools/sweep_conv.py).  Keys and their T2I_* environment
  * defaults: force_tile (T2I_FORCE_TILE: 22, 21, 12, 11 = 128x128 ... 64x64; 0 = planner), force_splitk, debug_plan, group_n,
  * no_ut, no_thin, winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc,
- * winograd_k4s2_bwdf, adam_blocks, max_chain (longest unsplit fp32 reduction chain, default 8192), split_cost.
+ * winograd_k4s2_bwdf, adam_blocks, max_chain (longest unsplit fp32 reduction chain, default 8192), split_cost, bf16_operands, cache_refresh.
  * Not a hot-path call; changes apply to launches planned afterwards (workspace queries included). */
 int t2i_tuning_set(const char* key, double value);
 
@@ -271,6 +271,24 @@ int t2i_filter_cache_attach(void* buf, size_t bytes);
 int t2i_filter_cache_enable(int on);
 void t2i_filter_cache_invalidate(const void* ptr, size_t bytes);
 size_t t2i_filter_cache_bytes(void);            /* bytes of the attached arena handed out so far */
+/* Regenerates, in ONE launch per 96 entries, every cached image whose filter lies in [ptr, ptr + bytes) (ptr NULL: all) and is
+ * stale in the launch context of `stream` (eager, or the capture active on it), and marks it filled for that context.
+ * Call it behind t2i_adam_tf for the arena it updated (or set the tuning key cache_refresh = 1 and t2i_adam_tf does), and at
+ * the head of a capture with (NULL, 0): an iteration then holds one batched regeneration per optimizer step instead of one
+ * small fill per (filter, kind) at its first use — ~60 launches.  The bytes moved are the same as with lazy fills as long as
+ * an image is not regenerated twice between two updates of its filter. */
+int t2i_filter_cache_refresh(const void* ptr, size_t bytes, t2i_stream_t stream);
+
+/* ---- bf16 operand images (T2I_MATH_BF16) --------------------------------------------------------------------------
+ * out[i] = bf16(x[i]), round to nearest even; n % 8 == 0, both buffers 16-byte aligned. */
+int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream);
+/* One-shot hand-over: the NEXT t2i_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_filter call on this thread may read a_h / b_h
+ * (either may be NULL) as the bf16 images — same shape and layout, made by t2i_cast_bf16 — of its first / second
+ * activation operand (fwd: x; bwd_data: dy; bwd_filter: x, dy) instead of staging its own copies into the workspace.  An
+ * activation feeds up to three convs of a training step and a gradient two, so the caller that keeps the image saves the
+ * repeated casts.  The call consumes the hand-over whatever path it dispatches to; paths that do not read bf16 operands
+ * from memory ignore it.  Results are identical with and without. */
+int t2i_conv2d_operand_images(const void* a_h, const void* b_h);
 
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):

@@ -370,6 +370,55 @@ def test_bf16_math_step_within_config3_tolerance(gpu, golden_step):
         K.set_math('f32')
 
 
+def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
+    """bf16 math at the benchmark's widths: (a) handing the convs caller-held bf16 images of their activation operands
+    (kernels.bf16_image + t2i_conv2d_operand_images: one cast per tensor instead of one per conv that reads it) and (b) the
+    batched regeneration of the cached filter images behind the optimizer steps and at the head of every captured graph
+    (t2i_filter_cache_refresh) change no bit of three training iterations — eager and replayed from a graph."""
+    from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    B = 8
+    cfg = _cfg(128, 1024, 128, 128, 128, B)
+    g = torch.Generator(device=gpu).manual_seed(5)
+    feed = {'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1, 'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+            'cond': torch.randn(B, 1024, generator=g, device=gpu), 'z': torch.randn(B, 128, generator=g, device=gpu),
+            'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4,
+            'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
+            'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)}
+
+    def run(images, refresh, graphs):
+        prev_i = K.bf16_images(images)
+        real_refresh = K.filter_cache_refresh
+        if not refresh:
+            K.filter_cache_refresh = lambda t=None: None        # every image is then filled lazily, at its first use
+        prev_c = K.filter_cache(True)
+        try:
+            m = WGanCls(cfg, device=gpu, seed=3)
+            tr = WGanClsTrainer(None, m, None, cfg)
+            tr.iteration(1, feed)
+            if graphs:
+                m.enable_graphs(feed)
+            tr.iteration(2, feed)
+            tr.iteration(3, feed)
+            torch.cuda.synchronize()
+            return {n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt)
+        finally:
+            K.bf16_images(prev_i)
+            K.filter_cache_refresh = real_refresh
+            K.filter_cache(prev_c)
+    K.set_math('bf16')
+    try:
+        base = run(False, False, False)
+        for variant in ((True, False, False), (False, True, False), (True, True, False), (True, True, True)):
+            got = run(*variant)
+            assert got[1] == base[1], variant
+            for n in base[0]:
+                assert torch.equal(got[0][n], base[0][n]), (variant, n)
+    finally:
+        K.set_math('f32')
+
+
 def test_filter_cache_full_width_bit_identical(gpu):
     """Transformed-filter cache (include/t2i_hip.h) at the benchmark's widths, where the Winograd paths are live: three
     iterations with the cache on — eager, and replayed from one hipGraph — leave exactly the weights, Adam state and kt of

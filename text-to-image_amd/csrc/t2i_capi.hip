@@ -129,6 +129,7 @@ static Tuning& tuning_mut() {
     v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 256);
     v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
     v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
+    v.cache_refresh = env_int("T2I_CACHE_REFRESH", 0);     // 1: t2i_adam_tf itself regenerates the cached filter images of its arena (else the caller: t2i_filter_cache_refresh)
     v.bf16_operands = env_int("T2I_BF16_OPERANDS", 1);     // bf16 math: stage bf16 operand copies (t2i_igemm_h.hip) where eligible
     v.max_chain = env_int("T2I_MAX_CHAIN", 8192);           // longest unsplit reduction on the 128x128 tile (see make_plan)
     const char* sc = getenv("T2I_SPLIT_COST");
@@ -299,6 +300,16 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
 // ------------------------------------------------------------------------------------------------------------------
 static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// One-shot bf16 images of the next conv call's activation operands (t2i_conv2d_operand_images): taken — and cleared — by
+// every t2i_conv2d_* entry point at entry, whatever path it then dispatches to.
+struct OperandImages { const void* a; const void* b; };
+static thread_local OperandImages g_opimg = {nullptr, nullptr};
+static inline OperandImages take_operand_images() {
+  const OperandImages r = g_opimg;
+  g_opimg.a = g_opimg.b = nullptr;
+  return r;
+}
+
 static bool h_eligible(const t2i_conv_desc& d, bool bwd_data) {
   const int C = bwd_data ? d.Cout : d.Cin;
   return d.math == T2I_MATH_BF16 && tuning().bf16_operands && C >= 64 && (C % 64) == 0;
@@ -328,7 +339,7 @@ static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
   return al256c(n_in * 2) + al256c((size_t)d->KH * d->KW * d->Cin * d->Cout * 2) + pl.ws_bytes;
 }
 
-static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const float* w, const float* bias, float* out, int act,
+static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
   IgemmParams p;
   size_t n_in, out_elems;
@@ -341,8 +352,12 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const float
     return T2I_ERR_WORKSPACE;
   }
   char* base = reinterpret_cast<char*>(ws);
-  int rc = check(cast_bf16_launch(in, n_in, base, stream), what);
-  if (rc != T2I_OK) return rc;
+  int rc = T2I_OK;
+  if (!in_h || !aligned16(in_h)) {                  // no caller-held image of the gathered tensor: stage one
+    rc = check(cast_bf16_launch(in, n_in, base, stream), what);
+    if (rc != T2I_OK) return rc;
+    in_h = base;
+  }
   bool fill = true;
   void* wh = filter_cache_get(w, mode == MODE_FWD ? 4 : 5, d->Cin, d->Cout, nw * 2, stream, &fill);
   if (!wh) { wh = base + off_w; fill = true; }
@@ -350,7 +365,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const float
     rc = check(wcast_launch(w, d->KH * d->KW, d->Cin, d->Cout, mode == MODE_FWD ? 1 : 0, wh, stream), what);
     if (rc != T2I_OK) return rc;
   }
-  p.a = reinterpret_cast<const float*>(base); p.b = reinterpret_cast<const float*>(wh);
+  p.a = reinterpret_cast<const float*>(in_h); p.b = reinterpret_cast<const float*>(wh);
   p.a_bytes = (uint32_t)(n_in * 2); p.b_bytes = (uint32_t)(nw * 2);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
@@ -385,8 +400,8 @@ static size_t conv_h_filter_ws(const t2i_conv_desc* d) {
   return al256c(nx * 2) + al256c(ny * 2) + h_filter_plan(d).ws_bytes;
 }
 
-static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy, const void* x_h, const void* dy_h, float* dw, int accumulate,
+                         void* ws, size_t ws_bytes, hipStream_t stream) {
   const char* what = "t2i_conv2d_bwd_filter(bf16 operands)";
   IgemmParams p;
   fill_common(p, d);
@@ -401,11 +416,18 @@ static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy
     return T2I_ERR_WORKSPACE;
   }
   char* base = reinterpret_cast<char*>(ws);
-  int rc = check(cast_bf16_launch(x, nx, base, stream), what);
-  if (rc != T2I_OK) return rc;
-  rc = check(cast_bf16_launch(dy, ny, base + off_y, stream), what);
-  if (rc != T2I_OK) return rc;
-  p.a = reinterpret_cast<const float*>(base); p.b = reinterpret_cast<const float*>(base + off_y);
+  int rc = T2I_OK;
+  if (!x_h || !aligned16(x_h)) {
+    rc = check(cast_bf16_launch(x, nx, base, stream), what);
+    if (rc != T2I_OK) return rc;
+    x_h = base;
+  }
+  if (!dy_h || !aligned16(dy_h)) {
+    rc = check(cast_bf16_launch(dy, ny, base + off_y, stream), what);
+    if (rc != T2I_OK) return rc;
+    dy_h = base + off_y;
+  }
+  p.a = reinterpret_cast<const float*>(x_h); p.b = reinterpret_cast<const float*>(dy_h);
   p.a_bytes = (uint32_t)(nx * 2); p.b_bytes = (uint32_t)(ny * 2);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.group_n = 1;
   p.splitk = pl.splitk; p.k_per_split = pl.k_per_split;
@@ -477,7 +499,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 3; }
+int t2i_version(void) { return 4; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -545,6 +567,7 @@ int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w,
 
 static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                            float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  const OperandImages img = take_operand_images();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
@@ -562,7 +585,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (h_eligible(*d, false) && aligned16(x) && aligned16(w))
-    return conv_h(MODE_FWD, d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
+    return conv_h(MODE_FWD, d, x, img.a, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -579,6 +602,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
 
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
                         float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  const OperandImages img = take_operand_images();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
@@ -595,7 +619,7 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   if (winograd_k4s2_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
     return winograd_k4s2_bwd_data(*d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (h_eligible(*d, true) && aligned16(dy) && aligned16(w))
-    return conv_h(MODE_BWD_DATA, d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
+    return conv_h(MODE_BWD_DATA, d, dy, img.a, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
@@ -612,6 +636,7 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
 
 int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                           size_t ws_bytes, t2i_stream_t stream) {
+  const OperandImages img = take_operand_images();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
@@ -629,7 +654,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return conv_h_filter(d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+    return conv_h_filter(d, x, dy, img.a, img.b, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;
@@ -905,7 +930,9 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
   if (!w || !g || !m || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
   if (!(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
   filter_cache_invalidate(w, (size_t)n * 4);          // transformed filters of this arena are stale from here on
-  return check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
+  const int rc = check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
+  if (rc != T2I_OK || !tuning().cache_refresh) return rc;
+  return filter_cache_refresh(w, (size_t)n * 4, (hipStream_t)stream);   // ... and regenerated behind the update, all in one launch
 }
 
 int t2i_tuning_set(const char* key, double value) {
@@ -916,7 +943,8 @@ int t2i_tuning_set(const char* key, double value) {
       {"no_ut", &t.no_ut}, {"no_thin", &t.no_thin}, {"winograd", &t.winograd}, {"winograd_minc", &t.winograd_minc},
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
-      {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands}};
+      {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
+      {"cache_refresh", &t.cache_refresh}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }
@@ -961,5 +989,20 @@ int t2i_filter_cache_enable(int on) { return filter_cache_enable(on); }
 void t2i_filter_cache_invalidate(const void* p, size_t bytes) { filter_cache_invalidate(p, bytes); }
 
 size_t t2i_filter_cache_bytes(void) { return filter_cache_bytes(); }
+
+int t2i_filter_cache_refresh(const void* p, size_t bytes, t2i_stream_t stream) { return filter_cache_refresh(p, bytes, (hipStream_t)stream); }
+
+int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream) {
+  if (!x || !out || n <= 0 || (n % 8) != 0 || !aligned16(x) || !aligned16(out)) {
+    set_error("t2i_cast_bf16: need n %% 8 == 0 and 16-byte aligned buffers");
+    return T2I_ERR_INVALID;
+  }
+  return check(cast_bf16_launch(x, (size_t)n, out, (hipStream_t)stream), "t2i_cast_bf16");
+}
+
+int t2i_conv2d_operand_images(const void* a_h, const void* b_h) {
+  g_opimg.a = a_h; g_opimg.b = b_h;
+  return T2I_OK;
+}
 
 }  // extern "C"

@@ -54,32 +54,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-// filter copies.  w is HWIO [T][Ci][Co] fp32.
-//   transpose = 0: out[T][Ci][Co] bf16 (plain cast: the K-inner image of the input-gradient GEMM, rows n = ci, k = co)
-//   transpose = 1: out[T][Co][Ci] bf16 (per-tap transpose: the K-inner image of the forward GEMM, rows n = co, k = ci)
-// One workgroup = a 32 (ci) x 32 (co) block of one tap through an LDS tile.
-__global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ w, int Ci, int Co, int transpose,
-                                                    __bf16* __restrict__ out) {
-  __shared__ float tile[32][33];
-  const int t = blockIdx.z, ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
-  const float* src = w + (size_t)t * Ci * Co;
-  __bf16* dst = out + (size_t)t * Ci * Co;
-  for (int j = ty; j < 32; j += 8) {
-    const int ci = ci0 + j, co = co0 + tx;
-    tile[j][tx] = (ci < Ci && co < Co) ? src[(size_t)ci * Co + co] : 0.f;
-  }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    if (transpose) {
-      const int co = co0 + j, ci = ci0 + tx;
-      if (co < Co && ci < Ci) dst[(size_t)co * Ci + ci] = (__bf16)tile[tx][j];
-    } else {
-      const int ci = ci0 + j, co = co0 + tx;
-      if (ci < Ci && co < Co) dst[(size_t)ci * Co + co] = (__bf16)tile[j][tx];
-    }
-  }
-}
+// (the filter copies — wcast_kernel, [tap][Cout][Cin] / [tap][Cin][Cout] bf16 — live with the filter cache in t2i_winograd.hip)
 
 hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream) {
   const size_t n8 = n >> 3;
@@ -87,12 +62,6 @@ hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t strea
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n8, reinterpret_cast<uint4*>(y));
-  return hipGetLastError();
-}
-
-hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream) {
-  dim3 grid((Co + 31) / 32, (Ci + 31) / 32, taps);
-  hipLaunchKernelGGL(wcast_kernel, grid, dim3(256), 0, stream, w, Ci, Co, transpose, reinterpret_cast<__bf16*>(out));
   return hipGetLastError();
 }
 

@@ -91,6 +91,7 @@ int filter_cache_enable(int on);
 int filter_cache_attach(void* buf, size_t bytes);
 void filter_cache_invalidate(const void* p, size_t bytes);
 size_t filter_cache_bytes();
+int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream);
 size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d);
 int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx, int act, float alpha,
                            void* ws, size_t ws_bytes, hipStream_t stream);
@@ -121,7 +122,7 @@ void set_error(const char* fmt, ...);
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh;
   double split_cost;
 };
 const Tuning& tuning();

@@ -112,11 +112,11 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // U[xi][ci][co] = (G g G^T)[xi] with g[r][c] = w[r][c][ci][co] (fwd) or w[2-r][2-c][ci][co] (bwd: the flipped filter; the
 // channel swap of the input-gradient conv is left to the GEMM, which reads U as [n = ci][k = co] — its K-inner B image).
 // Reads and writes are both contiguous along co.
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cin, int Cout, int bwd,
-                                                          float* __restrict__ U) {
+__device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, int Cin, int Cout, int bwd, float* __restrict__ U,
+                                                 unsigned vb, unsigned nvb) {
   const int K = Cin, N = Cout;
   const size_t total = (size_t)K * N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)vb * 256 + threadIdx.x; i < total; i += (size_t)nvb * 256) {
     const int n = (int)(i % N), k = (int)(i / N);
     const int ci = k, co = n;
     float g[3][3];
@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
       U[((size_t)(r * 4 + 3) * K + k) * N + n] = u3;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cin, int Cout, int bwd,
+                                                          float* __restrict__ U) {
+  wino_filter_body(w, Cin, Cout, bwd, U, blockIdx.x, gridDim.x);
 }
 
 // V[xi][t][c]: one thread = one tile x 4 channels
@@ -388,11 +393,11 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
 //   M[xi] = V[xi] * U[xi]             9 batched GEMMs [T x 4Cin] x [4Cin x Cout]
 //   y tile = A^T M A + bias, act      (3x3 -> 2x2)                                                          AT = [1 1 0; 0 1 1]
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino2_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+__device__ __forceinline__ void wino2_filter_body(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U, unsigned vb, unsigned nvb) {
   const int N4 = Cout >> 2;
   const size_t total = (size_t)4 * Cin * N4;             // (phase, ci, co4)
   const size_t plane = (size_t)4 * Cin * N4;             // one xi plane of U, in float4
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)vb * 256 + threadIdx.x; i < total; i += (size_t)nvb * 256) {
     const int n4 = (int)(i % N4);
     const int ci = (int)((i / N4) % Cin);
     const int ph = (int)(i / ((size_t)N4 * Cin));
@@ -412,6 +417,10 @@ __global__ __launch_bounds__(256) void wino2_filter_kernel(const float* __restri
       o[(size_t)(r * 3 + 2) * plane] = s[r][1];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wino2_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+  wino2_filter_body(w, Cin, Cout, U, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void wino2_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw, size_t T,
@@ -541,11 +550,11 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
 //     dx[2q+ph][2r+pw][ci] = sum_{a,b,co} dy[q + oh_off - 1 + a][r + ow_off - 1 + b][co] * w[kh0 + 2(1-a)][kw0 + 2(1-b)][ci][co]
 // (kh0 = 1 - ph, oh_off = ph for pad 1).  36 batched GEMMs (4 phases x 9 tile positions) [T x Cout] x [Cin x Cout]^T.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino2b_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+__device__ __forceinline__ void wino2b_filter_body(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U, unsigned vb, unsigned nvb) {
   const int N4 = Cout >> 2;
   const size_t total = (size_t)4 * Cin * N4;             // (phase, ci, co4)
   const size_t plane = (size_t)Cin * N4;                 // one [ci][co] matrix, in float4
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)vb * 256 + threadIdx.x; i < total; i += (size_t)nvb * 256) {
     const int n4 = (int)(i % N4);
     const int ci = (int)((i / N4) % Cin);
     const int phs = (int)(i / ((size_t)N4 * Cin));
@@ -566,6 +575,10 @@ __global__ __launch_bounds__(256) void wino2b_filter_kernel(const float* __restr
       o[(size_t)(r * 3 + 2) * plane] = s[r][1];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wino2b_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+  wino2b_filter_body(w, Cin, Cout, U, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void wino2b_input_kernel(const float* __restrict__ dy, int Ho, int Wo, int C, int Th, int Tw, size_t T,
@@ -783,6 +796,146 @@ int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const floa
   hipLaunchKernelGGL(wino2_dw_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, P, d.Cin, d.Cout, S, accumulate, dw);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("winograd k4s2 filter gradient: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Batched refresh of the filter cache.  After an optimizer step every cached image of the arena it updated is stale; filled
+// lazily they cost one small launch per (filter, kind) and iteration — ~60 launches of 5-8 us at the benchmark's widths,
+// 0.4-0.5 ms of a 15 ms (fp32) / 8 ms (bf16) iteration.  t2i_filter_cache_refresh regenerates all of them in ONE launch
+// (per 96 entries): the table of (filter, image, dims, kind, first block) rides in the kernel arguments, a workgroup finds
+// its entry by bisection on the scalar unit and runs that kind's transform body on its share of the entry.
+//   kinds 0/1  U = G g G^T of a 3x3 filter (forward / flipped for the input gradient)        wino_filter_body
+//   kind  2    F(2x2,2x2) images of the four 2x2 phase filters of a 4x4 stride-2 conv         wino2_filter_body
+//   kind  3    the same for its input gradient (36 matrices)                                  wino2b_filter_body
+//   kinds 4/5  bf16 K-inner images [tap][Cout][Cin] (per-tap transpose) / [tap][Cin][Cout]    wcast_body
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+
+// One workgroup = a 32 (ci) x 32 (co) block of one tap through an LDS tile; vb enumerates (tap, ci block, co block).
+__device__ __forceinline__ void wcast_body(const float* __restrict__ w, int Ci, int Co, int transpose, bf16_t* __restrict__ out,
+                                           float (*tile)[33], unsigned vb) {
+  const unsigned nbx = (Co + 31) / 32, nby = (Ci + 31) / 32;
+  const int bx = vb % nbx, by = (vb / nbx) % nby, t = vb / (nbx * nby);
+  const int ci0 = by * 32, co0 = bx * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const float* src = w + (size_t)t * Ci * Co;
+  bf16_t* dst = out + (size_t)t * Ci * Co;
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + tx;
+    tile[j][tx] = (ci < Ci && co < Co) ? src[(size_t)ci * Co + co] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    if (transpose) {
+      const int co = co0 + j, ci = ci0 + tx;
+      if (co < Co && ci < Ci) dst[(size_t)co * Ci + ci] = (bf16_t)tile[tx][j];
+    } else {
+      const int ci = ci0 + j, co = co0 + tx;
+      if (ci < Ci && co < Co) dst[(size_t)ci * Co + co] = (bf16_t)tile[j][tx];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ w, int Ci, int Co, int transpose, bf16_t* __restrict__ out) {
+  __shared__ float tile[32][33];
+  wcast_body(w, Ci, Co, transpose, out, tile, blockIdx.x);
+}
+
+hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream) {
+  const unsigned blocks = (unsigned)(((Co + 31) / 32) * ((Ci + 31) / 32) * taps);
+  hipLaunchKernelGGL(wcast_kernel, dim3(blocks), dim3(256), 0, stream, w, Ci, Co, transpose, reinterpret_cast<bf16_t*>(out));
+  return hipGetLastError();
+}
+
+struct RefreshItem { const float* w; void* U; int32_t Cin, Cout, kind, taps; uint32_t block0, nblocks; };   // 40 bytes
+constexpr int REFRESH_MAX = 96;
+struct RefreshBatch { int32_t n, pad; RefreshItem it[REFRESH_MAX]; };                                       // 3848 bytes of kernarg
+
+__device__ __forceinline__ RefreshItem load_refresh_item(int idx) {
+  RefreshItem r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char* KernArg;
+  typedef const __attribute__((address_space(4))) int32_t* Words;
+  const Words src = (Words)((KernArg)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RefreshBatch, it) + (size_t)idx * sizeof(RefreshItem));
+  int32_t* dst = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(RefreshItem) / 4); ++i) dst[i] = src[i];
+#else
+  (void)idx;
+  r = RefreshItem();
+#endif
+  return r;
+}
+
+__device__ __forceinline__ uint32_t load_refresh_block0(int idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) char* KernArg;
+  typedef const __attribute__((address_space(4))) uint32_t* Words;
+  return *(Words)((KernArg)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RefreshBatch, it) + (size_t)idx * sizeof(RefreshItem) + offsetof(RefreshItem, block0));
+#else
+  (void)idx;
+  return 0;
+#endif
+}
+
+__global__ __launch_bounds__(256) void filter_refresh_kernel(RefreshBatch tb) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = tb.n - 1;                       // last entry whose first block is <= blockIdx.x (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (load_refresh_block0(mid) <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RefreshItem it = load_refresh_item(lo);
+  const unsigned vb = blockIdx.x - it.block0;
+  switch (it.kind) {
+    case 0: case 1: wino_filter_body(it.w, it.Cin, it.Cout, it.kind, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
+    case 2: wino2_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
+    case 3: wino2b_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
+    default: wcast_body(it.w, it.Cin, it.Cout, it.kind == 4 ? 1 : 0, reinterpret_cast<bf16_t*>(it.U), tile, vb); break;
+  }
+}
+
+// Regenerates every cache entry whose filter lies in [p, p + bytes) (p == NULL: every entry) and that this launch context may
+// use (same rules as filter_cache_get), marking it valid for the context: eager launches after it, or the rest of the capture
+// it was recorded into, find the images filled.
+int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
+  if (!g_fc_on) return T2I_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return T2I_OK; }
+  const unsigned long long cap = st == hipStreamCaptureStatusActive ? id + 1 : 0;
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  if (!g_fc_buf) return T2I_OK;
+  const char* lo = reinterpret_cast<const char*>(p);
+  RefreshBatch tb;
+  tb.n = 0; tb.pad = 0;
+  uint32_t blocks = 0;
+  auto flush = [&]() {
+    if (tb.n > 0) hipLaunchKernelGGL(filter_refresh_kernel, dim3(blocks), dim3(256), 0, stream, tb);
+    tb.n = 0; blocks = 0;
+  };
+  for (auto& e : g_fc) {
+    const char* q = reinterpret_cast<const char*>(e.w);
+    if (p && !(q >= lo && q < lo + bytes)) continue;
+    if (!cap && e.stream != stream) continue;
+    if (e.valid && e.cap == cap) continue;          // already fresh in this context
+    RefreshItem it;
+    it.w = e.w; it.U = e.U; it.Cin = e.Cin; it.Cout = e.Cout; it.kind = e.kind; it.taps = 0;
+    size_t nb;
+    if (e.kind <= 1) nb = ((size_t)e.Cin * e.Cout + 255) / 256;
+    else if (e.kind <= 3) nb = ((size_t)4 * e.Cin * (e.Cout / 4) + 255) / 256;
+    else { it.taps = (int32_t)(e.bytes / ((size_t)e.Cin * e.Cout * 2)); nb = (size_t)((e.Cout + 31) / 32) * ((e.Cin + 31) / 32) * it.taps; }
+    if (e.kind <= 3 && nb > 2048) nb = 2048;        // the transform bodies stride over their entry
+    it.block0 = blocks; it.nblocks = (uint32_t)nb;
+    tb.it[tb.n++] = it;
+    blocks += (uint32_t)nb;
+    e.valid = true; e.cap = cap;
+    if (tb.n == REFRESH_MAX) flush();
+  }
+  flush();
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { set_error("t2i_filter_cache_refresh: %s", hipGetErrorString(err)); return T2I_ERR_LAUNCH; }
   return T2I_OK;
 }
 

@@ -24,14 +24,18 @@ class StepGraphs(object):
             if v is not None and v is not buf:
                 buf.copy_(v, non_blocking=True)
 
-    def capture(self, name, body, capture_error_mode='global'):
+    def capture(self, name, body, capture_error_mode='global', refresh=True):
         """body(static_feed) -> anything holding device tensors (kept alive and returned by replay).
         capture_error_mode='thread_local' when another thread touches the HIP runtime during the capture (the process
-        group's watchdog under data parallelism)."""
+        group's watchdog under data parallelism).  refresh: start the graph with ONE batched regeneration of every cached filter
+        image (kernels.filter_cache_refresh) — a graph must contain every transform it depends on, and filled lazily they are
+        one small launch per filter; pass False for a segment that runs no convolution."""
         dev = next(iter(self.static.values())).device
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._pool, capture_error_mode=capture_error_mode):
+            if refresh:
+                K.filter_cache_refresh()             # one batched launch; the convs of this graph then find every known image filled
             out = body(self.static)
         if self._pool is None:
             self._pool = g.pool()

@@ -8,6 +8,7 @@ the host-logic tests and by variable creation, in which launches are skipped and
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -172,12 +173,63 @@ def _ws_args(t, nbytes):
     return _ptr(buf), buf.numel()
 
 
+# bf16 math: the GEMMs read bf16 images of their activation operands.  An activation is used by up to three convs (forward,
+# filter gradient, the second-order pieces of the gradient penalty), a gradient by two (input and filter gradient): the image
+# is made once per tensor (and version) here, kept on the tensor object and handed to every conv that reads the tensor
+# (t2i_conv2d_operand_images), instead of each entry point staging its own copy into the workspace.
+_BF16_IMAGES = [os.environ.get('T2I_BF16_IMAGES', '1') != '0']
+_H_ALGO = {}
+
+
+def bf16_images(on):
+    prev, _BF16_IMAGES[0] = _BF16_IMAGES[0], bool(on)
+    return prev
+
+
+def _h_path(d, mode):
+    """does this descriptor's `mode` run the GEMM with bf16 operands in memory?"""
+    if d.math != MATH_BF16 or not _BF16_IMAGES[0]:
+        return False
+    key = (id(d), mode)
+    hit = _H_ALGO.get(key)
+    if hit is None:
+        hit = _H_ALGO[key] = (conv_algo(d, mode) == 'implicit_gemm_bf16_operands')
+    return hit
+
+
+def cast_bf16(t):
+    _chk(t, 't')
+    img = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    check(lib.t2i_cast_bf16(_ptr(t), t.numel(), _ptr(img), _stream()), 't2i_cast_bf16')
+    return img
+
+
+def bf16_image(t):
+    """The bf16 image of fp32 tensor `t` (None if it cannot have one): cached on the tensor object with the version it was made of."""
+    if t.numel() % 8 != 0 or t.data_ptr() % 16 != 0:
+        return None
+    c = getattr(t, '_t2i_h', None)
+    if c is not None and c[0] == t._version and c[2] == t.data_ptr():
+        return c[1]
+    img = cast_bf16(t)
+    t._t2i_h = (t._version, img, t.data_ptr())
+    return img
+
+
+def _bind_images(a, b=None):
+    ia = bf16_image(a) if a is not None else None
+    ib = bf16_image(b) if b is not None else None
+    check(lib.t2i_conv2d_operand_images(_ptr(ia), _ptr(ib)), 't2i_conv2d_operand_images')
+    return ia, ib          # alive until the conv call behind this has been issued
+
+
 def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     _chk(x, 'x'); _chk(w, 'w')
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
+        keep = _bind_images(x) if _h_path(d, 'fwd') else None
         check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                  _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
         if ev is not None:
@@ -273,6 +325,7 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
         chunks, tile_rows = ctypes.c_int32(0), ctypes.c_int32(0)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
+        keep = _bind_images(x) if _h_path(d, 'fwd') else None
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                        _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), ctypes.byref(tile_rows), wsp, wsn,
                                        _stream()), 't2i_conv2d_fwd_stats')
@@ -291,6 +344,7 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     if _live(dy):
         wsp, wsn = _ws_args(dy, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_data')) if _TIMER[0] is not None else None
+        keep = _bind_images(dy) if _h_path(d, 'bwd_data') else None
         check(lib.t2i_conv2d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w),
                                       _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, wsp,
                                       wsn, _stream()), 't2i_conv2d_bwd_data')
@@ -310,6 +364,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_filter')) if _TIMER[0] is not None else None
+        keep = _bind_images(x, dy) if _h_path(d, 'bwd_filter') else None
         check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, wsp, wsn,
                                         _stream()),
               't2i_conv2d_bwd_filter')
@@ -671,6 +726,7 @@ def tuning_set(key, value):
     were computed under the old setting."""
     check(lib.t2i_tuning_set(key.encode(), float(value)), 't2i_tuning_set')
     _DESC_CACHE.clear()
+    _H_ALGO.clear()
 
 
 def kt_sgd(kt, wdist_sums, scale, lr):
@@ -691,6 +747,16 @@ def filter_cache_invalidate(t=None):
 
 def filter_cache_bytes():
     return int(lib.t2i_filter_cache_bytes())
+
+
+def filter_cache_refresh(t=None):
+    """Regenerate, in one launch, every cached filter image (of the filters inside tensor `t`, default: all) that is stale in the
+    current launch context.  t2i_adam_tf does this for its arena; graphs.StepGraphs.capture does it at the head of every graph,
+    so that a graph holds ONE batched refresh instead of one small fill per filter at its first use."""
+    if t is None:
+        check(lib.t2i_filter_cache_refresh(None, 0, _stream()), 't2i_filter_cache_refresh')
+    else:
+        check(lib.t2i_filter_cache_refresh(_ptr(t), t.numel() * t.element_size(), _stream()), 't2i_filter_cache_refresh')
 
 
 def lerp_dev(a, b, t_dev, mode=0):

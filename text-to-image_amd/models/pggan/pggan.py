@@ -182,9 +182,9 @@ class PGGAN(object):
         self._capturing = True
         try:
             self._graphs.capture('d', self.d_losses, capture_error_mode='thread_local')
-            self._graphs.capture('d_upd', lambda f: self.D_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local')
+            self._graphs.capture('d_upd', lambda f: self.D_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local', refresh=False)
             self._graphs.capture('g', self.g_losses, capture_error_mode='thread_local')
-            self._graphs.capture('g_upd', lambda f: self.G_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local')
+            self._graphs.capture('g_upd', lambda f: self.G_optimizer.apply(grad_scale=scale), capture_error_mode='thread_local', refresh=False)
         finally:
             self._capturing = False
 

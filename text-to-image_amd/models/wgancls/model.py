@@ -164,7 +164,7 @@ class WGanCls(object):
 
     def _d_update(self, out, scale):
         """Adam on the critic arena + the kt step; `scale` turns rank-summed gradients (and batch means) into the mean."""
-        self.D_optim.apply(grad_scale=scale)
+        self.D_optim.apply(grad_scale=scale, refresh=True if self.dp is None else None)   # the generator half reads these filters next
         K.kt_sgd(self.kt, out['wd_sums'], scale, self.kt_lr)          # GradientDescentOptimizer(0.001) on balance_loss (model.py:100)
 
     def _d_body(self, feed):
@@ -303,12 +303,17 @@ class WGanCls(object):
         torch.cuda.synchronize(self.device)
         gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.dp is None:
+            # every graph starts with ONE batched regeneration of the cached filter images (a graph contains every transform
+            # it depends on; filled lazily they are ~60 small launches)
             with torch.cuda.graph(gd):
+                K.filter_cache_refresh()
                 d_out = self._d_body(static)
             with torch.cuda.graph(gg, pool=gd.pool()):
+                K.filter_cache_refresh()
                 g_out = self._g_body(static)
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
             with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
+                K.filter_cache_refresh()
                 d_out2 = self._d_body(static)
                 g_out2 = self._g_body(static)
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),

@@ -66,10 +66,18 @@ class AdamTF(object):
         self.lr_t_dev.fill_(lr_t)
         return lr_t
 
-    def apply(self, grad_scale=1.0):
-        """Device half: one kernel over the arena, step size read from the device scalar (graph-capturable)."""
+    def apply(self, grad_scale=1.0, refresh=None):
+        """Device half: one kernel over the arena, step size read from the device scalar (graph-capturable).
+        refresh: regenerate the cached filter images of this arena behind the update, in one launch
+        (kernels.filter_cache_refresh).  Default: yes for eager launches; not inside a capture, whose successor graph starts
+        with a refresh of everything — pass True where the same capture goes on to use these filters (the critic's update in
+        a one-graph iteration)."""
         K.adam_tf(self.arena.flat, self.arena.grad, self.m, self.v, 0.0, self.beta1, self.beta2, self.eps, grad_scale,
                   lr_t_dev=self.lr_t_dev)
+        if refresh is None:
+            refresh = self.arena.flat.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if refresh and self.arena.flat.is_cuda:
+            K.filter_cache_refresh(self.arena.flat)
 
     def step(self, lr, grad_scale=1.0):
         self.prepare(lr)
