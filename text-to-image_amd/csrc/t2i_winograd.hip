@@ -812,45 +812,79 @@ int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const floa
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16_t;
 
-// One workgroup = a 32 (ci) x 32 (co) block of one tap through an LDS tile; vb enumerates (tap, ci block, co block).
-__device__ __forceinline__ void wcast_body(const float* __restrict__ w, int Ci, int Co, int transpose, bf16_t* __restrict__ out,
-                                           float (*tile)[33], unsigned vb) {
-  const unsigned nbx = (Co + 31) / 32, nby = (Ci + 31) / 32;
+// One workgroup = a 64 (ci) x 64 (co) block of one tap through an LDS tile; vb enumerates (tap, ci block, co block).  The
+// fp32 block is read once (float4 along co) and leaves as either or both bf16 images: `plain` [tap][Ci][Co] (4 consecutive
+// co per 8-byte store) and `trans` [tap][Co][Ci] (4 consecutive ci per 8-byte store, read down the LDS tile's columns).
+// Ragged edges (Ci or Co not a multiple of 64, or Co % 4 != 0) take the element-wise path.
+constexpr int WC_T = 64;
+__device__ __forceinline__ unsigned wc_pk2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+  f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+__device__ __forceinline__ unsigned wcast_blocks(int Ci, int Co, int taps) {
+  return (unsigned)(((Co + WC_T - 1) / WC_T) * ((Ci + WC_T - 1) / WC_T) * taps);
+}
+__device__ __forceinline__ void wcast_body(const float* __restrict__ w, int Ci, int Co, bf16_t* __restrict__ plain, bf16_t* __restrict__ trans,
+                                           float (*tile)[WC_T + 1], unsigned vb) {
+  const unsigned nbx = (Co + WC_T - 1) / WC_T, nby = (Ci + WC_T - 1) / WC_T;
   const int bx = vb % nbx, by = (vb / nbx) % nby, t = vb / (nbx * nby);
-  const int ci0 = by * 32, co0 = bx * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const int ci0 = by * WC_T, co0 = bx * WC_T;
   const float* src = w + (size_t)t * Ci * Co;
-  bf16_t* dst = out + (size_t)t * Ci * Co;
-  for (int j = ty; j < 32; j += 8) {
-    const int ci = ci0 + j, co = co0 + tx;
-    tile[j][tx] = (ci < Ci && co < Co) ? src[(size_t)ci * Co + co] : 0.f;
+  const size_t tap_off = (size_t)t * Ci * Co;
+  const int tid = threadIdx.x;
+  const bool full = (ci0 + WC_T <= Ci) && (co0 + WC_T <= Co) && (Co % 4 == 0) && (Ci % 4 == 0);
+  if (full) {
+    const int c4 = tid & 15, r = tid >> 4;            // 16 float4 per row, 16 rows per pass
+#pragma unroll
+    for (int j = 0; j < WC_T; j += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(ci0 + r + j) * Co + co0 + c4 * 4);
+      tile[r + j][c4 * 4 + 0] = v.x; tile[r + j][c4 * 4 + 1] = v.y; tile[r + j][c4 * 4 + 2] = v.z; tile[r + j][c4 * 4 + 3] = v.w;
+      if (plain)
+        *reinterpret_cast<uint2*>(plain + tap_off + (size_t)(ci0 + r + j) * Co + co0 + c4 * 4) = make_uint2(wc_pk2(v.x, v.y), wc_pk2(v.z, v.w));
+    }
+    if (trans) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < WC_T; j += 16) {            // thread -> (co = r + j, 4 consecutive ci = c4 * 4 ..)
+        const int co = r + j;
+        *reinterpret_cast<uint2*>(trans + tap_off + (size_t)(co0 + co) * Ci + ci0 + c4 * 4) =
+            make_uint2(wc_pk2(tile[c4 * 4 + 0][co], tile[c4 * 4 + 1][co]), wc_pk2(tile[c4 * 4 + 2][co], tile[c4 * 4 + 3][co]));
+      }
+    }
+    return;
   }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    if (transpose) {
+  const int tx = tid & 63, ty = tid >> 6;             // 64 x 4
+  for (int j = ty; j < WC_T; j += 4) {
+    const int ci = ci0 + j, co = co0 + tx;
+    const float v = (ci < Ci && co < Co) ? src[(size_t)ci * Co + co] : 0.f;
+    tile[j][tx] = v;
+    if (plain && ci < Ci && co < Co) plain[tap_off + (size_t)ci * Co + co] = (bf16_t)v;
+  }
+  if (trans) {
+    __syncthreads();
+    for (int j = ty; j < WC_T; j += 4) {
       const int co = co0 + j, ci = ci0 + tx;
-      if (co < Co && ci < Ci) dst[(size_t)co * Ci + ci] = (bf16_t)tile[tx][j];
-    } else {
-      const int ci = ci0 + j, co = co0 + tx;
-      if (ci < Ci && co < Co) dst[(size_t)ci * Co + co] = (bf16_t)tile[j][tx];
+      if (co < Co && ci < Ci) trans[tap_off + (size_t)co * Ci + ci] = (bf16_t)tile[tx][j];
     }
   }
 }
 
 __global__ __launch_bounds__(256) void wcast_kernel(const float* __restrict__ w, int Ci, int Co, int transpose, bf16_t* __restrict__ out) {
-  __shared__ float tile[32][33];
-  wcast_body(w, Ci, Co, transpose, out, tile, blockIdx.x);
+  __shared__ float tile[WC_T][WC_T + 1];
+  wcast_body(w, Ci, Co, transpose ? nullptr : out, transpose ? out : nullptr, tile, blockIdx.x);
 }
 
 hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream) {
-  const unsigned blocks = (unsigned)(((Co + 31) / 32) * ((Ci + 31) / 32) * taps);
+  const unsigned blocks = (unsigned)(((Co + WC_T - 1) / WC_T) * ((Ci + WC_T - 1) / WC_T) * taps);
   hipLaunchKernelGGL(wcast_kernel, dim3(blocks), dim3(256), 0, stream, w, Ci, Co, transpose, reinterpret_cast<bf16_t*>(out));
   return hipGetLastError();
 }
 
-struct RefreshItem { const float* w; void* U; int32_t Cin, Cout, kind, taps; uint32_t block0, nblocks; };   // 40 bytes
-constexpr int REFRESH_MAX = 96;
-struct RefreshBatch { int32_t n, pad; RefreshItem it[REFRESH_MAX]; };                                       // 3848 bytes of kernarg
+struct RefreshItem { const float* w; void* U; void* U2; int32_t Cin, Cout, kind, taps; uint32_t block0, nblocks; };   // 48 bytes
+constexpr int REFRESH_MAX = 80;
+struct RefreshBatch { int32_t n, pad; RefreshItem it[REFRESH_MAX]; };                                                 // 3848 bytes of kernarg
 
 __device__ __forceinline__ RefreshItem load_refresh_item(int idx) {
   RefreshItem r;
@@ -880,7 +914,7 @@ __device__ __forceinline__ uint32_t load_refresh_block0(int idx) {
 }
 
 __global__ __launch_bounds__(256) void filter_refresh_kernel(RefreshBatch tb) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[WC_T][WC_T + 1];
   int lo = 0, hi = tb.n - 1;                       // last entry whose first block is <= blockIdx.x (uniform: scalar loads)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -892,7 +926,9 @@ __global__ __launch_bounds__(256) void filter_refresh_kernel(RefreshBatch tb) {
     case 0: case 1: wino_filter_body(it.w, it.Cin, it.Cout, it.kind, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
     case 2: wino2_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
     case 3: wino2b_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
-    default: wcast_body(it.w, it.Cin, it.Cout, it.kind == 4 ? 1 : 0, reinterpret_cast<bf16_t*>(it.U), tile, vb); break;
+    default:      // 4: transposed image in U; 5: plain image in U; 6: both (U transposed, U2 plain) from one read of the filter
+      wcast_body(it.w, it.Cin, it.Cout, reinterpret_cast<bf16_t*>(it.kind == 5 ? it.U : it.U2), reinterpret_cast<bf16_t*>(it.kind == 5 ? nullptr : it.U), tile, vb);
+      break;
   }
 }
 
@@ -921,11 +957,24 @@ int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
     if (!cap && e.stream != stream) continue;
     if (e.valid && e.cap == cap) continue;          // already fresh in this context
     RefreshItem it;
-    it.w = e.w; it.U = e.U; it.Cin = e.Cin; it.Cout = e.Cout; it.kind = e.kind; it.taps = 0;
+    it.w = e.w; it.U = e.U; it.U2 = nullptr; it.Cin = e.Cin; it.Cout = e.Cout; it.kind = e.kind; it.taps = 0;
     size_t nb;
     if (e.kind <= 1) nb = ((size_t)e.Cin * e.Cout + 255) / 256;
     else if (e.kind <= 3) nb = ((size_t)4 * e.Cin * (e.Cout / 4) + 255) / 256;
-    else { it.taps = (int32_t)(e.bytes / ((size_t)e.Cin * e.Cout * 2)); nb = (size_t)((e.Cout + 31) / 32) * ((e.Cin + 31) / 32) * it.taps; }
+    else {
+      it.taps = (int32_t)(e.bytes / ((size_t)e.Cin * e.Cout * 2));
+      nb = (size_t)((e.Cout + WC_T - 1) / WC_T) * ((e.Cin + WC_T - 1) / WC_T) * it.taps;
+      // the other bf16 image of the same filter, if stale too: one read of the filter serves both
+      for (auto& o : g_fc)
+        if (&o != &e && o.w == e.w && o.kind == 9 - e.kind && o.Cin == e.Cin && o.Cout == e.Cout && o.bytes == e.bytes &&
+            !(o.valid && o.cap == cap) && (cap || o.stream == stream)) {
+          it.kind = 6;
+          it.U = e.kind == 4 ? e.U : o.U;            // transposed image
+          it.U2 = e.kind == 4 ? o.U : e.U;           // plain image
+          o.valid = true; o.cap = cap;
+          break;
+        }
+    }
     if (e.kind <= 3 && nb > 2048) nb = 2048;        // the transform bodies stride over their entry
     it.block0 = blocks; it.nblocks = (uint32_t)nb;
     tb.it[tb.n++] = it;

@@ -25,6 +25,32 @@ LAYERS = [
 
 
 def timeit(fn, reps):
+    """Device time per call: `reps` back-to-back calls captured into ONE hipGraph and replayed (no host launch cost between
+    them — a bf16 conv of 20 us would otherwise be timed at the host's ~25 us issue rate).  T2I_BENCH_EAGER=1: eager launches."""
+    if os.environ.get('T2I_BENCH_EAGER') != '1':
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        s.record()
+        for _ in range(n):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        del g
+        return s.elapsed_time(e) / (reps * n) * 1e-3
+    return timeit_eager(fn, reps)
+
+
+def timeit_eager(fn, reps):
     import time
     t0 = time.perf_counter()
     n = 0

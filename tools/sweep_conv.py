@@ -38,6 +38,12 @@ for name, B in WANT:
                     res.append((timeit(fn, 10), tile, sk))
                 except Exception as e:
                     pass
+        if os.environ.get('T2I_SWEEP_DUMP'):
+            M, N, Kd = {'fwd': (B * d.Ho * d.Wo, Co, k * k * Ci), 'bwdD': (B * ((H + s - 1) // s) * ((W + s - 1) // s), Ci, (k // s) * (k // s) * Co if s > 1 else k * k * Co),
+                        'bwdF': (k * k * Ci, Co, B * d.Ho * d.Wo)}[mode]
+            print('DUMP %s %d %s M=%d N=%d K=%d nphase=%d out=%d auto=%.2f %s' % (name, B, mode, M, N, Kd, s * s if mode == 'bwdD' else 1,
+                  {'fwd': B * d.Ho * d.Wo * Co, 'bwdD': B * H * W * Ci, 'bwdF': k * k * Ci * Co}[mode], t0 * 1e6,
+                  ' '.join('%d/%d:%.2f' % (tl, sk, t * 1e6) for t, tl, sk in res)))
         res.sort()
         print('%-5s B=%-3d %-5s auto %7.1f us (%5.1f TF) | best: %s' % (
             name, B, mode, t0 * 1e6, fl / t0 / 1e12,
