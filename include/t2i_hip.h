@@ -289,6 +289,17 @@ int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream);
  * repeated casts.  The call consumes the hand-over whatever path it dispatches to; paths that do not read bf16 operands
  * from memory ignore it.  Results are identical with and without. */
 int t2i_conv2d_operand_images(const void* a_h, const void* b_h);
+/* One-shot, the producer side of the same idea: the NEXT call on this thread to one of t2i_conv2d_fwd / _fwd_stats / _bwd_data
+ * (bf16-operand path), t2i_bn_apply, t2i_act_fwd, t2i_act_bwd, t2i_add_act or t2i_act_bwd_colsum also writes the bf16 image
+ * of its output tensor to y_h (same shape, 16-byte aligned) in the same pass, so that the conv reading that tensor next
+ * needs no cast at all.  The call consumes the request; t2i_output_image_written() tells whether the path it took wrote the
+ * image (vectorised paths only: element count % 4 == 0, aligned) — if not, the caller casts as usual.  Set it only directly
+ * in front of one of the calls listed. */
+int t2i_output_image(void* y_h);
+int t2i_output_image_written(void);
+/* 0 for an eager stream, else a number unique to the capture active on `stream`: a caller that keeps bf16 images (or any
+ * derived buffer) across calls must not let a capture reuse one made outside it — the graph would not contain its producer. */
+uint64_t t2i_capture_id(t2i_stream_t stream);
 
 /* ---- data pipeline: reference preprocess/dataset.py ------------------------------ */
 /* out[b] = crop/flip/normalise of stored image ids[b] (reference Dataset.next_batch + transform, dataset.py:83-96,150):

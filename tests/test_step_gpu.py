@@ -374,7 +374,7 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
     """bf16 math at the benchmark's widths: (a) handing the convs caller-held bf16 images of their activation operands
     (kernels.bf16_image + t2i_conv2d_operand_images: one cast per tensor instead of one per conv that reads it) and (b) the
     batched regeneration of the cached filter images behind the optimizer steps and at the head of every captured graph
-    (t2i_filter_cache_refresh) change no bit of three training iterations — eager and replayed from a graph."""
+    (t2i_filter_cache_refresh) and (c) the bf16 twins the producing kernels write next to their fp32 outputs (t2i_output_image) change no bit of three training iterations — eager and replayed from a graph."""
     from t2i_amd import kernels as K
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
@@ -387,8 +387,9 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
             'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
             'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)}
 
-    def run(images, refresh, graphs):
+    def run(images, refresh, graphs, twins=False):
         prev_i = K.bf16_images(images)
+        prev_t = K.bf16_twins(twins)
         real_refresh = K.filter_cache_refresh
         if not refresh:
             K.filter_cache_refresh = lambda t=None: None        # every image is then filled lazily, at its first use
@@ -405,12 +406,14 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
             return {n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt)
         finally:
             K.bf16_images(prev_i)
+            K.bf16_twins(prev_t)
             K.filter_cache_refresh = real_refresh
             K.filter_cache(prev_c)
     K.set_math('bf16')
     try:
         base = run(False, False, False)
-        for variant in ((True, False, False), (False, True, False), (True, True, False), (True, True, True)):
+        for variant in ((True, False, False), (False, True, False), (True, True, False), (True, True, True), (True, True, False, True),
+                        (True, True, True, True)):
             got = run(*variant)
             assert got[1] == base[1], variant
             for n in base[0]:

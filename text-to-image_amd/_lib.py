@@ -63,6 +63,9 @@ SIGNATURES = {
     't2i_filter_cache_refresh': (ctypes.c_int, [_p, _sz, _p]),
     't2i_cast_bf16': (ctypes.c_int, [_p, _i64, _p, _p]),
     't2i_conv2d_operand_images': (ctypes.c_int, [_p, _p]),
+    't2i_output_image': (ctypes.c_int, [_p]),
+    't2i_output_image_written': (ctypes.c_int, []),
+    't2i_capture_id': (ctypes.c_uint64, [_p]),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),
     't2i_conv2d_fwd_stats': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, ctypes.POINTER(ctypes.c_int32),
                                             ctypes.POINTER(ctypes.c_int32), _p, _sz, _p]),

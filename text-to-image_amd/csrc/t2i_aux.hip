@@ -510,10 +510,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   }
 }
 
+// two floats -> packed bf16 pair (round to nearest even): the bf16 twins of activation tensors (t2i_output_image)
+__device__ __forceinline__ unsigned aux_pk2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+  f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, size_t n, int C, int act,
-                                                       float alpha, float* __restrict__ y) {
+                                                       float alpha, float* __restrict__ y, uint2* __restrict__ yh) {
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       v.z = apply_act(v.z * sc.z + sh.z, act, alpha);
       v.w = apply_act(v.w * sc.w + sh.w, act, alpha);
       reinterpret_cast<float4*>(y)[i] = v;
+      if (yh) yh[i] = make_uint2(aux_pk2(v.x, v.y), aux_pk2(v.z, v.w));
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -637,16 +646,16 @@ hipError_t bn_finalize_launch(const float* sum, const float* sumsq, int64_t n, i
 }
 
 hipError_t bn_apply_launch(const float* x, const float* scale, const float* shift, int64_t rows, int C, int act,
-                           float alpha, float* y, hipStream_t stream) {
+                           float alpha, float* y, hipStream_t stream, void* y_h) {
   const bool al = C > 0;          // the C API passes -C when some pointer is not 16-byte aligned
   if (C < 0) C = -C;
   const size_t n = (size_t)rows * C;
   if (al && (C & 3) == 0)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act,
-                       alpha, y);
+                       alpha, y, reinterpret_cast<uint2*>(y_h));
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, scale, shift, n, C, act,
-                       alpha, y);
+                       alpha, y, (uint2*)nullptr);
   return hipGetLastError();
 }
 
@@ -700,7 +709,8 @@ __device__ __forceinline__ float ew_op(float a, float b, int act, float alpha, f
 
 template <int OP, bool HAS_B>
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
-                                                 size_t n4, int act, float alpha, float beta, float* __restrict__ y) {
+                                                 size_t n4, int act, float alpha, float beta, float* __restrict__ y,
+                                                 uint2* __restrict__ yh) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (size_t i = t; i < n4; i += stride) {
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
     o.z = ew_op<OP>(va.z, vb.z, act, alpha, beta);
     o.w = ew_op<OP>(va.w, vb.w, act, alpha, beta);
     reinterpret_cast<float4*>(y)[i] = o;
+    if (yh) yh[i] = make_uint2(aux_pk2(o.x, o.y), aux_pk2(o.z, o.w));
   }
   for (size_t i = (n4 << 2) + t; i < n; i += stride) y[i] = ew_op<OP>(a[i], HAS_B ? b[i] : 0.f, act, alpha, beta);
 }
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
                                                              const float* __restrict__ x2, const float* __restrict__ center,
                                                              int64_t rows, int C, int64_t rows_per_chunk, int act, float alpha,
                                                              float* __restrict__ dx, float* __restrict__ part,
-                                                             float* __restrict__ part1) {
+                                                             float* __restrict__ part1, unsigned short* __restrict__ dxh) {
   __shared__ float4 red[16][16];
   __shared__ float4 red1[SECOND ? 16 : 1][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -743,6 +754,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
       d.x = g.x * act_grad_from_output(o.x, act, alpha); d.y = g.y * act_grad_from_output(o.y, act, alpha);
       d.z = g.z * act_grad_from_output(o.z, act, alpha); d.w = g.w * act_grad_from_output(o.w, act, alpha);
       *reinterpret_cast<float4*>(dx + r * C + c) = d;
+      if (dxh) *reinterpret_cast<uint2*>(dxh + r * C + c) = make_uint2(aux_pk2(d.x, d.y), aux_pk2(d.z, d.w));
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
       if (SECOND) {
         const float4 v = *reinterpret_cast<const float4*>(x2 + r * C + c);
@@ -768,7 +780,8 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
 }
 
 hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int C, int act,
-                                 float alpha, float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream) {
+                                 float alpha, float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream, void* dx_h) {
+  unsigned short* dxh = reinterpret_cast<unsigned short*>(dx_h);
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
@@ -776,10 +789,10 @@ hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x
   const bool second = x2 != nullptr && sum1 != nullptr;
   if (second)
     hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
-                       dx, part, part1);
+                       dx, part, part1, dxh);
   else
     hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
-                       dx, part, part1);
+                       dx, part, part1, dxh);
   hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
                      sum0, second ? sum1 : (float*)nullptr, accumulate);
   return hipGetLastError();
@@ -796,7 +809,7 @@ hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, 
   const float* g = dy;
   if (y) {
     hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha, gmask, part,
-                       part1);
+                       part1, (unsigned short*)nullptr);
     g = gmask;
   } else {
     hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean);
@@ -810,19 +823,20 @@ hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, 
 }
 
 hipError_t ew_launch(int op, const float* a, const float* b, size_t n_flag, int act, float alpha, float beta, float* y,
-                     hipStream_t stream) {
+                     hipStream_t stream, void* y_h) {
+  uint2* yh = reinterpret_cast<uint2*>(y_h);          // bf16 twin of y (only with the float4 body: n % 4 == 0, aligned)
   // bit 63 of n_flag set => some pointer is not 16-byte aligned: no float4 body, everything through the scalar tail
   const bool al = (n_flag >> 63) == 0;
   const size_t n = n_flag & ~(1ull << 63);
   const size_t n4 = al ? (n >> 2) : 0;
   dim3 g(ew_blocks(al ? ((n + 3) >> 2) : n)), blk(256);
   switch (op) {
-    case EW_ACT_FWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_FWD, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
-    case EW_ACT_BWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_BWD, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
-    case EW_ADD_ACT: hipLaunchKernelGGL((ew_kernel<EW_ADD_ACT, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y); break;
+    case EW_ACT_FWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_FWD, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
+    case EW_ACT_BWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_BWD, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
+    case EW_ADD_ACT: hipLaunchKernelGGL((ew_kernel<EW_ADD_ACT, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
     default:
-      if (b) hipLaunchKernelGGL((ew_kernel<EW_AXPBY, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y);
-      else hipLaunchKernelGGL((ew_kernel<EW_AXPBY, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y);
+      if (b) hipLaunchKernelGGL((ew_kernel<EW_AXPBY, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);
+      else hipLaunchKernelGGL((ew_kernel<EW_AXPBY, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);
   }
   return hipGetLastError();
 }

@@ -32,10 +32,10 @@ hipError_t bn_bwd_fused_launch(const float*, const float*, const float*, const f
                                float*, float*, float*, float*, int, void*, hipStream_t);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
-hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t);
+hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h = nullptr);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                          int64_t, int, float*, float*, float*, float*, int, hipStream_t);
-hipError_t ew_launch(int, const float*, const float*, size_t, int, float, float, float*, hipStream_t);
+hipError_t ew_launch(int, const float*, const float*, size_t, int, float, float, float*, hipStream_t, void* y_h = nullptr);
 hipError_t interp_launch(const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t concat_tile_fwd_launch(const float*, const float*, int, int, int, int, float*, hipStream_t);
 hipError_t concat_tile_bwd_launch(const float*, int, int, int, int, float*, float*, hipStream_t);
@@ -57,7 +57,7 @@ hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, 
                           hipStream_t);
 hipError_t kt_sgd_launch(float*, const float*, float, float, hipStream_t);
 hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, const float*, int64_t, int, int, float, float*, float*,
-                                 float*, int, void*, hipStream_t);
+                                 float*, int, void*, hipStream_t, void* dx_h = nullptr);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -304,6 +304,15 @@ static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
 // every t2i_conv2d_* entry point at entry, whatever path it then dispatches to.
 struct OperandImages { const void* a; const void* b; };
 static thread_local OperandImages g_opimg = {nullptr, nullptr};
+// One-shot bf16 twin of the next producer's output (t2i_output_image), taken at entry by the entry points that can write one.
+static thread_local void* g_outimg = nullptr;
+static thread_local int g_outimg_written = 0;
+static inline void* take_output_image() {
+  void* r = g_outimg;
+  g_outimg = nullptr;
+  g_outimg_written = 0;
+  return r;
+}
 static inline OperandImages take_operand_images() {
   const OperandImages r = g_opimg;
   g_opimg.a = g_opimg.b = nullptr;
@@ -339,8 +348,8 @@ static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
   return al256c(n_in * 2) + al256c((size_t)d->KH * d->KW * d->Cin * d->Cout * 2) + pl.ws_bytes;
 }
 
-static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, int act,
-                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, void* out_h,
+                  int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
   IgemmParams p;
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
@@ -376,11 +385,16 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
     p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
   } else {
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = 0;
+    if (out_h && aligned16(out_h)) { p.c_h = out_h; g_outimg_written = 1; }
   }
   rc = check(igemm_h_launch(mode, p, pl.wmt, pl.wnt, stream), what);
   if (rc != T2I_OK) return rc;
-  if (pl.splitk > 1)
-    rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(base + off_s), pl.splitk, out_elems, bias, p.N, act, alpha, out, 0, stream), what);
+  if (pl.splitk > 1) {
+    bool wrote = false;
+    rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(base + off_s), pl.splitk, out_elems, bias, p.N, act, alpha, out, 0, stream,
+                                    (out_h && aligned16(out_h)) ? out_h : nullptr, &wrote), what);
+    if (wrote) g_outimg_written = 1;
+  }
   return rc;
 }
 
@@ -568,6 +582,7 @@ int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w,
 static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                            float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   const OperandImages img = take_operand_images();
+  void* y_h = take_output_image();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
@@ -585,7 +600,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
     return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (h_eligible(*d, false) && aligned16(x) && aligned16(w))
-    return conv_h(MODE_FWD, d, x, img.a, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
+    return conv_h(MODE_FWD, d, x, img.a, w, bias, y, y_h, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -603,6 +618,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
                         float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   const OperandImages img = take_operand_images();
+  void* dx_h = take_output_image();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
@@ -619,7 +635,7 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   if (winograd_k4s2_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
     return winograd_k4s2_bwd_data(*d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (h_eligible(*d, true) && aligned16(dy) && aligned16(w))
-    return conv_h(MODE_BWD_DATA, d, dy, img.a, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
+    return conv_h(MODE_BWD_DATA, d, dy, img.a, w, bias, dx, dx_h, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
@@ -764,9 +780,12 @@ int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, 
 
 int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act, float alpha,
                  float* y, t2i_stream_t stream) {
+  void* y_h = take_output_image();
   if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) { set_error("t2i_bn_apply: bad argument"); return T2I_ERR_INVALID; }
   const bool al = aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift);
-  return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, y, (hipStream_t)stream), "t2i_bn_apply");
+  if (!(al && (C & 3) == 0 && aligned16(y_h))) y_h = nullptr;
+  if (y_h) g_outimg_written = 1;
+  return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, y, (hipStream_t)stream, y_h), "t2i_bn_apply");
 }
 
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -784,10 +803,13 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
 
 static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y,
                    t2i_stream_t stream, const char* what, bool need_b) {
+  void* y_h = take_output_image();
   if (!a || !y || n <= 0 || (need_b && !b)) { set_error("%s: bad argument", what); return T2I_ERR_INVALID; }
   const bool al = aligned16(a) && aligned16(y) && (!b || aligned16(b));
+  if (!(al && (n & 3) == 0 && aligned16(y_h))) y_h = nullptr;
+  if (y_h) g_outimg_written = 1;
   // unaligned views take the scalar tail path: tell the kernel there is no float4 body
-  return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, y, (hipStream_t)stream), what);
+  return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, y, (hipStream_t)stream, y_h), what);
 }
 
 int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
@@ -799,13 +821,16 @@ int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha
 int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
                        float alpha, float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
                        t2i_stream_t stream) {
+  void* dx_h = take_output_image();
   if (center && (!x2 || !aligned16(center))) { set_error("t2i_act_bwd_colsum: center needs x2 and 16-byte alignment"); return T2I_ERR_INVALID; }
   if ((x2 == nullptr) != (colsum_x2 == nullptr) || (x2 && !aligned16(x2))) { set_error("t2i_act_bwd_colsum: x2 / colsum_x2 must come together, 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
   if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
+  if (!aligned16(dx_h)) dx_h = nullptr;
+  if (dx_h) g_outimg_written = 1;
   return check(act_bwd_colsum_launch(dy, y, x2, center, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
-                                     (hipStream_t)stream), "t2i_act_bwd_colsum");
+                                     (hipStream_t)stream, dx_h), "t2i_act_bwd_colsum");
 }
 int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
   return ew_call(2, a, b, n, act, alpha, 0.f, y, stream, "t2i_add_act", true);
@@ -999,6 +1024,21 @@ int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream) {
   }
   return check(cast_bf16_launch(x, (size_t)n, out, (hipStream_t)stream), "t2i_cast_bf16");
 }
+
+uint64_t t2i_capture_id(t2i_stream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return st == hipStreamCaptureStatusActive ? (uint64_t)id + 1 : 0;
+}
+
+int t2i_output_image(void* y_h) {
+  g_outimg = y_h;
+  g_outimg_written = 0;
+  return T2I_OK;
+}
+
+int t2i_output_image_written(void) { return g_outimg_written; }
 
 int t2i_conv2d_operand_images(const void* a_h, const void* b_h) {
   g_opimg.a = a_h; g_opimg.b = b_h;

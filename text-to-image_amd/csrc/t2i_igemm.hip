@@ -725,7 +725,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splitk,
                                                             size_t out_elems, const float* __restrict__ bias, int N,
-                                                            int act, float alpha, float* __restrict__ out, int accumulate) {
+                                                            int act, float alpha, float* __restrict__ out, int accumulate,
+                                                            uint2* __restrict__ outh) {
   const size_t n4 = out_elems >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(slabs)[i];
@@ -744,6 +745,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
     reinterpret_cast<float4*>(out)[i] = s;
+    if (outh) {                     // bf16 twin of the finished output (t2i_output_image)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+      f2 lo = {s.x, s.y}, hi = {s.z, s.w};
+      outh[i] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2)));
+    }
   }
 }
 
@@ -848,7 +855,8 @@ hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int va
 }
 
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
-                                float alpha, float* out, int accumulate, hipStream_t stream) {
+                                float alpha, float* out, int accumulate, hipStream_t stream, void* out_h, bool* wrote_h) {
+  if (wrote_h) *wrote_h = false;
   if ((out_elems & 3) == 0 && (N & 3) == 0) {
     size_t n4 = out_elems >> 2;
     if (splitk >= 32 && n4 <= 65536) {           // few outputs, many slabs: parallelise over slabs too
@@ -860,7 +868,8 @@ hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splitk, out_elems, bias, N, act,
-                       alpha, out, accumulate);
+                       alpha, out, accumulate, reinterpret_cast<uint2*>(out_h));
+    if (wrote_h && out_h) *wrote_h = true;
   } else {
     int blocks = (int)((out_elems + 255) / 256);
     if (blocks > 4096) blocks = 4096;

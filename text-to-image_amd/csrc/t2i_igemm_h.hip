@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
             if (p.bias) v += p.bias[n];
             v = apply_act(v, p.act, p.alpha);
             if (p.accumulate) v += out[rowoff + n];
+            if (p.c_h) reinterpret_cast<__bf16*>(p.c_h)[rowoff + n] = (__bf16)v;
           }
           out[rowoff + n] = v;
         }

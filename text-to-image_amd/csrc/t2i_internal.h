@@ -48,6 +48,7 @@ struct IgemmParams {
   const float* a;
   const float* b;
   float* c;
+  void* c_h;                  // bf16-operand kernels, unsplit: also write the output's bf16 twin here (or NULL)
   const float* bias;
   int32_t act;
   float alpha;
@@ -113,7 +114,7 @@ hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose,
 // slot of the caller-owned filter-cache arena for (filter, kind) — nullptr when the cache cannot serve it (t2i_winograd.hip)
 float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
-                                float alpha, float* out, int accumulate, hipStream_t stream);
+                                float alpha, float* out, int accumulate, hipStream_t stream, void* out_h = nullptr, bool* wrote_h = nullptr);
 
 void set_error(const char* fmt, ...);
 

@@ -204,15 +204,24 @@ def cast_bf16(t):
     return img
 
 
+def _image_holder(t):
+    """The tensor object the image is kept on: the base of `t` when t is a full view of it (the layout helpers of utils/ops.py hand
+    the convs permuted-and-permuted-back views of the producing kernel's output: same memory, same order, another object)."""
+    b = t._base
+    return b if (b is not None and b.data_ptr() == t.data_ptr() and b.numel() == t.numel()) else t
+
+
 def bf16_image(t):
     """The bf16 image of fp32 tensor `t` (None if it cannot have one): cached on the tensor object with the version it was made of."""
     if t.numel() % 8 != 0 or t.data_ptr() % 16 != 0:
         return None
-    c = getattr(t, '_t2i_h', None)
-    if c is not None and c[0] == t._version and c[2] == t.data_ptr():
+    h = _image_holder(t)
+    c = getattr(h, '_t2i_h', None)
+    cap = int(lib.t2i_capture_id(_stream()))      # an image made outside the current capture (eager, or an earlier capture) is
+    if c is not None and c[0] == t._version and c[2] == t.data_ptr() and c[3] == cap:      # not part of this graph: never reused
         return c[1]
     img = cast_bf16(t)
-    t._t2i_h = (t._version, img, t.data_ptr())
+    h._t2i_h = (t._version, img, t.data_ptr(), cap)
     return img
 
 
@@ -223,6 +232,31 @@ def _bind_images(a, b=None):
     return ia, ib          # alive until the conv call behind this has been issued
 
 
+# ... and where the tensor a conv will read comes out of one of our own kernels (activation / batch-norm apply / residual join /
+# a conv epilogue with its activation fused / activation backward), that kernel writes the bf16 image as a TWIN of its fp32
+# output in the same pass (t2i_output_image): no cast launch at all for it.
+_TWINS = [os.environ.get('T2I_BF16_TWINS', '1') != '0']
+
+
+def bf16_twins(on):
+    prev, _TWINS[0] = _TWINS[0], bool(on)
+    return prev
+
+
+def _twin_begin(out):
+    """Ask the next producer call for the bf16 twin of `out` (bf16 math, a multiple of 64 channels: a conv reads it next)."""
+    if _MATH[0] != MATH_BF16 or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
+        return None
+    img = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+    check(lib.t2i_output_image(_ptr(img)), 't2i_output_image')
+    return img
+
+
+def _twin_end(out, img):
+    if img is not None and lib.t2i_output_image_written():
+        out._t2i_h = (out._version, img, out.data_ptr(), int(lib.t2i_capture_id(_stream())))
+
+
 def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     _chk(x, 'x'); _chk(w, 'w')
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
@@ -230,8 +264,10 @@ def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         keep = _bind_images(x) if _h_path(d, 'fwd') else None
+        twin = _twin_begin(y) if (act != ACT_NONE and d.math == MATH_BF16) else None     # conv + bias + lrelu feeds the next conv directly
         check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                  _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
+        _twin_end(y, twin)
         if ev is not None:
             ev.record()
     return y
@@ -345,9 +381,11 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         wsp, wsn = _ws_args(dy, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_data')) if _TIMER[0] is not None else None
         keep = _bind_images(dy) if _h_path(d, 'bwd_data') else None
+        twin = _twin_begin(dx) if (act != ACT_NONE and d.math == MATH_BF16) else None
         check(lib.t2i_conv2d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w),
                                       _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, wsp,
                                       wsn, _stream()), 't2i_conv2d_bwd_data')
+        _twin_end(dx, twin)
         if ev is not None:
             ev.record()
     return dx
@@ -410,8 +448,10 @@ def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
     C = x.shape[-1]
     y = torch.empty_like(x)
     if _live(x):
+        twin = _twin_begin(y)
         check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _stream()),
               't2i_bn_apply')
+        _twin_end(y, twin)
     return y
 
 
@@ -437,7 +477,9 @@ def act_fwd(x, act, alpha=0.2):
     _chk(x, 'x')
     y = torch.empty_like(x)
     if _live(x):
+        twin = _twin_begin(y)
         check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _stream()), 't2i_act_fwd')
+        _twin_end(y, twin)
     return y
 
 
@@ -445,7 +487,9 @@ def act_bwd(dy, y, act, alpha=0.2):
     _chk(dy, 'dy'); _chk(y, 'y')
     dx = torch.empty_like(dy)
     if _live(dy):
+        twin = _twin_begin(dx)
         check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _stream()), 't2i_act_bwd')
+        _twin_end(dx, twin)
     return dx
 
 
@@ -465,9 +509,11 @@ def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
     if _live(dy):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(dy, need)
+        twin = _twin_begin(dx) if x2 is None else None      # conv bias path: dx is the next input / filter gradient's operand
         check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), _ptr(_chk(center, 'center') if center is not None else None), rows, C,
                                      act, alpha, _ptr(dx), _ptr(s), _ptr(s2),
                                      1 if out is not None else 0, wsp, wsn, _stream()), 't2i_act_bwd_colsum')
+        _twin_end(dx, twin)
     return (dx, s) if x2 is None else (dx, s, s2)
 
 
@@ -476,7 +522,9 @@ def add_act(a, b, act=ACT_NONE, alpha=0.2):
     assert a.shape == b.shape
     y = torch.empty_like(a)
     if _live(a):
+        twin = _twin_begin(y)
         check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _stream()), 't2i_add_act')
+        _twin_end(y, twin)
     return y
 
 
