@@ -62,6 +62,7 @@ def _stream():
 # ---- workspace: one grow-only buffer per (device, lane); all users of a buffer are ordered on one stream.  Lane 0 is the
 # caller's current stream; autograd's filter-gradient side stream launches under lane 1 (WS_LANE) -----------------------
 WS_LANE = [0]
+_STREAM_LANE = {}        # hipStream_t -> lane, for streams that run convolutions of their own (stream_lane)
 _WS = {}
 _WS_MIN = 64 << 20
 _WS_CAPTURED = set()     # lanes whose CURRENT buffer has been handed to a kernel inside a graph capture
@@ -73,7 +74,10 @@ def workspace(device, nbytes):
     address baked into its kernel arguments, so once a capture has used a buffer it is never freed: a later eager call
     that needs more (the sampler at SAMPLE_NUM > BATCH_SIZE, a bigger batch) gets a NEW buffer and the old one is retired
     but kept alive — replays keep writing into memory they still own."""
-    key = (device.type, device.index, WS_LANE[0])
+    lane = WS_LANE[0]
+    if lane == 0 and _STREAM_LANE and device.type == 'cuda':
+        lane = _STREAM_LANE.get(torch.cuda.current_stream(device).cuda_stream, 0)
+    key = (device.type, device.index, lane)
     buf = _WS.get(key)
     capturing = torch.cuda.is_available() and device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
     if buf is None or buf.numel() < nbytes:
@@ -87,6 +91,20 @@ def workspace(device, nbytes):
     if capturing:
         _WS_CAPTURED.add(key)
     return buf
+
+
+def stream_lane(stream, lane, device=None):
+    """Give `stream` its own workspace lane (launches on it then never share scratch with the main stream's), sized like lane 0."""
+    _STREAM_LANE[stream.cuda_stream] = lane
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    main = _WS.get((dev.type, dev.index, 0))
+    key = (dev.type, dev.index, lane)
+    if main is not None and (_WS.get(key) is None or _WS[key].numel() < main.numel()):
+        if _WS.get(key) is not None and key in _WS_CAPTURED:
+            _WS_RETIRED.append(_WS[key]); _WS_CAPTURED.discard(key)
+        _WS[key] = torch.empty(main.numel(), dtype=torch.uint8, device=dev)
 
 
 # ---- convolution geometry (TF padding rules; reference utils/ops.py:58-71 passes the string through to TF) -------------

@@ -26,6 +26,8 @@ from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_tra
 # capture mode of the data-parallel graph segments: thread-local, because the process group's watchdog thread polls events
 # while the capture is open (T2I_DP_CAPTURE_MODE=global for diagnostics with a backend that has no such thread)
 _CAPTURE_MODE = os.environ.get('T2I_DP_CAPTURE_MODE', 'thread_local')
+# one-graph iteration (single GPU): issue the G step's generator forward on a second stream beside the critic step
+_OVERLAP_G_FORWARD = os.environ.get('T2I_OVERLAP_G_FORWARD', '1') != '0'
 
 
 class WGanCls(object):
@@ -221,8 +223,27 @@ class WGanCls(object):
             G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
         return dict(G_loss=G_loss, G_kl_loss=G_kl_loss, D_loss_fake=D_loss_fake, G=G.detach())
 
-    def _g_body(self, feed):
-        out = self.g_losses(feed)
+    def _g_forward_ahead(self, feed):
+        """_g_forward issued on a second stream, forked from the current one: the G step's generator forward reads only the
+        generator's variables and the feed, so it can run BESIDE the critic step (whose own generator pass is a no_grad
+        evaluation that updates nothing) instead of after it.  Its ~70 launches are small (B x 4x4..32x32 maps, batch-norm
+        reductions) and leave most of the chip idle; next to the critic's large GEMMs they are nearly free.  The caller joins
+        with `torch.cuda.current_stream().wait_stream(self._ahead)` before the critic reads G."""
+        if getattr(self, '_ahead', None) is None:
+            self._ahead = torch.cuda.Stream(device=self.device)
+        K.stream_lane(self._ahead, 2, self.device)           # its convolutions get their own scratch
+        self._ahead.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._ahead):
+            fwd = self._g_forward(feed)
+        return fwd
+
+    def _g_body(self, feed, fwd=None):
+        if fwd is not None:                                  # issued ahead on the second stream: join, and tell the allocator
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._ahead)
+            for t in fwd:
+                t.record_stream(cur)
+        out = self.g_losses(feed, fwd)
         scale = 1.0
         if self.dp is not None:
             scale = self.dp.allreduce_arena(self.g_arena)
@@ -314,8 +335,9 @@ class WGanCls(object):
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
             with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
                 K.filter_cache_refresh()
+                ahead = self._g_forward_ahead(static) if _OVERLAP_G_FORWARD else None   # beside the critic step, not after it
                 d_out2 = self._d_body(static)
-                g_out2 = self._g_body(static)
+                g_out2 = self._g_body(static, ahead)
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
                             'static': static, 'loaded': False}
             return
