@@ -271,7 +271,8 @@ int t2i_filter_cache_attach(void* buf, size_t bytes);
 int t2i_filter_cache_enable(int on);
 void t2i_filter_cache_invalidate(const void* ptr, size_t bytes);
 size_t t2i_filter_cache_bytes(void);            /* bytes of the attached arena handed out so far */
-/* Regenerates, in ONE launch per 96 entries, every cached image whose filter lies in [ptr, ptr + bytes) (ptr NULL: all) and is
+/* Regenerates, in ONE launch per 80 entries, every cached image whose filter lies inside [ptr, ptr + bytes) (ptr NULL: all —
+ * only if every filter the cache has ever seen is still allocated: entries outlive their filters) and is
  * stale in the launch context of `stream` (eager, or the capture active on it), and marks it filled for that context.
  * Call it behind t2i_adam_tf for the arena it updated (or set the tuning key cache_refresh = 1 and t2i_adam_tf does), and at
  * the head of a capture with (NULL, 0): an iteration then holds one batched regeneration per optimizer step instead of one

@@ -953,7 +953,10 @@ int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
   };
   for (auto& e : g_fc) {
     const char* q = reinterpret_cast<const char*>(e.w);
-    if (p && !(q >= lo && q < lo + bytes)) continue;
+    // the filter this entry was made of must lie INSIDE the caller's range: an entry left behind by a filter that no longer
+    // exists (another model's arena, freed since) is never read again
+    const size_t wbytes = (size_t)(e.kind <= 1 ? 9 : e.kind <= 3 ? 16 : (int)(e.bytes / ((size_t)e.Cin * e.Cout * 2))) * e.Cin * e.Cout * 4;
+    if (p && !(q >= lo && q + wbytes <= lo + bytes)) continue;
     if (!cap && e.stream != stream) continue;
     if (e.valid && e.cap == cap) continue;          // already fresh in this context
     RefreshItem it;

@@ -12,8 +12,10 @@ from . import kernels as K
 
 
 class StepGraphs(object):
-    def __init__(self, example_feed, keys):
-        """example_feed: name -> device tensor (shapes/dtypes of every later feed); keys: the entries the bodies read."""
+    def __init__(self, example_feed, keys, filters=()):
+        """example_feed: name -> device tensor (shapes/dtypes of every later feed); keys: the entries the bodies read;
+        filters: the tensors holding the convolution filters the bodies use (the optimizer arenas) — see capture(refresh=)."""
+        self.filters = list(filters)
         self.static = {k: example_feed[k].clone() for k in keys if example_feed.get(k) is not None}
         self.graphs, self.outs, self._pool = {}, {}, None
 
@@ -35,7 +37,8 @@ class StepGraphs(object):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._pool, capture_error_mode=capture_error_mode):
             if refresh:
-                K.filter_cache_refresh()             # one batched launch; the convs of this graph then find every known image filled
+                for t in self.filters:               # one batched launch per arena; the convs of this graph then find every
+                    K.filter_cache_refresh(t)        # known image of these filters filled
             out = body(self.static)
         if self._pool is None:
             self._pool = g.pool()

@@ -816,8 +816,8 @@ def filter_cache_bytes():
 
 
 def filter_cache_refresh(t=None):
-    """Regenerate, in one launch, every cached filter image (of the filters inside tensor `t`, default: all) that is stale in the
-    current launch context.  t2i_adam_tf does this for its arena; graphs.StepGraphs.capture does it at the head of every graph,
+    """Regenerate, in one launch, every cached filter image (of the filters inside tensor `t`; None = all, legal only while every
+    filter the cache has seen is still allocated) that is stale in the current launch context.  t2i_adam_tf does this for its arena; graphs.StepGraphs.capture does it at the head of every graph,
     so that a graph holds ONE batched refresh instead of one small fill per filter at its first use."""
     if t is None:
         check(lib.t2i_filter_cache_refresh(None, 0, _stream()), 't2i_filter_cache_refresh')

@@ -89,7 +89,7 @@ class GanClsTrainer(object):
         from ...graphs import StepGraphs
         if self.model.dp is not None:
             raise RuntimeError('graph capture with data parallelism is not supported yet')
-        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'))
+        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'), filters=(self.model.d_arena.flat, self.model.g_arena.flat))
         self._graphs.capture('d', self._d_body)
         self._graphs.capture('g', self._g_body)
 

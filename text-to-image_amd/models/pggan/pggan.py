@@ -169,7 +169,8 @@ class PGGAN(object):
         for k, shape in (('eps_graph', (B,)), ('ca_noise_d', (B, self.compr_embed_dim)), ('ca_noise_g', (B, self.compr_embed_dim))):
             if feed.get(k) is None:
                 feed[k] = torch.empty(shape, device=dev)
-        self._graphs = StepGraphs(feed, ('x', 'x_mismatch', 'cond', 'z', 'eps_graph', 'ca_noise_d', 'ca_noise_g'))
+        self._graphs = StepGraphs(feed, ('x', 'x_mismatch', 'cond', 'z', 'eps_graph', 'ca_noise_d', 'ca_noise_g'),
+                                  filters=(self.d_arena.flat, self.g_arena.flat))
         self._redraw(feed)
         self._graphs.load(feed)
         if self.dp is None:

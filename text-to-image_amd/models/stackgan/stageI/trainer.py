@@ -112,7 +112,8 @@ class ConditionalGanTrainer(object):
         for k in self.NOISE_KEYS:
             if feed.get(k) is None:
                 feed[k] = torch.empty(feed['z'].shape[0], self._noise_dim(k), device=m.device)
-        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z') + tuple(self.NOISE_KEYS))
+        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z') + tuple(self.NOISE_KEYS),
+                                  filters=(m.d_arena.flat, m.g_arena.flat))
         self._draw_noise(feed)
         self._graphs.load(feed)
         if m.dp is None:

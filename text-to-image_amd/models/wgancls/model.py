@@ -223,15 +223,23 @@ class WGanCls(object):
             G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
         return dict(G_loss=G_loss, G_kl_loss=G_kl_loss, D_loss_fake=D_loss_fake, G=G.detach())
 
+    def _refresh_filters(self):
+        """Head of a captured graph: one batched regeneration per arena of the cached filter images (kernels.filter_cache_refresh)."""
+        K.filter_cache_refresh(self.d_arena.flat)
+        K.filter_cache_refresh(self.g_arena.flat)
+
+    def _prepare_ahead(self):
+        """The second stream and its workspace lane (sized like the main lane) — allocated OUTSIDE any capture."""
+        if getattr(self, '_ahead', None) is None:
+            self._ahead = torch.cuda.Stream(device=self.device)
+        K.stream_lane(self._ahead, 2, self.device)           # its convolutions get their own scratch
+
     def _g_forward_ahead(self, feed):
         """_g_forward issued on a second stream, forked from the current one: the G step's generator forward reads only the
         generator's variables and the feed, so it can run BESIDE the critic step (whose own generator pass is a no_grad
         evaluation that updates nothing) instead of after it.  Its ~70 launches are small (B x 4x4..32x32 maps, batch-norm
         reductions) and leave most of the chip idle; next to the critic's large GEMMs they are nearly free.  The caller joins
         with `torch.cuda.current_stream().wait_stream(self._ahead)` before the critic reads G."""
-        if getattr(self, '_ahead', None) is None:
-            self._ahead = torch.cuda.Stream(device=self.device)
-        K.stream_lane(self._ahead, 2, self.device)           # its convolutions get their own scratch
         self._ahead.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._ahead):
             fwd = self._g_forward(feed)
@@ -321,20 +329,22 @@ class WGanCls(object):
         for k in ('ca_noise_d', 'ca_noise_g'):
             if k not in static:   # re-drawn in place before every replay (_load_static); nothing is drawn here, so the
                 static[k] = torch.zeros(feed['cond'].shape[0], self.compressed_embed_dim, device=self.device)   # RNG stream stays the eager one
+        if self.dp is None and _OVERLAP_G_FORWARD:
+            self._prepare_ahead()
         torch.cuda.synchronize(self.device)
         gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.dp is None:
             # every graph starts with ONE batched regeneration of the cached filter images (a graph contains every transform
             # it depends on; filled lazily they are ~60 small launches)
             with torch.cuda.graph(gd):
-                K.filter_cache_refresh()
+                self._refresh_filters()
                 d_out = self._d_body(static)
             with torch.cuda.graph(gg, pool=gd.pool()):
-                K.filter_cache_refresh()
+                self._refresh_filters()
                 g_out = self._g_body(static)
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
             with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
-                K.filter_cache_refresh()
+                self._refresh_filters()
                 ahead = self._g_forward_ahead(static) if _OVERLAP_G_FORWARD else None   # beside the critic step, not after it
                 d_out2 = self._d_body(static)
                 g_out2 = self._g_body(static, ahead)
