@@ -290,6 +290,17 @@ int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream);
  * repeated casts.  The call consumes the hand-over whatever path it dispatches to; paths that do not read bf16 operands
  * from memory ignore it.  Results are identical with and without. */
 int t2i_conv2d_operand_images(const void* a_h, const void* b_h);
+/* ---- shared Winograd input transform (fp32) --------------------------------------------------------------------------
+ * The forward conv of a layer and its filter gradient transform the same x (V = B^T x B per tile: 4x resp. 2.25x the size
+ * of x).  t2i_conv2d_input_transform_bytes(d) > 0 says both take a Winograd path for `d`; then
+ *   t2i_conv2d_input_transform(buf, bytes, 1) in front of t2i_conv2d_fwd / _fwd_stats makes it leave V in `buf` (check
+ *   t2i_conv2d_input_transform_kept() afterwards: an unaligned operand sends the call down another path), and
+ *   t2i_conv2d_input_transform(buf, bytes, 2) in front of t2i_conv2d_bwd_filter (same d, same x) makes it read V from there
+ * instead of transforming x again.  One-shot like the image hand-overs above; ignored by paths that have no use for it. */
+size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);
+int t2i_conv2d_input_transform(void* buf, size_t bytes, int32_t mode);
+int t2i_conv2d_input_transform_kept(void);   /* 1 if the last forward conv on this thread left V in the buffer it was offered */
+
 /* One-shot, the producer side of the same idea: the NEXT call on this thread to one of t2i_conv2d_fwd / _fwd_stats / _bwd_data
  * (bf16-operand path), t2i_bn_apply, t2i_act_fwd, t2i_act_bwd, t2i_add_act or t2i_act_bwd_colsum also writes the bf16 image
  * of its output tensor to y_h (same shape, 16-byte aligned) in the same pass, so that the conv reading that tensor next

@@ -422,6 +422,54 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
         K.set_math('f32')
 
 
+def test_shared_winograd_input_transform_bit_identical(gpu):
+    """fp32 at the benchmark's widths (Winograd live): the filter gradient reading the input transform its forward conv left
+    behind (t2i_conv2d_input_transform) changes no bit of three iterations — eager, and replayed from the one-graph iteration."""
+    from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    B = 8
+    cfg = _cfg(128, 1024, 128, 128, 128, B)
+    g = torch.Generator(device=gpu).manual_seed(9)
+    feed = {'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1, 'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+            'cond': torch.randn(B, 1024, generator=g, device=gpu), 'z': torch.randn(B, 128, generator=g, device=gpu),
+            'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4,
+            'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
+            'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)}
+    used = []
+    real = K.conv_bwd_filter
+
+    def spy(x, dy, d, ws_bytes, out=None, xform=None):
+        used.append(xform is not None)
+        return real(x, dy, d, ws_bytes, out=out, xform=xform)
+
+    def run(share, graphs):
+        prev = K.share_xform(share)
+        K.conv_bwd_filter = spy
+        try:
+            m = WGanCls(cfg, device=gpu, seed=3)
+            tr = WGanClsTrainer(None, m, None, cfg)
+            tr.iteration(1, feed)
+            if graphs:
+                m.enable_graphs(feed)
+            tr.iteration(2, feed)
+            tr.iteration(3, feed)
+            torch.cuda.synchronize()
+            return {n: v.detach().clone() for n, v in m.store.vars.items()}, float(m.kt)
+        finally:
+            K.share_xform(prev)
+            K.conv_bwd_filter = real
+    base = run(False, False)
+    assert not any(used)
+    for variant in ((True, False), (True, True)):
+        del used[:]
+        got = run(*variant)
+        assert sum(used) >= 10, sum(used)            # the Winograd layers of both nets really took the shared transform
+        assert got[1] == base[1], variant
+        for n in base[0]:
+            assert torch.equal(got[0][n], base[0][n]), (variant, n)
+
+
 def test_filter_cache_full_width_bit_identical(gpu):
     """Transformed-filter cache (include/t2i_hip.h) at the benchmark's widths, where the Winograd paths are live: three
     iterations with the cache on — eager, and replayed from one hipGraph — leave exactly the weights, Adam state and kt of

@@ -64,6 +64,9 @@ SIGNATURES = {
     't2i_cast_bf16': (ctypes.c_int, [_p, _i64, _p, _p]),
     't2i_conv2d_operand_images': (ctypes.c_int, [_p, _p]),
     't2i_output_image': (ctypes.c_int, [_p]),
+    't2i_conv2d_input_transform_bytes': (ctypes.c_size_t, [_dp]),
+    't2i_conv2d_input_transform': (ctypes.c_int, [_p, _sz, _i32]),
+    't2i_conv2d_input_transform_kept': (ctypes.c_int, []),
     't2i_output_image_written': (ctypes.c_int, []),
     't2i_capture_id': (ctypes.c_uint64, [_p]),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),

@@ -85,23 +85,26 @@ def side_join():
         SIDE.keep.clear()
 
 
-def _filter_grad(x, gpre, geom, w):
-    """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function."""
+def _filter_grad(x, gpre, geom, w, xform=None):
+    """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function.
+    xform: the Winograd input transform of `x` the forward conv left behind (kernels.LAST_XFORM), or None."""
     if not torch.is_grad_enabled():
         sink = sink_at(w.data_ptr())
         if sink is not None:
             xs, gs = _c(x), _c(gpre)
+            if xs is not x:
+                xform = None
             if SIDE.stream is not None:
                 SIDE.stream.wait_stream(torch.cuda.current_stream())      # x, gpre and the zeroed arena are ready
                 K.WS_LANE[0] = 1                                          # its own split-K workspace
                 try:
                     with torch.cuda.stream(SIDE.stream):
-                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink)
+                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform)
                 finally:
                     K.WS_LANE[0] = 0
-                SIDE.keep.append((xs, gs))
+                SIDE.keep.append((xs, gs, xform))
             else:
-                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink)
+                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform)
             _notify(w)
             return None
     if os.environ.get('T2I_DP_DEBUG') == '1' and NOTIFY[0] is not None:
@@ -170,7 +173,12 @@ class Conv2dFn(Function):
         x = _c(x)
         ctx.set_materialize_grads(False)   # an undefined upstream gradient must not become a zero-filled conv launch
         # want_stats: a batch norm consumes this output next; the GEMM epilogue leaves it the per-tile column sums
-        y = K.conv_fwd_stats(x, w, b, d, ws, act, alpha) if want_stats else K.conv_fwd(x, w, b, d, ws, act, alpha)
+        # the filter gradient of this layer transforms the same x (fp32 Winograd): keep the transform if a gradient will be asked for
+        keep = bool(ctx.needs_input_grad[1]) and not _INPUTS_ONLY[0]
+        y = (K.conv_fwd_stats(x, w, b, d, ws, act, alpha, keep_xform=keep) if want_stats
+             else K.conv_fwd(x, w, b, d, ws, act, alpha, keep_xform=keep))
+        ctx.xform = K.LAST_XFORM[0] if keep else None
+        K.LAST_XFORM[0] = None
         ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
         ctx.bias_ref = b            # only its address is used (gradient sink lookup)
@@ -199,7 +207,8 @@ class Conv2dFn(Function):
             elif want_b:
                 gb = ColSumFn.apply(gpre)
         gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
-        gw = _filter_grad(x, gpre, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
+        gw = _filter_grad(x, gpre, ctx.geom, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
+        ctx.xform = None
         return gx, gw, gb, None, None, None, None
 
 

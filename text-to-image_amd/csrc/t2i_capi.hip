@@ -304,6 +304,23 @@ static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
 // every t2i_conv2d_* entry point at entry, whatever path it then dispatches to.
 struct OperandImages { const void* a; const void* b; };
 static thread_local OperandImages g_opimg = {nullptr, nullptr};
+// One-shot hand-over of a Winograd input transform (t2i_conv2d_input_transform): mode 1 = the next forward conv keeps V of its
+// x in the caller's buffer, mode 2 = the next filter gradient finds V of its x there.
+struct XformSlot { void* buf; size_t bytes; int mode; };
+static thread_local XformSlot g_xform = {nullptr, 0, 0};
+static thread_local int g_xform_kept = 0;
+static inline XformSlot take_xform() {
+  const XformSlot r = g_xform;
+  g_xform.buf = nullptr; g_xform.bytes = 0; g_xform.mode = 0;
+  return r;
+}
+// bytes of the input transform the forward conv of `d` and its filter gradient share (0: they do not both take a Winograd path)
+static size_t xform_bytes(const t2i_conv_desc& d) {
+  if (winograd_eligible(d, false)) return (size_t)16 * ((size_t)d.B * (d.H / 2) * (d.W / 2)) * d.Cin * 4;
+  if (winograd_k4s2_eligible(d, false) && tuning().winograd_k4s2_bwdf) return (size_t)9 * ((size_t)d.B * (d.Ho / 2) * (d.Wo / 2)) * 4 * d.Cin * 4;
+  return 0;
+}
+
 // One-shot bf16 twin of the next producer's output (t2i_output_image), taken at entry by the entry points that can write one.
 static thread_local void* g_outimg = nullptr;
 static thread_local int g_outimg_written = 0;
@@ -583,9 +600,12 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
                            float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   const OperandImages img = take_operand_images();
   void* y_h = take_output_image();
+  const XformSlot xf = take_xform();
+  g_xform_kept = 0;
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
+  float* vkeep = (xf.mode == 1 && xf.buf && aligned16(xf.buf) && xform_bytes(*d) && xf.bytes >= xform_bytes(*d)) ? reinterpret_cast<float*>(xf.buf) : nullptr;
   if (stats_chunks) *stats_chunks = 0;
   if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
@@ -596,9 +616,15 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
       return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(stem)");
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
-    return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  {
+    g_xform_kept = vkeep ? 1 : 0;
+    return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, vkeep);
+  }
   if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
-    return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+  {
+    g_xform_kept = vkeep ? 1 : 0;
+    return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, vkeep);
+  }
   if (h_eligible(*d, false) && aligned16(x) && aligned16(w))
     return conv_h(MODE_FWD, d, x, img.a, w, bias, y, y_h, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
   IgemmParams p;
@@ -653,9 +679,11 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
 int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                           size_t ws_bytes, t2i_stream_t stream) {
   const OperandImages img = take_operand_images();
+  const XformSlot xf = take_xform();
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
+  const float* vhave = (xf.mode == 2 && xf.buf && aligned16(xf.buf) && xform_bytes(*d) && xf.bytes >= xform_bytes(*d)) ? reinterpret_cast<const float*>(xf.buf) : nullptr;
   if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
@@ -666,9 +694,9 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
     }
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+    return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
   if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
     return conv_h_filter(d, x, dy, img.a, img.b, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
@@ -1030,6 +1058,20 @@ uint64_t t2i_capture_id(t2i_stream_t stream) {
   unsigned long long id = 0;
   if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return st == hipStreamCaptureStatusActive ? (uint64_t)id + 1 : 0;
+}
+
+size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d) {
+  if (!d || validate_desc(d)) return 0;
+  if (!((d->Cin % 4) == 0 && (d->Cout % 4) == 0)) return 0;
+  return xform_bytes(*d);
+}
+
+int t2i_conv2d_input_transform_kept(void) { return g_xform_kept; }
+
+int t2i_conv2d_input_transform(void* buf, size_t bytes, int32_t mode) {
+  if (mode < 0 || mode > 2) { set_error("t2i_conv2d_input_transform: mode is 0 (clear), 1 (keep) or 2 (use)"); return T2I_ERR_INVALID; }
+  g_xform.buf = mode ? buf : nullptr; g_xform.bytes = mode ? bytes : 0; g_xform.mode = mode;
+  return T2I_OK;
 }
 
 int t2i_output_image(void* y_h) {

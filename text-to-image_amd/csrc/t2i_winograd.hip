@@ -259,7 +259,7 @@ size_t winograd_ws(const t2i_conv_desc& d, bool bwd) {
 }
 
 int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float* w, const float* bias, float* out, int act,
-                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t stream, float* Vkeep) {
   size_t T; int K, N;
   wino_dims(d, bwd, &T, &K, &N);
   if (!ws || ws_bytes < winograd_ws(d, bwd) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
@@ -268,7 +268,7 @@ int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float
   }
   char* base = reinterpret_cast<char*>(ws);
   float* U = reinterpret_cast<float*>(base);
-  float* V = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4));
+  float* V = Vkeep ? Vkeep : reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4));      // Vkeep: the caller keeps the input transform
   float* Mx = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4) + al256(16 * T * K * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
   bool fill = true;
@@ -358,7 +358,7 @@ size_t winograd_filter_grad_ws(const t2i_conv_desc& d) {
 }
 
 int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const float* Vhave) {
   const size_t T = (size_t)d.B * (d.H / 2) * (d.W / 2);
   if (!ws || ws_bytes < winograd_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_filter_grad_ws(d));
@@ -369,7 +369,8 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
   float* Z = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4));
   float* P = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  if (Vhave) V = const_cast<float*>(Vhave);          // the forward conv's input transform of this x, kept by the caller
+  else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
   hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.H, d.W, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
@@ -517,7 +518,7 @@ size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
 }
 
 int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                      void* ws, size_t ws_bytes, hipStream_t stream) {
+                      void* ws, size_t ws_bytes, hipStream_t stream, float* Vkeep) {
   const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
   if (!ws || ws_bytes < winograd_k4s2_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd k4s2 conv: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_ws(d));
@@ -525,7 +526,7 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
   }
   char* base = reinterpret_cast<char*>(ws);
   float* U = reinterpret_cast<float*>(base);
-  float* V = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4));
+  float* V = Vkeep ? Vkeep : reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4));
   float* Mx = reinterpret_cast<float*>(base + al256(9 * K * d.Cout * 4) + al256(9 * T * K * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
   bool fill = true;
@@ -774,7 +775,7 @@ size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d) {
 }
 
 int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                              hipStream_t stream) {
+                              hipStream_t stream, const float* Vhave) {
   const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
   if (!ws || ws_bytes < winograd_k4s2_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd k4s2 filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_filter_grad_ws(d));
@@ -786,7 +787,8 @@ int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const floa
   float* Z = reinterpret_cast<float*>(base + al256(9 * T * K * 4));
   float* P = reinterpret_cast<float*>(base + al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
-  hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  if (Vhave) V = const_cast<float*>(Vhave);
+  else hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
   hipLaunchKernelGGL(wino2_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)(T / S); gd.Cin = (int32_t)K; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;

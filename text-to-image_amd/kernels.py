@@ -275,7 +275,44 @@ def _twin_end(out, img):
         out._t2i_h = (out._version, img, out.data_ptr(), int(lib.t2i_capture_id(_stream())))
 
 
-def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
+# fp32 Winograd: the forward conv of a layer and its filter gradient transform the same x.  conv_fwd(..., keep_xform=True) leaves
+# the transform in a tensor it returns through `LAST_XFORM` (None if the call took another path); conv_bwd_filter(..., xform=V)
+# reads it instead of transforming x again (t2i_conv2d_input_transform).
+_XFORM_BYTES = {}
+LAST_XFORM = [None]
+_SHARE_XFORM = [os.environ.get('T2I_SHARE_XFORM', '1') != '0']
+
+
+def share_xform(on):
+    prev, _SHARE_XFORM[0] = _SHARE_XFORM[0], bool(on)
+    return prev
+
+
+def conv_xform_bytes(d):
+    if d.math != MATH_F32 or not _SHARE_XFORM[0]:
+        return 0
+    n = _XFORM_BYTES.get(id(d))
+    if n is None:
+        n = _XFORM_BYTES[id(d)] = int(lib.t2i_conv2d_input_transform_bytes(ctypes.byref(d)))
+    return n
+
+
+def _xform_offer(x, d, keep):
+    LAST_XFORM[0] = None
+    nb = conv_xform_bytes(d) if keep else 0
+    if not nb:
+        return None
+    V = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+    check(lib.t2i_conv2d_input_transform(_ptr(V), nb, 1), 't2i_conv2d_input_transform')
+    return V
+
+
+def _xform_taken(V):
+    if V is not None and lib.t2i_conv2d_input_transform_kept():
+        LAST_XFORM[0] = V
+
+
+def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False):
     _chk(x, 'x'); _chk(w, 'w')
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
@@ -283,9 +320,11 @@ def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         keep = _bind_images(x) if _h_path(d, 'fwd') else None
         twin = _twin_begin(y) if (act != ACT_NONE and d.math == MATH_BF16) else None     # conv + bias + lrelu feeds the next conv directly
+        V = _xform_offer(x, d, keep_xform)
         check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                  _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
         _twin_end(y, twin)
+        _xform_taken(V)
         if ev is not None:
             ev.record()
     return y
@@ -369,7 +408,7 @@ def bn_stats(x):
     return s0, s1
 
 
-def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
+def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False):
     """conv_fwd whose epilogue also leaves the per-tile column sums of y, y*y for the batch norm behind it (take_stats)."""
     _chk(x, 'x'); _chk(w, 'w')
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
@@ -380,9 +419,11 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
         chunks, tile_rows = ctypes.c_int32(0), ctypes.c_int32(0)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         keep = _bind_images(x) if _h_path(d, 'fwd') else None
+        V = _xform_offer(x, d, keep_xform)
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
                                        _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), ctypes.byref(tile_rows), wsp, wsn,
                                        _stream()), 't2i_conv2d_fwd_stats')
+        _xform_taken(V)
         if ev is not None:
             ev.record()
         if chunks.value > 0:
@@ -409,7 +450,7 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     return dx
 
 
-def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
+def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
     """dw = x (*) dy.  out: an existing [KH,KW,Cin,Cout]-sized buffer to ACCUMULATE into (dw += ...), e.g. the
     optimizer's gradient arena; returns it."""
     _chk(x, 'x'); _chk(dy, 'dy')
@@ -421,6 +462,8 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_filter')) if _TIMER[0] is not None else None
         keep = _bind_images(x, dy) if _h_path(d, 'bwd_filter') else None
+        if xform is not None and conv_xform_bytes(d):
+            check(lib.t2i_conv2d_input_transform(_ptr(xform), xform.numel() * 4, 2), 't2i_conv2d_input_transform')
         check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, wsp, wsn,
                                         _stream()),
               't2i_conv2d_bwd_filter')
@@ -793,6 +836,7 @@ def tuning_set(key, value):
     check(lib.t2i_tuning_set(key.encode(), float(value)), 't2i_tuning_set')
     _DESC_CACHE.clear()
     _H_ALGO.clear()
+    _XFORM_BYTES.clear()
 
 
 def kt_sgd(kt, wdist_sums, scale, lr):
