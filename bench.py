@@ -317,7 +317,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize()
         ticks_per_ms = 1000000 / max(e0.elapsed_time(e1), 1e-3)
-        headstart = int(float(os.environ.get('T2I_INSTRUMENT_HEADSTART_MS', '25')) * ticks_per_ms)
+        headstart = int(float(os.environ.get('T2I_INSTRUMENT_HEADSTART_MS', '60')) * ticks_per_ms)
         K.set_conv_timer(timer)
         for i in range(inst_steps):
             torch.cuda._sleep(headstart)

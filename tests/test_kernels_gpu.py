@@ -588,3 +588,29 @@ def test_stem_conv_forward(K, B, H):
     finally:
         K.tuning_set('no_thin', 0)
     assert relerr(y, y2.double().cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize('B,H', [(2, 64), (3, 16), (1, 6), (64, 64), (192, 64)])
+def test_stem_filter_gradient(K, B, H):
+    """Filter gradient of the 3 -> 128 k4 s2 stem on its own kernel (one wave owns the 64x128 accumulator, MFMA k = pixel,
+    fixed-order joins): against float64 at the gradient tolerance, ragged pixel counts and padding rows / columns included,
+    plain and accumulate-into-arena, twice (same bits: no atomics anywhere)."""
+    rng = np.random.default_rng(10 * B + H)
+    x = rng.uniform(-1, 1, (B, H, H, 3)).astype(np.float32)
+    Ho = H // 2
+    dy = rng.standard_normal((B, Ho, Ho, 128)).astype(np.float32)
+    d, ws = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+    assert K.conv_algo(d, 'bwd_filter') == 'direct_small'
+    dw = K.conv_bwd_filter(dev(x), dev(dy), d, ws)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    gt = torch.from_numpy(dy).double().permute(0, 3, 1, 2)
+    wt = torch.zeros(128, 3, 4, 4, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (1, 1, 1, 1)), wt, stride=2)
+    (ref,) = torch.autograd.grad(y, wt, gt)
+    ref = ref.permute(2, 3, 1, 0).numpy()               # OIHW -> HWIO
+    assert relerr(dw, ref) <= 1e-5
+    assert torch.equal(dw, K.conv_bwd_filter(dev(x), dev(dy), d, ws))
+    base = rng.standard_normal((4, 4, 3, 128)).astype(np.float32)
+    acc = dev(base)
+    K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc)
+    assert relerr(acc, base + ref) <= 1e-5

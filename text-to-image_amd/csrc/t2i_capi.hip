@@ -69,6 +69,9 @@ hipError_t head_fwd_launch(const t2i_conv_desc&, const float*, const float*, con
 hipError_t head_bwd_data_launch(const t2i_conv_desc&, const float*, const float*, float*, hipStream_t);
 hipError_t head_bwd_filter_launch(const t2i_conv_desc&, const float*, const float*, float*, int, hipStream_t);
 bool stem_fwd_eligible(const t2i_conv_desc& d);
+bool stem_bwdf_eligible(const t2i_conv_desc& d);
+size_t stem_bwdf_ws(const t2i_conv_desc& d);
+hipError_t stem_bwdf_launch(const t2i_conv_desc&, const float*, const float*, float*, int, void*, hipStream_t);
 hipError_t stem_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
 bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
 hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -560,6 +563,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (h_eligible(*d, true) && conv_h_ws(d, MODE_BWD_DATA) > need) need = conv_h_ws(d, MODE_BWD_DATA);
   if (h_filter_eligible(*d) && conv_h_filter_ws(d) > need) need = conv_h_filter_ws(d);
   if (tiny_bwdw_eligible(*d) && tiny_bwdw_ws(*d) > need) need = tiny_bwdw_ws(*d);
+  if (stem_bwdf_eligible(*d) && stem_bwdf_ws(*d) > need) need = stem_bwdf_ws(*d);
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
   if (winograd_eligible(*d, false) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
@@ -691,6 +695,11 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
       const size_t need = tiny_bwdw_ws(*d);
       if (!ws || ws_bytes < need || !aligned16(ws)) { set_error("t2i_conv2d_bwd_filter: workspace %zu B < %zu B required", ws_bytes, need); return T2I_ERR_WORKSPACE; }
       return check(tiny_bwdw_launch(*d, x, dy, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_conv2d_bwd_filter(tiny)");
+    }
+    if (stem_bwdf_eligible(*d) && aligned16(dw)) {
+      const size_t need = stem_bwdf_ws(*d);
+      if (!ws || ws_bytes < need || !aligned16(ws)) { set_error("t2i_conv2d_bwd_filter: workspace %zu B < %zu B required", ws_bytes, need); return T2I_ERR_WORKSPACE; }
+      return check(stem_bwdf_launch(*d, x, dy, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stem)");
     }
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
@@ -1024,7 +1033,7 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
     if (winograd_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
   } else {
-    if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
+    if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d) || stem_bwdf_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
     if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf) return T2I_ALGO_WINOGRAD_F2X2_2X2;
     if (h_filter_eligible(*d)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;

@@ -462,6 +462,170 @@ __global__ __launch_bounds__(256) void tiny_bwdw_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient of the 3 -> 128 k4 s2 stem (the critic's first layer):
+//     dw[kh][kw][ci][co] = sum over pixels (b, oh, ow) of  x[b, 2oh-1+kh, 2ow-1+kw, ci] * dy[b, oh, ow, co]
+// a [48 x P] x [P x 128] product, P = B*Ho*Wo up to 2e5.  As a split-K launch of the general kernel it gathered its 48-row
+// A operand with one scalar load per element (26 us at B = 64, 64 us at 3B, plus the reduce); the work is 0.8 GFLOP and the
+// traffic is dy once (33.5 MB at B = 64).  Here one wave owns the whole 64 x 128 accumulator (rows 48..63 stay zero: 2 x 4
+// MFMA 32x32x2 blocks, 128 registers) and walks its own run of pixels two at a time (k = pixel): per step a lane loads its
+// A element (the x pixel under its tap for its k) twice (two row blocks), its B element (dy, 128-byte runs per pixel) four
+// times, and issues 8 MFMAs; the next step's six loads are in flight meanwhile.  The four waves of a workgroup are joined in
+// a fixed order through LDS, each workgroup writes one [48][128] partial and splitk_reduce sums the partials in slab order —
+// deterministic, like every other reduction here.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                             int B, int H, int W, int Ho, int Wo, int pix_per_wave, FastDiv div_wo, FastDiv div_ho) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // 2 x [64][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int P = B * Ho * Wo;                          // < 2^31: 32-bit index arithmetic throughout (a 64-bit divide is ~200 instructions)
+  const int p_begin = (blockIdx.x * 4 + wave) * pix_per_wave;
+  int p_end = p_begin + pix_per_wave;
+  if (p_end > P) p_end = P;
+  // this lane's two A rows: m = l31 and m = 32 + l31 (rows >= 48 are padding)
+  int a_off[2]; bool a_ok[2]; int a_kh[2], a_kw[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const int m = blk * 32 + l31;
+    a_ok[blk] = m < 48;
+    const int tap = m / 3, ci = m - tap * 3;
+    a_kh[blk] = tap >> 2; a_kw[blk] = tap & 3;
+    a_off[blk] = (a_kh[blk] * W + a_kw[blk]) * 3 + ci;
+  }
+  stem_f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // loads go through buffer resources: padding taps, rows >= 48 and pixels past the wave's run select an out-of-range OFFSET
+  // (the load returns 0), so nothing depends on a load's result until the MFMA that consumes it — a select on the loaded
+  // value would put an s_waitcnt behind every load
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((size_t)B * H * W * 3 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), (short)0, (int)((size_t)P * 128 * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  auto load = [&](int p, float (&a)[2], float (&b)[4]) __attribute__((always_inline)) {
+    const int pix = p + lh;                           // k = lh
+    const bool ok = pix < p_end;
+    const int pp = ok ? pix : p_begin;
+    const int t = div_wo.div(pp);
+    const int ow = pp - t * Wo;
+    const int img = div_ho.div(t);
+    const int oh = t - img * Ho;
+    const int ih0 = 2 * oh - 1, iw0 = 2 * ow - 1;
+    const int xbase = ((img * H + ih0) * W + iw0) * 3;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const bool in = ok & a_ok[blk] & ((unsigned)(ih0 + a_kh[blk]) < (unsigned)H) & ((unsigned)(iw0 + a_kw[blk]) < (unsigned)W);
+      a[blk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (unsigned)(xbase + a_off[blk]) * 4u : OOB, 0, 0));
+    }
+    const unsigned ybase = ok ? ((unsigned)pp * 128u + (unsigned)l31) * 4u : OOB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? ybase + j * 128u : OOB, 0, 0));
+  };
+
+  // 8 pixels (4 MFMA k-steps) per macro step; the 24 loads of the next macro step are issued before this one's 32 MFMAs,
+  // so a full memory latency hides behind 2048 MFMA cycles (one wave per SIMD: nobody else would hide it)
+  float a0[4][2], b0[4][4], a1[4][2], b1[4][4];
+  auto load8 = [&](int p, float (&a)[4][2], float (&b)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load(p + 2 * s, a[s], b[s]);
+  };
+  auto mma8 = [&](float (&a)[4][2], float (&b)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+  };
+  load8(p_begin, a0, b0);                           // pixels beyond p_end load zeros (out-of-range offsets): no branch in the loop
+  for (int p = p_begin; p < p_end; p += 16) {
+    load8(p + 8, a1, b1);
+    mma8(a0, b0);
+    load8(p + 16, a0, b0);
+    mma8(a1, b1);
+  }
+
+  // ---- join the four waves in a fixed order: (w0 + w2) + (w1 + w3) ---------------------------------------------------------
+  auto put = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 128 + j * 32 + l31] = acc[i][j][e];
+  };
+  auto add = [&](const float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 128 + j * 32 + l31];
+  };
+  float* buf0 = red;
+  float* buf1 = red + 64 * 128;
+  if (wave == 2) put(buf0);
+  if (wave == 3) put(buf1);
+  __syncthreads();
+  if (wave == 0) add(buf0);
+  if (wave == 1) add(buf1);
+  __syncthreads();
+  if (wave == 1) put(buf0);
+  __syncthreads();
+  if (wave == 0) {
+    add(buf0);
+    float* o = part + (size_t)blockIdx.x * 48 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < 48) o[m * 128 + j * 32 + l31] = acc[i][j][e];
+        }
+  }
+}
+
+bool stem_bwdf_eligible(const t2i_conv_desc& d) { return stem_fwd_eligible(d); }
+
+static int stem_bwdf_groups(const t2i_conv_desc& d, int* pix_per_wave) {
+  const long P = (long)d.B * d.Ho * d.Wo;
+  long ppw = (P + 1023) / 1024;                      // aim at 256 workgroups of 4 waves
+  if (ppw < 16) ppw = 16;
+  ppw = (ppw + 15) & ~15L;                           // whole double macro steps
+  *pix_per_wave = (int)ppw;
+  return (int)((P + 4 * ppw - 1) / (4 * ppw));
+}
+
+size_t stem_bwdf_ws(const t2i_conv_desc& d) {
+  int ppw;
+  return (size_t)stem_bwdf_groups(d, &ppw) * 48 * 128 * sizeof(float);
+}
+
+hipError_t stem_bwdf_launch(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, hipStream_t stream) {
+  int ppw;
+  const int G = stem_bwdf_groups(d, &ppw);
+  float* part = reinterpret_cast<float*>(ws);
+  const size_t lds = (size_t)2 * 64 * 128 * sizeof(float);
+  auto k = stem_k4s2_bwdf_kernel;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  FastDiv dwo, dho;
+  dwo.set((uint32_t)d.Wo); dho.set((uint32_t)d.Ho);
+  hipLaunchKernelGGL(k, dim3(G), dim3(256), lds, stream, x, dy, part, d.B, d.H, d.W, d.Ho, d.Wo, ppw, dwo, dho);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return splitk_reduce_launch(part, G, (size_t)48 * 128, nullptr, 128, T2I_ACT_NONE, 0.f, dw, accumulate, stream);
+}
+
 bool tiny_bwdw_eligible(const t2i_conv_desc& d) { return d.Cin == 3 && d.Cout == 3 && d.KH <= 3 && d.KW <= 3; }
 
 static int tiny_bwdw_blocks(const t2i_conv_desc& d) {
