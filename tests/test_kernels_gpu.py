@@ -614,3 +614,86 @@ def test_stem_filter_gradient(K, B, H):
     acc = dev(base)
     K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc)
     assert relerr(acc, base + ref) <= 1e-5
+
+
+def _rne_bf16(a):
+    """numpy float32 -> the float32 value of its bf16 rounding (round to nearest even)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def test_bf16_twins_are_the_rounded_outputs(K):
+    """t2i_output_image: every producer that can write the bf16 twin of its output writes exactly RNE(bf16) of the fp32 values it
+    stores — batch-norm apply, activation forward / backward, residual join, fused activation-backward + bias gradient, the
+    bf16-operand conv (unsplit epilogue and split-K reduce); t2i_cast_bf16 likewise.  The request is one-shot."""
+    from t2i_amd._lib import lib
+    rng = np.random.default_rng(3)
+    shape = (4, 8, 8, 128)
+    a = dev(rng.standard_normal(shape).astype(np.float32)); b = dev(rng.standard_normal(shape).astype(np.float32))
+    K.set_math('bf16')
+    try:
+        def check_twin(t):
+            assert hasattr(t, '_t2i_h'), 'no twin written'
+            img = t._t2i_h[1]
+            assert img.dtype == torch.bfloat16 and img.shape == t.shape
+            assert np.array_equal(img.float().cpu().numpy(), _rne_bf16(t.cpu().numpy()))
+        check_twin(K.act_fwd(a, K.ACT_LRELU, 0.2))
+        check_twin(K.act_bwd(a, b, K.ACT_LRELU, 0.2))
+        check_twin(K.add_act(a, b, K.ACT_RELU))
+        sc = dev(rng.standard_normal(128).astype(np.float32)); sh = dev(rng.standard_normal(128).astype(np.float32))
+        check_twin(K.bn_apply(a, sc, sh, K.ACT_RELU))
+        check_twin(K.act_bwd_colsum(a, b, K.ACT_LRELU, 0.2)[0])
+        assert not hasattr(K.act_bwd_colsum(a, b, K.ACT_LRELU, 0.2, x2=a)[0], '_t2i_h')      # batch-norm path: the output is not a conv operand
+        assert np.array_equal(K.cast_bf16(a).float().cpu().numpy(), _rne_bf16(a.cpu().numpy()))
+        # conv epilogues: unsplit (forced) and through the split-K reduce (forced)
+        x = dev(rng.standard_normal((8, 8, 8, 128)).astype(np.float32)); w = dev((rng.standard_normal((3, 3, 128, 128)) * 0.05).astype(np.float32))
+        bias = dev(rng.standard_normal(128).astype(np.float32))
+        for fs in (1, 4):
+            K.tuning_set('force_splitk', fs)
+            d, ws = K.conv_desc(8, 8, 8, 128, 128, 3, 3, 1, 1, 'SAME')
+            assert K.conv_algo(d, 'fwd') == 'implicit_gemm_bf16_operands'
+            check_twin(K.conv_fwd(x, w, bias, d, max(ws, 64 << 20), K.ACT_LRELU, 0.2))
+            y = K.conv_fwd(x, w, bias, d, max(ws, 64 << 20))                              # no activation fused: no twin asked for
+            assert not hasattr(y, '_t2i_h')
+        K.tuning_set('force_splitk', 0)
+        # one-shot: a request that no producer consumed does not leak into a later call
+        img = torch.empty(shape, dtype=torch.bfloat16, device='cuda')
+        lib.t2i_output_image(ctypes_ptr(img))
+        K.set_math('f32')
+        y = K.act_fwd(a, K.ACT_LRELU, 0.2)                                              # consumes (and, here, honours) the request
+        assert lib.t2i_output_image_written() == 1 and not hasattr(y, '_t2i_h')
+        y = K.act_fwd(a, K.ACT_LRELU, 0.2)
+        assert lib.t2i_output_image_written() == 0
+    finally:
+        K.tuning_set('force_splitk', 0)
+        K.set_math('f32')
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_filter_cache_refresh_regenerates_only_the_named_range(K):
+    """t2i_filter_cache_refresh(ptr, bytes): stale images of filters INSIDE the range are regenerated in one launch and then
+    served without a fill; filters outside it are left alone (their entries may belong to memory that no longer exists)."""
+    rng = np.random.default_rng(5)
+    prev = K.filter_cache(True)
+    try:
+        C = 256
+        arena = dev((rng.standard_normal(2 * 9 * C * C) * 0.05).astype(np.float32))
+        w1, w2 = arena[:9 * C * C].view(3, 3, C, C), arena[9 * C * C:].view(3, 3, C, C)
+        other = dev((rng.standard_normal((3, 3, C, C)) * 0.05).astype(np.float32))
+        x = dev(rng.standard_normal((64, 8, 8, C)).astype(np.float32))
+        d, ws = K.conv_desc(64, 8, 8, C, C, 3, 3, 1, 1, 'SAME')
+        assert K.conv_algo(d, 'fwd') == 'winograd_f2x2_3x3'
+        ref = [K.conv_fwd(x, w, None, d, ws).clone() for w in (w1, w2, other)]          # fills the three entries
+        arena.mul_(2.0); other.mul_(2.0)                                                   # the filters change behind the cache's back ...
+        K.filter_cache_invalidate()
+        K.filter_cache_refresh(arena)                                                      # ... only the arena's images are regenerated
+        got = [K.conv_fwd(x, w, None, d, ws) for w in (w1, w2, other)]                     # `other` refills lazily at first use
+        for g, r in zip(got, ref):
+            assert relerr(g, 2.0 * r.double().cpu().numpy()) <= 2e-6
+    finally:
+        K.filter_cache(prev)
