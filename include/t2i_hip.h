@@ -302,7 +302,7 @@ int t2i_conv2d_input_transform(void* buf, size_t bytes, int32_t mode);
 int t2i_conv2d_input_transform_kept(void);   /* 1 if the last forward conv on this thread left V in the buffer it was offered */
 
 /* One-shot, the producer side of the same idea: the NEXT call on this thread to one of t2i_conv2d_fwd / _fwd_stats / _bwd_data
- * (bf16-operand path), t2i_bn_apply, t2i_act_fwd, t2i_act_bwd, t2i_add_act or t2i_act_bwd_colsum also writes the bf16 image
+ * (bf16-operand path), t2i_bn_apply, t2i_bn_bwd_fused (dx), t2i_act_fwd, t2i_act_bwd, t2i_add_act or t2i_act_bwd_colsum also writes the bf16 image
  * of its output tensor to y_h (same shape, 16-byte aligned) in the same pass, so that the conv reading that tensor next
  * needs no cast at all.  The call consumes the request; t2i_output_image_written() tells whether the path it took wrote the
  * image (vectorised paths only: element count % 4 == 0, aligned) — if not, the caller casts as usual.  Set it only directly

@@ -646,6 +646,11 @@ def test_bf16_twins_are_the_rounded_outputs(K):
         check_twin(K.act_bwd_colsum(a, b, K.ACT_LRELU, 0.2)[0])
         assert not hasattr(K.act_bwd_colsum(a, b, K.ACT_LRELU, 0.2, x2=a)[0], '_t2i_h')      # batch-norm path: the output is not a conv operand
         assert np.array_equal(K.cast_bf16(a).float().cpu().numpy(), _rne_bf16(a.cpu().numpy()))
+        mean = dev(rng.standard_normal(128).astype(np.float32)); rstd = dev(rng.uniform(0.5, 2.0, 128).astype(np.float32))
+        check_twin(K.bn_bwd_fused(a, None, b, mean, rstd, sc, K.ACT_NONE)[0])               # the conv in front of a batch norm reads this dx
+        x3 = dev(rng.uniform(-1, 1, (2, 64, 64, 3)).astype(np.float32)); w3 = dev((rng.standard_normal((4, 4, 3, 128)) / 7).astype(np.float32))
+        d3, ws3 = K.conv_desc(2, 64, 64, 3, 128, 4, 4, 2, 2, 'SAME')
+        check_twin(K.conv_fwd(x3, w3, sh, d3, ws3, K.ACT_LRELU, 0.2))                       # the 3 -> 128 stem feeds the first 128-channel conv
         # conv epilogues: unsplit (forced) and through the split-K reduce (forced)
         x = dev(rng.standard_normal((8, 8, 8, 128)).astype(np.float32)); w = dev((rng.standard_normal((3, 3, 128, 128)) * 0.05).astype(np.float32))
         bias = dev(rng.standard_normal(128).astype(np.float32))

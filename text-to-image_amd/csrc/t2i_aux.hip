@@ -612,7 +612,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ k_dy, const float* __restrict__ k_x,
                                                            const float* __restrict__ k_0, size_t n, int C,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, uint2* __restrict__ dxh) {
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -628,6 +628,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o.z = a.z * d.z + b.z * v.z + e.z;
       o.w = a.w * d.w + b.w * v.w + e.w;
       reinterpret_cast<float4*>(dx)[i] = o;
+      if (dxh) dxh[i] = make_uint2(aux_pk2(o.x, o.y), aux_pk2(o.z, o.w));
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -671,10 +672,10 @@ hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, con
   const size_t n = (size_t)rows * C;
   if (al && (C & 3) == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0,
-                       n, C, dx);
+                       n, C, dx, (uint2*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0, n,
-                       C, dx);
+                       C, dx, (uint2*)nullptr);
   return hipGetLastError();
 }
 
@@ -800,7 +801,7 @@ hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x
 
 hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
                                int64_t rows, int C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta,
-                               int accumulate, void* ws, hipStream_t stream) {
+                               int accumulate, void* ws, hipStream_t stream, void* dx_h) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
@@ -818,7 +819,8 @@ hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, 
   hipLaunchKernelGGL(bn_bwd_stage2_coef_v4, dim3(ct), dim3(256), 0, stream, part, part1, nc, C, mean, rstd, gamma, (float)rows, dgamma, dbeta,
                      k_dy, k_x, k_0, accumulate);
   const size_t n = (size_t)rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
+                     reinterpret_cast<uint2*>(dx_h));
   return hipGetLastError();
 }
 

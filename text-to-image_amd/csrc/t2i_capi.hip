@@ -29,7 +29,7 @@ hipError_t bn_stats_launch(const float*, int64_t, int, float*, float*, const flo
 hipError_t bn_stats_tiles_launch(const float*, const float*, int, int, int64_t, int, float*, float*, const float*, const float*, float, float,
                                  float*, float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_bwd_fused_launch(const float*, const float*, const float*, const float*, const float*, const float*, int64_t, int, int, float,
-                               float*, float*, float*, float*, int, void*, hipStream_t);
+                               float*, float*, float*, float*, int, void*, hipStream_t, void* dx_h = nullptr);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h = nullptr);
@@ -72,7 +72,7 @@ bool stem_fwd_eligible(const t2i_conv_desc& d);
 bool stem_bwdf_eligible(const t2i_conv_desc& d);
 size_t stem_bwdf_ws(const t2i_conv_desc& d);
 hipError_t stem_bwdf_launch(const t2i_conv_desc&, const float*, const float*, float*, int, void*, hipStream_t);
-hipError_t stem_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+hipError_t stem_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t, void* y_h = nullptr);
 bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
 hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
 
@@ -616,8 +616,10 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
     if (tiny_conv_eligible(*d, false))
       return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
-    if (stem_fwd_eligible(*d) && aligned16(w))
-      return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(stem)");
+    if (stem_fwd_eligible(*d) && aligned16(w)) {
+      if (y_h) g_outimg_written = 1;
+      return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream, y_h), "t2i_conv2d_fwd(stem)");
+    }
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
   {
@@ -772,6 +774,7 @@ size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C) {
 int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
                      int32_t C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws,
                      size_t ws_bytes, t2i_stream_t stream) {
+  void* dx_h = take_output_image();
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || (y && !gmask)) {
     set_error("t2i_bn_bwd_fused: bad argument (C % 4 == 0 required; gmask needed with an activation)");
     return T2I_ERR_INVALID;
@@ -781,8 +784,10 @@ int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const floa
     return T2I_ERR_INVALID;
   }
   if (!ws || ws_bytes < t2i_bn_bwd_fused_workspace_bytes(rows, C) || !aligned16(ws)) { set_error("t2i_bn_bwd_fused: workspace too small"); return T2I_ERR_WORKSPACE; }
+  if (!aligned16(dx_h)) dx_h = nullptr;
+  if (dx_h) g_outimg_written = 1;
   return check(bn_bwd_fused_launch(dy, y, x, mean, rstd, gamma, rows, C, act, alpha, gmask, dx, dgamma, dbeta, accumulate ? 1 : 0, ws,
-                                   (hipStream_t)stream), "t2i_bn_bwd_fused");
+                                   (hipStream_t)stream, dx_h), "t2i_bn_bwd_fused");
 }
 
 int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,

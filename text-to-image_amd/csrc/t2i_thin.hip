@@ -303,7 +303,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 template <int CI, int NB>      // NB = Cout / 32 accumulator blocks per wave (4 for the critic's 128 channels)
 __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int H, int W,
-                                                            int act, float alpha) {
+                                                            int act, float alpha, __bf16* __restrict__ yh) {
   constexpr int K = 16 * CI, Co = 32 * NB;
   extern __shared__ __attribute__((aligned(16))) float lds_stem[];
   const int Wo = W >> 1, Ho = H >> 1;
@@ -368,7 +368,12 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ow = ow0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (ow < Wo) y[((size_t)(b * Ho + oh) * Wo + ow) * Co + j * 32 + l31] = apply_act(acc[j][e] + bv, act, alpha);
+        if (ow < Wo) {
+          const float v = apply_act(acc[j][e] + bv, act, alpha);
+          const size_t o = ((size_t)(b * Ho + oh) * Wo + ow) * Co + j * 32 + l31;
+          y[o] = v;
+          if (yh) yh[o] = (__bf16)v;             // bf16 twin for the conv that reads this tensor next (t2i_output_image)
+        }
       }
     }
   }
@@ -380,11 +385,11 @@ bool stem_fwd_eligible(const t2i_conv_desc& d) {
 }
 
 hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                           hipStream_t stream) {
+                           hipStream_t stream, void* y_h) {
   const size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * 128) * sizeof(float);
   auto k = stem_k4s2_fwd_kernel<3, 4>;
   dim3 grid((d.Wo + 31) / 32, (d.Ho + 3) / 4, d.B);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, x, w, bias, y, d.H, d.W, act, alpha);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, x, w, bias, y, d.H, d.W, act, alpha, reinterpret_cast<__bf16*>(y_h));
   return hipGetLastError();
 }
 

@@ -389,9 +389,11 @@ def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, d
     dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, int(lib.t2i_bn_bwd_fused_workspace_bytes(rows, C)))
+        twin = _twin_begin(dx)                  # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
         check(lib.t2i_bn_bwd_fused(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
                                    rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
                                    _stream()), 't2i_bn_bwd_fused')
+        _twin_end(dx, twin)
     return dx, dgamma, dbeta
 
 
