@@ -169,7 +169,7 @@ def test_conv_algorithm_choice_on_the_benchmark_layers():
     from t2i_amd import kernels as K
     G, W3, W2, S = 'implicit_gemm', 'winograd_f2x2_3x3', 'winograd_f2x2_2x2', 'direct_small'
     want = {   # (H, W, Cin, Cout, k, stride, pad): (fwd, bwd_data, bwd_filter)
-        (64, 64, 3, 128, 4, 2, 'SAME'): (S, S, G),            # critic layer 1 / generator out_deconv (as its adjoint conv): stem kernels
+        (64, 64, 3, 128, 4, 2, 'SAME'): (S, S, S),            # critic layer 1 / generator out_deconv (as its adjoint conv): stem kernels (fwd, thin deconv, filter gradient)
         (32, 32, 128, 256, 4, 2, 'SAME'): (W2, G, W2),        # 128-channel side: per-phase transforms of dy cost more than they save
         (16, 16, 256, 512, 4, 2, 'SAME'): (W2, W2, W2),
         (8, 8, 512, 1024, 4, 2, 'SAME'): (W2, W2, W2),
@@ -188,3 +188,37 @@ def test_conv_algorithm_choice_on_the_benchmark_layers():
     d, _ = K.conv_desc(64, 8, 8, 512, 512, 3, 3, 1, 1, 'SAME', math=K.MATH_BF16)
     # bf16 math mode: no Winograd; all three primitives stage bf16 operand copies where the channel counts allow
     assert all(K.conv_algo(d, m) == 'implicit_gemm_bf16_operands' for m in ('fwd', 'bwd_data', 'bwd_filter'))
+
+
+def test_bf16_image_cache_is_keyed_on_base_version_and_capture(monkeypatch):
+    """kernels.bf16_image (host logic, no GPU): one image per tensor — found again through a permuted-and-permuted-back view
+    (the layout helpers hand the convs such views), made anew after an in-place write, and never shared between launch
+    contexts (an image made eagerly or in another capture is not part of the graph being captured)."""
+    import torch
+    from t2i_amd import kernels as K
+    made = []
+
+    class Shim(object):
+        cap = 0
+
+        def t2i_capture_id(self, stream):
+            return self.cap
+    shim = Shim()
+    monkeypatch.setattr(K, 'lib', shim)
+    monkeypatch.setattr(K, '_stream', lambda: None)
+    monkeypatch.setattr(K, 'cast_bf16', lambda t: made.append(t) or torch.zeros(t.shape, dtype=torch.bfloat16))
+    y = torch.randn(2, 4, 4, 8)
+    img = K.bf16_image(y)
+    assert len(made) == 1 and K.bf16_image(y) is img and len(made) == 1
+    view = y.permute(0, 3, 1, 2).permute(0, 2, 3, 1)                 # NHWC -> "NCHW" -> NHWC: another object, same memory, same order
+    assert view is not y and K.bf16_image(view) is img and len(made) == 1
+    assert K.bf16_image(y[1:]) is not img and len(made) == 2        # a slice is another tensor (different address)
+    y.add_(1.0)                                                       # version bump: the image is stale
+    img2 = K.bf16_image(view)
+    assert img2 is not img and len(made) == 3 and K.bf16_image(y) is img2
+    shim.cap = 7                                                      # inside a capture: the eager image is not reused ...
+    img3 = K.bf16_image(y)
+    assert img3 is not img2 and len(made) == 4 and K.bf16_image(view) is img3
+    shim.cap = 8                                                      # ... nor is one made in an earlier capture
+    assert K.bf16_image(y) is not img3 and len(made) == 5
+    assert K.bf16_image(torch.randn(3, 5)) is None                    # 15 elements: no 8-element groups
