@@ -35,6 +35,8 @@ def main():
         recs.append((e - s, gap, name, grid, s - t0))
     print('last iteration: %d dispatches, span %.3f ms, kernels %.3f ms, idle gaps %.3f ms (avg %.2f us)' % (
         len(it), span / 1e6, busy_total / 1e6, idle_total / 1e6, idle_total / 1e3 / len(it)))
+    short = [r for r in recs if r[0] < 8000]
+    print('dispatches shorter than 8 us: %d, %.3f ms in total (VERDICT round 1, item 6: the launch-bound tail)' % (len(short), sum(r[0] for r in short) / 1e6))
     print('%-46s %6s %10s %10s %9s' % ('kernel', 'calls', 'busy us', 'gap-before', 'avg us'))
     for name, (c, b, g) in sorted(busy.items(), key=lambda kv: -kv[1][1] - kv[1][2]):
         print('%-46s %6d %10.1f %10.1f %9.1f' % (name[:46], c, b / 1e3, g / 1e3, b / 1e3 / c))
