@@ -981,7 +981,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
   for (size_t i = t; i < n4; i += stride) {
     float4 W = reinterpret_cast<float4*>(w)[i];
     const float4 G0 = reinterpret_cast<const float4*>(g)[i];
-    float4 M = reinterpret_cast<float4*>(m)[i];
+    // beta1 == 0 (the wgancls optimizers: Adam(0, 0.9)): m_t = g_t whatever m_{t-1} was — the old moment is not read
+    // (6 instead of 7 streams over the arena); it is still written, the checkpoint carries it
+    float4 M = b1 != 0.f ? reinterpret_cast<float4*>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 V = reinterpret_cast<float4*>(v)[i];
     float gx = G0.x * gscale, gy = G0.y * gscale, gz = G0.z * gscale, gw = G0.w * gscale;
     M.x = b1 * M.x + (1.f - b1) * gx; M.y = b1 * M.y + (1.f - b1) * gy;
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
   }
   for (size_t i = (n4 << 2) + t; i < n; i += stride) {
     const float gg = g[i] * gscale;
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float mm = b1 * (b1 != 0.f ? m[i] : 0.f) + (1.f - b1) * gg;
     const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
     m[i] = mm; v[i] = vv;
     w[i] -= lr_t * mm / (sqrtf(vv) + eps);
