@@ -14,6 +14,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL / cross-process tensors fail with the legacy mode); the boxes
+# export it already — kept here so that a bare environment behaves the same
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
