@@ -94,7 +94,13 @@ def workspace(device, nbytes):
 
 
 def stream_lane(stream, lane, device=None):
-    """Give `stream` its own workspace lane (launches on it then never share scratch with the main stream's), sized like lane 0."""
+    """Give `stream` its own workspace lane (launches on it then never share scratch with the main stream's), sized like lane 0.
+    A lane has ONE user at a time: when it passes to another stream (a new model's), everything queued so far is drained first."""
+    holders = [s for s, l in _STREAM_LANE.items() if l == lane and s != stream.cuda_stream]
+    if holders:
+        torch.cuda.synchronize()
+        for s in holders:
+            del _STREAM_LANE[s]
     _STREAM_LANE[stream.cuda_stream] = lane
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     if dev.index is None:
