@@ -93,15 +93,12 @@ def workspace(device, nbytes):
     return buf
 
 
-def stream_lane(stream, lane, device=None):
-    """Give `stream` its own workspace lane (launches on it then never share scratch with the main stream's), sized like lane 0.
-    A lane has ONE user at a time: when it passes to another stream (a new model's), everything queued so far is drained first."""
-    holders = [s for s, l in _STREAM_LANE.items() if l == lane and s != stream.cuda_stream]
-    if holders:
-        torch.cuda.synchronize()
-        for s in holders:
-            del _STREAM_LANE[s]
-    _STREAM_LANE[stream.cuda_stream] = lane
+def stream_lane(stream, device=None):
+    """Give the HIP stream behind `stream` its own workspace lane, sized like lane 0: launches on it never share scratch with the
+    main stream's.  The lane belongs to the underlying hipStream_t (PyTorch hands out 32 pooled streams per device round-robin):
+    two models whose second streams are different pool streams get different lanes; if the pool gives two models the SAME stream
+    their work is ordered on it anyway, and sharing the lane is safe.  At most 32 lanes ever exist."""
+    lane = _STREAM_LANE.setdefault(stream.cuda_stream, 2 + len(_STREAM_LANE))
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     if dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())

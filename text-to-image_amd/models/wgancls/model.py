@@ -232,7 +232,7 @@ class WGanCls(object):
         """The second stream and its workspace lane (sized like the main lane) — allocated OUTSIDE any capture."""
         if getattr(self, '_ahead', None) is None:
             self._ahead = torch.cuda.Stream(device=self.device)
-        K.stream_lane(self._ahead, 2, self.device)           # its convolutions get their own scratch
+        K.stream_lane(self._ahead, self.device)              # its convolutions get their own scratch
 
     def _g_forward_ahead(self, feed):
         """_g_forward issued on a second stream, forked from the current one: the G step's generator forward reads only the
