@@ -69,7 +69,7 @@ int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arc
 /* Tuning / diagnostic switch `key` := value (tests, sweeps: tools/sweep_conv.py).  Keys and their T2I_* environment
  * defaults: force_tile (T2I_FORCE_TILE: 22, 21, 12, 11 = 128x128 ... 64x64; 0 = planner), force_splitk, debug_plan, group_n,
  * no_ut, no_thin, winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc,
- * winograd_k4s2_bwdf, adam_blocks, max_chain (longest unsplit fp32 reduction chain, default 8192), split_cost, bf16_operands, cache_refresh.
+ * winograd_k4s2_bwdf, adam_blocks, max_chain (longest unsplit fp32 reduction chain, default 8192), split_cost, bf16_operands, cache_refresh, thin_parts.
  * Not a hot-path call; changes apply to launches planned afterwards (workspace queries included). */
 int t2i_tuning_set(const char* key, double value);
 

@@ -133,6 +133,7 @@ static Tuning& tuning_mut() {
     v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
     v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
     v.cache_refresh = env_int("T2I_CACHE_REFRESH", 0);     // 1: t2i_adam_tf itself regenerates the cached filter images of its arena (else the caller: t2i_filter_cache_refresh)
+    v.thin_parts = env_int("T2I_THIN_PARTS", 2);          // 128 -> 3 k4s2 transposed conv: passes over the channels (Co / parts staged at a time)
     v.bf16_operands = env_int("T2I_BF16_OPERANDS", 1);     // bf16 math: stage bf16 operand copies (t2i_igemm_h.hip) where eligible
     v.max_chain = env_int("T2I_MAX_CHAIN", 8192);           // longest unsplit reduction on the 128x128 tile (see make_plan)
     const char* sc = getenv("T2I_SPLIT_COST");
@@ -1011,7 +1012,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

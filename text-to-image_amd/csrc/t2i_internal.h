@@ -123,7 +123,7 @@ void set_error(const char* fmt, ...);
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts;
   double split_cost;
 };
 const Tuning& tuning();

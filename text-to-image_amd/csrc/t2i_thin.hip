@@ -22,28 +22,17 @@ namespace t2i {
 template <int CI>
 __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ dx,
-                                                               int H, int W, int Co, int act, float alpha) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [10][10][Co+4] dy patch, then [16][CI][Co] filter
+                                                               int H, int W, int Co, int CH, int act, float alpha) {
+  // CH = channels staged per pass (Co or Co / 2): with half the channels in LDS at a time a workgroup needs half the LDS, twice
+  // as many are resident per CU, and one workgroup's staging overlaps another's arithmetic (the kernel is bound by staging)
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [10][10][CH+4] dy patch, then [16 taps][CI][CH] filter
   const int Ho = H >> 1, Wo = W >> 1;
-  const int PS = Co + 4;                       // pixel stride in LDS
+  const int PS = CH + 4;                       // pixel stride in LDS
   const int b = blockIdx.z;
   const int ih0 = blockIdx.y * 16, iw0 = blockIdx.x * 16;
   const int oh0 = (ih0 >> 1) - 1, ow0 = (iw0 >> 1) - 1;
-  const int c4n = Co >> 2;                     // float4 per pixel
-  // ---- stage the dy patch (zero outside the image) ----------------------------------------------------------------
-  for (int i = threadIdx.x; i < 100 * c4n; i += 256) {
-    const int pix = i / c4n, c4 = i - pix * c4n;
-    const int r = pix / 10, c = pix - r * 10;
-    const int oh = oh0 + r, ow = ow0 + c;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo)
-      v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * Co + c4 * 4);
-    *reinterpret_cast<float4*>(&tile[pix * PS + c4 * 4]) = v;
-  }
-  float* wlds = tile + 100 * PS;               // the whole filter [16 taps][CI][Co]
-  for (int i = threadIdx.x; i < 4 * CI * Co; i += 256)
-    reinterpret_cast<float4*>(wlds)[i] = reinterpret_cast<const float4*>(w)[i];
-  __syncthreads();
+  const int c4n = CH >> 2;                     // float4 per pixel and pass
+  float* wlds = tile + 100 * PS;
   // ---- wave = stride phase; lane = one of its 8x8 pixels --------------------------------------------------------------
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ph = wv >> 1, pw = wv & 1;
@@ -53,22 +42,40 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __re
   float acc[CI];
 #pragma unroll
   for (int ci = 0; ci < CI; ++ci) acc[ci] = 0.f;
+  for (int cbase = 0; cbase < Co; cbase += CH) {
+    if (cbase) __syncthreads();                // everyone is done reading the previous pass
+    // ---- stage the dy patch (zero outside the image) and the filter slice --------------------------------------------
+    for (int i = threadIdx.x; i < 100 * c4n; i += 256) {
+      const int pix = i / c4n, c4 = i - pix * c4n;
+      const int r = pix / 10, c = pix - r * 10;
+      const int oh = oh0 + r, ow = ow0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo)
+        v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * Co + cbase + c4 * 4);
+      *reinterpret_cast<float4*>(&tile[pix * PS + c4 * 4]) = v;
+    }
+    for (int i = threadIdx.x; i < 16 * CI * c4n; i += 256) {          // [tap][ci][CH] <- w[tap][ci][cbase .. cbase+CH)
+      const int row = i / c4n, c4 = i - row * c4n;
+      reinterpret_cast<float4*>(wlds)[i] = *reinterpret_cast<const float4*>(w + (size_t)row * Co + cbase + c4 * 4);
+    }
+    __syncthreads();
 #pragma unroll
-  for (int jh = 0; jh < 2; ++jh) {
+    for (int jh = 0; jh < 2; ++jh) {
 #pragma unroll
-    for (int jw = 0; jw < 2; ++jw) {
-      const int r = py + 1 + ph - jh, c = px + 1 + pw - jw;           // patch coordinates of the contributing dy pixel
-      const float* src = &tile[(r * 10 + c) * PS];
-      // this tap's filter rows in LDS: every lane of the wave reads the SAME address (broadcast, conflict-free).
-      // (v1 read them with scalar loads straight from global: 384 dependent s_load per wave, ~35 us of the kernel's 65.)
-      const float* wt = wlds + (((kh0 + 2 * jh) * 4 + (kw0 + 2 * jw)) * CI) * Co;
+      for (int jw = 0; jw < 2; ++jw) {
+        const int r = py + 1 + ph - jh, c = px + 1 + pw - jw;           // patch coordinates of the contributing dy pixel
+        const float* src = &tile[(r * 10 + c) * PS];
+        // this tap's filter rows in LDS: every lane of the wave reads the SAME address (broadcast, conflict-free).
+        // (v1 read them with scalar loads straight from global: 384 dependent s_load per wave, ~35 us of the kernel's 65.)
+        const float* wt = wlds + (((kh0 + 2 * jh) * 4 + (kw0 + 2 * jw)) * CI) * CH;
 #pragma unroll 4
-      for (int c4 = 0; c4 < c4n; ++c4) {
-        const float4 d = *reinterpret_cast<const float4*>(src + c4 * 4);
+        for (int c4 = 0; c4 < c4n; ++c4) {
+          const float4 d = *reinterpret_cast<const float4*>(src + c4 * 4);
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) {
-          const float4 f = *reinterpret_cast<const float4*>(wt + ci * Co + c4 * 4);
-          acc[ci] = fmaf(d.x, f.x, fmaf(d.y, f.y, fmaf(d.z, f.z, fmaf(d.w, f.w, acc[ci]))));
+          for (int ci = 0; ci < CI; ++ci) {
+            const float4 f = *reinterpret_cast<const float4*>(wt + ci * CH + c4 * 4);
+            acc[ci] = fmaf(d.x, f.x, fmaf(d.y, f.y, fmaf(d.z, f.z, fmaf(d.w, f.w, acc[ci]))));
+          }
         }
       }
     }
@@ -87,7 +94,11 @@ bool thin_deconv_eligible(const t2i_conv_desc& d) {
 
 hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx,
                               int act, float alpha, hipStream_t stream) {
-  const size_t lds = ((size_t)100 * (d.Cout + 4) + (size_t)16 * d.Cin * d.Cout) * sizeof(float);
+  int parts = tuning().thin_parts;                  // passes over the channels (1, 2 or 4): Co / parts are staged at a time
+  if (parts < 1) parts = 1;
+  while (parts > 1 && ((d.Cout % (4 * parts)) != 0 || d.Cout / parts < 32)) parts >>= 1;
+  const int CH = d.Cout / parts;
+  const size_t lds = ((size_t)100 * (CH + 4) + (size_t)16 * d.Cin * CH) * sizeof(float);
   dim3 grid(d.W / 16, d.H / 16, d.B);
 #define T2I_THIN(CI)                                                                                              \
   case CI: {                                                                                                      \
@@ -96,7 +107,7 @@ hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const flo
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                              \
     }                                                                                                             \
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, dy, w, bias, dx, d.H, d.W, d.Cout, act, alpha);           \
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, dy, w, bias, dx, d.H, d.W, d.Cout, CH, act, alpha);       \
     break;                                                                                                        \
   }
   switch (d.Cin) {
