@@ -2,8 +2,11 @@
 tests/test_step_b64_gpu.py: StackGAN Stage-II at its real 256x256 resolution and full width (GF=128, DF=64, critic up to
 2048 channels), and a PGGAN transition stage at 64x64 (stage 5: the first stage with 256-channel layers next to the 512 ones).
 Tolerances: PGGAN — SURVEY 8(c)'s (loss scalars 1e-5 relative, gradients max|d|/max|ref| <= 1e-4 per tensor).  Stage-II —
-~60 conv + batch-norm layers in series at batch 2, statistics over as few as 32 values: loss scalars 5e-5, the tanh image
-2e-4 absolute, gradients 2e-4 per tensor (measured: 1.5e-5 / 8e-5 / 1.1e-4; before the batch-norm statistics were made
+~60 conv + batch-norm layers in series at batch 2, statistics over as few as 32 values: loss scalars 1e-4, the tanh image
+2e-4 absolute, gradients 2e-4 per tensor (measured: <= 5.8e-5 / 7e-5 / 1.1e-4; the loss on the generated image moves between
+4.3e-5 and 5.8e-5 with nothing but the SUMMATION ORDER of the 128 -> 3 transposed conv — one, four or two passes over its
+channels, t2i_tuning_set("thin_parts") — while the image error itself stays at 6.4-6.9e-5: rounding noise through batch
+norms over two samples, so the scalar bound is the image's order of magnitude, not tighter; before the batch-norm statistics were made
 stable — sum x^2 - (sum x)^2/n replaced by shifted chunk moments + Chan merging, DESIGN 4.6 — the same quantities sat at
 8e-5 / 9e-4 / 7e-4 and the committed test allowed 8e-2).  Where a tensor's exact gradient is zero (biases in front of a
 batch norm) the bound is absolute.  Batch sizes are the smallest that keep the
@@ -95,7 +98,7 @@ def test_stackgan_stage2_full_size(gpu):
     with T.use_tape(T.SectionTape(masks)):
         ref = SG.d_step(P, o2, feed, 2, o1)
     for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
-        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 5e-5)
+        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 1e-4)
     chk('G (256x256 image, tanh output)', relerr(d['G'], ref['G'], scale=1.0), 2e-4)
     chk.grads(m.d_arena, m.d_vars, ref['grads'], 2e-4)
     with torch.no_grad():                      # undo the moving-average side effect of the probe pass
@@ -116,7 +119,7 @@ def test_stackgan_stage2_full_size(gpu):
     with T.use_tape(T.SectionTape(masks)):
         gref = SG.g_step(P, o2, feed, 2, o1)
     for k in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
-        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 5e-5)
+        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 1e-4)
     chk.grads(m.g_arena, m.g_vars, gref['grads'], 2e-4)
     assert not chk.bad, chk.bad
 
