@@ -127,3 +127,49 @@ def test_stackgan1_dp_eager_and_segments_match_plain(group):
     segments = run(DataParallel(bucket_bytes=4096), True)
     _same(plain, eager)
     _same(plain, segments)
+
+
+def test_gancls_dp_eager_and_segments_match_plain(group):
+    """gancls (the sigmoid-cross-entropy variant) under dp.DataParallel with a 1-rank RCCL communicator: eager with the
+    bucketed exchange, and replayed from graph segments cut at the two exchange steps, leave the bits of the plain run."""
+    from t2i_amd import autograd as A
+    from t2i_amd.dp import DataParallel
+    from t2i_amd.models.gancls.model import GanCls
+    from t2i_amd.models.gancls.trainer import GanClsTrainer
+    from t2i_amd.utils.config import AttrDict
+    mg = _make_golden()
+    gs = np.load(os.path.join(ROOT, 'tests', 'golden', 'gancls_tiny.npz'))
+    t = mg.GANCLS_TINY
+    dev = torch.device('cuda')
+    cfg = AttrDict({'MODEL': {'Z_DIM': t['z_dim'], 'OUTPUT_SIZE': 64, 'EMBED_DIM': t['embed_dim'], 'COMPRESSED_EMBED_DIM': t['compressed'],
+                              'GF_DIM': t['gf'], 'DF_DIM': t['df'], 'IMAGE_SHAPE': {'W': 64, 'H': 64, 'D': 3}},
+                    'TRAIN': {'BATCH_SIZE': t['batch'], 'SAMPLE_NUM': 4, 'EPOCH': 1, 'D_LR': 2e-4, 'D_BETA_DECAY': 0.5, 'G_LR': 2e-4,
+                              'G_BETA_DECAY': 0.5, 'COEFF': {'ALPHA_MISMATCH_LOSS': 0.5}}})
+    f = {k[len('feed/'):]: torch.tensor(gs[k], dtype=torch.float32, device=dev) for k in gs.files if k.startswith('feed/')}
+    g = torch.Generator(device=dev).manual_seed(12)
+    feeds = [{'inputs': torch.rand(f['x'].shape, generator=g, device=dev) * 2 - 1, 'wrong_inputs': f['x_mismatch'],
+              'phi_inputs': torch.randn(f['cond'].shape, generator=g, device=dev), 'z': torch.randn(f['z'].shape, generator=g, device=dev)}
+             for _ in range(4)]
+
+    def run(dp, graphs):
+        try:
+            m = GanCls(cfg, device=dev, dp=dp)
+            m.store.load({k[len('param/'):]: gs[k] for k in gs.files if k.startswith('param/')})
+            tr = GanClsTrainer(None, m, None, cfg)
+            outs = []
+            for i in range(4):
+                if graphs and i == 1:
+                    tr.enable_graphs(feeds[0])
+                outs.append(tr.iteration(feeds[i]))
+            torch.cuda.synchronize()
+            return ({n: v.detach().clone() for n, v in m.store.vars.items()}, float(outs[-1]['d']['D_loss']), float(outs[-1]['g']['G_loss']))
+        finally:
+            A.NOTIFY[0] = None
+
+    plain = run(None, False)
+    eager = run(DataParallel(bucket_bytes=4096), False)
+    segments = run(DataParallel(bucket_bytes=4096), True)
+    plain_graphs = run(None, True)
+    _same(plain, eager)
+    _same(plain, segments)
+    _same(plain, plain_graphs)

@@ -42,7 +42,7 @@ class GanClsTrainer(object):
         D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
         D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
         m.d_arena.zero_grad()
-        if m.dp is not None:
+        if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.d_arena)
         D_loss.backward(inputs=list(m.d_vars.values()))
         A.side_join()
@@ -63,7 +63,7 @@ class GanClsTrainer(object):
                 m.discriminator(xw, phi, reuse=True)
         G_loss = sigmoid_cross_entropy_with_logits(l_fake, 1.0).mean()
         m.g_arena.zero_grad()
-        if m.dp is not None:
+        if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.g_arena)
         G_loss.backward(inputs=list(m.g_vars.values()))
         A.side_join()
@@ -85,23 +85,43 @@ class GanClsTrainer(object):
         return g
 
     def enable_graphs(self, feed):
-        """Capture the two halves into hipGraphs and replay them from then on (single GPU; call after one eager iteration)."""
+        """Capture the two halves into hipGraphs and replay them from then on (call after one eager iteration).  With data
+        parallelism each half is cut at its exchange step — [losses + backward] | all-reduce of the gradient arena, issued
+        eagerly | [Adam] — as in models/wgancls and models/stackgan: no collective is ever captured."""
         from ...graphs import StepGraphs
-        if self.model.dp is not None:
-            raise RuntimeError('graph capture with data parallelism is not supported yet')
-        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'), filters=(self.model.d_arena.flat, self.model.g_arena.flat))
-        self._graphs.capture('d', self._d_body)
-        self._graphs.capture('g', self._g_body)
+        m = self.model
+        self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'), filters=(m.d_arena.flat, m.g_arena.flat))
+        if m.dp is None:
+            self._graphs.capture('d', self._d_body)
+            self._graphs.capture('g', self._g_body)
+            return
+        scale = 1.0 / m.dp.world
+        self._capturing = True
+        try:
+            self._graphs.capture('d', self.d_losses, capture_error_mode='thread_local')
+            self._graphs.capture('d_upd', lambda f: self.D_optim.apply(grad_scale=scale), capture_error_mode='thread_local', refresh=False)
+            self._graphs.capture('g', self.g_losses, capture_error_mode='thread_local')
+            self._graphs.capture('g_upd', lambda f: self.G_optim.apply(grad_scale=scale), capture_error_mode='thread_local', refresh=False)
+        finally:
+            self._capturing = False
 
     def iteration(self, feed):
         lr_d, lr_g = float(self.cfg.TRAIN.D_LR), float(self.cfg.TRAIN.G_LR)
         graphs = getattr(self, '_graphs', None)
         if graphs is not None:
             graphs.load(feed)
+            dp = self.model.dp
             self.D_optim.prepare(lr_d)
             d = graphs.replay('d')
+            if dp is not None:
+                dp.allreduce_arena(self.model.d_arena)
+                graphs.replay('d_upd')
             self.G_optim.prepare(lr_g)
-            return {'d': d, 'g': graphs.replay('g')}
+            g = graphs.replay('g')
+            if dp is not None:
+                dp.allreduce_arena(self.model.g_arena)
+                graphs.replay('g_upd')
+            return {'d': d, 'g': g}
         self.D_optim.prepare(lr_d)
         d = self._d_body(feed)
         self.G_optim.prepare(lr_g)
