@@ -186,79 +186,25 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, exact=Tru
     return report
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graphs', action='store_true', help='keep the step eager (default: hipGraph replay on 1 GPU)')
-    ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
-                    help='where the per-launch HIP events for the roofline block are recorded')
-    ap.add_argument('--math', choices=['f32', 'bf16'], default='f32',
-                    help="conv arithmetic: f32 = BASELINE config 2 (the headline metric); bf16 = config 3 (bf16 MFMA "
-                         "operands, fp32 accumulation and fp32 tensors) -- reported with dtype 'bf16', never the default")
-    ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
-                    help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
-    ap.add_argument('--repeats', type=int, default=3,
-                    help='timed regions of --steps iterations each, every one bracketed by barrier + synchronize; the MEDIAN is reported')
-    ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.cpu_baseline_only:
-        cpu_baseline_child(args.cpu_baseline_only)
-        return
-
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
-    # Pre-flight hooks for boxes with ONE GPU: T2I_SAME_DEVICE=1 puts every rank on device 0 and T2I_DIST_BACKEND=gloo
-    # replaces RCCL (which refuses two ranks on one device), so the whole multi-process path — rendezvous, bucket order,
-    # overlap hooks, barriers, max-over-ranks timing — runs for real, minus the xGMI transport.  Never set by the driver.
-    if os.environ.get('T2I_SAME_DEVICE') == '1':
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-
-    import t2i_amd  # noqa: F401
+def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, headline=True):
+    """Builds the model in arithmetic `math` ('f32' = BASELINE config 2, the metric; 'bf16' = config 3), warms it up, times it and
+    (rank 0) attaches the roofline block.  Everything it creates is released before it returns, so that a second configuration
+    can run in the same process (cached filter images of the first are dropped: their graphs are gone)."""
+    import gc
+    import math as _m
+    from t2i_amd import autograd as A
     from t2i_amd import kernels as K
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
-
-    dp = None
-    # T2I_FORCE_DP=1 exercises the data-parallel machinery (RCCL communicator, bucket hooks, side stream) on ONE rank
-    use_dp = world > 1 or os.environ.get('T2I_FORCE_DP') == '1'
-    if use_dp:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        backend = os.environ.get('T2I_DIST_BACKEND', 'nccl')
-        import datetime
-        tmo = datetime.timedelta(seconds=int(os.environ.get('T2I_DIST_TIMEOUT_S', '600')))   # a stuck collective aborts the run instead of hanging it
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device, timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
-        from t2i_amd.dp import DataParallel
-        # gradient buckets: fp32 in place for the fp32 metric; bf16 (half the bytes per link, fp32 arena on arrival) for config 3
-        grad_dtype = os.environ.get('T2I_DP_GRAD_DTYPE', 'bf16' if args.math == 'bf16' else 'f32')
-        dp = DataParallel(bucket_bytes=int(os.environ.get('T2I_DP_BUCKET_MB', '32')) << 20, grad_dtype=grad_dtype)
-
-    K.set_math(args.math)
-    K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # transformed Winograd filters reused until Adam changes them
+    K.set_math(math)
     cfg = make_cfg(args.batch)
+    dp, grad_dtype = make_dp(math)
     use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
     preflight = None
     if world > 1 and os.environ.get('T2I_PREFLIGHT', '1') != '0':
-        from t2i_amd.dp import DataParallel as _DP
-        preflight = dp_preflight(cfg, device, lambda: _DP(bucket_bytes=int(os.environ.get('T2I_DP_BUCKET_MB', '32')) << 20, grad_dtype=grad_dtype),
-                                 use_graphs, rank, world, args.batch, exact=(grad_dtype == 'f32'))
+        preflight = dp_preflight(cfg, device, lambda: make_dp(math)[0], use_graphs, rank, world, args.batch, exact=(grad_dtype == 'f32'))
         if rank == 0:
-            sys.stderr.write('[bench] data-parallel preflight passed: %r\n' % (preflight,))
+            sys.stderr.write('[bench] data-parallel preflight (%s) passed: %r\n' % (math, preflight))
     model = WGanCls(cfg, device=device, seed=0, dp=dp)
     if dp is not None:
         dp.broadcast_variables(model.store)
@@ -277,9 +223,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: each half of the iteration is cut at its exchange step ([losses+backward] | all-reduce | [Adam]); the collectives
-    # themselves are never captured.  T2I_DP_GRAPHS=0 keeps the data-parallel step eager (bucketed overlap, dp.py).
-    from t2i_amd import autograd as A
+    # N > 1: the iteration is cut at its exchange steps and the collectives themselves are never captured.
+    # T2I_DP_GRAPHS=0 keeps the data-parallel step eager (bucketed overlap, dp.py).
     if args.side_stream:
         A.enable_side_stream(True)
     if use_graphs:
@@ -291,11 +236,13 @@ def main():
     for i in range(args.warmup):
         trainer.iteration(3 + i, feed)
     timer = ConvTimer()
-    regions = []                                # --repeats timed regions of exactly --steps iterations each
     it = 3 + args.warmup
-    for r in range(max(1, args.repeats)):
+
+    def timed_region(record=False):
+        """EXACTLY --steps iterations between barrier + synchronize on both sides; max over ranks."""
+        nonlocal it
         barrier()
-        if args.instrument == 'inline' and r == 0:
+        if record:
             K.set_conv_timer(timer)
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -304,11 +251,25 @@ def main():
         barrier()
         dt_r = time.perf_counter() - t0
         K.set_conv_timer(None)
-        if use_dp:                              # the region's time is the slowest rank's
+        if use_dp:
             t = torch.tensor([dt_r], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt_r = float(t)
-        regions.append(dt_r)
+        return dt_r
+
+    # --repeats timed regions at least, and as many more as it takes to keep the GPU busy for --min-busy-s seconds in total (a
+    # 20-step region lasts 0.3 s: the driver's once-a-second utilisation sampler saw an idle GPU in round 2); every region is
+    # exactly --steps iterations, the MEDIAN region is reported and all are listed
+    regions = [timed_region(record=(args.instrument == 'inline'))]
+    want = max(1, args.repeats)
+    if args.min_busy_s > 0 and regions[0] > 0:
+        want = max(want, min(int(_m.ceil(args.min_busy_s / regions[0])), 64))
+    if use_dp:                                  # every rank must run the same number of regions
+        t = torch.tensor([want], device=device, dtype=torch.int64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        want = int(t)
+    while len(regions) < want:
+        regions.append(timed_region())
     dt = sorted(regions)[len(regions) // 2]     # median region
     inst_steps = args.steps
     if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
@@ -353,73 +314,179 @@ def main():
             sys.stderr.write('[bench] replica sync check passed: %s\n' % sig.tolist())
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
+    schedule = getattr(model, 'dp_schedule', None)
 
     out = {'metric': 'images/sec (G+D step) at 64x64 batch=64', 'value': value, 'unit': 'images/sec', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': args.math, 'data': 'synthetic',
-           'config': {'workload': 'wgancls 64x64 batch=%d/GPU ' % args.batch + ('fp32' if args.math == 'f32' else
-                                  'bf16-MFMA operands / fp32 accumulate+tensors (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
+           'vs_baseline': None, 'dtype': math, 'data': 'synthetic',
+           'config': {'workload': 'wgancls 64x64 batch=%d/GPU ' % args.batch + ('fp32' if math == 'f32' else
+                                  'bf16-MFMA operands / fp32 accumulate + master weights (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                      'gradient_exchange': (grad_dtype + ' buckets over RCCL') if use_dp else None,
-                      'launch': ('hipGraph replay (%s)' % ('4 graphs + 2 eager all-reduces/iteration, critic exchange overlapped with the generator forward' if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
+                      'gradient_exchange': (grad_dtype + ' buckets over RCCL' + (' (fp32 accumulation)' if grad_dtype == 'bf16' else '')) if use_dp else None,
+                      'launch': ('hipGraph replay (%s)' % ((schedule or 'graph segments + eager all-reduces') if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
            'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12,
            'timing': {'regions': len(regions), 'steps_per_region': args.steps, 'statistic': 'median over regions (max over ranks per region)',
-                      'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
+                      'gpu_busy_s': sum(regions), 'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
     if preflight is not None:
         out['dp_preflight'] = preflight
-    if rank == 0:
-        if args.instrument != 'off':
-            s = timer.summary()
-            info = K.device_info(local_rank)
-            achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
-            peak = FP32_MATRIX_PEAK_TFLOPS if args.math == 'f32' else BF16_MATRIX_PEAK_TFLOPS
-            # HBM-side bytes per launch and MFMA pipe utilisation come from rocprofv3 PMC passes over this same command
-            # (separate --pmc runs, tools/pmc_summary.py), NOT from this run: they are labelled "from_profile", carry the
-            # profile's own launch count, and are dropped when that count is not this run's (another planner / algorithm mix)
-            traffic, mfma_util, prof = None, None, None
-            launches_per_step = s['launches'] / float(inst_steps)
-            # the profile counts igemm_kernel dispatches; every conv entry-point call launches exactly one, except the small direct kernels
-            igemm_per_step = launches_per_step - (s['by_algo'].get('direct_small', [0])[0] / float(inst_steps))
-            for cand in ('r02_pmc_igemm%s.json' % ('' if args.math == 'f32' else '_bf16'), 'r01_pmc_igemm.json'):
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
-                except Exception:
-                    continue
-                if pmc.get('math', 'f32') != args.math:
-                    continue
-                prof = {'source': 'from_profile', 'file': 'profiles/' + cand, 'counters': 'FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES',
-                        'profile_igemm_launches_per_step': pmc.get('launches_per_iteration'), 'run_igemm_launches_per_step': igemm_per_step}
-                same = pmc.get('launches_per_iteration') is not None and abs(pmc['launches_per_iteration'] - igemm_per_step) <= 0.02 * igemm_per_step
-                prof['counts_agree'] = bool(same)
-                if same:
-                    traffic, mfma_util = pmc.get('traffic_bytes_per_launch'), pmc.get('mfma_util')
-                    # the GEMM kernels alone (rocprofv3 durations of the PMC pass): the conv entry points above also contain the
-                    # Winograd transforms / bf16 staging casts / split-K reductions that run around them
-                    if pmc.get('igemm_ms_per_iteration_profiled'):
-                        gk = s['flop'] / inst_steps / (pmc['igemm_ms_per_iteration_profiled'] * 1e-3) / 1e12
-                        prof['gemm_kernels_only'] = {'ms_per_step': pmc['igemm_ms_per_iteration_profiled'], 'algorithmic_tflops': gk,
-                                                     'frac': gk / peak}
-                break
-            out['roofline'] = {
-                'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': achieved / peak, 'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
-                'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
-                'launches_per_step': launches_per_step, 'igemm_ms_per_step': s['ms'] / inst_steps,
-                'igemm_gflop_per_step': s['flop'] / inst_steps / 1e9, 'events': args.instrument,
-                # `achieved` counts direct-convolution FLOPs; the Winograd paths issue 1/2.25 resp. 9/16 of them
-                'executed_tflops': sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0,
-                'executed_frac': (sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 / peak) if s['ms'] > 0 else 0.0,
-                'note': 'frac counts direct-convolution FLOPs (Winograd issues 1/2.25 resp. 9/16 of them): read it together with '
-                        'executed_frac (multiply-adds actually issued to the matrix cores / peak) and mfma_util (PMC)',
-                'by_algorithm': {a: {'calls_per_step': r[0] / float(inst_steps), 'ms_per_step': r[1] / inst_steps,
-                                     'algorithmic_tflops': r[2] / (r[1] * 1e-3) / 1e12 if r[1] > 0 else 0.0}
-                                 for a, r in sorted(s['by_algo'].items())},
-                'device': info}
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
-            out['cpu_baseline'] = cpu_baseline(16)              # BASELINE configs[0]
-            out['cpu_baseline_b64'] = cpu_baseline(64)          # and the batch the metric is quoted on
+    if rank == 0 and args.instrument != 'off':
+        s = timer.summary()
+        info = K.device_info(local_rank)
+        achieved = s['flop'] / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0
+        peak = FP32_MATRIX_PEAK_TFLOPS if math == 'f32' else BF16_MATRIX_PEAK_TFLOPS
+        # HBM-side bytes per launch and MFMA pipe utilisation come from rocprofv3 PMC passes over this same command
+        # (separate --pmc runs, tools/pmc_summary.py), NOT from this run: they are labelled "from_profile", carry the
+        # profile's own launch count, and are dropped when that count is not this run's (another planner / algorithm mix)
+        traffic, mfma_util, prof = None, None, None
+        launches_per_step = s['launches'] / float(inst_steps)
+        # the profile counts igemm_kernel dispatches; every conv entry-point call launches exactly one, except the small direct kernels
+        igemm_per_step = launches_per_step - (s['by_algo'].get('direct_small', [0])[0] / float(inst_steps))
+        suffix = '' if math == 'f32' else '_bf16'
+        for cand in ('r03_pmc_igemm%s.json' % suffix, 'r02_pmc_igemm%s.json' % suffix, 'r01_pmc_igemm.json'):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
+            except Exception:
+                continue
+            if pmc.get('math', 'f32') != math:
+                continue
+            prof = {'source': 'from_profile', 'file': 'profiles/' + cand, 'counters': 'FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES',
+                    'profile_igemm_launches_per_step': pmc.get('launches_per_iteration'), 'run_igemm_launches_per_step': igemm_per_step}
+            same = pmc.get('launches_per_iteration') is not None and abs(pmc['launches_per_iteration'] - igemm_per_step) <= 0.02 * igemm_per_step
+            prof['counts_agree'] = bool(same)
+            if same:
+                traffic, mfma_util = pmc.get('traffic_bytes_per_launch'), pmc.get('mfma_util')
+                # the GEMM kernels alone (rocprofv3 durations of the PMC pass) against the multiply-adds they actually issue
+                # (round 2 credited them with the direct-convolution FLOPs of the Winograd layers: > 1 by construction)
+                if pmc.get('igemm_ms_per_iteration_profiled'):
+                    ex = sum(r[3] for a, r in s['by_algo'].items() if a != 'direct_small') / inst_steps
+                    gk = ex / (pmc['igemm_ms_per_iteration_profiled'] * 1e-3) / 1e12
+                    prof['gemm_kernels_only'] = {'ms_per_step': pmc['igemm_ms_per_iteration_profiled'], 'executed_tflops': gk,
+                                                 'executed_frac': gk / peak,
+                                                 'note': 'multiply-adds issued by the GEMM kernels / their profiled time (transforms, reductions and thin kernels excluded)'}
+            break
+        flop_per_step = s['flop'] / inst_steps
+        out['roofline'] = {
+            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
+            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': achieved / peak, 'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
+            # the same algorithmic FLOPs against the driver-visible clock: the WHOLE iteration (everything that is not a
+            # convolution included) as `ms_per_step` measures it under graph replay
+            'frac_vs_driver_ms': flop_per_step / (ms * 1e-3) / 1e12 / peak,
+            'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
+            'launches_per_step': launches_per_step, 'igemm_ms_per_step': s['ms'] / inst_steps,
+            'igemm_gflop_per_step': flop_per_step / 1e9, 'events': args.instrument,
+            # `achieved` counts direct-convolution FLOPs; the Winograd paths issue 1/2.25 resp. 9/16 of them
+            'executed_tflops': sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0,
+            'executed_frac': (sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 / peak) if s['ms'] > 0 else 0.0,
+            'note': 'frac = direct-convolution FLOPs / time in the conv entry points (eager instrumented pass; Winograd issues 1/2.25 resp. '
+                    '9/16 of them); frac_vs_driver_ms = the same FLOPs / ms_per_step; executed_frac = multiply-adds actually issued / peak; '
+                    'mfma_util = PMC pipe-busy fraction (from_profile)',
+            'by_algorithm': {a: {'calls_per_step': r[0] / float(inst_steps), 'ms_per_step': r[1] / inst_steps,
+                                 'algorithmic_tflops': r[2] / (r[1] * 1e-3) / 1e12 if r[1] > 0 else 0.0}
+                             for a, r in sorted(s['by_algo'].items())},
+            'device': info}
+    # release everything this configuration holds (graphs first: they point into the filter cache and the workspace)
+    A.enable_side_stream(False)
+    model._graphs = None
+    del trainer, model, feed, dp
+    gc.collect()
+    torch.cuda.synchronize()
+    K.filter_cache_reset()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='keep the step eager (default: hipGraph replay on 1 GPU)')
+    ap.add_argument('--instrument', choices=['inline', 'after', 'off'], default='after',
+                    help='where the per-launch HIP events for the roofline block are recorded')
+    ap.add_argument('--math', choices=['f32', 'bf16'], default='f32',
+                    help="conv arithmetic: f32 = BASELINE config 2 (the headline metric); bf16 = config 3 (bf16 MFMA "
+                         "operands, fp32 accumulation and fp32 tensors) -- reported with dtype 'bf16', never the default")
+    ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
+                    help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='timed regions of --steps iterations each, every one bracketed by barrier + synchronize; the MEDIAN is reported')
+    ap.add_argument('--min-busy-s', type=float, default=3.0,
+                    help='keep adding timed regions (each exactly --steps iterations) until the GPU has been busy this long in total')
+    ap.add_argument('--no-config3', action='store_true', help='skip the config3_bf16 block (bf16 arithmetic) behind the fp32 headline')
+    ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_child(args.cpu_baseline_only)
+        return
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
+    # Pre-flight hooks for boxes with ONE GPU: T2I_SAME_DEVICE=1 puts every rank on device 0 and T2I_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device), so the whole multi-process path — rendezvous, bucket order,
+    # overlap hooks, barriers, max-over-ranks timing — runs for real, minus the xGMI transport.  Never set by the driver.
+    if os.environ.get('T2I_SAME_DEVICE') == '1':
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    import t2i_amd  # noqa: F401
+    from t2i_amd import kernels as K
+
+    # T2I_FORCE_DP=1 exercises the data-parallel machinery (RCCL communicator, bucket hooks, side stream) on ONE rank
+    use_dp = world > 1 or os.environ.get('T2I_FORCE_DP') == '1'
+    if use_dp:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        backend = os.environ.get('T2I_DIST_BACKEND', 'nccl')
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get('T2I_DIST_TIMEOUT_S', '600')))   # a stuck collective aborts the run instead of hanging it
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device, timeout=tmo)
+        else:
+            dist.init_process_group(backend, timeout=tmo)
+
+    K.filter_cache(os.environ.get('T2I_FILTER_CACHE', '1') != '0')     # transformed Winograd filters reused until Adam changes them
+    bucket = int(os.environ.get('T2I_DP_BUCKET_MB', '32')) << 20
+
+    def make_dp(math):
+        if not use_dp:
+            return None, None
+        from t2i_amd.dp import DataParallel
+        # gradient buckets: fp32 in place for the fp32 metric; bf16 on the wire (half the bytes per link), summed in fp32, for config 3
+        gd = os.environ.get('T2I_DP_GRAD_DTYPE', 'bf16' if math == 'bf16' else 'f32')
+        return DataParallel(bucket_bytes=bucket, grad_dtype=gd), gd
+
+    out = run_config(args, args.math, device, rank, local_rank, world, use_dp, make_dp, headline=True)
+    # BASELINE config 3 (bf16 MFMA operands, fp32 accumulate / master weights, bf16 gradient buckets under data parallelism) rides
+    # on the SAME JSON line as a block of its own, so the driver's record holds it; the headline stays the fp32 metric.
+    if args.math == 'f32' and not args.no_config3 and os.environ.get('T2I_BENCH_CONFIG3', '1') != '0':
+        import copy
+        a3 = copy.copy(args)
+        a3.repeats = max(1, min(args.repeats, 3))
+        c3 = run_config(a3, 'bf16', device, rank, local_rank, world, use_dp, make_dp, headline=False)
+        if rank == 0:
+            keep = ('value', 'unit', 'ms_per_step', 'dtype', 'n_gpus', 'steps', 'warmup', 'config', 'timing', 'roofline', 'dp_preflight')
+            blk = {k: c3[k] for k in keep if k in c3}
+            blk['vs_fp32_line'] = c3['value'] / out['value'] if out.get('value') else None
+            blk['parity'] = {
+                'test': 'tests/test_step_b64_gpu.py::test_b64_bf16_steps_mask_pinned (B=64, full width, mask-pinned vs the float64 oracle)',
+                'bounds_relative_l2': {'G': 2e-2, 'D(x_hat)': 5e-2, 'loss_scalars': 2e-2, 'critic_step_gradients': 2e-2,
+                                       'generator_step_gradients': 1.2e-1},
+                'kernel_arithmetic': 'tests/test_kernels_gpu.py::test_bf16_operand_gemm_matches_rounded_oracle: 1e-5 / 1e-4 vs float64 on bf16-rounded operands'}
+            out['config3_bf16'] = blk
+    if rank == 0 and not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
+        out['cpu_baseline'] = cpu_baseline(16)              # BASELINE configs[0]
+        out['cpu_baseline_b64'] = cpu_baseline(64)          # and the batch the metric is quoted on
     if use_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

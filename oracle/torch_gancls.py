@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from .torch_step import AdamTF, _bn, _conv, _deconv_k4s2, is_trainable, trainable  # noqa: F401
+from .torch_step import lrelu as _lrelu, relu as _relu, tape_section  # activations that honour an installed SectionTape (branch pinning)
 
 
 class Cfg(object):
@@ -90,10 +91,6 @@ def init_variables(cfg, seed=0, dtype=torch.float32):
     return P
 
 
-def _lrelu(x):
-    return F.leaky_relu(x, 0.2)
-
-
 def generator(P, cfg, z, embed, train=True, stats=None):
     """-> img NHWC.  Activations are kept NCHW internally; the NHWC reshape of dense_1 (model.py:126) is honoured."""
     g = cfg.gf
@@ -112,13 +109,13 @@ def generator(P, cfg, z, embed, train=True, stats=None):
         return _deconv_k4s2(x, P[n + '/kernel'], P[n + '/bias'])
 
     bn = lambda i, x: _bn(P, 'g_net/BatchNorm_%d' % i, x, train, stats)
-    r = F.relu(bn(1, cv(0, h0, 'VALID'))); r = F.relu(bn(2, cv(1, r))); r = bn(3, cv(2, r))
-    h1 = F.relu(h0 + r)
+    r = _relu(bn(1, cv(0, h0, 'VALID'))); r = _relu(bn(2, cv(1, r))); r = bn(3, cv(2, r))
+    h1 = _relu(h0 + r)
     h2 = bn(4, cv(3, dc(0, h1)))
-    r = F.relu(bn(5, cv(4, h2, 'VALID'))); r = F.relu(bn(6, cv(5, r))); r = bn(7, cv(6, r))
-    h3 = F.relu(h2 + r)
-    h4 = F.relu(bn(8, cv(7, dc(1, h3))))
-    h5 = F.relu(bn(9, cv(8, dc(2, h4))))
+    r = _relu(bn(5, cv(4, h2, 'VALID'))); r = _relu(bn(6, cv(5, r))); r = bn(7, cv(6, r))
+    h3 = _relu(h2 + r)
+    h4 = _relu(bn(8, cv(7, dc(1, h3))))
+    h5 = _relu(bn(9, cv(8, dc(2, h4))))
     return torch.tanh(cv(9, dc(3, h5))).permute(0, 2, 3, 1)
 
 
@@ -155,11 +152,14 @@ def d_step(P, cfg, feed):
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
     gstats, dstats = {}, []
-    with torch.no_grad():
+    with torch.no_grad(), tape_section('G'):
         G = generator(P, cfg, feed['z'], feed['cond'], True, gstats)
-    lf = discriminator(Q, cfg, G, feed['cond'], True, dstats, 'fake')
-    lm = discriminator(Q, cfg, feed['x'], feed['cond'], True, dstats, 'match')
-    lw = discriminator(Q, cfg, feed['x_mismatch'], feed['cond'], True, dstats, 'mismatch')
+    with tape_section('Dfake'):
+        lf = discriminator(Q, cfg, G, feed['cond'], True, dstats, 'fake')
+    with tape_section('Dmatch'):
+        lm = discriminator(Q, cfg, feed['x'], feed['cond'], True, dstats, 'match')
+    with tape_section('Dmis'):
+        lw = discriminator(Q, cfg, feed['x_mismatch'], feed['cond'], True, dstats, 'mismatch')
     fake, match, mism = sigmoid_ce(lf, 0.0), sigmoid_ce(lm, 0.9), sigmoid_ce(lw, 0.0)
     D_loss = match + cfg.alpha * mism + (1.0 - cfg.alpha) * fake
     grads = torch.autograd.grad(D_loss, [Q[n] for n in names])
@@ -174,13 +174,17 @@ def g_step(P, cfg, feed):
     for n in names:
         Q[n] = P[n].detach().requires_grad_(True)
     gstats, dstats = {}, []
-    G = generator(Q, cfg, feed['z'], feed['cond'], True, gstats)
-    lf = discriminator(Q, cfg, G, feed['cond'], True, dstats, 'fake')
+    with tape_section('G'):
+        G = generator(Q, cfg, feed['z'], feed['cond'], True, gstats)
+    with tape_section('Dfake'):
+        lf = discriminator(Q, cfg, G, feed['cond'], True, dstats, 'fake')
     G_loss = sigmoid_ce(lf, 1.0)
     grads = torch.autograd.grad(G_loss, [Q[n] for n in names])
     with torch.no_grad():   # the other two critic passes only exist in this run for their UPDATE_OPS (trainer.py:46-51)
-        discriminator(P, cfg, feed['x'], feed['cond'], True, dstats, 'match')
-        discriminator(P, cfg, feed['x_mismatch'], feed['cond'], True, dstats, 'mismatch')
+        with tape_section('Dmatch'):
+            discriminator(P, cfg, feed['x'], feed['cond'], True, dstats, 'match')
+        with tape_section('Dmis'):
+            discriminator(P, cfg, feed['x_mismatch'], feed['cond'], True, dstats, 'mismatch')
     return dict(G_loss=float(G_loss.detach()), grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)),
                 G=G.detach(), g_stats=gstats, d_stats=dstats)
 

@@ -11,7 +11,12 @@ stable — sum x^2 - (sum x)^2/n replaced by shifted chunk moments + Chan mergin
 8e-5 / 9e-4 / 7e-4 and the committed test allowed 8e-2).  Where a tensor's exact gradient is zero (biases in front of a
 batch norm) the bound is absolute.  Batch sizes are the smallest that keep the
 float64 oracle at ~30 s (2 and 4); the tiny-width golden steps (tests/test_stackgan.py, tests/test_pggan.py) stay as the
-committed-fixture checks."""
+committed-fixture checks.
+
+Round 3 adds the remaining full-width cases of the hot path's own variants and of the next rows: gancls at the reference's own
+dimensions (models/gancls/cfg/flowers.yml: GF 128, DF 64, z 100; B = 64, the metric's batch, and B = 8, the yml's), StackGAN
+Stage-I at full width (B = 16), and PGGAN stages 6 (128x128) and 7 in transition (256x256) at B = 2.  All at SURVEY 8(c)'s
+tolerances (loss scalars 1e-5, gradients 1e-4 per tensor) unless a looser bound is stated next to the case with its reason."""
 import os
 from collections import OrderedDict
 
@@ -124,15 +129,18 @@ def test_stackgan_stage2_full_size(gpu):
     assert not chk.bad, chk.bad
 
 
-@pytest.mark.parametrize('stage', [5])
-def test_pggan_transition_stage_full_width(gpu, stage):
+@pytest.mark.parametrize('stage,trans,B', [(5, True, 4), (6, False, 2), (7, True, 2)])
+def test_pggan_stage_full_width(gpu, stage, trans, B):
+    """reference models/pggan/pggan.py:251-316 (generator / critic of a stage), train_pggan.py:17-69 (the stage schedule: 5t =
+    64x64 in transition, 6 = 128x128 stabilisation, 7t = 256x256 in transition; batch 16 -> 8 from stage 6 on, here the smallest
+    batches that keep the float64 oracle below a minute)."""
     from oracle import torch_pggan as PG, torch_step as T
     from t2i_amd.models.pggan.pggan import PGGAN
-    B, alpha = 4, 0.3
+    alpha = 0.3
     cfg = PG.Cfg(batch=B)
-    P = OrderedDict((n, v.float().double()) for n, v in PG.init_variables(cfg, stage, True, seed=0).items())
+    P = OrderedDict((n, v.float().double()) for n, v in PG.init_variables(cfg, stage, trans, seed=0).items())
     feed = {k: v.float().double() for k, v in PG.synthetic_feed(cfg, stage, seed=1).items()}
-    m = PGGAN(B, 100, None, None, None, None, None, stage, True, device=gpu)
+    m = PGGAN(B, 100, None, None, None, None, None, stage, trans, device=gpu)
     m.store.load({n: v.numpy() for n, v in P.items()})
     m.set_alpha(alpha)
     f = {k: v.float().to(gpu) for k, v in feed.items()}
@@ -145,13 +153,13 @@ def test_pggan_transition_stage_full_width(gpu, stage):
         torch.cuda.synchronize()
     own = T.SectionTape()
     with T.use_tape(own):
-        PG.d_step(P, cfg, feed, stage, True, alpha)
+        PG.d_step(P, cfg, feed, stage, trans, alpha)
     masks = split_sections(rec, own.record, [('G',), ('Dg', 'Dx', 'Dxmi'), ('Dxh',)])
     fl, units = flips(own.record, masks)
-    print('PGGAN stage %dt critic step: %d of %d branches differ (%.2e)' % (stage, fl, units, fl / units))
+    print('PGGAN stage %d%s critic step: %d of %d branches differ (%.2e)' % (stage, 't' if trans else '', fl, units, fl / units))
     assert fl <= 1e-4 * units
     with T.use_tape(T.SectionTape(masks)):
-        ref = PG.d_step(P, cfg, feed, stage, True, alpha)
+        ref = PG.d_step(P, cfg, feed, stage, trans, alpha)
     for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
         chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 1e-5)
     chk('G (%dx%d image)' % (m.output_size, m.output_size), relerr(d['G'], ref['G']), 1e-5)
@@ -163,14 +171,108 @@ def test_pggan_transition_stage_full_width(gpu, stage):
         torch.cuda.synchronize()
     own = T.SectionTape()
     with T.use_tape(own):
-        PG.g_step(P, cfg, feed, stage, True, alpha)
+        PG.g_step(P, cfg, feed, stage, trans, alpha)
     masks = split_sections(rec, own.record, [('G',), ('Dg',)])
     fl, units = flips(own.record, masks)
-    print('PGGAN stage %dt generator step: %d of %d branches differ (%.2e)' % (stage, fl, units, fl / units))
+    print('PGGAN stage %d%s generator step: %d of %d branches differ (%.2e)' % (stage, 't' if trans else '', fl, units, fl / units))
     assert fl <= 1e-4 * units
     with T.use_tape(T.SectionTape(masks)):
-        gref = PG.g_step(P, cfg, feed, stage, True, alpha)
+        gref = PG.g_step(P, cfg, feed, stage, trans, alpha)
     for k in ('G_loss', 'G_kl_loss'):
         chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 1e-5)
     chk.grads(m.g_arena, m.g_vars, gref['grads'])
+    assert not chk.bad, chk.bad
+
+
+def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, chk, T, loss_tol=1e-5, grad_tol=1e-4, img_tol=1e-5):
+    """Critic step then generator step of a sigmoid-CE conditional GAN (gancls, StackGAN Stage-I) against its float64 oracle,
+    mask-pinned; d_oracle / g_oracle: callables that run the oracle step under whatever tape is installed."""
+    moving0 = {n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n}
+    plan = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
+    rec = []
+    with record_branches(rec):
+        d = tr.d_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        d_oracle()
+    masks = split_sections(rec, own.record, plan)
+    fl, units = flips(own.record, masks)
+    print('%s critic step: %d of %d branches differ (%.2e)' % (tag, fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        ref = d_oracle()
+    for k in loss_keys_d:
+        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), loss_tol)
+    chk('G (tanh output)', relerr(d['G'], ref['G'], scale=1.0), img_tol)
+    chk.grads(m.d_arena, m.d_vars, ref['grads'], grad_tol)
+    with torch.no_grad():                      # undo the moving-average side effect of the probe pass
+        for n, v in moving0.items():
+            m.store.vars[n].copy_(v)
+    rec = []
+    with record_branches(rec):
+        g = tr.g_losses(hf)
+        torch.cuda.synchronize()
+    own = T.SectionTape()
+    with T.use_tape(own):
+        g_oracle()
+    masks = split_sections(rec, own.record, plan)
+    fl, units = flips(own.record, masks)
+    print('%s generator step: %d of %d branches differ (%.2e)' % (tag, fl, units, fl / units))
+    assert fl <= 1e-4 * units
+    with T.use_tape(T.SectionTape(masks)):
+        gref = g_oracle()
+    for k in loss_keys_g:
+        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), loss_tol)
+    chk.grads(m.g_arena, m.g_vars, gref['grads'], grad_tol)
+
+
+@pytest.mark.parametrize('B', [64, 8])
+def test_gancls_full_width(gpu, B):
+    """gancls at the reference's own dimensions (models/gancls/cfg/flowers.yml:9-19: z 100, GF 128, DF 64; model.py:54-192,
+    trainer.py:19-51) — the second variant north_star names.  B = 64 is the metric's batch, B = 8 the yml's."""
+    from oracle import torch_gancls as GC, torch_step as T
+    from t2i_amd.models.gancls.model import GanCls
+    from t2i_amd.models.gancls.trainer import GanClsTrainer
+    from t2i_amd.utils.config import config_from_yaml
+    cfg = config_from_yaml(os.path.join(ROOT, 'text-to-image_amd', 'models', 'gancls', 'cfg', 'flowers.yml'))
+    cfg.TRAIN.BATCH_SIZE = B
+    ocfg = GC.Cfg(batch=B)
+    P = OrderedDict((n, v.float().double()) for n, v in GC.init_variables(ocfg, seed=0, dtype=torch.float64).items())
+    feed = {k: v.float().double() for k, v in GC.synthetic_feed(ocfg, seed=1, dtype=torch.float64).items()}
+    m = GanCls(cfg, device=gpu)
+    assert [n for n in m.store.vars] == list(P) and (m.gf_dim, m.df_dim, m.z_dim) == (128, 64, 100)
+    m.store.load({n: v.numpy() for n, v in P.items()})
+    f = {k: v.float().to(gpu) for k, v in feed.items()}
+    hf = {'inputs': f['x'], 'wrong_inputs': f['x_mismatch'], 'phi_inputs': f['cond'], 'z': f['z']}
+    tr = GanClsTrainer(None, m, None, cfg)
+    chk = Checker()
+    _cgan_steps('gancls B=%d' % B, tr, m, hf, lambda: GC.d_step(P, ocfg, feed), lambda: GC.g_step(P, ocfg, feed),
+                ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'), ('G_loss',), chk, T)
+    assert not chk.bad, chk.bad
+
+
+def test_stackgan_stage1_full_width(gpu):
+    """StackGAN Stage-I at full width (reference models/stackgan/stageI/model.py:76-171, trainer.py:19-53; GF 128, DF 64,
+    conditioning augmentation + KL), B = 16."""
+    from oracle import torch_stackgan as SG, torch_step as T
+    from t2i_amd.models.stackgan.stageI.model import ConditionalGan as StageI
+    from t2i_amd.models.stackgan.stageI.trainer import ConditionalGanTrainer
+    from t2i_amd.utils.config import config_from_yaml
+    B = 16
+    c1 = config_from_yaml(os.path.join(ROOT, 'text-to-image_amd', 'models', 'stackgan', 'stageI', 'cfg', 'flowers.yml'))
+    c1.TRAIN.BATCH_SIZE = B
+    o1 = SG.Cfg(batch=B)
+    P = OrderedDict((n, v.float().double()) for n, v in SG.init_variables(o1, 1, seed=0).items())
+    feed = {k: v.float().double() for k, v in SG.synthetic_feed(o1, 1, seed=1).items()}
+    m = StageI(c1, device=gpu)
+    assert [n for n in m.store.vars] == list(P)
+    m.store.load({n: v.numpy() for n, v in P.items()})
+    f = {k: v.float().to(gpu) for k, v in feed.items()}
+    hf = {'inputs': f['x'], 'wrong_inputs': f['x_mismatch'], 'phi_inputs': f['cond'], 'z': f['z']}
+    hf.update({k: v for k, v in f.items() if k.startswith('ca_noise')})
+    tr = ConditionalGanTrainer(None, m, None, c1)
+    chk = Checker()
+    _cgan_steps('Stage-I B=%d' % B, tr, m, hf, lambda: SG.d_step(P, o1, feed, 1), lambda: SG.g_step(P, o1, feed, 1),
+                ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'), ('G_loss', 'G_gan_loss', 'G_kl_loss'), chk, T)
     assert not chk.bad, chk.bad

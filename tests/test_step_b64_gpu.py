@@ -16,9 +16,11 @@ asserted to be tiny (< 1e-4 of all units) — mask pinning must not be able to h
 
 What "max|ref|" means for the critic's gradients: D_loss = -(1+kt) mean D(x) + mean D(G) + kt mean D(x_mis) + 150 (gp + gp2);
 the three critic-mean terms carry a large sample-independent part whose coefficients sum to zero, so a few tensors (biases
-above all) are small differences of large numbers.  Their error bound is relative to the un-cancelled scale
-(oracle.torch_step.d_step_term_scales: max_i |coef_i| max|d term_i / d theta|), which is what 1e-4 of fp32 arithmetic can
-promise; the test prints both ratios and asserts the plain one wherever no cancellation is involved.
+above all) are small differences of large numbers.  Round 2 bounded those against the un-cancelled scale
+(oracle.torch_step.d_step_term_scales: max_i |coef_i| max|d term_i / d theta|) only; measured, they sit at <= 3.1e-6 of their
+own max|ref|, so since round 3 EVERY tensor with a non-zero gradient is held to the plain 1e-4 bound, the list of tensors whose
+uncancelled scale exceeds 4 max|ref| is printed and pinned, and only the logit bias — whose gradient is identically zero,
+-(1+kt) + 1 + kt — keeps the scale-relative bound.
 """
 import os
 
@@ -119,7 +121,7 @@ def test_b64_critic_step_mask_pinned(setup):
     # applies to the conv output, and |dG| <= |dlogits| because tanh' <= 1 — so G's error is measured against max|logits|.
     # (Yardstick: torch-CPU fp32 on the same step sits 5.8e-5 from float64 on G, i.e. 3.3e-6 of max|logits|.)
     chk('G (vs max|logits| %.1f)' % ref['G_logits_absmax'], relerr(d['G'], ref['G'], scale=ref['G_logits_absmax']), 1e-5)
-    chk('D(x_hat)', relerr(d['Dx_hat_logit'], ref['Dx_hat']), 2e-5)      # 12 layers in series, each at the 1e-5 kernel tolerance: measured 0.7-1.1e-5
+    chk('D(x_hat)', relerr(d['Dx_hat_logit'], ref['Dx_hat']), 1e-5)      # SURVEY 8(c)'s forward bound (12 layers in series; measured 0.7e-5)
     # ---- losses: 1e-5 relative
     for k in ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'reg_loss'):
         e = abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0)
@@ -129,14 +131,33 @@ def test_b64_critic_step_mask_pinned(setup):
     chk('grad_x_hat', relerr(d['grad_x_hat'], ref['grad_x_hat']), 1e-4)
     chk('grad_cond', relerr(d['grad_cond'], ref['grad_cond']), 1e-4)
     scales = T.d_step_term_scales(P, ocfg, feed, 0.7)
+    cancelling, exact_zero = [], []
     for n in m.d_vars:
         r = ref['grads'][n]
+        rmax = float(r.abs().max())
+        uncancelled = relerr(m.d_arena.grad_of(n), r, scale=max(rmax, scales[n]))
+        if rmax < 1e-9 * scales[n]:
+            # the logit bias: dD_loss/db = -(1+kt) + 1 + kt = 0 identically (the critic-mean coefficients sum to zero), so there
+            # is no max|ref| to divide by; the residue is bounded against the scale of the three terms that cancel
+            exact_zero.append(n)
+            print('  %-22s exact zero; uncancelled scale %.3e' % (n, scales[n]))
+            chk('grad ' + n + ' (exact zero: vs uncancelled scale)', uncancelled, 1e-4)
+            continue
         plain = relerr(m.d_arena.grad_of(n), r)
-        uncancelled = relerr(m.d_arena.grad_of(n), r, scale=max(float(r.abs().max()), scales[n]))
-        print('  %-22s max|ref| %.3e  uncancelled scale %.3e  err/max|ref| %.2e' % (n, float(r.abs().max()), scales[n], plain))
+        print('  %-22s max|ref| %.3e  uncancelled scale %.3e (x%.1f)  err/max|ref| %.2e' % (n, rmax, scales[n], scales[n] / rmax, plain))
+        if scales[n] > 4.0 * rmax:
+            cancelling.append(n)
+        chk('grad ' + n, plain, 1e-4)                  # the plain SURVEY 8(c) bound for EVERY tensor with a non-zero gradient
         chk('grad ' + n + ' (uncancelled)', uncancelled, 1e-4)
-        if scales[n] <= 4.0 * float(r.abs().max()):          # no cancellation: the plain SURVEY 8(c) bound
-            chk('grad ' + n, plain, 1e-4)
+    # Round 2 bounded tensors that are small differences of large terms (uncancelled scale > 4 max|ref|) against that scale only.
+    # They are the biases above the residual / text join (measured ratios 4.6-5.2) and they meet the plain bound with two orders
+    # of magnitude to spare (<= 3.1e-6), so the plain bound is now asserted for them too; the list is printed and pinned so that
+    # it cannot grow silently, and only the identically-zero logit bias is left with a scale-relative bound.
+    print('tensors with uncancelled scale > 4 max|ref| (informational, all held to the plain bound): %s' % cancelling)
+    print('tensors with an identically zero gradient (scale-relative bound): %s' % exact_zero)
+    allowed = {'d_net/Conv_5/biases', 'd_net/Conv_6/biases', 'd_net/Conv_7/biases', 'd_net/Conv_8/biases', 'd_net/dense/bias'}
+    assert set(cancelling) <= allowed, sorted(set(cancelling) - allowed)
+    assert exact_zero == ['d_net/Conv_9/biases'], exact_zero
     assert not bad, bad
     # ---- second, clearly labelled check: UN-pinned oracle, kink-tolerant criteria (tests/test_step_gpu.py)
     from test_step_gpu import _check_grad_kinks

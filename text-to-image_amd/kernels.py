@@ -835,6 +835,17 @@ def filter_cache(on, device=None):
     return bool(lib.t2i_filter_cache_enable(1 if on else 0))
 
 
+def filter_cache_reset():
+    """Drop every cached filter image and hand the library the same arena again, empty.  Legal only when no captured graph that
+    used the cache is alive any more (bench.py calls it between two configurations, after the first model and its graphs are gone):
+    slots are never moved or reused while attached, so a process that builds model after model would otherwise fill the arena with
+    images of filters that no longer exist."""
+    if _FC_ARENA[0] is not None:
+        buf = _FC_ARENA[0]
+        check(lib.t2i_filter_cache_attach(None, 0), 't2i_filter_cache_attach')
+        check(lib.t2i_filter_cache_attach(_ptr(buf), buf.numel()), 't2i_filter_cache_attach')
+
+
 def tuning_set(key, value):
     """Planner / diagnostic switch (include/t2i_hip.h t2i_tuning_set); drops cached descriptors, whose workspace sizes
     were computed under the old setting."""

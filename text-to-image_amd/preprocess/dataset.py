@@ -50,17 +50,22 @@ class Dataset(object):
     class_ids = property(lambda self: self._class_id)
 
     def saveIDs(self):
-        self._saveIDs = np.arange(self._num_examples)
-        np.random.shuffle(self._saveIDs)
-        return self._saveIDs
+        """A shuffled id list for the test-time dumps (dataset.py:66-69); one np.random.shuffle, as in the reference constructor."""
+        order = np.arange(self._num_examples)
+        np.random.shuffle(order)
+        self._saveIDs = order
+        return order
+
+    def _caption_path(self, filename, class_id):
+        """flowers keeps its caption files under class_%05d/ instead of jpg/ (dataset.py:71-76)."""
+        if 'jpg/' in filename:
+            filename = filename.replace('jpg/', 'class_%05d/' % (class_id + 1))
+        return os.path.join(self.workdir, 'text_c10', filename + '.txt')
 
     def readCaptions(self, filenames, class_id):
-        name = filenames
-        if name.find('jpg/') != -1:                                  # flowers: captions live under class_%05d/
-            name = name.replace('jpg/', 'class_%05d/' % (class_id + 1))
-        with open('%s/text_c10/%s.txt' % (self.workdir, name), 'r') as f:
-            captions = f.read().split('\n')
-        return [cap for cap in captions if len(cap) > 0]
+        """The non-empty lines of one image's caption file (dataset.py:71-81)."""
+        with open(self._caption_path(filenames, class_id), 'r') as f:
+            return [line for line in f.read().split('\n') if line]
 
     # ---- the reference's random decisions, in its order (dataset.py:83-96) ------------------------------------------------
     def _draw_crops(self, n, ori_size):
@@ -115,59 +120,57 @@ class Dataset(object):
         out = K.gather_mean(emb, dev(np.asarray(embeddings_ids)), dev(np.stack(choice)))
         return out.squeeze(), captions
 
-    def next_batch(self, batch_size, window=None, wrong_img=False, embeddings=False, labels=False):
-        """-> [images, wrong_images | None, embeddings | None, captions | None, class ids | None]  (dataset.py:122-184)"""
-        start = self._index_in_epoch
-        self._index_in_epoch += batch_size
-        if self._index_in_epoch > self._num_examples:      # finished epoch: reshuffle, start over
+    # ---- batches.  The order of the random draws IS the interface (equal seeds -> the reference's batches, bit for bit):
+    #      [epoch shuffle] -> crops/flips of the batch -> mismatched ids -> ONE collision offset (drawn whether or not anything
+    #      collides) -> crops/flips of the mismatched images -> caption choices.
+    def _advance(self, batch_size):
+        """Ids of the next `batch_size` examples of the current epoch permutation; a batch that would run past the end starts a
+        new epoch (fresh permutation) instead — the tail of the old one is dropped (dataset.py:124-139)."""
+        stop = self._index_in_epoch + batch_size
+        if stop > self._num_examples:
+            if batch_size > self._num_examples:
+                raise AssertionError('batch of %d from %d examples' % (batch_size, self._num_examples))
             self._epochs_completed += 1
             self._perm = np.arange(self._num_examples)
             np.random.shuffle(self._perm)
-            start = 0
-            self._index_in_epoch = batch_size
-            assert batch_size <= self._num_examples
-        end = self._index_in_epoch
-        current_ids = self._perm[start:end]
-        ret_list = [self._images_for(current_ids)]
-        if wrong_img:
-            fake_ids = np.random.randint(self._num_examples, size=batch_size)
-            collision_flag = (self._class_id[current_ids] == self._class_id[fake_ids])
-            fake_ids[collision_flag] = (fake_ids[collision_flag] + np.random.randint(100, 200)) % self._num_examples
-            ret_list.append(self._images_for(fake_ids))
-        else:
-            ret_list.append(None)
-        if self._embeddings is not None and embeddings:
-            filenames = [self._filenames[i] for i in current_ids] if self._filenames is not None else [None] * len(current_ids)
-            class_id = [self._class_id[i] for i in current_ids]
-            sampled_embeddings, sampled_captions = self.sample_embeddings(current_ids, filenames, class_id, window)
-            ret_list.append(sampled_embeddings)
-            ret_list.append(sampled_captions)
-        else:
-            ret_list.append(None)
-            ret_list.append(None)
-        if self._labels is not None and labels:
-            ret_list.append([self._class_id[i] for i in current_ids])
-        else:
-            ret_list.append(None)
-        return ret_list
+            stop = batch_size
+        self._index_in_epoch = stop
+        return self._perm[stop - batch_size:stop]
+
+    def _mismatched_ids(self, ids):
+        """Uniform ids for the "wrong image" of every example; the ones that landed in the example's own class are moved on by
+        one shared offset in [100, 200) (dataset.py:154-159)."""
+        wrong = np.random.randint(self._num_examples, size=len(ids))
+        offset = np.random.randint(100, 200)
+        same_class = self._class_id[ids] == self._class_id[wrong]
+        return np.where(same_class, (wrong + offset) % self._num_examples, wrong)
+
+    def _text_for(self, ids, window):
+        names = [None] * len(ids) if self._filenames is None else [self._filenames[i] for i in ids]
+        return self.sample_embeddings(ids, names, [self._class_id[i] for i in ids], window)
+
+    def next_batch(self, batch_size, window=None, wrong_img=False, embeddings=False, labels=False):
+        """-> [images, wrong_images | None, embeddings | None, captions | None, class ids | None]  (dataset.py:122-184)"""
+        ids = self._advance(batch_size)
+        images = self._images_for(ids)
+        wrong = self._images_for(self._mismatched_ids(ids)) if wrong_img else None
+        text, captions = self._text_for(ids, window) if (embeddings and self._embeddings is not None) else (None, None)
+        classes = [self._class_id[i] for i in ids] if (labels and self._labels is not None) else None
+        return [images, wrong, text, captions, classes]
 
     def next_batch_test(self, batch_size, start, max_captions):
-        """-> [images, [embeddings of caption 0, 1, ...], save ids, captions]  (dataset.py:186-216)"""
-        if (start + batch_size) > self._num_examples:
-            end = self._num_examples
-            start = end - batch_size
-        else:
-            end = start + batch_size
-        ids = np.arange(start, end)
-        sampled_images = self._images_for(ids)
-        sampled_embeddings = self._embeddings[start:end]
-        embedding_num = sampled_embeddings.shape[1]
-        sampled_captions = []
-        if self._filenames is not None and self.workdir is not None and os.path.isdir(os.path.join(self.workdir, 'text_c10')):
-            for i in range(start, end):
-                sampled_captions.append(self.readCaptions(self._filenames[i], self._class_id[i]))
-        batches = [sampled_embeddings[:, i, :].squeeze() for i in range(min(max_captions, embedding_num))]
-        return [sampled_images, batches, self._saveIDs[start:end], sampled_captions]
+        """-> [images, [embeddings of caption 0, 1, ...], save ids, captions]  (dataset.py:186-216).  A window that would run
+        past the end is moved back so that it ends at the last example."""
+        start = min(start, self._num_examples - batch_size)
+        window = slice(start, start + batch_size)
+        images = self._images_for(np.arange(window.start, window.stop))
+        emb = self._embeddings[window]
+        per_caption = [emb[:, j, :].squeeze() for j in range(min(max_captions, emb.shape[1]))]
+        captions = []
+        have_text = self._filenames is not None and self.workdir is not None and os.path.isdir(os.path.join(self.workdir, 'text_c10'))
+        if have_text:
+            captions = [self.readCaptions(self._filenames[i], self._class_id[i]) for i in range(window.start, window.stop)]
+        return [images, per_caption, self._saveIDs[window], captions]
 
     def class_to_index(self):
         return {class_id: idx for idx, class_id in enumerate(np.unique(self._class_id))}
