@@ -17,7 +17,10 @@
  *     safe to capture into a hipGraph: no allocation, no synchronisation.  Host-side state is limited to (a) the tuning
  *     switches, read from the T2I_* environment once at first use and changed afterwards only through t2i_tuning_set, and
  *     (b) the bookkeeping (not the storage) of the filter cache, mutex-guarded; the planner never consults the environment
- *     at call time, so equal descriptors take equal paths for the life of the process.
+ *     at call time, so equal descriptors take equal paths for the life of the process.  There is NO per-thread hand-over
+ *     state: everything a call reads or writes besides its tensors travels in its own arguments (t2i_conv_opts for the
+ *     conv family, an explicit image pointer for the elementwise producers) — ABI v5 removed the one-shot "arm the next
+ *     call" entry points of v4 (t2i_conv2d_operand_images, t2i_output_image, t2i_conv2d_input_transform, *_written, *_kept).
  */
 #ifndef T2I_HIP_H
 #define T2I_HIP_H
@@ -60,8 +63,9 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 4 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
-                                   * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images) */
+int t2i_version(void);            /* ABI version, currently 5 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+                                   * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
+                                   * and explicit image arguments instead of thread-local one-shot hand-overs) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
@@ -76,10 +80,39 @@ int t2i_tuning_set(const char* key, double value);
 /* ---- convolution family: reference utils/ops.py:58-63 (conv2d) and :66-71 (conv2d_transpose) ------------------ */
 size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fwd / bwd_data / bwd_filter */
 
+/* Optional side inputs / outputs of ONE conv call (pass NULL for none).  Plain data, owned by the caller, read at entry and
+ * written (the two out-flags) before the call returns; the library keeps no pointer to it.  Results of the convolution are
+ * identical with and without any of these.
+ *   a_image / b_image   bf16 math: bf16 images (same shape and layout, made by t2i_cast_bf16 or written as a twin by the
+ *                       producer) of the call's first / second ACTIVATION operand (fwd: x; bwd_data: dy; bwd_filter: x, dy).
+ *                       An activation feeds up to three convs of a training step and a gradient two, so the caller that keeps
+ *                       the image saves the repeated casts.  Paths that do not read bf16 operands from memory ignore them.
+ *   out_image           bf16 math, fwd / fwd_stats / bwd_data: also write the bf16 image of the output tensor here (16-byte
+ *                       aligned), in the epilogue's own pass; out_image_written tells whether the path taken did.
+ *   xform, xform_bytes, xform_mode
+ *                       fp32 Winograd: the forward conv of a layer and its filter gradient transform the same x (V = B^T x B
+ *                       per tile, 4x resp. 2.25x the size of x).  T2I_XFORM_KEEP on t2i_conv2d_fwd / _fwd_stats leaves V in
+ *                       `xform` (>= t2i_conv2d_input_transform_bytes(d) bytes; xform_kept tells whether the call took a path
+ *                       that has one); T2I_XFORM_HAVE on t2i_conv2d_bwd_filter (same d, same unchanged x) reads V from there
+ *                       instead of transforming x again. */
+enum { T2I_XFORM_NONE = 0, T2I_XFORM_KEEP = 1, T2I_XFORM_HAVE = 2 };
+typedef struct t2i_conv_opts {
+  const void* a_image;
+  const void* b_image;
+  void* out_image;
+  void* xform;
+  size_t xform_bytes;
+  int32_t xform_mode;
+  int32_t out_image_written; /* out */
+  int32_t xform_kept;        /* out */
+  int32_t reserved;
+} t2i_conv_opts;
+size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);   /* > 0: fwd and bwd_filter of `d` both take a Winograd path */
+
 /* y = act(conv(x, w) + bias).  bias may be NULL.  Serves ops.conv2d (utils/ops.py:58-63), ops.fc as a 1x1 conv on
  * [B,1,1,in] (utils/ops.py:84-87), and the double-backward term adj_gy = conv(ggx, w) of the gradient penalty. */
 int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                   float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
+                   float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* t2i_conv2d_fwd that also hands the batch norm behind it its statistics: if the launch takes the unsplit path,
  * *chunks = number of M-tiles, *tile_rows = their height and stats = [2][chunks][Cout]: per tile the column sums of y and
@@ -88,19 +121,19 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
  * (t2i_bn_stats).  stats must hold t2i_conv2d_stats_bytes(d). */
 size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d);
 int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, void* ws,
-                         size_t ws_bytes, t2i_stream_t stream);
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, t2i_conv_opts* opts,
+                         void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* dx = conv^T(dy, w) (+ bias over Cin if non-NULL, then act).  This IS ops.conv2d_transpose (utils/ops.py:66-71):
  * TF stores the deconv filter as [KH,KW,Cout_deconv,Cin_deconv], i.e. the HWIO filter of the adjoint conv, so the
  * descriptor is that adjoint conv's (d->Cin = deconv output channels) and no re-layout is needed. */
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx,
-                        int act, float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream);
+                        int act, float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* dw = x (*) dy over all B*Ho*Wo positions (tf.gradients wrt `weights`, reference models/wgancls/model.py:94-106);
  * accumulate != 0: dw += x (*) dy in the epilogue, i.e. the gradient is summed straight into the optimizer's arena. */
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                          size_t ws_bytes, t2i_stream_t stream);
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                          t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);
@@ -134,9 +167,14 @@ int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* p
 int t2i_bn_finalize(const float* sum, const float* m2, int64_t n, int32_t C, const float* gamma,
                     const float* beta, float eps, float decay, float* mean, float* rstd, float* scale, float* shift,
                     float* moving_mean, float* moving_var, t2i_stream_t stream);
-/* y = act(x*scale[c] + shift[c])  (normalise + affine + activation in one pass; also eval-mode BN). */
+/* y = act(x*scale[c] + shift[c])  (normalise + affine + activation in one pass; also eval-mode BN).
+ * y_h (here and in t2i_bn_bwd_fused, t2i_act_fwd, t2i_act_bwd, t2i_act_bwd_colsum, t2i_add_act): NULL, or a buffer that receives
+ * the bf16 image (round to nearest even) of the output tensor in the same pass — the "twin" a bf16-math conv reading that
+ * tensor next takes as its operand image (t2i_conv_opts.a_image), so that no cast launch is needed.  Requires the vectorised
+ * path: every tensor and y_h 16-byte aligned and C % 4 == 0 (n % 4 == 0); otherwise the call fails with T2I_ERR_INVALID
+ * instead of silently not writing it. */
 int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act,
-                 float alpha, float* y, t2i_stream_t stream);
+                 float alpha, float* y, void* y_h, t2i_stream_t stream);
 /* dx = gamma*rstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n), xhat = (x-mean)*rstd, sum_dy_xhat = rstd * sum_dy_x with
  * sum_dy_x = sum dy*(x - mean) (t2i_col_reduce / t2i_act_bwd_colsum with center = mean).  Also emits dgamma, dbeta. */
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -149,23 +187,23 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
  * behind the batch norm (g = dy, gmask unused).  gmask: caller's [rows, C] buffer for g.  C % 4 == 0, 16-byte alignment. */
 size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C);
 int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
-                     int32_t C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     int32_t C, int act, float alpha, float* gmask, float* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
                      size_t ws_bytes, t2i_stream_t stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------------- */
 /* y = act(x) */
-int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
+int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream);
 /* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
-int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream);
+int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, void* dx_h, t2i_stream_t stream);
 /* Fused activation backward + column sums: dx = dy * act'(y), colsum[c] = sum_r dx[r,c] and, if x2 != NULL,
  * colsum_x2[c] = sum_r dx[r,c]*(x2[r,c] - center[c]) (center NULL = 0), in ONE pass over a [rows, C] view (C % 4 == 0,
  * 16-byte aligned).  Serves the bias gradient of a conv layer and the two reductions of the batch-norm backward (x2 = the
  * layer input, center = its batch mean).  accumulate: sums are added to the outputs.  Workspace as t2i_col_reduce. */
 int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
-                       float alpha, float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       float alpha, float* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
                        t2i_stream_t stream);
 /* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
-int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream);
+int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream);
 /* y = alpha*a + beta*b (b may be NULL). */
 int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream);
 /* x_hat[b,:] = eps[b]*g[b,:] + (1-eps[b])*x[b,:]   (reference models/wgancls/model.py:53). */
@@ -281,34 +319,9 @@ size_t t2i_filter_cache_bytes(void);            /* bytes of the attached arena h
 int t2i_filter_cache_refresh(const void* ptr, size_t bytes, t2i_stream_t stream);
 
 /* ---- bf16 operand images (T2I_MATH_BF16) --------------------------------------------------------------------------
- * out[i] = bf16(x[i]), round to nearest even; n % 8 == 0, both buffers 16-byte aligned. */
+ * out[i] = bf16(x[i]), round to nearest even; n % 8 == 0, both buffers 16-byte aligned.  The image of an activation tensor
+ * is handed to the convs that read it through t2i_conv_opts.a_image / b_image. */
 int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream);
-/* One-shot hand-over: the NEXT t2i_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_filter call on this thread may read a_h / b_h
- * (either may be NULL) as the bf16 images — same shape and layout, made by t2i_cast_bf16 — of its first / second
- * activation operand (fwd: x; bwd_data: dy; bwd_filter: x, dy) instead of staging its own copies into the workspace.  An
- * activation feeds up to three convs of a training step and a gradient two, so the caller that keeps the image saves the
- * repeated casts.  The call consumes the hand-over whatever path it dispatches to; paths that do not read bf16 operands
- * from memory ignore it.  Results are identical with and without. */
-int t2i_conv2d_operand_images(const void* a_h, const void* b_h);
-/* ---- shared Winograd input transform (fp32) --------------------------------------------------------------------------
- * The forward conv of a layer and its filter gradient transform the same x (V = B^T x B per tile: 4x resp. 2.25x the size
- * of x).  t2i_conv2d_input_transform_bytes(d) > 0 says both take a Winograd path for `d`; then
- *   t2i_conv2d_input_transform(buf, bytes, 1) in front of t2i_conv2d_fwd / _fwd_stats makes it leave V in `buf` (check
- *   t2i_conv2d_input_transform_kept() afterwards: an unaligned operand sends the call down another path), and
- *   t2i_conv2d_input_transform(buf, bytes, 2) in front of t2i_conv2d_bwd_filter (same d, same x) makes it read V from there
- * instead of transforming x again.  One-shot like the image hand-overs above; ignored by paths that have no use for it. */
-size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);
-int t2i_conv2d_input_transform(void* buf, size_t bytes, int32_t mode);
-int t2i_conv2d_input_transform_kept(void);   /* 1 if the last forward conv on this thread left V in the buffer it was offered */
-
-/* One-shot, the producer side of the same idea: the NEXT call on this thread to one of t2i_conv2d_fwd / _fwd_stats / _bwd_data
- * (bf16-operand path), t2i_bn_apply, t2i_bn_bwd_fused (dx), t2i_act_fwd, t2i_act_bwd, t2i_add_act or t2i_act_bwd_colsum also writes the bf16 image
- * of its output tensor to y_h (same shape, 16-byte aligned) in the same pass, so that the conv reading that tensor next
- * needs no cast at all.  The call consumes the request; t2i_output_image_written() tells whether the path it took wrote the
- * image (vectorised paths only: element count % 4 == 0, aligned) — if not, the caller casts as usual.  Set it only directly
- * in front of one of the calls listed. */
-int t2i_output_image(void* y_h);
-int t2i_output_image_written(void);
 /* 0 for an eager stream, else a number unique to the capture active on `stream`: a caller that keeps bf16 images (or any
  * derived buffer) across calls must not let a capture reuse one made outside it — the graph would not contain its producer. */
 uint64_t t2i_capture_id(t2i_stream_t stream);

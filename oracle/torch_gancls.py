@@ -146,7 +146,12 @@ def sigmoid_ce(logits, label):
     return torch.mean(torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs())))
 
 
-def d_step(P, cfg, feed):
+def d_step(P, cfg, feed, term_scales=False):
+    """term_scales: also return `scales`, per critic tensor max_i |coef_i| max|d term_i / d theta| over the three loss terms of
+    D_loss = match + alpha mismatch + (1 - alpha) fake — the magnitude a gradient has BEFORE the terms cancel.  The logit bias is
+    the case that needs it: its gradient is sum_i coef_i mean(sigmoid(l_i) - y_i), three numbers of order 0.1-0.4 that cancel to
+    ~1e-5 on some batches, where fp32 (any fp32: torch-CPU float32 differs from float64 by 8e-3 there) can only promise 1e-4 of
+    the terms, not of the difference."""
     names = trainable(P, 'd_net')
     Q = dict(P)
     for n in names:
@@ -162,10 +167,19 @@ def d_step(P, cfg, feed):
         lw = discriminator(Q, cfg, feed['x_mismatch'], feed['cond'], True, dstats, 'mismatch')
     fake, match, mism = sigmoid_ce(lf, 0.0), sigmoid_ce(lm, 0.9), sigmoid_ce(lw, 0.0)
     D_loss = match + cfg.alpha * mism + (1.0 - cfg.alpha) * fake
+    scales = None
+    if term_scales:
+        scales = OrderedDict((n, 0.0) for n in names)
+        for coef, term in ((1.0, match), (cfg.alpha, mism), (1.0 - cfg.alpha, fake)):
+            gs = torch.autograd.grad(term, [Q[n] for n in names], retain_graph=True, allow_unused=True)
+            for n, g in zip(names, gs):
+                if g is not None:
+                    scales[n] = max(scales[n], abs(coef) * float(g.abs().max()))
     grads = torch.autograd.grad(D_loss, [Q[n] for n in names])
     f = lambda t: float(t.detach())
     return dict(D_loss=f(D_loss), D_real_match_loss=f(match), D_real_mismatch_loss=f(mism), D_synthetic_loss=f(fake),
-                grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), G=G.detach(), g_stats=gstats, d_stats=dstats)
+                grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), G=G.detach(), g_stats=gstats, d_stats=dstats,
+                scales=scales)
 
 
 def g_step(P, cfg, feed):

@@ -224,7 +224,8 @@ def scopes(stage):
     return ('g_net', 'd_net') if stage == 1 else ('stageII_g_net', 'stageII_d_net')
 
 
-def d_step(P, cfg, feed, stage=1, cfg1=None):
+def d_step(P, cfg, feed, stage=1, cfg1=None, term_scales=False):
+    """term_scales: see oracle/torch_gancls.d_step (per tensor, the gradient magnitude before the three loss terms cancel)."""
     gs, ds = scopes(stage)
     names = trainable(P, ds)
     Q = dict(P)
@@ -241,10 +242,19 @@ def d_step(P, cfg, feed, stage=1, cfg1=None):
         lw = _disc(Q, cfg, stage, feed['x_mismatch'], feed['cond'], dstats[2])
     fake, match, mism = sigmoid_ce(lf, 0.0), sigmoid_ce(lm, cfg.real_label), sigmoid_ce(lw, 0.0)
     D_loss = match + cfg.alpha * mism + (1.0 - cfg.alpha) * fake
+    scales = None
+    if term_scales:
+        scales = OrderedDict((n, 0.0) for n in names)
+        for coef, term in ((1.0, match), (cfg.alpha, mism), (1.0 - cfg.alpha, fake)):
+            gs_ = torch.autograd.grad(term, [Q[n] for n in names], retain_graph=True, allow_unused=True)
+            for n, g in zip(names, gs_):
+                if g is not None:
+                    scales[n] = max(scales[n], abs(coef) * float(g.abs().max()))
     grads = torch.autograd.grad(D_loss, [Q[n] for n in names])
     f = lambda t: float(t.detach())
     return dict(D_loss=f(D_loss), D_real_match_loss=f(match), D_real_mismatch_loss=f(mism), D_synthetic_loss=f(fake),
-                grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), G=G.detach(), g_stats=gstats, d_stats=dstats)
+                grads=OrderedDict((n, g.detach()) for n, g in zip(names, grads)), G=G.detach(), g_stats=gstats, d_stats=dstats,
+                scales=scales)
 
 
 def g_step(P, cfg, feed, stage=1, cfg1=None):

@@ -624,9 +624,9 @@ def _rne_bf16(a):
 
 
 def test_bf16_twins_are_the_rounded_outputs(K):
-    """t2i_output_image: every producer that can write the bf16 twin of its output writes exactly RNE(bf16) of the fp32 values it
-    stores — batch-norm apply, activation forward / backward, residual join, fused activation-backward + bias gradient, the
-    bf16-operand conv (unsplit epilogue and split-K reduce); t2i_cast_bf16 likewise.  The request is one-shot."""
+    """bf16 twins (the y_h / dx_h arguments and t2i_conv_opts.out_image): every producer that can write the bf16 twin of its output
+    writes exactly RNE(bf16) of the fp32 values it stores — batch-norm apply, activation forward / backward, residual join, fused
+    activation-backward + bias gradient, the bf16-operand conv (unsplit epilogue and split-K reduce); t2i_cast_bf16 likewise."""
     from t2i_amd._lib import lib
     rng = np.random.default_rng(3)
     shape = (4, 8, 8, 128)
@@ -662,14 +662,21 @@ def test_bf16_twins_are_the_rounded_outputs(K):
             y = K.conv_fwd(x, w, bias, d, max(ws, 64 << 20))                              # no activation fused: no twin asked for
             assert not hasattr(y, '_t2i_h')
         K.tuning_set('force_splitk', 0)
-        # one-shot: a request that no producer consumed does not leak into a later call
-        img = torch.empty(shape, dtype=torch.bfloat16, device='cuda')
-        lib.t2i_output_image(ctypes_ptr(img))
-        K.set_math('f32')
-        y = K.act_fwd(a, K.ACT_LRELU, 0.2)                                              # consumes (and, here, honours) the request
-        assert lib.t2i_output_image_written() == 1 and not hasattr(y, '_t2i_h')
-        y = K.act_fwd(a, K.ACT_LRELU, 0.2)
-        assert lib.t2i_output_image_written() == 0
+        # ABI v5: the image pointer is an explicit argument — nothing is armed on the library side, so a call that passes none
+        # writes none whatever came before it, and one that cannot write it (unaligned tensor) fails loudly instead of skipping
+        img = torch.full(shape, 7.0, dtype=torch.bfloat16, device='cuda')
+        y = torch.empty_like(a)
+        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), None)
+        torch.cuda.synchronize()
+        assert rc == 0 and np.array_equal(img.float().cpu().numpy(), _rne_bf16(y.cpu().numpy()))
+        img.fill_(7.0)
+        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), None, None)
+        torch.cuda.synchronize()
+        assert rc == 0 and float(img.float().min()) == 7.0 and float(img.float().max()) == 7.0
+        import ctypes
+        odd = ctypes.c_void_p(a.data_ptr() + 4)
+        assert lib.t2i_act_fwd(odd, a.numel() - 4, K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), None) != 0
+        assert b'16-byte' in lib.t2i_last_error()
     finally:
         K.tuning_set('force_splitk', 0)
         K.set_math('f32')

@@ -372,9 +372,9 @@ def test_bf16_math_step_within_config3_tolerance(gpu, golden_step):
 
 def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
     """bf16 math at the benchmark's widths: (a) handing the convs caller-held bf16 images of their activation operands
-    (kernels.bf16_image + t2i_conv2d_operand_images: one cast per tensor instead of one per conv that reads it) and (b) the
+    (kernels.bf16_image + t2i_conv_opts.a_image / b_image: one cast per tensor instead of one per conv that reads it) and (b) the
     batched regeneration of the cached filter images behind the optimizer steps and at the head of every captured graph
-    (t2i_filter_cache_refresh) and (c) the bf16 twins the producing kernels write next to their fp32 outputs (t2i_output_image) change no bit of three training iterations — eager and replayed from a graph."""
+    (t2i_filter_cache_refresh) and (c) the bf16 twins the producing kernels write next to their fp32 outputs (y_h arguments / t2i_conv_opts.out_image) change no bit of three training iterations — eager and replayed from a graph."""
     from t2i_amd import kernels as K
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer

@@ -13,9 +13,19 @@ class ConvDesc(ctypes.Structure):
                 ('B', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'SH', 'SW', 'pad_t', 'pad_l', 'math')]
 
 
+class ConvOpts(ctypes.Structure):
+    """t2i_conv_opts: optional side inputs / outputs of one conv call (include/t2i_hip.h)"""
+    _fields_ = [('a_image', ctypes.c_void_p), ('b_image', ctypes.c_void_p), ('out_image', ctypes.c_void_p), ('xform', ctypes.c_void_p),
+                ('xform_bytes', ctypes.c_size_t), ('xform_mode', ctypes.c_int32), ('out_image_written', ctypes.c_int32),
+                ('xform_kept', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+XFORM_NONE, XFORM_KEEP, XFORM_HAVE = 0, 1, 2
+
 _p = ctypes.c_void_p
 _i32, _i64, _f, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _dp = ctypes.POINTER(ConvDesc)
+_op = ctypes.POINTER(ConvOpts)
 
 # name -> (restype, argtypes); must list every symbol include/t2i_hip.h declares (tests/test_abi.py checks that)
 SIGNATURES = {
@@ -23,23 +33,23 @@ SIGNATURES = {
     't2i_last_error': (ctypes.c_char_p, []),
     't2i_device_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _sz]),
     't2i_conv2d_workspace_bytes': (_sz, [_dp]),
-    't2i_conv2d_fwd': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, _p]),
-    't2i_conv2d_bwd_data': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, _p]),
-    't2i_conv2d_bwd_filter': (ctypes.c_int, [_dp, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_conv2d_fwd': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _op, _p, _sz, _p]),
+    't2i_conv2d_bwd_data': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _op, _p, _sz, _p]),
+    't2i_conv2d_bwd_filter': (ctypes.c_int, [_dp, _p, _p, _p, ctypes.c_int, _op, _p, _sz, _p]),
     't2i_col_reduce_workspace_bytes': (_sz, [_i64, _i32]),
     't2i_col_reduce': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_bn_stats': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
     't2i_bn_stats_tiles': (ctypes.c_int, [_p, _p, _i32, _i32, _i64, _i32, _p, _p, _p]),
     't2i_bn_train_fwd_stats': (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     't2i_bn_bwd_fused_workspace_bytes': (_sz, [_i64, _i32]),
-    't2i_bn_bwd_fused': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_bn_bwd_fused': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
     't2i_bn_finalize': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p]),
+    't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p]),
     't2i_bn_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
-    't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p]),
-    't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
-    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
-    't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p]),
+    't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p, _p]),
+    't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _p]),
+    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _p]),
     't2i_axpby': (ctypes.c_int, [_p, _f, _p, _f, _i64, _p, _p]),
     't2i_interp': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
     't2i_concat_tile_fwd': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
@@ -62,16 +72,11 @@ SIGNATURES = {
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),
     't2i_filter_cache_refresh': (ctypes.c_int, [_p, _sz, _p]),
     't2i_cast_bf16': (ctypes.c_int, [_p, _i64, _p, _p]),
-    't2i_conv2d_operand_images': (ctypes.c_int, [_p, _p]),
-    't2i_output_image': (ctypes.c_int, [_p]),
     't2i_conv2d_input_transform_bytes': (ctypes.c_size_t, [_dp]),
-    't2i_conv2d_input_transform': (ctypes.c_int, [_p, _sz, _i32]),
-    't2i_conv2d_input_transform_kept': (ctypes.c_int, []),
-    't2i_output_image_written': (ctypes.c_int, []),
     't2i_capture_id': (ctypes.c_uint64, [_p]),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),
     't2i_conv2d_fwd_stats': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _p, _sz, ctypes.POINTER(ctypes.c_int32),
-                                            ctypes.POINTER(ctypes.c_int32), _p, _sz, _p]),
+                                            ctypes.POINTER(ctypes.c_int32), _op, _p, _sz, _p]),
     't2i_col_reduce_partials': (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, ctypes.c_int, _p]),
     't2i_pool2_sum': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),
     't2i_upscale2': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _f, _p, _p]),

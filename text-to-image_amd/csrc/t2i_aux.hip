@@ -402,26 +402,40 @@ __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restric
   Agg4 a;
   a.n = 0.f; a.mean = make_float4(0.f, 0.f, 0.f, 0.f); a.m2 = a.mean;
   if (c < C) {
-    for (int k = ty; k < nchunks; k += 16) {
-      const int64_t rbeg = (int64_t)k * rows_per_chunk;
-      int64_t rend = rbeg + rows_per_chunk;
-      if (rend > rows) rend = rows;
-      Agg4 b;
-      b.n = (float)(rend - rbeg);
-      const float4 p0 = *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c);
-      const float4 p1 = *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c);
-      const float inv = 1.f / b.n;
-      if (TILES) {
-        b.mean = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
-        b.m2 = p1;
-      } else {
-        const float4 s = *reinterpret_cast<const float4*>(x + rbeg * C + c);
-        const float4 d = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
-        b.mean = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
-        b.m2 = make_float4(fmaxf(p1.x - p0.x * d.x, 0.f), fmaxf(p1.y - p0.y * d.y, 0.f), fmaxf(p1.z - p0.z * d.z, 0.f),
-                           fmaxf(p1.w - p0.w * d.w, 0.f));
+    // four chunks per round: all twelve loads are issued before the first merge (a merge is a dependent chain of divisions; with
+    // one chunk per round the kernel was a string of load -> merge latencies, 13 us for 16 rounds).  Merge order unchanged.
+    for (int k0 = ty; k0 < nchunks; k0 += 64) {
+      float4 p0[4], p1[4], s0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 16 * u;
+        const bool ok = k < nchunks;
+        const int64_t rbeg = (int64_t)k * rows_per_chunk;
+        p0[u] = ok ? *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p1[u] = ok ? *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TILES) s0[u] = ok ? *reinterpret_cast<const float4*>(x + rbeg * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      a = agg4_merge(a, b);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 16 * u;
+        if (k >= nchunks) break;
+        const int64_t rbeg = (int64_t)k * rows_per_chunk;
+        int64_t rend = rbeg + rows_per_chunk;
+        if (rend > rows) rend = rows;
+        Agg4 b;
+        b.n = (float)(rend - rbeg);
+        const float inv = 1.f / b.n;
+        if (TILES) {
+          b.mean = make_float4(p0[u].x * inv, p0[u].y * inv, p0[u].z * inv, p0[u].w * inv);
+          b.m2 = p1[u];
+        } else {
+          const float4 d = make_float4(p0[u].x * inv, p0[u].y * inv, p0[u].z * inv, p0[u].w * inv);
+          b.mean = make_float4(s0[u].x + d.x, s0[u].y + d.y, s0[u].z + d.z, s0[u].w + d.w);
+          b.m2 = make_float4(fmaxf(p1[u].x - p0[u].x * d.x, 0.f), fmaxf(p1[u].y - p0[u].y * d.y, 0.f), fmaxf(p1[u].z - p0[u].z * d.z, 0.f),
+                             fmaxf(p1[u].w - p0[u].w * d.w, 0.f));
+        }
+        a = agg4_merge(a, b);
+      }
     }
   }
   sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2;
@@ -1288,18 +1302,41 @@ hipError_t wgan_d_head_launch(const float* logits, const float* s1, const float*
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void ca_kl_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ ls,
-                                                        const float* __restrict__ eps, int n, float* __restrict__ code,
-                                                        float* __restrict__ kl) {
-  __shared__ float red[4];
+// One workgroup of 1024 threads (the KL term is one scalar over all B*128 elements): a thread's elements are fetched with all
+// loads in flight before the first expf (the 256-thread version walked 32 dependent load -> expf rounds: 27 us for 8192
+// elements), summed in index order per thread, then lanes by shuffle and the 16 waves in fixed order.
+__global__ __launch_bounds__(1024) void ca_kl_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ ls,
+                                                         const float* __restrict__ eps, int n, float* __restrict__ code,
+                                                         float* __restrict__ kl) {
+  __shared__ float red[16];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float m = mean[i], l = ls[i], e = expf(l);
-    code[i] = m + e * eps[i];
-    acc += -l + 0.5f * (-1.f + e * e + m * m);
+  for (int base = 0; base < n; base += 8 * 1024) {
+    float m[8], l[8], z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + j * 1024 + (int)threadIdx.x;
+      const bool ok = i < n;
+      m[j] = ok ? mean[i] : 0.f; l[j] = ok ? ls[i] : 0.f; z[j] = ok ? eps[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + j * 1024 + (int)threadIdx.x;
+      if (i < n) {
+        const float e = expf(l[j]);
+        code[i] = m[j] + e * z[j];
+        acc += -l[j] + 0.5f * (-1.f + e * e + m[j] * m[j]);
+      }
+    }
   }
-  acc = block_sum256(acc, red);
-  if (threadIdx.x == 0) kl[0] = acc / (float)n;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    kl[0] = t / (float)n;
+  }
 }
 
 __global__ __launch_bounds__(256) void ca_kl_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ ls,
@@ -1316,7 +1353,7 @@ __global__ __launch_bounds__(256) void ca_kl_bwd_kernel(const float* __restrict_
 }
 
 hipError_t ca_kl_fwd_launch(const float* mean, const float* ls, const float* eps, int n, float* code, float* kl, hipStream_t stream) {
-  hipLaunchKernelGGL(ca_kl_fwd_kernel, dim3(1), dim3(256), 0, stream, mean, ls, eps, n, code, kl);
+  hipLaunchKernelGGL(ca_kl_fwd_kernel, dim3(1), dim3(1024), 0, stream, mean, ls, eps, n, code, kl);
   return hipGetLastError();
 }
 

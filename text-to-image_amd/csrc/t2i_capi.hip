@@ -268,11 +268,14 @@ static inline int split_cap_for(int mode) { return mode == MODE_BWD_FILTER ? 256
 
 static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* out, const float* bias, int act,
                     float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what, int accumulate = 0,
-                    int* stats_chunks = nullptr) {
+                    int* stats_chunks = nullptr, int* stats_tile_rows = nullptr) {
   Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, split_cap_for(mode), p.d.math);
   if (stats_chunks) {          // epilogue statistics exist only on the unsplit path; the caller falls back otherwise
     if (pl.splitk > 1) { p.stats = nullptr; *stats_chunks = 0; }
-    else *stats_chunks = pl.tiles_m;
+    else {
+      *stats_chunks = pl.tiles_m;
+      if (stats_tile_rows) *stats_tile_rows = pl.wmt * 64;       // the M-tile height of THIS plan (2 x 2 waves of wmt 32-row blocks)
+    }
   }
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
@@ -304,40 +307,11 @@ static int run_gemm(int mode, IgemmParams& p, size_t out_elems, int var, float* 
 // ------------------------------------------------------------------------------------------------------------------
 static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// One-shot bf16 images of the next conv call's activation operands (t2i_conv2d_operand_images): taken — and cleared — by
-// every t2i_conv2d_* entry point at entry, whatever path it then dispatches to.
-struct OperandImages { const void* a; const void* b; };
-static thread_local OperandImages g_opimg = {nullptr, nullptr};
-// One-shot hand-over of a Winograd input transform (t2i_conv2d_input_transform): mode 1 = the next forward conv keeps V of its
-// x in the caller's buffer, mode 2 = the next filter gradient finds V of its x there.
-struct XformSlot { void* buf; size_t bytes; int mode; };
-static thread_local XformSlot g_xform = {nullptr, 0, 0};
-static thread_local int g_xform_kept = 0;
-static inline XformSlot take_xform() {
-  const XformSlot r = g_xform;
-  g_xform.buf = nullptr; g_xform.bytes = 0; g_xform.mode = 0;
-  return r;
-}
 // bytes of the input transform the forward conv of `d` and its filter gradient share (0: they do not both take a Winograd path)
 static size_t xform_bytes(const t2i_conv_desc& d) {
   if (winograd_eligible(d, false)) return (size_t)16 * ((size_t)d.B * (d.H / 2) * (d.W / 2)) * d.Cin * 4;
   if (winograd_k4s2_eligible(d, false) && tuning().winograd_k4s2_bwdf) return (size_t)9 * ((size_t)d.B * (d.Ho / 2) * (d.Wo / 2)) * 4 * d.Cin * 4;
   return 0;
-}
-
-// One-shot bf16 twin of the next producer's output (t2i_output_image), taken at entry by the entry points that can write one.
-static thread_local void* g_outimg = nullptr;
-static thread_local int g_outimg_written = 0;
-static inline void* take_output_image() {
-  void* r = g_outimg;
-  g_outimg = nullptr;
-  g_outimg_written = 0;
-  return r;
-}
-static inline OperandImages take_operand_images() {
-  const OperandImages r = g_opimg;
-  g_opimg.a = g_opimg.b = nullptr;
-  return r;
 }
 
 static bool h_eligible(const t2i_conv_desc& d, bool bwd_data) {
@@ -370,7 +344,7 @@ static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
 }
 
 static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, void* out_h,
-                  int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+                  int32_t* out_h_written, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
   IgemmParams p;
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
@@ -406,7 +380,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
     p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f; p.accumulate = 0;
   } else {
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = 0;
-    if (out_h && aligned16(out_h)) { p.c_h = out_h; g_outimg_written = 1; }
+    if (out_h && aligned16(out_h)) { p.c_h = out_h; if (out_h_written) *out_h_written = 1; }
   }
   rc = check(igemm_h_launch(mode, p, pl.wmt, pl.wnt, stream), what);
   if (rc != T2I_OK) return rc;
@@ -414,7 +388,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
     bool wrote = false;
     rc = check(splitk_reduce_launch(reinterpret_cast<const float*>(base + off_s), pl.splitk, out_elems, bias, p.N, act, alpha, out, 0, stream,
                                     (out_h && aligned16(out_h)) ? out_h : nullptr, &wrote), what);
-    if (wrote) g_outimg_written = 1;
+    if (wrote && out_h_written) *out_h_written = 1;
   }
   return rc;
 }
@@ -534,7 +508,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 4; }
+int t2i_version(void) { return 5; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -581,59 +555,62 @@ size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d) {
 }
 
 static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                           float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream);
+                           float alpha, float* stats, int* stats_chunks, int* stats_tile_rows, t2i_conv_opts* opts, void* ws, size_t ws_bytes,
+                           t2i_stream_t stream);
 
 int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                   float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
-  return conv2d_fwd_impl(d, x, w, bias, y, act, alpha, nullptr, nullptr, ws, ws_bytes, stream);
+                   float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  return conv2d_fwd_impl(d, x, w, bias, y, act, alpha, nullptr, nullptr, nullptr, opts, ws, ws_bytes, stream);
 }
 
 int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, void* ws,
-                         size_t ws_bytes, t2i_stream_t stream) {
+                         float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, t2i_conv_opts* opts,
+                         void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!stats || !chunks || !tile_rows || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
-  int c = 0;
-  const int rc = conv2d_fwd_impl(d, x, w, bias, y, act, alpha, stats, &c, ws, ws_bytes, stream);
+  int c = 0, tr = 0;          // number of M-tiles and their height, reported by the plan that launched (run_gemm)
+  const int rc = conv2d_fwd_impl(d, x, w, bias, y, act, alpha, stats, &c, &tr, opts, ws, ws_bytes, stream);
   *chunks = c;
-  // the M-tile height of the launch that produced the partials: tiles are 128 or 64 rows, and c = ceil(M / height)
-  const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
-  *tile_rows = (c > 0 && (M + 127) / 128 == c) ? 128 : 64;
+  *tile_rows = tr;
   return rc;
 }
 
 static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                           float alpha, float* stats, int* stats_chunks, void* ws, size_t ws_bytes, t2i_stream_t stream) {
-  const OperandImages img = take_operand_images();
-  void* y_h = take_output_image();
-  const XformSlot xf = take_xform();
-  g_xform_kept = 0;
+                           float alpha, float* stats, int* stats_chunks, int* stats_tile_rows, t2i_conv_opts* opts, void* ws, size_t ws_bytes,
+                           t2i_stream_t stream) {
+  const void* x_h = opts ? opts->a_image : nullptr;
+  void* y_h = opts ? opts->out_image : nullptr;
+  int32_t scratch_flag = 0;
+  int32_t* y_h_written = opts ? &opts->out_image_written : &scratch_flag;
+  if (opts) { opts->out_image_written = 0; opts->xform_kept = 0; }
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
-  float* vkeep = (xf.mode == 1 && xf.buf && aligned16(xf.buf) && xform_bytes(*d) && xf.bytes >= xform_bytes(*d)) ? reinterpret_cast<float*>(xf.buf) : nullptr;
+  float* vkeep = (opts && opts->xform_mode == T2I_XFORM_KEEP && opts->xform && aligned16(opts->xform) && xform_bytes(*d) &&
+                  opts->xform_bytes >= xform_bytes(*d)) ? reinterpret_cast<float*>(opts->xform) : nullptr;
   if (stats_chunks) *stats_chunks = 0;
+  if (stats_tile_rows) *stats_tile_rows = 0;
   if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
     if (tiny_conv_eligible(*d, false))
       return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
     if (stem_fwd_eligible(*d) && aligned16(w)) {
-      if (y_h) g_outimg_written = 1;
+      if (y_h) *y_h_written = 1;
       return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream, y_h), "t2i_conv2d_fwd(stem)");
     }
   }
   if (winograd_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
   {
-    g_xform_kept = vkeep ? 1 : 0;
+    if (opts) opts->xform_kept = vkeep ? 1 : 0;
     return winograd_conv(*d, false, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, vkeep);
   }
   if (winograd_k4s2_eligible(*d, false) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)))
   {
-    g_xform_kept = vkeep ? 1 : 0;
+    if (opts) opts->xform_kept = vkeep ? 1 : 0;
     return winograd_k4s2_fwd(*d, x, w, bias, y, act, alpha, ws, ws_bytes, (hipStream_t)stream, vkeep);
   }
   if (h_eligible(*d, false) && aligned16(x) && aligned16(w))
-    return conv_h(MODE_FWD, d, x, img.a, w, bias, y, y_h, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
+    return conv_h(MODE_FWD, d, x, x_h, w, bias, y, y_h, y_h_written, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = w;
@@ -645,13 +622,14 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
   const int var = !vec ? 0 : ((d->Cin % 32 == 0) ? 2 : 1);     // 2: a 32-wide K-tile never straddles a filter tap
   p.stats = stats;
   return run_gemm(MODE_FWD, p, (size_t)p.M * p.N, var, y, bias, act, alpha, ws, ws_bytes, (hipStream_t)stream,
-                  "t2i_conv2d_fwd", 0, stats_chunks);
+                  "t2i_conv2d_fwd", 0, stats_chunks, stats_tile_rows);
 }
 
 int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
-                        float alpha, void* ws, size_t ws_bytes, t2i_stream_t stream) {
-  const OperandImages img = take_operand_images();
-  void* dx_h = take_output_image();
+                        float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  const void* dy_h = opts ? opts->a_image : nullptr;
+  void* dx_h = opts ? opts->out_image : nullptr;
+  if (opts) { opts->out_image_written = 0; opts->xform_kept = 0; }
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!dy || !w || !dx) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
@@ -668,7 +646,8 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
   if (winograd_k4s2_eligible(*d, true) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)))
     return winograd_k4s2_bwd_data(*d, dy, w, bias, dx, act, alpha, ws, ws_bytes, (hipStream_t)stream);
   if (h_eligible(*d, true) && aligned16(dy) && aligned16(w))
-    return conv_h(MODE_BWD_DATA, d, dy, img.a, w, bias, dx, dx_h, act, alpha, ws, ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
+    return conv_h(MODE_BWD_DATA, d, dy, dy_h, w, bias, dx, dx_h, opts ? &opts->out_image_written : nullptr, act, alpha, ws, ws_bytes, (hipStream_t)stream,
+                  "t2i_conv2d_bwd_data(bf16 operands)");
   IgemmParams p;
   fill_common(p, d);
   p.a = dy; p.b = w;
@@ -683,14 +662,14 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
                   (hipStream_t)stream, "t2i_conv2d_bwd_data");
 }
 
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                          size_t ws_bytes, t2i_stream_t stream) {
-  const OperandImages img = take_operand_images();
-  const XformSlot xf = take_xform();
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                          t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  if (opts) { opts->out_image_written = 0; opts->xform_kept = 0; }
   int rc = validate_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
-  const float* vhave = (xf.mode == 2 && xf.buf && aligned16(xf.buf) && xform_bytes(*d) && xf.bytes >= xform_bytes(*d)) ? reinterpret_cast<const float*>(xf.buf) : nullptr;
+  const float* vhave = (opts && opts->xform_mode == T2I_XFORM_HAVE && opts->xform && aligned16(opts->xform) && xform_bytes(*d) &&
+                        opts->xform_bytes >= xform_bytes(*d)) ? reinterpret_cast<const float*>(opts->xform) : nullptr;
   if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
@@ -710,7 +689,7 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
   if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return conv_h_filter(d, x, dy, img.a, img.b, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+    return conv_h_filter(d, x, dy, opts ? opts->a_image : nullptr, opts ? opts->b_image : nullptr, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;
   fill_common(p, d);
   p.a = x; p.b = dy;
@@ -773,9 +752,8 @@ size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C) {
 }
 
 int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
-                     int32_t C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     int32_t C, int act, float alpha, float* gmask, float* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
                      size_t ws_bytes, t2i_stream_t stream) {
-  void* dx_h = take_output_image();
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || (y && !gmask)) {
     set_error("t2i_bn_bwd_fused: bad argument (C % 4 == 0 required; gmask needed with an activation)");
     return T2I_ERR_INVALID;
@@ -785,8 +763,7 @@ int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const floa
     return T2I_ERR_INVALID;
   }
   if (!ws || ws_bytes < t2i_bn_bwd_fused_workspace_bytes(rows, C) || !aligned16(ws)) { set_error("t2i_bn_bwd_fused: workspace too small"); return T2I_ERR_WORKSPACE; }
-  if (!aligned16(dx_h)) dx_h = nullptr;
-  if (dx_h) g_outimg_written = 1;
+  if (!aligned16(dx_h)) { set_error("t2i_bn_bwd_fused: dx_h must be 16-byte aligned"); return T2I_ERR_INVALID; }
   return check(bn_bwd_fused_launch(dy, y, x, mean, rstd, gamma, rows, C, act, alpha, gmask, dx, dgamma, dbeta, accumulate ? 1 : 0, ws,
                                    (hipStream_t)stream, dx_h), "t2i_bn_bwd_fused");
 }
@@ -822,12 +799,10 @@ int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, 
 }
 
 int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act, float alpha,
-                 float* y, t2i_stream_t stream) {
-  void* y_h = take_output_image();
+                 float* y, void* y_h, t2i_stream_t stream) {
   if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) { set_error("t2i_bn_apply: bad argument"); return T2I_ERR_INVALID; }
   const bool al = aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift);
-  if (!(al && (C & 3) == 0 && aligned16(y_h))) y_h = nullptr;
-  if (y_h) g_outimg_written = 1;
+  if (y_h && !(al && (C & 3) == 0 && aligned16(y_h))) { set_error("t2i_bn_apply: y_h needs 16-byte aligned tensors and C %% 4 == 0"); return T2I_ERR_INVALID; }
   return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, y, (hipStream_t)stream, y_h), "t2i_bn_apply");
 }
 
@@ -844,42 +819,38 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
                              reinterpret_cast<float*>(ws), accumulate ? 1 : 0, (hipStream_t)stream), "t2i_bn_bwd");
 }
 
-static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y,
+static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y, void* y_h,
                    t2i_stream_t stream, const char* what, bool need_b) {
-  void* y_h = take_output_image();
   if (!a || !y || n <= 0 || (need_b && !b)) { set_error("%s: bad argument", what); return T2I_ERR_INVALID; }
   const bool al = aligned16(a) && aligned16(y) && (!b || aligned16(b));
-  if (!(al && (n & 3) == 0 && aligned16(y_h))) y_h = nullptr;
-  if (y_h) g_outimg_written = 1;
+  if (y_h && !(al && (n & 3) == 0 && aligned16(y_h))) { set_error("%s: the bf16 image needs 16-byte aligned tensors and n %% 4 == 0", what); return T2I_ERR_INVALID; }
   // unaligned views take the scalar tail path: tell the kernel there is no float4 body
   return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, y, (hipStream_t)stream, y_h), what);
 }
 
-int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
-  return ew_call(0, x, nullptr, n, act, alpha, 0.f, y, stream, "t2i_act_fwd", false);
+int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream) {
+  return ew_call(0, x, nullptr, n, act, alpha, 0.f, y, y_h, stream, "t2i_act_fwd", false);
 }
-int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, t2i_stream_t stream) {
-  return ew_call(1, dy, y, n, act, alpha, 0.f, dx, stream, "t2i_act_bwd", true);
+int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, void* dx_h, t2i_stream_t stream) {
+  return ew_call(1, dy, y, n, act, alpha, 0.f, dx, dx_h, stream, "t2i_act_bwd", true);
 }
 int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
-                       float alpha, float* dx, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       float alpha, float* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
                        t2i_stream_t stream) {
-  void* dx_h = take_output_image();
   if (center && (!x2 || !aligned16(center))) { set_error("t2i_act_bwd_colsum: center needs x2 and 16-byte alignment"); return T2I_ERR_INVALID; }
   if ((x2 == nullptr) != (colsum_x2 == nullptr) || (x2 && !aligned16(x2))) { set_error("t2i_act_bwd_colsum: x2 / colsum_x2 must come together, 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
   if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
-  if (!aligned16(dx_h)) dx_h = nullptr;
-  if (dx_h) g_outimg_written = 1;
+  if (!aligned16(dx_h)) { set_error("t2i_act_bwd_colsum: dx_h must be 16-byte aligned"); return T2I_ERR_INVALID; }
   return check(act_bwd_colsum_launch(dy, y, x2, center, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
                                      (hipStream_t)stream, dx_h), "t2i_act_bwd_colsum");
 }
-int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, t2i_stream_t stream) {
-  return ew_call(2, a, b, n, act, alpha, 0.f, y, stream, "t2i_add_act", true);
+int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream) {
+  return ew_call(2, a, b, n, act, alpha, 0.f, y, y_h, stream, "t2i_add_act", true);
 }
 int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream) {
-  return ew_call(3, a, b, n, T2I_ACT_NONE, alpha, beta, y, stream, "t2i_axpby", false);
+  return ew_call(3, a, b, n, T2I_ACT_NONE, alpha, beta, y, nullptr, stream, "t2i_axpby", false);
 }
 
 int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int64_t per_sample, float* xhat,
@@ -1079,27 +1050,6 @@ size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d) {
   if (!d || validate_desc(d)) return 0;
   if (!((d->Cin % 4) == 0 && (d->Cout % 4) == 0)) return 0;
   return xform_bytes(*d);
-}
-
-int t2i_conv2d_input_transform_kept(void) { return g_xform_kept; }
-
-int t2i_conv2d_input_transform(void* buf, size_t bytes, int32_t mode) {
-  if (mode < 0 || mode > 2) { set_error("t2i_conv2d_input_transform: mode is 0 (clear), 1 (keep) or 2 (use)"); return T2I_ERR_INVALID; }
-  g_xform.buf = mode ? buf : nullptr; g_xform.bytes = mode ? bytes : 0; g_xform.mode = mode;
-  return T2I_OK;
-}
-
-int t2i_output_image(void* y_h) {
-  g_outimg = y_h;
-  g_outimg_written = 0;
-  return T2I_OK;
-}
-
-int t2i_output_image_written(void) { return g_outimg_written; }
-
-int t2i_conv2d_operand_images(const void* a_h, const void* b_h) {
-  g_opimg.a = a_h; g_opimg.b = b_h;
-  return T2I_OK;
 }
 
 }  // extern "C"

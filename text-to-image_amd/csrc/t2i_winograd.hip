@@ -7,7 +7,7 @@
 //   M[xi][t][n]   = V[xi] * U[xi]      16 independent [T x K] x [K x N] GEMMs in ONE launch of igemm_kernel (grid.z)
 //   y[b,2ty+i,2tx+j,n] = (A^T M A)[i][j] + bias, activation                     wino_output_kernel
 // Both conv_fwd and conv_bwd_data take this path: the input gradient of a 3x3 stride-1 SAME conv is the same
-// correlation with the filter flipped and its channel axes swapped, done by the filter transform's index map.
+// correlation with the filter flipped and its channel axes swapped; it reads the forward filter image (wino_slot).
 // fp32 throughout (the GEMM follows the descriptor's math mode); transforms use only +, - and *0.5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -109,10 +109,11 @@ static inline int wino_blocks(size_t n) {
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// U[xi][ci][co] = (G g G^T)[xi] with g[r][c] = w[r][c][ci][co] (fwd) or w[2-r][2-c][ci][co] (bwd: the flipped filter; the
-// channel swap of the input-gradient conv is left to the GEMM, which reads U as [n = ci][k = co] — its K-inner B image).
+// U[xi][ci][co] = (G g G^T)[xi] with g[r][c] = w[r][c][ci][co].  The input gradient needs the same transform of the flipped
+// filter, which is this image with plane rows / columns 0 and 3 exchanged (wino_slot below), and the channel swap of the
+// input-gradient conv is left to the GEMM, which reads U as [n = ci][k = co] — its K-inner B image: ONE image per filter.
 // Reads and writes are both contiguous along co.
-__device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, int Cin, int Cout, int bwd, float* __restrict__ U,
+__device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U,
                                                  unsigned vb, unsigned nvb) {
   const int K = Cin, N = Cout;
   const size_t total = (size_t)K * N;
@@ -123,10 +124,7 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, in
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int rr = bwd ? 2 - r : r, cc = bwd ? 2 - c : c;
-        g[r][c] = w[((size_t)(rr * 3 + cc) * Cin + ci) * Cout + co];
-      }
+      for (int c = 0; c < 3; ++c) g[r][c] = w[((size_t)(r * 3 + c) * Cin + ci) * Cout + co];
     float s[4][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -146,14 +144,22 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, in
   }
 }
 
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cin, int Cout, int bwd,
-                                                          float* __restrict__ U) {
-  wino_filter_body(w, Cin, Cout, bwd, U, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
+  wino_filter_body(w, Cin, Cout, U, blockIdx.x, gridDim.x);
+}
+
+// Plane slot of tile position (r, c).  The input gradient of a 3x3 stride-1 conv is the same correlation with the filter flipped,
+// and G flip(g) G^T is U with rows / columns 0 and 3 exchanged (rows 1 and 2 of G are symmetric in g): instead of keeping a
+// second filter image, the input-gradient call stores V[xi] (and finds M[xi]) in the slot of the forward position whose U it
+// needs — the batched GEMM then runs over the FORWARD image with uniform strides.
+__device__ __forceinline__ int wino_slot(int r, int c, int flip) {
+  const int rr = (flip && (r == 0 || r == 3)) ? 3 - r : r, cc = (flip && (c == 0 || c == 3)) ? 3 - c : c;
+  return rr * 4 + cc;
 }
 
 // V[xi][t][c]: one thread = one tile x 4 channels
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw,
-                                                         size_t T, float* __restrict__ V) {
+                                                         size_t T, float* __restrict__ V, int flip) {
   const int C4 = C >> 2;
   const size_t total = T * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -186,10 +192,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const size_t plane = T * C4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[(size_t)(r * 4 + 0) * plane] = f4sub(tt[r][0], tt[r][2]);
-      o[(size_t)(r * 4 + 1) * plane] = f4add(tt[r][1], tt[r][2]);
-      o[(size_t)(r * 4 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
-      o[(size_t)(r * 4 + 3) * plane] = f4sub(tt[r][1], tt[r][3]);
+      o[(size_t)wino_slot(r, 0, flip) * plane] = f4sub(tt[r][0], tt[r][2]);
+      o[(size_t)wino_slot(r, 1, flip) * plane] = f4add(tt[r][1], tt[r][2]);
+      o[(size_t)wino_slot(r, 2, flip) * plane] = f4sub(tt[r][2], tt[r][1]);
+      o[(size_t)wino_slot(r, 3, flip) * plane] = f4sub(tt[r][1], tt[r][3]);
     }
   }
 }
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // y[b, 2ty+i, 2tx+j, n] = act((A^T M A)[i][j] + bias[n]): one thread = one tile x 4 output channels
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, int H,
                                                           int W, int N, int Th, int Tw, size_t T, int act, float alpha,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, int flip) {
   const int N4 = N >> 2;
   const size_t total = T * N4;
   const size_t plane = T * N4;
@@ -211,8 +217,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     float4 z[2][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float4 m0 = m[(size_t)(0 * 4 + c) * plane], m1 = m[(size_t)(1 * 4 + c) * plane], m2 = m[(size_t)(2 * 4 + c) * plane],
-                   m3 = m[(size_t)(3 * 4 + c) * plane];
+      const float4 m0 = m[(size_t)wino_slot(0, c, flip) * plane], m1 = m[(size_t)wino_slot(1, c, flip) * plane],
+                   m2 = m[(size_t)wino_slot(2, c, flip) * plane], m3 = m[(size_t)wino_slot(3, c, flip) * plane];
       z[0][c] = f4add(f4add(m0, m1), m2);
       z[1][c] = f4sub(f4sub(m1, m2), m3);
     }
@@ -272,15 +278,17 @@ int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float
   float* Mx = reinterpret_cast<float*>(base + al256((size_t)16 * K * N * 4) + al256(16 * T * K * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
   bool fill = true;
-  if (float* Uc = filter_cache_get(w, bwd ? 1 : 0, d.Cin, d.Cout, (size_t)16 * K * N * 4, stream, &fill)) U = Uc;
+  // ONE image per filter (kind 0) serves both directions: the input gradient permutes its V / M plane slots instead (wino_slot)
+  if (float* Uc = filter_cache_get(w, 0, d.Cin, d.Cout, (size_t)16 * K * N * 4, stream, &fill)) U = Uc;
   if (fill)
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, bwd ? 1 : 0, U);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V);
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V, bwd ? 1 : 0);
   t2i_conv_desc gd = d;                // the 16 GEMMs as a batch of 1x1 convolutions over T "pixels" (fwd) / their input gradient (bwd)
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;   // Cin, Cout as in d
   const int rc = run_batched_gemm(gd, bwd ? MODE_BWD_DATA : MODE_FWD, 16, V, U, Mx, (int64_t)T * K, (int64_t)d.Cin * d.Cout, (int64_t)T * N, stream, "winograd gemm");
   if (rc != T2I_OK) return rc;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks(T * (N / 4))), dim3(256), 0, stream, Mx, bias, d.H, d.W, N, Th, Tw, T, act, alpha, out);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks(T * (N / 4))), dim3(256), 0, stream, Mx, bias, d.H, d.W, N, Th, Tw, T, act, alpha, out,
+                     bwd ? 1 : 0);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("winograd conv: %s", hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
   return T2I_OK;
@@ -370,7 +378,7 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
   float* P = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
   if (Vhave) V = const_cast<float*>(Vhave);          // the forward conv's input transform of this x, kept by the caller
-  else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, 0);
   hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.H, d.W, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
@@ -551,36 +559,12 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
 //     dx[2q+ph][2r+pw][ci] = sum_{a,b,co} dy[q + oh_off - 1 + a][r + ow_off - 1 + b][co] * w[kh0 + 2(1-a)][kw0 + 2(1-b)][ci][co]
 // (kh0 = 1 - ph, oh_off = ph for pad 1).  36 batched GEMMs (4 phases x 9 tile positions) [T x Cout] x [Cin x Cout]^T.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino2b_filter_body(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U, unsigned vb, unsigned nvb) {
-  const int N4 = Cout >> 2;
-  const size_t total = (size_t)4 * Cin * N4;             // (phase, ci, co4)
-  const size_t plane = (size_t)Cin * N4;                 // one [ci][co] matrix, in float4
-  for (size_t i = (size_t)vb * 256 + threadIdx.x; i < total; i += (size_t)nvb * 256) {
-    const int n4 = (int)(i % N4);
-    const int ci = (int)((i / N4) % Cin);
-    const int phs = (int)(i / ((size_t)N4 * Cin));
-    const int ph = phs >> 1, pw = phs & 1;
-    const int kh0 = 1 - ph, kw0 = 1 - pw;
-    float4 g[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        g[a][b] = reinterpret_cast<const float4*>(w + ((size_t)((kh0 + 2 * (1 - a)) * 4 + (kw0 + 2 * (1 - b))) * Cin + ci) * Cout)[n4];
-    float4 s[3][2] = {{g[0][0], g[0][1]}, {f4add(g[0][0], g[1][0]), f4add(g[0][1], g[1][1])}, {g[1][0], g[1][1]}};
-    float4* o = reinterpret_cast<float4*>(U) + (size_t)phs * 9 * plane + (size_t)ci * N4 + n4;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
-      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
-      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void wino2b_filter_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
-  wino2b_filter_body(w, Cin, Cout, U, blockIdx.x, gridDim.x);
-}
+// Plane slot of (tile position (r, c), output phase phs) in V and M of the input-gradient form.  Output phase (ph, pw) correlates dy
+// with the FLIPPED sub-filter of the forward conv's input phase (1 - ph, 1 - pw), and G flip(g) G^T is the forward image with rows /
+// columns 0 and 2 exchanged — so the 36 matrices are exactly the forward image U[xi][(p, q)][ci][co] (kind 2) read as
+// [ci][co] blocks at block index xi' * 4 + (3 - phs), xi' = (2 - r, 2 - c): V and M use that block index as their plane slot and the
+// batched GEMM walks the forward image with a uniform stride of Cin * Cout.  No second filter image.
+__device__ __forceinline__ int wino2b_slot(int r, int c, int phs) { return ((2 - r) * 3 + (2 - c)) * 4 + (3 - phs); }
 
 __global__ __launch_bounds__(256) void wino2b_input_kernel(const float* __restrict__ dy, int Ho, int Wo, int C, int Th, int Tw, size_t T,
                                                            float* __restrict__ V) {
@@ -614,12 +598,12 @@ __global__ __launch_bounds__(256) void wino2b_input_kernel(const float* __restri
       tt[1][c] = d[1][c];
       tt[2][c] = f4sub(d[2][c], d[1][c]);
     }
-    float4* o = reinterpret_cast<float4*>(V) + (size_t)phs * 9 * plane + t * C4 + c4;
+    float4* o = reinterpret_cast<float4*>(V) + t * C4 + c4;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[(size_t)(r * 3 + 0) * plane] = f4sub(tt[r][0], tt[r][1]);
-      o[(size_t)(r * 3 + 1) * plane] = tt[r][1];
-      o[(size_t)(r * 3 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
+      o[(size_t)wino2b_slot(r, 0, phs) * plane] = f4sub(tt[r][0], tt[r][1]);
+      o[(size_t)wino2b_slot(r, 1, phs) * plane] = tt[r][1];
+      o[(size_t)wino2b_slot(r, 2, phs) * plane] = f4sub(tt[r][2], tt[r][1]);
     }
   }
 }
@@ -637,11 +621,12 @@ __global__ __launch_bounds__(256) void wino2b_output_kernel(const float* __restr
     const int tx = (int)(t % Tw);
     const int ty = (int)((t / Tw) % Th);
     const size_t b = t / ((size_t)Tw * Th);
-    const float4* m = reinterpret_cast<const float4*>(Mx) + (size_t)phs * 9 * plane + t * N4 + n4;
+    const float4* m = reinterpret_cast<const float4*>(Mx) + t * N4 + n4;
     float4 z[2][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float4 m0 = m[(size_t)(0 * 3 + c) * plane], m1 = m[(size_t)(1 * 3 + c) * plane], m2 = m[(size_t)(2 * 3 + c) * plane];
+      const float4 m0 = m[(size_t)wino2b_slot(0, c, phs) * plane], m1 = m[(size_t)wino2b_slot(1, c, phs) * plane],
+                   m2 = m[(size_t)wino2b_slot(2, c, phs) * plane];
       z[0][c] = f4add(m0, m1);
       z[1][c] = f4add(m1, m2);
     }
@@ -680,9 +665,9 @@ int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float*
   float* Mx = reinterpret_cast<float*>(base + al256((size_t)36 * d.Cin * d.Cout * 4) + al256(36 * T * d.Cout * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
   bool fill = true;
-  if (float* Uc = filter_cache_get(w, 3, d.Cin, d.Cout, (size_t)36 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;
+  if (float* Uc = filter_cache_get(w, 2, d.Cin, d.Cout, (size_t)36 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;      // the forward image
   if (fill)
-    hipLaunchKernelGGL(wino2b_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+    hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
   hipLaunchKernelGGL(wino2b_input_kernel, dim3(wino_blocks(T * d.Cout)), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
@@ -807,9 +792,10 @@ int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const floa
 // 0.4-0.5 ms of a 15 ms (fp32) / 8 ms (bf16) iteration.  t2i_filter_cache_refresh regenerates all of them in ONE launch
 // (per 96 entries): the table of (filter, image, dims, kind, first block) rides in the kernel arguments, a workgroup finds
 // its entry by bisection on the scalar unit and runs that kind's transform body on its share of the entry.
-//   kinds 0/1  U = G g G^T of a 3x3 filter (forward / flipped for the input gradient)        wino_filter_body
-//   kind  2    F(2x2,2x2) images of the four 2x2 phase filters of a 4x4 stride-2 conv         wino2_filter_body
-//   kind  3    the same for its input gradient (36 matrices)                                  wino2b_filter_body
+//   kind  0    U = G g G^T of a 3x3 filter (the input gradient reads the same image, wino_slot)  wino_filter_body
+//   kind  2    F(2x2,2x2) images of the four 2x2 phase filters of a 4x4 stride-2 conv; its      wino2_filter_body
+//              input gradient reads the same 36 [ci][co] blocks in another order (wino2b_slot)
+//              (kinds 1 and 3, the separate input-gradient images of rounds 1-2, are gone: half the bytes per refresh)
 //   kinds 4/5  bf16 K-inner images [tap][Cout][Cin] (per-tap transpose) / [tap][Cin][Cout]    wcast_body
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16_t;
@@ -925,9 +911,8 @@ __global__ __launch_bounds__(256) void filter_refresh_kernel(RefreshBatch tb) {
   const RefreshItem it = load_refresh_item(lo);
   const unsigned vb = blockIdx.x - it.block0;
   switch (it.kind) {
-    case 0: case 1: wino_filter_body(it.w, it.Cin, it.Cout, it.kind, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
+    case 0: wino_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
     case 2: wino2_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
-    case 3: wino2b_filter_body(it.w, it.Cin, it.Cout, reinterpret_cast<float*>(it.U), vb, it.nblocks); break;
     default:      // 4: transposed image in U; 5: plain image in U; 6: both (U transposed, U2 plain) from one read of the filter
       wcast_body(it.w, it.Cin, it.Cout, reinterpret_cast<bf16_t*>(it.kind == 5 ? it.U : it.U2), reinterpret_cast<bf16_t*>(it.kind == 5 ? nullptr : it.U), tile, vb);
       break;
@@ -957,15 +942,15 @@ int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
     const char* q = reinterpret_cast<const char*>(e.w);
     // the filter this entry was made of must lie INSIDE the caller's range: an entry left behind by a filter that no longer
     // exists (another model's arena, freed since) is never read again
-    const size_t wbytes = (size_t)(e.kind <= 1 ? 9 : e.kind <= 3 ? 16 : (int)(e.bytes / ((size_t)e.Cin * e.Cout * 2))) * e.Cin * e.Cout * 4;
+    const size_t wbytes = (size_t)(e.kind == 0 ? 9 : e.kind == 2 ? 16 : (int)(e.bytes / ((size_t)e.Cin * e.Cout * 2))) * e.Cin * e.Cout * 4;
     if (p && !(q >= lo && q + wbytes <= lo + bytes)) continue;
     if (!cap && e.stream != stream) continue;
     if (e.valid && e.cap == cap) continue;          // already fresh in this context
     RefreshItem it;
     it.w = e.w; it.U = e.U; it.U2 = nullptr; it.Cin = e.Cin; it.Cout = e.Cout; it.kind = e.kind; it.taps = 0;
     size_t nb;
-    if (e.kind <= 1) nb = ((size_t)e.Cin * e.Cout + 255) / 256;
-    else if (e.kind <= 3) nb = ((size_t)4 * e.Cin * (e.Cout / 4) + 255) / 256;
+    if (e.kind == 0) nb = ((size_t)e.Cin * e.Cout + 255) / 256;
+    else if (e.kind == 2) nb = ((size_t)4 * e.Cin * (e.Cout / 4) + 255) / 256;
     else {
       it.taps = (int32_t)(e.bytes / ((size_t)e.Cin * e.Cout * 2));
       nb = (size_t)((e.Cout + WC_T - 1) / WC_T) * ((e.Cin + WC_T - 1) / WC_T) * it.taps;

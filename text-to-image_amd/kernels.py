@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import ConvDesc, check, lib
+from ._lib import XFORM_HAVE, XFORM_KEEP, ConvDesc, ConvOpts, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -197,7 +197,7 @@ def _ws_args(t, nbytes):
 # bf16 math: the GEMMs read bf16 images of their activation operands.  An activation is used by up to three convs (forward,
 # filter gradient, the second-order pieces of the gradient penalty), a gradient by two (input and filter gradient): the image
 # is made once per tensor (and version) here, kept on the tensor object and handed to every conv that reads the tensor
-# (t2i_conv2d_operand_images), instead of each entry point staging its own copy into the workspace.
+# (t2i_conv_opts.a_image / b_image), instead of each entry point staging its own copy into the workspace.
 _BF16_IMAGES = [os.environ.get('T2I_BF16_IMAGES', '1') != '0']
 _H_ALGO = {}
 
@@ -233,7 +233,10 @@ def _image_holder(t):
 
 
 def bf16_image(t):
-    """The bf16 image of fp32 tensor `t` (None if it cannot have one): cached on the tensor object with the version it was made of."""
+    """The bf16 image of fp32 tensor `t` (None if it cannot have one): cached on the tensor object with the version it was made of.
+    INVARIANT: the kernels of this package write through raw pointers and do not bump tensor._version, so every wrapper that
+    overwrites an EXISTING tensor (the `out=` arguments of axpby, col_reduce, conv_bwd_filter) drops the cached image of that
+    tensor itself (_drop_image); all other wrappers write freshly allocated outputs."""
     if t.numel() % 8 != 0 or t.data_ptr() % 16 != 0:
         return None
     h = _image_holder(t)
@@ -246,16 +249,19 @@ def bf16_image(t):
     return img
 
 
-def _bind_images(a, b=None):
+def _operand_images(opts, a, b=None):
+    """Put the bf16 images of the call's activation operands into its t2i_conv_opts; the returned tensors must stay alive until
+    the conv call has been issued."""
     ia = bf16_image(a) if a is not None else None
     ib = bf16_image(b) if b is not None else None
-    check(lib.t2i_conv2d_operand_images(_ptr(ia), _ptr(ib)), 't2i_conv2d_operand_images')
-    return ia, ib          # alive until the conv call behind this has been issued
+    opts.a_image = ia.data_ptr() if ia is not None else None
+    opts.b_image = ib.data_ptr() if ib is not None else None
+    return ia, ib
 
 
 # ... and where the tensor a conv will read comes out of one of our own kernels (activation / batch-norm apply / residual join /
 # a conv epilogue with its activation fused / activation backward), that kernel writes the bf16 image as a TWIN of its fp32
-# output in the same pass (t2i_output_image): no cast launch at all for it.
+# output in the same pass (the y_h arguments / t2i_conv_opts.out_image): no cast launch at all for it.
 _TWINS = [os.environ.get('T2I_BF16_TWINS', '1') != '0']
 
 
@@ -264,17 +270,19 @@ def bf16_twins(on):
     return prev
 
 
-def _twin_begin(out):
-    """Ask the next producer call for the bf16 twin of `out` (bf16 math, a multiple of 64 channels: a conv reads it next)."""
+def _twin_for(out, *inputs):
+    """A buffer for the bf16 twin of `out` (bf16 math, a multiple of 64 channels: a conv reads it next), or None.  The producers
+    write it on their vectorised path only, so every tensor of the call must be 16-byte aligned (the entry points refuse otherwise)."""
     if _MATH[0] != MATH_BF16 or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
         return None
-    img = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
-    check(lib.t2i_output_image(_ptr(img)), 't2i_output_image')
-    return img
+    if any(t is not None and t.data_ptr() % 16 for t in (out,) + inputs):
+        return None
+    return torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
 
 
-def _twin_end(out, img):
-    if img is not None and lib.t2i_output_image_written():
+def _twin_keep(out, img, written=True):
+    """Remember `img` as the bf16 image of `out` (the call that was handed it has been issued and wrote it)."""
+    if img is not None and written:
         out._t2i_h = (out._version, img, out.data_ptr(), int(lib.t2i_capture_id(_stream())))
 
 
@@ -300,18 +308,19 @@ def conv_xform_bytes(d):
     return n
 
 
-def _xform_offer(x, d, keep):
+def _xform_offer(opts, x, d, keep):
+    """Offer the forward conv a buffer to leave its Winograd input transform in (t2i_conv_opts.xform, T2I_XFORM_KEEP)."""
     LAST_XFORM[0] = None
     nb = conv_xform_bytes(d) if keep else 0
     if not nb:
         return None
     V = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
-    check(lib.t2i_conv2d_input_transform(_ptr(V), nb, 1), 't2i_conv2d_input_transform')
+    opts.xform, opts.xform_bytes, opts.xform_mode = V.data_ptr(), nb, XFORM_KEEP
     return V
 
 
-def _xform_taken(V):
-    if V is not None and lib.t2i_conv2d_input_transform_kept():
+def _xform_taken(opts, V):
+    if V is not None and opts.xform_kept:
         LAST_XFORM[0] = V
 
 
@@ -321,13 +330,15 @@ def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
-        keep = _bind_images(x) if _h_path(d, 'fwd') else None
-        twin = _twin_begin(y) if (act != ACT_NONE and d.math == MATH_BF16) else None     # conv + bias + lrelu feeds the next conv directly
-        V = _xform_offer(x, d, keep_xform)
+        opts = ConvOpts()          # every allocation happens BEFORE the call; nothing is armed on the library side
+        keep = _operand_images(opts, x) if _h_path(d, 'fwd') else None
+        twin = _twin_for(y) if (act != ACT_NONE and d.math == MATH_BF16) else None     # conv + bias + lrelu feeds the next conv directly
+        opts.out_image = twin.data_ptr() if twin is not None else None
+        V = _xform_offer(opts, x, d, keep_xform)
         check(lib.t2i_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
-                                 _ptr(y), act, alpha, wsp, wsn, _stream()), 't2i_conv2d_fwd')
-        _twin_end(y, twin)
-        _xform_taken(V)
+                                 _ptr(y), act, alpha, ctypes.byref(opts), wsp, wsn, _stream()), 't2i_conv2d_fwd')
+        _twin_keep(y, twin, opts.out_image_written)
+        _xform_taken(opts, V)
         if ev is not None:
             ev.record()
     return y
@@ -392,11 +403,11 @@ def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, d
     dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, int(lib.t2i_bn_bwd_fused_workspace_bytes(rows, C)))
-        twin = _twin_begin(dx)                  # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
+        twin = _twin_for(dx)                    # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
         check(lib.t2i_bn_bwd_fused(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
-                                   rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
+                                   rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(twin), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
                                    _stream()), 't2i_bn_bwd_fused')
-        _twin_end(dx, twin)
+        _twin_keep(dx, twin)
     return dx, dgamma, dbeta
 
 
@@ -423,12 +434,13 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=
         part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
         chunks, tile_rows = ctypes.c_int32(0), ctypes.c_int32(0)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
-        keep = _bind_images(x) if _h_path(d, 'fwd') else None
-        V = _xform_offer(x, d, keep_xform)
+        opts = ConvOpts()
+        keep = _operand_images(opts, x) if _h_path(d, 'fwd') else None
+        V = _xform_offer(opts, x, d, keep_xform)
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
-                                       _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), ctypes.byref(tile_rows), wsp, wsn,
-                                       _stream()), 't2i_conv2d_fwd_stats')
-        _xform_taken(V)
+                                       _ptr(y), act, alpha, _ptr(part), nbytes, ctypes.byref(chunks), ctypes.byref(tile_rows),
+                                       ctypes.byref(opts), wsp, wsn, _stream()), 't2i_conv2d_fwd_stats')
+        _xform_taken(opts, V)
         if ev is not None:
             ev.record()
         if chunks.value > 0:
@@ -444,12 +456,14 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
     if _live(dy):
         wsp, wsn = _ws_args(dy, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_data')) if _TIMER[0] is not None else None
-        keep = _bind_images(dy) if _h_path(d, 'bwd_data') else None
-        twin = _twin_begin(dx) if (act != ACT_NONE and d.math == MATH_BF16) else None
+        opts = ConvOpts()
+        keep = _operand_images(opts, dy) if _h_path(d, 'bwd_data') else None
+        twin = _twin_for(dx) if (act != ACT_NONE and d.math == MATH_BF16) else None
+        opts.out_image = twin.data_ptr() if twin is not None else None
         check(lib.t2i_conv2d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w),
-                                      _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, wsp,
-                                      wsn, _stream()), 't2i_conv2d_bwd_data')
-        _twin_end(dx, twin)
+                                      _ptr(_chk(bias, 'bias') if bias is not None else None), _ptr(dx), act, alpha, ctypes.byref(opts),
+                                      wsp, wsn, _stream()), 't2i_conv2d_bwd_data')
+        _twin_keep(dx, twin, opts.out_image_written)
         if ev is not None:
             ev.record()
     return dx
@@ -462,16 +476,17 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
     if out is not None:
         _chk(out, 'out')
         assert out.numel() == d.KH * d.KW * d.Cin * d.Cout
+        _drop_image(out)
     dw = out if out is not None else torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_filter')) if _TIMER[0] is not None else None
-        keep = _bind_images(x, dy) if _h_path(d, 'bwd_filter') else None
+        opts = ConvOpts()
+        keep = _operand_images(opts, x, dy) if _h_path(d, 'bwd_filter') else None
         if xform is not None and conv_xform_bytes(d):
-            check(lib.t2i_conv2d_input_transform(_ptr(xform), xform.numel() * 4, 2), 't2i_conv2d_input_transform')
-        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, wsp, wsn,
-                                        _stream()),
-              't2i_conv2d_bwd_filter')
+            opts.xform, opts.xform_bytes, opts.xform_mode = xform.data_ptr(), xform.numel() * 4, XFORM_HAVE
+        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, ctypes.byref(opts),
+                                        wsp, wsn, _stream()), 't2i_conv2d_bwd_filter')
         if ev is not None:
             ev.record()
     return dw
@@ -485,6 +500,7 @@ def col_reduce(a, b=None, want_second=False, out=None, center=None):
     rows = a.numel() // C
     if out is not None:
         assert out.numel() == C and not want_second
+        _drop_image(out)
     out0 = out if out is not None else torch.empty(C, dtype=torch.float32, device=a.device)
     out1 = torch.empty(C, dtype=torch.float32, device=a.device) if want_second else None
     if b is not None:
@@ -514,10 +530,10 @@ def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
     C = x.shape[-1]
     y = torch.empty_like(x)
     if _live(x):
-        twin = _twin_begin(y)
-        check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _stream()),
+        twin = _twin_for(y, x, scale, shift)
+        check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _ptr(twin), _stream()),
               't2i_bn_apply')
-        _twin_end(y, twin)
+        _twin_keep(y, twin)
     return y
 
 
@@ -543,9 +559,9 @@ def act_fwd(x, act, alpha=0.2):
     _chk(x, 'x')
     y = torch.empty_like(x)
     if _live(x):
-        twin = _twin_begin(y)
-        check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _stream()), 't2i_act_fwd')
-        _twin_end(y, twin)
+        twin = _twin_for(y, x)
+        check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _ptr(twin), _stream()), 't2i_act_fwd')
+        _twin_keep(y, twin)
     return y
 
 
@@ -553,9 +569,9 @@ def act_bwd(dy, y, act, alpha=0.2):
     _chk(dy, 'dy'); _chk(y, 'y')
     dx = torch.empty_like(dy)
     if _live(dy):
-        twin = _twin_begin(dx)
-        check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _stream()), 't2i_act_bwd')
-        _twin_end(dx, twin)
+        twin = _twin_for(dx, dy, y)
+        check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _ptr(twin), _stream()), 't2i_act_bwd')
+        _twin_keep(dx, twin)
     return dx
 
 
@@ -575,11 +591,11 @@ def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
     if _live(dy):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(dy, need)
-        twin = _twin_begin(dx) if x2 is None else None      # conv bias path: dx is the next input / filter gradient's operand
+        twin = _twin_for(dx) if x2 is None else None        # conv bias path: dx is the next input / filter gradient's operand
         check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), _ptr(_chk(center, 'center') if center is not None else None), rows, C,
-                                     act, alpha, _ptr(dx), _ptr(s), _ptr(s2),
+                                     act, alpha, _ptr(dx), _ptr(twin), _ptr(s), _ptr(s2),
                                      1 if out is not None else 0, wsp, wsn, _stream()), 't2i_act_bwd_colsum')
-        _twin_end(dx, twin)
+        _twin_keep(dx, twin)
     return (dx, s) if x2 is None else (dx, s, s2)
 
 
@@ -588,15 +604,25 @@ def add_act(a, b, act=ACT_NONE, alpha=0.2):
     assert a.shape == b.shape
     y = torch.empty_like(a)
     if _live(a):
-        twin = _twin_begin(y)
-        check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _stream()), 't2i_add_act')
-        _twin_end(y, twin)
+        twin = _twin_for(y, a, b)
+        check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _ptr(twin), _stream()), 't2i_add_act')
+        _twin_keep(y, twin)
     return y
 
 
+def _drop_image(t):
+    """A wrapper wrote `t` through its raw pointer: tensor._version does not move, so a bf16 image cached on it would be stale."""
+    if t is not None:
+        h = _image_holder(t)
+        if getattr(h, '_t2i_h', None) is not None:
+            h._t2i_h = None
+
+
 def axpby(a, alpha, b=None, beta=0.0, out=None):
+    """out: an existing tensor to overwrite (its cached bf16 image, if any, is dropped — see bf16_image)."""
     _chk(a, 'a')
     y = torch.empty_like(a) if out is None else out
+    _drop_image(out)
     if _live(a):
         check(lib.t2i_axpby(_ptr(a), alpha, _ptr(_chk(b, 'b') if b is not None else None), beta, a.numel(), _ptr(y),
                             _stream()), 't2i_axpby')
