@@ -29,7 +29,7 @@ def _signature(cmd, env_extra):
 
 def _two_ranks(port, args, env_extra):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), 'bench.py', '--gpus', '2', '--instrument', 'off', '--no-cpu-baseline', '--repeats', '1'] + args
+           '--master-port', str(port), 'bench.py', '--gpus', '2', '--instrument', 'off', '--no-cpu-baseline', '--repeats', '1', '--min-busy-s', '0', '--no-config3'] + args
     env = dict(T2I_SAME_DEVICE='1', T2I_DIST_BACKEND='gloo', T2I_CHECK_SYNC='1')
     env.update(env_extra)
     return _signature(cmd, env)
@@ -40,12 +40,16 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     single = _signature([sys.executable, 'bench.py', '--no-graphs', '--instrument', 'off', '--no-cpu-baseline', '--repeats', '1',
-                         '--warmup', '3', '--steps', '1'], {})
+                         '--min-busy-s', '0', '--no-config3', '--warmup', '3', '--steps', '1'], {})
     assert single[0] == 4
     # eager schedule: buckets leave while the backward is still running (first step learns the contribution counts)
     eager = _two_ranks(29811, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0'})
-    # graph segments: 2 eager set-up iterations, capture, then replays with the critic exchange behind the generator forward
+    # graph segments (the default): 2 eager set-up iterations, capture, then replays — both backward passes cut once, the first
+    # part's gradients on the wire while the rest (and the generator forward) runs
     graphs = _two_ranks(29812, ['--warmup', '1', '--steps', '1'], {})
+    # the same segment sequence launched eagerly (WGanCls._dg_cut_eager)
+    cut_eager = _two_ranks(29813, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_DP_CUT_EAGER': '1'})
     assert eager == single, (eager, single)
     assert graphs == single, (graphs, single)
+    assert cut_eager == single, (cut_eager, single)
     # (both two-rank runs also went through bench.py's own data-parallel preflight, which aborts the run on a mismatch)

@@ -100,9 +100,9 @@ def _worker(rank, world, port, mode, q):
         dist.all_gather_object(gathered, {n: v.clone() for n, v in local.items()})
         for n in params:
             want = sum(g[n] for g in gathered)
-            if mode == 'bf16':     # each rank's contribution was rounded to bf16 (2^-9 relative) before the sum, which is again bf16
-                want = sum(g[n].bfloat16() for g in gathered).float()
-                assert torch.allclose(arena.grad_of(n), want, rtol=2e-2, atol=1e-2), n
+            if mode == 'bf16':     # each rank's contribution is rounded to bf16 ONCE, the sum is taken in fp32 and rounded to bf16 once:
+                want = sum(g[n].bfloat16().float() for g in gathered).bfloat16().float()      # bit for bit, on every rank
+                assert torch.equal(arena.grad_of(n), want), (n, (arena.grad_of(n) - want).abs().max())
                 assert arena.grad_of(n).dtype == torch.float32
             else:
                 assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n

@@ -28,7 +28,7 @@ def _build(which, dp):
     """-> (iterate(i), [arenas], device-free feed)"""
     from t2i_amd.utils.config import AttrDict
     B = 2
-    if which == 'wgancls':
+    if which in ('wgancls', 'wgancls_cut'):
         from t2i_amd.models.wgancls.model import WGanCls
         from t2i_amd.models.wgancls.trainer import WGanClsTrainer
         cfg = AttrDict({'MODEL': {'Z_DIM': 8, 'OUTPUT_SIZE': 64, 'EMBED_DIM': 32, 'COMPRESSED_EMBED_DIM': 16, 'GF_DIM': 8, 'DF_DIM': 8,
@@ -36,6 +36,7 @@ def _build(which, dp):
                         'TRAIN': {'BATCH_SIZE': B, 'SAMPLE_NUM': 4, 'D_LR': 1e-4, 'G_LR': 1e-4, 'BETA1': 0.0, 'BETA2': 0.9, 'N_CRITIC': 1,
                                   'SUMMARY_PERIOD': 10, 'MAX_STEPS': 10, 'COEFF': {'KL': 1.0, 'LAMBDA': 100.0}}})
         m = WGanCls(cfg, device='cpu', dp=dp)
+        m.dp_cut_eager = which == 'wgancls_cut'      # the segment sequence of the graph schedule: each backward cut once
         tr = WGanClsTrainer(None, m, None, cfg)
         feed = {'x': torch.zeros(B, 64, 64, 3), 'x_mismatch': torch.zeros(B, 64, 64, 3), 'cond': torch.zeros(B, 32), 'z': torch.zeros(B, 8),
                 'epsilon': torch.zeros(B, 1, 1, 1), 'ca_noise_d': torch.zeros(B, 16), 'ca_noise_g': torch.zeros(B, 16),
@@ -94,11 +95,19 @@ def _worker(rank, world, port, which, q):
                     got = sorted((s, e) for s, e, _ in per_arena[id(a)])
                     assert got[0][0] == 0 and got[-1][1] == a.numel and all(x[1] == y[0] for x, y in zip(got, got[1:])), (which, i, got)
                     st = dp._arenas[id(a)]
+                    if which == 'wgancls_cut':
+                        # two exchanges per arena, the FIRST being the tail of the arena (the layers whose gradients are final
+                        # after the first part of the cut backward: Conv_3.. of the critic, Conv2d_transpose.. of the generator)
+                        first_var = model._CUT_D if a is model.d_arena else model._CUT_G
+                        cut = a.offsets[first_var][0]
+                        order = [(s_, e_) for s_, e_, _ in per_arena[id(a)]]
+                        assert order == [(cut, a.numel), (0, cut)], (which, i, order, cut)
+                        continue
                     assert st['expect'] and len(st['buckets']) > 1
                     if i > 1:        # counts learned on step 1: from then on the first bucket leaves before the backward has ended
                         seen = [n for _, _, n in per_arena[id(a)]]
                         assert min(seen) < sum(st['expect'].values()), (which, i, seen)
-            if which == 'wgancls':   # the kt means travelled as `extra`: both ranks contributed (zeros in a dry run) and kt is finite
+            if which in ('wgancls', 'wgancls_cut'):   # the kt means travelled as `extra`: both ranks contributed (zeros in a dry run) and kt is finite
                 assert torch.isfinite(model.kt).all()
         dist.barrier()
         dist.destroy_process_group()
@@ -108,7 +117,7 @@ def _worker(rank, world, port, which, q):
         q.put((rank, 'FAILED: %s\n%s' % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize('which', ['wgancls', 'stackgan1', 'pggan'])
+@pytest.mark.parametrize('which', ['wgancls', 'wgancls_cut', 'stackgan1', 'pggan'])
 def test_model_iteration_exchanges_every_gradient_once(which):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -26,9 +26,13 @@ import torch.distributed as dist
 
 class DataParallel(object):
     def __init__(self, bucket_bytes=32 << 20, process_group=None, grad_dtype='f32'):
-        """grad_dtype: 'f32' (exchange the fp32 arena in place) or 'bf16' (BASELINE config 3: a bucket is rounded to bf16
-        into a staging buffer, all-reduced in bf16 — half the bytes on every xGMI link — and written back into the fp32
-        arena on arrival; the optimizer and its moments stay fp32)."""
+        """grad_dtype: 'f32' (exchange the fp32 arena in place) or 'bf16' (BASELINE config 3: bf16 on the wire — half the bytes
+        on every xGMI link — with the SUM taken in fp32: a bucket is rounded to bf16 once (RNE), the ranks exchange chunks
+        (all-to-all: rank j receives everybody's j-th chunk), each sums the N chunks it received in fp32, rounds that sum to
+        bf16 once and the sums are all-gathered; the fp32 arena receives the result.  A ring all-reduce in bf16 would round the
+        running sum at every one of its N-1 hops instead.  Same bytes per link as the ring: 2 (N-1)/N of the bf16 bucket.
+        For N a power of two, N identical contributions come back EXACTLY (N x is representable whenever x is), which is what
+        bench.dp_preflight demands.  The optimizer and its moments stay fp32)."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed must be initialised (init_process_group) before DataParallel')
         self.group = process_group
@@ -41,7 +45,7 @@ class DataParallel(object):
         if grad_dtype not in ('f32', 'bf16'):
             raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (grad_dtype,))
         self.grad_dtype = grad_dtype
-        self._stage = {}                      # id(arena) -> bf16 staging buffer of the arena's size
+        self._stage = {}                      # id(arena) -> (send, recv, [offset]) bf16 staging buffers
         # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
         self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
 
@@ -138,6 +142,8 @@ class DataParallel(object):
         if not self.overlap:                 # exchange after the backward (allreduce_arena launches every bucket then)
             return
         st['pending'] = [len(names) for _, _, names in st['buckets']]
+        if id(arena) in self._stage:
+            self._stage[id(arena)][2][0] = 0     # a new exchange: its buckets take fresh slices of the staging buffers
         st['works'] = []
         st['seen'] = {}
         st['launched'] = set()
@@ -157,14 +163,41 @@ class DataParallel(object):
             return
         self._launch_range(st, start, end)
 
+    def _stage_buffers(self, st, n):
+        """Two bf16 staging buffers per arena, each holding the arena padded to world x (chunk of a multiple of 8 elements)."""
+        key = id(st['arena'])
+        bufs = self._stage.get(key)
+        if bufs is None:
+            cap = -(-st['arena'].numel // (8 * self.world)) * 8 * self.world + 8 * self.world * len(st['buckets'])
+            dev = st['arena'].grad.device
+            bufs = self._stage[key] = (torch.zeros(cap, dtype=torch.bfloat16, device=dev), torch.zeros(cap, dtype=torch.bfloat16, device=dev), [0])
+        return bufs
+
+    def _exchange_bf16(self, st, buf):
+        """bf16 on the wire, fp32 accumulation (see __init__): all-to-all of chunks -> local fp32 sum -> all-gather of the sums.
+        Runs on the calling stream (the communication stream); every rank leaves with the same bits in `buf`."""
+        n, N = buf.numel(), self.world
+        chunk = -(-n // (8 * N)) * 8
+        send_all, recv_all, used = self._stage_buffers(st, n)
+        if used[0] + N * chunk > send_all.numel():      # buckets of one exchange use disjoint slices (they may be in flight together)
+            used[0] = 0
+        send = send_all[used[0]:used[0] + N * chunk]
+        recv = recv_all[used[0]:used[0] + N * chunk]
+        used[0] += N * chunk
+        send[:n].copy_(buf)                             # fp32 -> bf16, round to nearest even
+        if N * chunk > n:
+            send[n:].zero_()
+        if N == 1:
+            buf.copy_(send[:n])
+            return
+        dist.all_to_all_single(recv, send, group=self.group)                    # recv[j] = rank j's chunk number `rank`
+        mine = recv.view(N, chunk).float().sum(0).to(torch.bfloat16)           # the sum in fp32, rounded once
+        dist.all_gather_into_tensor(send, mine, group=self.group)               # send now holds every rank's reduced chunk
+        buf.copy_(send[:n])
+
     def _launch_range(self, st, start, end):
         buf = st['arena'].grad[start:end]
-        stage = None
-        if self.grad_dtype == 'bf16':
-            full = self._stage.get(id(st['arena']))
-            if full is None:
-                full = self._stage[id(st['arena'])] = torch.empty(st['arena'].numel, dtype=torch.bfloat16, device=buf.device)
-            stage = full[start:end]
+        bf16 = self.grad_dtype == 'bf16'
         if buf.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=buf.device)
@@ -173,19 +206,14 @@ class DataParallel(object):
             if A.SIDE.stream is not None:                                   # ... including the filter-gradient stream's
                 self._side.wait_stream(A.SIDE.stream)
             with torch.cuda.stream(self._side):
-                if stage is None:
+                if not bf16:
                     st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                else:                # fp32 -> bf16 (RNE), exchange, bf16 -> fp32, all ordered on the communication stream
-                    stage.copy_(buf)
-                    w = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    w.wait()
-                    buf.copy_(stage)
-        elif stage is None:
+                else:                # everything ordered on the communication stream
+                    self._exchange_bf16(st, buf)
+        elif not bf16:
             st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
-            stage.copy_(buf)
-            dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
-            buf.copy_(stage)
+            self._exchange_bf16(st, buf)
 
     def allreduce_arena(self, arena, extra=None):
         """Finish the exchange for `arena` (launch whatever the hooks did not, wait) and return the factor that turns the
@@ -193,10 +221,12 @@ class DataParallel(object):
         self.start_allreduce(arena, extra)
         return self.finish_allreduce(arena)
 
-    def start_allreduce(self, arena, extra=None):
+    def start_allreduce(self, arena, extra=None, ranges=None):
         """Issue every all-reduce of `arena` that is not in flight yet (communication stream; the calling stream is not
         blocked).  Work enqueued on the calling stream between this and finish_allreduce overlaps the exchange — it must not
-        touch the arena's gradients."""
+        touch the arena's gradients.  ranges (graph-segment schedule only, i.e. not armed): [(start, end), ...] element ranges
+        of the arena whose gradients are final NOW — the part of a backward that has been cut in two; the caller issues the
+        remaining ranges with another call before finish_allreduce."""
         st = self.attach(arena)
         if st.get('snap'):                      # ... and compare with what the backward finally left there
             torch.cuda.synchronize()
@@ -220,9 +250,18 @@ class DataParallel(object):
             for bi in range(len(st['buckets'])):   # whatever hooks / notifications did not complete (unused parameters,
                 self._launch(st, bi)               # the learning step): launched now; _launch skips the ones in flight
         else:                                      # not armed (graph segments, exchange-after-backward): the gradients are
-            st['works'] = []                       # all final, so ONE collective over the whole arena — ring all-reduce is
-            st['launched'] = set(range(len(st['buckets'])))      # per-link bound, fewer and larger is better
-            self._launch_range(st, 0, arena.numel)
+            if ranges is None or not st.get('partial'):
+                st['works'] = []                   # all final, so ONE collective over the whole arena (or one per cut) — ring
+            st['partial'] = ranges is not None     # all-reduce is per-link bound, fewer and larger is better
+            st['launched'] = set(range(len(st['buckets'])))
+            if ranges is None:
+                if id(arena) in self._stage:
+                    self._stage[id(arena)][2][0] = 0
+                self._launch_range(st, 0, arena.numel)
+            else:
+                for a, b in ranges:
+                    if b > a:
+                        self._launch_range(st, a, b)
         st['in_start'] = False
         if extra is not None:
             if extra.is_cuda and self._side is not None:
@@ -241,6 +280,9 @@ class DataParallel(object):
             torch.cuda.current_stream(arena.grad.device).wait_stream(self._side)
         st['armed'] = False
         st['works'] = []
+        st['partial'] = False
+        if id(arena) in self._stage:
+            self._stage[id(arena)][2][0] = 0
         return 1.0 / self.world
 
     def broadcast_variables(self, store, src=0):

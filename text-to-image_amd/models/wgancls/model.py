@@ -49,6 +49,8 @@ class WGanCls(object):
         self.store = S.set_default_store(S.VariableStore(device=device, seed=seed))
         self.device = self.store.device
         self.dp = dp
+        self.dp_cut_eager = os.environ.get('T2I_DP_CUT_EAGER') == '1'
+        self.dp_schedule = None
         self.global_step = 0
         self._graphs = None
         self._capturing = False
@@ -125,9 +127,34 @@ class WGanCls(object):
             torch.nn.init.trunc_normal_(n, mean=0.0, std=1.0, a=-2.0, b=2.0)
         return n
 
-    def d_losses(self, feed):
+    # Where the data-parallel graph schedule cuts the two backward passes so that the exchange of the gradients that are final
+    # first starts while the rest of the backward still runs ("launch as each bwd-filter completes"):
+    #   critic: at the input of Conv_3.  Backward order is Conv_9 ... Conv_3 | Conv_2, Conv_1, Conv: the first part leaves
+    #           105.5 of the arena's 116 MB final (Conv_7 42 MB, Conv_3 34 MB, Conv_6 19 MB are produced first); the gradient
+    #           penalty's second-order contributions to ALL layers also fall into the first part (the double-backward chain runs
+    #           Conv -> Conv_9 before the main pass runs back), so after it only the main-pass terms of Conv..Conv_2 are missing.
+    #   generator: at the 4x4 -> 8x8 boundary (output of the first bottleneck).  First part: the critic's input gradient and the
+    #           generator from out_conv back to Conv2d_transpose (57 MB of 90.6); rest: the 4x4 bottleneck, dense_2, the two
+    #           conditioning heads (+ the KL term's gradient, which only reaches those heads).
+    _CUT_D = 'd_net/Conv_3/weights'                 # first variable (creation order = arena order) of the critic's FIRST backward part
+    _CUT_G = 'g_net/Conv2d_transpose/weights'       # ... of the generator's
+
+    def _cut_ranges(self, arena, first_var):
+        """([(start, end)] of the part that is final after the first half of the cut backward, [(start, end)] of the rest)."""
+        o = arena.offsets[first_var][0]
+        return [(o, arena.numel)], [(0, o)]
+
+    @staticmethod
+    def _split_vars(variables, first_var):
+        names = list(variables)
+        i = names.index(first_var)
+        return [variables[n] for n in names[i:]], [variables[n] for n in names[:i]]
+
+    def d_losses(self, feed, cut=False):
         """Everything `sess.run([D_optim, kt_optim, D_loss])` evaluates before the updates.  Returns a dict of scalar
-        tensors; leaves the critic gradients in the arena (self.d_arena.grad)."""
+        tensors; leaves the critic gradients in the arena (self.d_arena.grad).
+        cut=True (data-parallel graph schedule): only the FIRST part of the backward is run (down to the input of Conv_3); the
+        caller starts the exchange of that part's gradients and then runs d_backward_rest()."""
         x, xm, cond, z, eps = feed['x'], feed['x_mismatch'], feed['cond'], feed['z'], feed['epsilon']
         B = x.shape[0]
         with torch.no_grad():
@@ -137,6 +164,7 @@ class WGanCls(object):
             x_hat = K.interp(eps, G, x)
         # D(G), D(x), D(x_mismatch): one batched pass (shared weights, no batch coupling in the critic)
         logits = self.discriminator(torch.cat([G, x, xm], 0), torch.cat([cond, cond, cond], 0), reuse=True).view(3, B)
+        d_cut = self._d_cut                    # of the batched pass (the x_hat pass below gets no first-order gradient)
         Dg_logit, Dx_logit, Dxmi_logit = logits[0], logits[1], logits[2]
         x_hat.requires_grad_(True)
         cond_inp = (cond + 0.0).requires_grad_(True)
@@ -152,8 +180,13 @@ class WGanCls(object):
         self.d_arena.zero_grad()
         if self.dp is not None and not self._capturing:
             self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this backward
-        torch.autograd.backward([logits, slopes1, slopes2], [seed_l.view_as(logits), seed_s1, seed_s2],
-                                inputs=list(self.d_vars.values()))
+        if cut:
+            first, rest = self._split_vars(self.d_vars, self._CUT_D)
+            torch.autograd.backward([logits, slopes1, slopes2], [seed_l.view_as(logits), seed_s1, seed_s2], inputs=[d_cut] + first)
+            self._d_rest = (d_cut, rest)
+        else:
+            torch.autograd.backward([logits, slopes1, slopes2], [seed_l.view_as(logits), seed_s1, seed_s2],
+                                    inputs=list(self.d_vars.values()))
         A.side_join()                          # filter gradients issued on the side stream are in the arena
         out = {k: scal[i] for i, k in enumerate(K.D_HEAD_KEYS)}
         # (wdist, wdist2): what the kt step needs.  Under data parallelism these two batch means are summed over the ranks
@@ -163,6 +196,14 @@ class WGanCls(object):
         out['wd_sums'] = scal[i0:i0 + 2].clone() if self.dp is not None else scal[i0:i0 + 2]
         out.update(G=G, Dx_hat_logit=Dx_hat_logit.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
         return out
+
+    def d_backward_rest(self):
+        """Second part of a cut critic backward: from the gradient at the input of Conv_3 through Conv_2, Conv_1, Conv."""
+        d_cut, rest = self._d_rest
+        self._d_rest = None
+        g, d_cut.grad = d_cut.grad, None
+        torch.autograd.backward([d_cut], [g], inputs=rest)
+        A.side_join()
 
     def _d_update(self, out, scale):
         """Adam on the critic arena + the kt step; `scale` turns rank-summed gradients (and batch means) into the mean."""
@@ -201,11 +242,15 @@ class WGanCls(object):
         with update_ops():   # G_optim runs under control_dependencies(UPDATE_OPS) (model.py:102)
             G, mean, log_sigma = self.generator(z, cond, reuse=True)
         G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
+        self._g_fwd_cut = self._g_cut          # the critic passes behind this do not touch it, but a later generator pass would
         return G, G_kl
 
-    def g_losses(self, feed, fwd=None):
+    def g_losses(self, feed, fwd=None, cut=False):
+        """cut=True: only the first part of the backward (the critic's input gradient and the generator back to the 4x4 -> 8x8
+        boundary); g_backward_rest() runs the remainder."""
         cond = feed['cond']
         G, G_kl = fwd if fwd is not None else self._g_forward(feed)
+        g_cut = self._g_fwd_cut                # recorded by _g_forward (a later no_grad generator pass does not overwrite it)
         with self.store.frozen('d_net'):
             Dg_logit = self.discriminator(G, cond, reuse=True)
         # G_loss = -mean(D(G)) + kl_coeff * KL (model.py:90-92): the KL value came out of the fused conditioning-augmentation
@@ -214,14 +259,28 @@ class WGanCls(object):
         self.g_arena.zero_grad()
         if self.dp is not None and not self._capturing:
             self.dp.arm(self.g_arena)
-        torch.autograd.backward([Dg_logit, G_kl], [self._const_like(Dg_logit, -1.0 / B), self._const_like(G_kl, self.kl_coeff)],
-                                inputs=list(self.g_vars.values()))
+        if cut:
+            first, rest = self._split_vars(self.g_vars, self._CUT_G)
+            torch.autograd.backward([Dg_logit], [self._const_like(Dg_logit, -1.0 / B)], inputs=[g_cut] + first)
+            self._g_rest = (g_cut, G_kl, rest)
+        else:
+            torch.autograd.backward([Dg_logit, G_kl], [self._const_like(Dg_logit, -1.0 / B), self._const_like(G_kl, self.kl_coeff)],
+                                    inputs=list(self.g_vars.values()))
         A.side_join()
         with torch.no_grad():
             D_loss_fake = Dg_logit.detach().mean()
             G_kl_loss = G_kl.detach().reshape(())
             G_loss = -D_loss_fake + self.kl_coeff * G_kl_loss
         return dict(G_loss=G_loss, G_kl_loss=G_kl_loss, D_loss_fake=D_loss_fake, G=G.detach())
+
+    def g_backward_rest(self):
+        """Second part of a cut generator backward: the 4x4 bottleneck, dense_2 and the conditioning heads, seeded with the gradient at
+        the cut and with dG_loss/dKL (the KL term only reaches the heads)."""
+        g_cut, G_kl, rest = self._g_rest
+        self._g_rest = None
+        g, g_cut.grad = g_cut.grad, None
+        torch.autograd.backward([g_cut, G_kl], [g, self._const_like(G_kl, self.kl_coeff)], inputs=rest)
+        A.side_join()
 
     def _refresh_filters(self):
         """Head of a captured graph: one batched regeneration per arena of the cached filter images (kernels.filter_cache_refresh)."""
@@ -280,6 +339,8 @@ class WGanCls(object):
         (tools/dp_phase_times.py); with data parallelism the critic's Adam segment and the generator half share a graph."""
         g = self._graphs
         if g is None:
+            if self.dp is not None and self.dp_cut_eager:
+                return self._dg_cut_eager(feed)
             return self.d_step(feed), self.g_step(feed)
         self.D_optim.prepare(float(feed['learning_rate_d']))
         self.G_optim.prepare(float(feed['learning_rate_g']))
@@ -288,16 +349,54 @@ class WGanCls(object):
         if self.dp is None:
             g['dg'].replay()
         else:
-            g['d'].replay()
-            self.dp.start_allreduce(self.d_arena, extra=g['d_out']['wd_sums'])
-            g['g_fwd'].replay()                    # generator forward overlaps the critic's gradient exchange
+            # five graph launches, four collectives; each backward is cut once so that the bulk of its gradients is on the wire
+            # while the rest of the backward (and, for the critic, the generator's forward) still runs — see enable_graphs
+            dA, dB = self._cut_ranges(self.d_arena, self._CUT_D)
+            gA, gB = self._cut_ranges(self.g_arena, self._CUT_G)
+            g['d_a'].replay()                      # critic losses + backward down to the input of Conv_3
+            self.dp.start_allreduce(self.d_arena, extra=g['dg_out'][0]['wd_sums'], ranges=dA)
+            g['gf_d_b'].replay()                   # generator forward (needs no critic variable) + the rest of the critic backward
+            self.dp.start_allreduce(self.d_arena, ranges=dB)
             self.dp.finish_allreduce(self.d_arena)
-            g['dupd_g'].replay()
-            self.dp.allreduce_arena(self.g_arena)
+            g['dupd_g_a'].replay()                 # critic Adam + kt; critic on G; backward down to the generator's 4x4 -> 8x8 boundary
+            self.dp.start_allreduce(self.g_arena, ranges=gA)
+            g['g_b'].replay()                      # the rest of the generator backward
+            self.dp.start_allreduce(self.g_arena, ranges=gB)
+            self.dp.finish_allreduce(self.g_arena)
             g['g_upd'].replay()
         K.filter_cache_invalidate()
         self.global_step += 1
         return g['dg_out']
+
+    def _dg_cut_eager(self, feed):
+        """The segment sequence of the data-parallel graph schedule (enable_graphs), launched eagerly: the same calls in the same
+        order, the exchanges between them.  Selected with `dp_cut_eager` (T2I_DP_CUT_EAGER=1); it is what the CPU gloo test and
+        the 2-ranks-on-1-GPU exactness test run without graphs, and a fallback where capture is not available.  (The default
+        eager data-parallel step is the bucket-overlap schedule driven by autograd.NOTIFY, dp.py.)"""
+        self.D_optim.prepare(float(feed['learning_rate_d']))
+        self.G_optim.prepare(float(feed['learning_rate_g']))
+        scale = 1.0 / self.dp.world
+        dA, dB = self._cut_ranges(self.d_arena, self._CUT_D)
+        gA, gB = self._cut_ranges(self.g_arena, self._CUT_G)
+        self._capturing = True                      # the exchanges are issued here, not by armed hooks
+        try:
+            d_out = self.d_losses(feed, cut=True)
+            self.dp.start_allreduce(self.d_arena, extra=d_out['wd_sums'], ranges=dA)
+            fwd = self._g_forward(feed)
+            self.d_backward_rest()
+            self.dp.start_allreduce(self.d_arena, ranges=dB)
+            self.dp.finish_allreduce(self.d_arena)
+            self._d_update(d_out, scale)
+            g_out = self.g_losses(feed, fwd=fwd, cut=True)
+            self.dp.start_allreduce(self.g_arena, ranges=gA)
+            self.g_backward_rest()
+            self.dp.start_allreduce(self.g_arena, ranges=gB)
+            self.dp.finish_allreduce(self.g_arena)
+            self.G_optim.apply(grad_scale=scale)
+        finally:
+            self._capturing = False
+        self.global_step += 1
+        return d_out, g_out
 
     # ---- hipGraph capture of the two halves of the iteration ---------------------------------------------------------------
     _STATIC_KEYS = ('x', 'x_mismatch', 'cond', 'z', 'epsilon', 'ca_noise_d', 'ca_noise_g')
@@ -364,20 +463,30 @@ class WGanCls(object):
                 g_out = self.g_losses(static)
             with torch.cuda.graph(ggu, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 self.G_optim.apply(grad_scale=scale)
-            # dg_step: generator forward on its own (replayed while the critic's gradients are on the wire), then the critic's
-            # update + the rest of the generator half in one launch; the autograd graph of the first capture is consumed by
-            # the second (both allocate from the same private pool, replayed in capture order)
-            ggf, gdug = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ggf, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
+            # dg_step (the trainer's iteration): each backward is cut once.  [critic losses + first part of its backward] |
+            # exchange of that part starts | [generator forward + rest of the critic backward] | exchange of the rest, wait |
+            # [critic Adam + kt; critic on G(z); first part of the generator step's backward] | exchange starts | [rest] |
+            # exchange, wait | [generator Adam].  The autograd graph recorded in one capture is consumed by a later one (all
+            # captures share one private pool and are replayed in capture order).
+            gda, ggfdb, gduga, ggb = (torch.cuda.CUDAGraph() for _ in range(4))
+            with torch.cuda.graph(gda, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
+                d_out2 = self.d_losses(static, cut=True)
+            with torch.cuda.graph(ggfdb, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 fwd = self._g_forward(static)
-            with torch.cuda.graph(gdug, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
-                self._d_update(d_out, scale)
-                g_out2 = self.g_losses(static, fwd=fwd)
+                self.d_backward_rest()
+            with torch.cuda.graph(gduga, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
+                self._d_update(d_out2, scale)
+                g_out2 = self.g_losses(static, fwd=fwd, cut=True)
+            with torch.cuda.graph(ggb, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
+                self.g_backward_rest()
             del fwd
         finally:
             self._capturing = False
-        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'g_fwd': ggf, 'dupd_g': gdug, 'd_out': d_out, 'g_out': g_out,
-                        'dg_out': (d_out, g_out2), 'static': static, 'loaded': False}
+        self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'd_a': gda, 'gf_d_b': ggfdb, 'dupd_g_a': gduga, 'g_b': ggb,
+                        'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2), 'static': static, 'loaded': False}
+        self.dp_schedule = ('5 graphs + 4 eager exchanges/iteration: both backward passes cut once (critic at the input of Conv_3: '
+                            '105 of 116 MB leave while the generator forward and the rest of the backward run; generator at the '
+                            '4x4->8x8 boundary: 57 of 91 MB leave before the 4x4 layers)')
 
     def sampler(self, z_sample, cond_sample):
         """eval-mode generator on fixed samples (reference model.py:57)"""
@@ -417,6 +526,7 @@ class WGanCls(object):
         with S.variable_scope('d_net', reuse=reuse):
             for mult in (1, 2, 4):                                             # d_net/Conv, Conv_1, Conv_2
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), act=act, df=fmt)
+            self._d_cut = h                                                    # where the data-parallel schedule cuts the backward (_CUT_D)
             trunk = conv2d(h, nf * 8, ks=(4, 4), s=(2, 2), df=fmt)             # Conv_3, linear
             r = conv2d(trunk, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_4
             r = conv2d(r, nf * 4, ks=(3, 3), s=(1, 1), act=act, df=fmt)        # Conv_5
@@ -450,6 +560,7 @@ class WGanCls(object):
             h = batch_norm(fc(code, nf * 8 * grid * grid), train=is_training, df=df)      # dense_2 + rank-2 BatchNorm
             h = reshape_to_map(h, nf * 8, grid, grid, df)                                 # [B,4,4,8nf]
             h = self._g_bottleneck(h, nf * 2, nf * 8, is_training, df)
+            self._g_cut = h                                                               # the 4x4 -> 8x8 boundary (_CUT_G)
             h = self._g_upsample(h, nf * 4, is_training, df, act=None)                    # 8x8
             h = self._g_bottleneck(h, nf, nf * 4, is_training, df)
             h = self._g_upsample(h, nf * 2, is_training, df, act=relu)                    # 16x16

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh [round]).
 # Kernel trace and each PMC group are separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
-# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r02);
+# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r03);
 # copy what should be judged into profiles/ with the round prefix.
 set -u
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-ROUND="${1:-r02}"
+ROUND="${1:-r03}"
 OUT="$REPO/gpurun_out/$ROUND"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off --repeats 1"
+BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off --repeats 1 --min-busy-s 0 --no-config3"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -o r -- $BENCH --steps 5 --warmup 2 > "$OUT/ktrace.log" 2>&1
 cp "$(find "$OUT/ktrace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bench_s5w2.csv"
 python "$REPO/tools/prof_summary.py" "$OUT/ktrace" 9 45 > "$OUT/kernel_stats_summary.txt" 2>&1
@@ -39,7 +39,6 @@ timeout 300 python tools/bench_aux.py 2>&1 | grep -v amdgpu > "$OUT/hbm_kernels.
   for b in 8 32; do timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch $b --steps 5 2>&1 | tail -1; done
   timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch 32 --steps 5 --math bf16 2>&1 | tail -1
   timeout 600 python text-to-image_amd/models/pggan/train_pggan.py --bench --iters 8 --first 6 --last 12 2>&1 | grep "^pggan"; } > "$OUT/next_rows_throughput.txt"
-timeout 300 python bench.py --math bf16 --no-cpu-baseline 2>/dev/null | grep '"metric"' > "$OUT/bench_line_bf16.json"
 timeout 600 python bench.py 2>/dev/null | grep '"metric"' > "$OUT/bench_line.json"
 # drop the bulky raw traces, keep the per-pass counter csv of the MFMA pass for reference
 rm -rf "$OUT/ktrace" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES"
