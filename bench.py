@@ -138,36 +138,45 @@ def _signature(model):
     return [model.d_arena.flat.clone(), model.g_arena.flat.clone(), model.D_optim.v.clone(), model.G_optim.v.clone(), model.kt.clone()]
 
 
-def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, exact=True):
+def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtype='f32'):
     """Self-check of the N-rank exchange before anything is timed (first contact with a multi-GPU node must diagnose itself):
     every rank runs 4 iterations on IDENTICAL data, once as a single replica (no communicator) and once through the
     data-parallel schedule that will be timed (2 eager iterations that learn the bucket counts, then the captured segments).
-    Averaging N identical gradients returns the gradient, so the two runs must agree: exactly for N = 2 (x + x and its
-    halving are exact in fp32; not with bf16 gradient buckets, which round every contribution), and to rounding for N > 2 (a ring sums 3x, 5x, ... which need not be representable) — there
-    the bound is Adam's own: no weight may differ by more than the 4 steps could move it, and all but 0.1 % must agree to
-    5 % of one step.  A bucket that is exchanged too early, twice, or not at all fails both by orders of magnitude."""
+    Averaging N identical gradients returns the gradient, so the two runs must agree:
+      * fp32 buckets: exactly for N = 2 (x + x and its halving are exact); for N > 2 a ring sums 3x, 5x, ... which need not be
+        representable, and the bound is Adam's own — no weight may differ by more than the 4 steps could move it, and all but
+        0.1 % must agree to 5 % of one step;
+      * bf16 buckets (fp32 accumulation, dp.DataParallel._exchange_bf16): exactly for every power-of-two N against a single
+        replica that rounds its gradient arena to bf16 once (dp.LocalRounding) — N bf16(x) is exact in fp32 and representable
+        in bf16.  Otherwise the Adam bound.
+    A bucket that is exchanged too early, twice, or not at all fails all of these by orders of magnitude."""
+    from t2i_amd.dp import LocalRounding
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
     feed = synthetic_feed(cfg, device, seed=977)            # the same batch and noise on every rank
     lr = float(cfg.TRAIN.D_LR)
     sigs, losses = [], []
-    for dp in (None, make_dp()):
+    for dp in ((LocalRounding() if grad_dtype == 'bf16' else None), make_dp()):
         model = WGanCls(cfg, device=device, seed=0, dp=dp)
-        if dp is not None:
+        real = dp is not None and not isinstance(dp, LocalRounding)
+        if real:
             dp.broadcast_variables(model.store)
         trainer = WGanClsTrainer(None, model, None, cfg)
         for i in range(2):
             out = trainer.iteration(1 + i, feed)
-        if dp is not None and use_graphs:
+        if real and use_graphs:
             model.enable_graphs(feed)
         for i in range(2):
             out = trainer.iteration(3 + i, feed)
         torch.cuda.synchronize()
         sigs.append(_signature(model))
         losses.append((float(out['d']['D_loss']), float(out['g']['G_loss'])))
+        model._graphs = None
         del trainer, model
     one, many = sigs
-    report = {'ranks': world, 'iterations': 4, 'exact': all(torch.equal(a, b) for a, b in zip(one, many))}
+    want_exact = (world == 2) if grad_dtype == 'f32' else (world & (world - 1)) == 0
+    report = {'ranks': world, 'iterations': 4, 'gradient_buckets': grad_dtype, 'exact': all(torch.equal(a, b) for a, b in zip(one, many)),
+              'exact_required': bool(want_exact)}
     worst, loose = 0.0, 0.0
     for a, b in zip(one[:2], many[:2]):                     # the two weight arenas
         d = (a - b).abs()
@@ -175,7 +184,7 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, exact=Tru
         loose = max(loose, float((d > 0.05 * lr).float().mean()))
     report.update(max_weight_diff_in_steps=worst, frac_weights_off_by_5pct_of_a_step=loose,
                   kt_diff=abs(float(one[4]) - float(many[4])), loss_single=losses[0], loss_dp=losses[1])
-    ok = report['exact'] if (world == 2 and exact) else (worst <= 4 * 2.0 * 1.001 and loose <= 1e-3 and report['kt_diff'] <= 1e-5 * max(abs(float(one[4])), 1.0))
+    ok = report['exact'] if want_exact else (worst <= 4 * 2.0 * 1.001 and loose <= 1e-3 and report['kt_diff'] <= 1e-5 * max(abs(float(one[4])), 1.0))
     report['ok'] = bool(ok)
     flag = torch.tensor([0 if ok else 1], device=device)
     torch.distributed.all_reduce(flag)
@@ -202,7 +211,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
     preflight = None
     if world > 1 and os.environ.get('T2I_PREFLIGHT', '1') != '0':
-        preflight = dp_preflight(cfg, device, lambda: make_dp(math)[0], use_graphs, rank, world, args.batch, exact=(grad_dtype == 'f32'))
+        preflight = dp_preflight(cfg, device, lambda: make_dp(math)[0], use_graphs, rank, world, args.batch, grad_dtype=grad_dtype)
         if rank == 0:
             sys.stderr.write('[bench] data-parallel preflight (%s) passed: %r\n' % (math, preflight))
     model = WGanCls(cfg, device=device, seed=0, dp=dp)

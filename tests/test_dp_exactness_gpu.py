@@ -52,4 +52,7 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
     assert eager == single, (eager, single)
     assert graphs == single, (graphs, single)
     assert cut_eager == single, (cut_eager, single)
+    # config 3: bf16 gradient buckets summed in fp32.  bench.py's preflight demands that the two-rank run on identical data equals,
+    # bit for bit, a single replica whose gradient arena is rounded to bf16 once (dp.LocalRounding) and aborts otherwise
+    _two_ranks(29814, ['--math', 'bf16', '--warmup', '1', '--steps', '1'], {})
     # (both two-rank runs also went through bench.py's own data-parallel preflight, which aborts the run on a mismatch)

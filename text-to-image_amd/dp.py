@@ -46,6 +46,7 @@ class DataParallel(object):
             raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (grad_dtype,))
         self.grad_dtype = grad_dtype
         self._stage = {}                      # id(arena) -> (send, recv, [offset]) bf16 staging buffers
+        self._a2a = None                      # does the backend have all-to-all on this device?  (None: not tried yet)
         # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
         self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
 
@@ -190,10 +191,23 @@ class DataParallel(object):
         if N == 1:
             buf.copy_(send[:n])
             return
-        dist.all_to_all_single(recv, send, group=self.group)                    # recv[j] = rank j's chunk number `rank`
-        mine = recv.view(N, chunk).float().sum(0).to(torch.bfloat16)           # the sum in fp32, rounded once
-        dist.all_gather_into_tensor(send, mine, group=self.group)               # send now holds every rank's reduced chunk
-        buf.copy_(send[:n])
+        if self._a2a is not False:
+            try:
+                dist.all_to_all_single(recv, send, group=self.group)            # recv[j] = rank j's chunk number `rank`
+                mine = recv.view(N, chunk).float().sum(0).to(torch.bfloat16)   # the sum in fp32, rounded once
+                dist.all_gather_into_tensor(send, mine, group=self.group)       # send now holds every rank's reduced chunk
+                self._a2a = True
+                buf.copy_(send[:n])
+                return
+            except RuntimeError:
+                if self._a2a:                   # it worked before: a real failure, not a missing collective
+                    raise
+                self._a2a = False               # e.g. gloo with device tensors (the 2-ranks-on-1-GPU pre-flight): no all-to-all
+        # same arithmetic without all-to-all: everybody gathers everybody's bf16 bucket and sums all of it in fp32 (N times the
+        # bytes — test transports only; RCCL takes the branch above)
+        parts = [torch.empty_like(send) for _ in range(N)]
+        dist.all_gather(parts, send, group=self.group)
+        buf.copy_(torch.stack(parts).float().sum(0).to(torch.bfloat16)[:n])
 
     def _launch_range(self, st, start, end):
         buf = st['arena'].grad[start:end]
@@ -291,3 +305,30 @@ class DataParallel(object):
             dist.broadcast(v.data, src=src, group=self.group)
         from . import kernels as K
         K.filter_cache_invalidate()
+
+
+class LocalRounding(object):
+    """A world-of-one stand-in with the DataParallel interface whose "exchange" only rounds the gradient arena to bf16 and back:
+    the single-replica REFERENCE of a bf16-bucket run.  N ranks (N a power of two) that contribute identical gradients x get back
+    N * bf16(x) from DataParallel(grad_dtype='bf16') — exactly, the sum being taken in fp32 — and Adam scales by 1/N: bit for bit
+    what this class leaves in the arena.  bench.dp_preflight demands that equality."""
+    world, rank, grad_dtype = 1, 0, 'bf16'
+
+    def arm(self, arena):
+        pass
+
+    def start_allreduce(self, arena, extra=None, ranges=None):
+        for a, b in (ranges if ranges is not None else [(0, arena.numel)]):
+            if b > a:
+                g = arena.grad[a:b]
+                g.copy_(g.bfloat16())
+
+    def finish_allreduce(self, arena):
+        return 1.0
+
+    def allreduce_arena(self, arena, extra=None):
+        self.start_allreduce(arena, extra)
+        return 1.0
+
+    def broadcast_variables(self, store, src=0):
+        pass

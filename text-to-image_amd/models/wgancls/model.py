@@ -53,6 +53,8 @@ class WGanCls(object):
         self.dp_schedule = None
         self.global_step = 0
         self._graphs = None
+        self._keep_cut = False
+        self._d_cut = self._g_cut = None
         self._capturing = False
         self._consts = {}
         self._kl = None
@@ -163,8 +165,12 @@ class WGanCls(object):
             G, _, _ = self.generator(z, cond, reuse=True)
             x_hat = K.interp(eps, G, x)
         # D(G), D(x), D(x_mismatch): one batched pass (shared weights, no batch coupling in the critic)
+        # (the cut tensor is recorded only when asked for: a reference kept on the model outlives the step and, in the one-graph
+        # capture of the single-GPU iteration, is released on another stream than it was made on)
+        self._keep_cut = cut
         logits = self.discriminator(torch.cat([G, x, xm], 0), torch.cat([cond, cond, cond], 0), reuse=True).view(3, B)
-        d_cut = self._d_cut                    # of the batched pass (the x_hat pass below gets no first-order gradient)
+        self._keep_cut = False
+        d_cut, self._d_cut = self._d_cut, None         # of the batched pass (the x_hat pass below gets no first-order gradient)
         Dg_logit, Dx_logit, Dxmi_logit = logits[0], logits[1], logits[2]
         x_hat.requires_grad_(True)
         cond_inp = (cond + 0.0).requires_grad_(True)
@@ -234,23 +240,25 @@ class WGanCls(object):
         self.global_step += 1
         return out
 
-    def _g_forward(self, feed):
+    def _g_forward(self, feed, keep_cut=False):
         """The generator's forward of the G step: depends on the generator's variables only, so under data parallelism
-        it can run while the critic's gradients are still being exchanged (dg_step)."""
+        it can run while the critic's gradients are still being exchanged (dg_step).  keep_cut: remember the tensor at the
+        4x4 -> 8x8 boundary for a cut backward (g_losses(cut=True))."""
         cond, z = feed['cond'], feed['z']
         self._noise = self._ca_noise(feed, 'ca_noise_g', cond[:, :self.compressed_embed_dim])
+        self._keep_cut = keep_cut
         with update_ops():   # G_optim runs under control_dependencies(UPDATE_OPS) (model.py:102)
             G, mean, log_sigma = self.generator(z, cond, reuse=True)
+        self._keep_cut = False
         G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
-        self._g_fwd_cut = self._g_cut          # the critic passes behind this do not touch it, but a later generator pass would
         return G, G_kl
 
     def g_losses(self, feed, fwd=None, cut=False):
         """cut=True: only the first part of the backward (the critic's input gradient and the generator back to the 4x4 -> 8x8
         boundary); g_backward_rest() runs the remainder."""
         cond = feed['cond']
-        G, G_kl = fwd if fwd is not None else self._g_forward(feed)
-        g_cut = self._g_fwd_cut                # recorded by _g_forward (a later no_grad generator pass does not overwrite it)
+        G, G_kl = fwd if fwd is not None else self._g_forward(feed, keep_cut=cut)
+        g_cut, self._g_cut = (self._g_cut, None) if cut else (None, None)
         with self.store.frozen('d_net'):
             Dg_logit = self.discriminator(G, cond, reuse=True)
         # G_loss = -mean(D(G)) + kl_coeff * KL (model.py:90-92): the KL value came out of the fused conditioning-augmentation
@@ -382,7 +390,7 @@ class WGanCls(object):
         try:
             d_out = self.d_losses(feed, cut=True)
             self.dp.start_allreduce(self.d_arena, extra=d_out['wd_sums'], ranges=dA)
-            fwd = self._g_forward(feed)
+            fwd = self._g_forward(feed, keep_cut=True)
             self.d_backward_rest()
             self.dp.start_allreduce(self.d_arena, ranges=dB)
             self.dp.finish_allreduce(self.d_arena)
@@ -472,7 +480,7 @@ class WGanCls(object):
             with torch.cuda.graph(gda, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 d_out2 = self.d_losses(static, cut=True)
             with torch.cuda.graph(ggfdb, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
-                fwd = self._g_forward(static)
+                fwd = self._g_forward(static, keep_cut=True)
                 self.d_backward_rest()
             with torch.cuda.graph(gduga, pool=gd.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._d_update(d_out2, scale)
@@ -526,7 +534,8 @@ class WGanCls(object):
         with S.variable_scope('d_net', reuse=reuse):
             for mult in (1, 2, 4):                                             # d_net/Conv, Conv_1, Conv_2
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), act=act, df=fmt)
-            self._d_cut = h                                                    # where the data-parallel schedule cuts the backward (_CUT_D)
+            if self._keep_cut:                                                 # where the data-parallel schedule cuts the backward (_CUT_D)
+                self._d_cut = h
             trunk = conv2d(h, nf * 8, ks=(4, 4), s=(2, 2), df=fmt)             # Conv_3, linear
             r = conv2d(trunk, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_4
             r = conv2d(r, nf * 4, ks=(3, 3), s=(1, 1), act=act, df=fmt)        # Conv_5
@@ -560,7 +569,8 @@ class WGanCls(object):
             h = batch_norm(fc(code, nf * 8 * grid * grid), train=is_training, df=df)      # dense_2 + rank-2 BatchNorm
             h = reshape_to_map(h, nf * 8, grid, grid, df)                                 # [B,4,4,8nf]
             h = self._g_bottleneck(h, nf * 2, nf * 8, is_training, df)
-            self._g_cut = h                                                               # the 4x4 -> 8x8 boundary (_CUT_G)
+            if self._keep_cut:                                                            # the 4x4 -> 8x8 boundary (_CUT_G)
+                self._g_cut = h
             h = self._g_upsample(h, nf * 4, is_training, df, act=None)                    # 8x8
             h = self._g_bottleneck(h, nf, nf * 4, is_training, df)
             h = self._g_upsample(h, nf * 2, is_training, df, act=relu)                    # 16x16
