@@ -303,7 +303,9 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which);
  * updates) or must be followed by t2i_filter_cache_invalidate(ptr, bytes) (ptr NULL = everything) — this includes
  * initialisation, checkpoint loads, broadcasts, and replaying a captured graph that contains t2i_adam_tf from a process
  * that also issues eager convs.  Launches captured into a hipGraph reuse only transforms filled in the same capture, so a
- * graph always contains every transform it depends on.  Results are bit-identical with and without the cache.  Off by
+ * graph always contains every transform it depends on; an image filled lazily by one captured stream is not handed to another
+ * stream of the same capture (no dependency between them) — only images regenerated by t2i_filter_cache_refresh, which must be
+ * issued before the capture's streams fork, are shared across its streams.  Results are bit-identical with and without the cache.  Off by
  * default; t2i_filter_cache_enable returns the previous state. */
 int t2i_filter_cache_attach(void* buf, size_t bytes);
 int t2i_filter_cache_enable(int on);

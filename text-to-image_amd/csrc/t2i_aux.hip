@@ -390,21 +390,23 @@ __device__ __forceinline__ Agg4 agg4_merge(const Agg4& a, const Agg4& b) {
   return r;
 }
 
+// 16 columns (4 lanes x float4) per workgroup, 64 chunk lanes: a lane merges its nchunks/64 chunks (<= 3), then the 64 lane
+// aggregates are merged 4 : 1 three times through LDS — a dependent chain of ~12 Chan merges (each a division) instead of the 28 of
+// the first version (16 chunk lanes x 12 chunks, then 16 serial merges by one thread: 13 us per launch, 20 launches per iteration).
+// The merge order is fixed, so results are repeatable; they differ from the first version's in the last bits.
 template <bool TILES>
 __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restrict__ part0, const float* __restrict__ part1,
                                                           const float* __restrict__ x, int nchunks, int64_t rows,
                                                           int64_t rows_per_chunk, int C, float* __restrict__ sum, float* __restrict__ m2,
                                                           BnFin fin) {
-  __shared__ float sn[16][16];
-  __shared__ float4 sm[16][16], sq[16][16];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int c = blockIdx.x * 64 + tx * 4;
+  __shared__ float sn[64][4];
+  __shared__ float4 sm[64][4], sq[64][4];
+  const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + tx * 4;
   Agg4 a;
   a.n = 0.f; a.mean = make_float4(0.f, 0.f, 0.f, 0.f); a.m2 = a.mean;
   if (c < C) {
-    // (a four-chunks-per-round variant with all loads issued before the first merge was measured 2x SLOWER — 26 us instead of
-    // 13: the unrolled body holds twelve float4 live across the merges; one chunk per round stays)
-    for (int k = ty; k < nchunks; k += 16) {
+    for (int k = ty; k < nchunks; k += 64) {
       const int64_t rbeg = (int64_t)k * rows_per_chunk;
       int64_t rend = rbeg + rows_per_chunk;
       if (rend > rows) rend = rows;
@@ -426,17 +428,24 @@ __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restric
       a = agg4_merge(a, b);
     }
   }
-  sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2;
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    Agg4 r;
-    r.n = sn[0][tx]; r.mean = sm[0][tx]; r.m2 = sq[0][tx];
+  // 64 -> 16 -> 4 -> 1 lanes; lane ty of a level merges entries 4 ty .. 4 ty + 3 of the level below, in that order
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      Agg4 b;
-      b.n = sn[k][tx]; b.mean = sm[k][tx]; b.m2 = sq[k][tx];
-      r = agg4_merge(r, b);
+  for (int width = 64; width > 1; width >>= 2) {
+    __syncthreads();
+    if (ty < width) { sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2; }
+    __syncthreads();
+    if (ty < (width >> 2)) {
+      a.n = sn[4 * ty][tx]; a.mean = sm[4 * ty][tx]; a.m2 = sq[4 * ty][tx];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        Agg4 b;
+        b.n = sn[4 * ty + j][tx]; b.mean = sm[4 * ty + j][tx]; b.m2 = sq[4 * ty + j][tx];
+        a = agg4_merge(a, b);
+      }
     }
+  }
+  if (ty == 0 && c < C) {
+    const Agg4 r = a;
     const float mu[4] = {r.mean.x, r.mean.y, r.mean.z, r.mean.w};
     const float mo[4] = {r.m2.x, r.m2.y, r.m2.z, r.m2.w};
 #pragma unroll
@@ -452,7 +461,7 @@ static void bn_stats_stage2_launch(const float* part0, const float* part1, const
                                    float* sum, float* m2, const BnFin& fin, hipStream_t stream) {
   const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(part0) | reinterpret_cast<uintptr_t>(part1) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   if (v4)
-    hipLaunchKernelGGL(bn_stats_stage2_v4<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
+    hipLaunchKernelGGL(bn_stats_stage2_v4<TILES>, dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
   else
     hipLaunchKernelGGL(bn_stats_stage2<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
 }

@@ -30,6 +30,7 @@ namespace t2i {
 // ------------------------------------------------------------------------------------------------------------------
 struct FilterEntry {
   const float* w; int kind, Cin, Cout; float* U; size_t bytes; unsigned long long cap; hipStream_t stream; bool valid;
+  hipStream_t cap_fill = nullptr;      // the stream that filled it lazily inside capture `cap`; nullptr = the batched refresh did
 };
 static std::mutex g_fc_mu;
 static std::vector<FilterEntry> g_fc;
@@ -88,13 +89,21 @@ float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t byte
     if (g_fc_used + need > g_fc_cap) return nullptr;          // arena full: this filter is transformed per call
     float* U = reinterpret_cast<float*>(g_fc_buf + g_fc_used);
     g_fc_used += need;
-    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, U, bytes, 0ull, stream, false});
+    g_fc.push_back(FilterEntry{w, kind, Cin, Cout, U, bytes, 0ull, stream, false, nullptr});
     e = &g_fc.back();
   }
   if (e->bytes < bytes) return nullptr;
   if (!cap && e->stream != stream) return nullptr;     // eager use from a second stream: no ordering with the fills / readers
-  if (e->valid && e->cap == cap) { *fill = false; return e->U; }
-  e->valid = true; e->cap = cap;
+  if (e->valid && e->cap == cap) {
+    // inside a capture an image may be read from any stream IF it was filled by the batched refresh at the head of the graph
+    // (cap_fill == nullptr: issued before the streams forked); an image filled lazily by one captured stream has no edge to the
+    // other streams of the capture, so those transform into their own workspace instead (round-2 review: the one-graph
+    // iteration reads the generator's images from the main and from the ahead stream)
+    if (cap && e->cap_fill != nullptr && e->cap_fill != stream) return nullptr;
+    *fill = false;
+    return e->U;
+  }
+  e->valid = true; e->cap = cap; e->cap_fill = stream;
   return e->U;
 }
 
@@ -961,7 +970,7 @@ int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
           it.kind = 6;
           it.U = e.kind == 4 ? e.U : o.U;            // transposed image
           it.U2 = e.kind == 4 ? o.U : e.U;           // plain image
-          o.valid = true; o.cap = cap;
+          o.valid = true; o.cap = cap; o.cap_fill = nullptr;
           break;
         }
     }
@@ -969,7 +978,7 @@ int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream) {
     it.block0 = blocks; it.nblocks = (uint32_t)nb;
     tb.it[tb.n++] = it;
     blocks += (uint32_t)nb;
-    e.valid = true; e.cap = cap;
+    e.valid = true; e.cap = cap; e.cap_fill = nullptr;
     if (tb.n == REFRESH_MAX) flush();
   }
   flush();

@@ -5,7 +5,9 @@ kt and Adam state, sees its own slice of the global batch, and gradients are ave
 replicas at local batch b behave as the reference at BATCH_SIZE = N*b with per-replica batch-norm statistics.  The kt
 step is not a gradient average: balance_loss = (kt*wdist2 - wdist)^2 is quadratic in two batch means, so the ranks
 exchange those means (summed next to the arena as `extra`) and each evaluates the gradient of the GLOBAL-batch loss
-(t2i_kt_sgd); tests/test_dp_gloo.py checks it on distinct per-rank data.
+(t2i_kt_sgd).  tests/test_dp_gloo.py[kt] checks the exchange of the means and the arithmetic on distinct per-rank data (in Python
+floats, not through the kernel); tests/test_kernels_gpu.py checks t2i_kt_sgd itself; the two-rank runs of
+tests/test_dp_exactness_gpu.py go through WGanCls._d_update on identical data.
 
 Exchange step: the gradient arena (optim.Arena.grad, one flat buffer per optimizer) is cut into contiguous buckets in
 REVERSE creation order (the order backward produces them).  Finished parameters are counted — by a post-accumulate
