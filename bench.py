@@ -205,7 +205,12 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     from t2i_amd import kernels as K
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    K.set_storage('f32')
     K.set_math(math)
+    storage = 'f32'
+    if math == 'bf16' and args.storage == 'bf16':
+        K.set_storage('bf16')           # config 3 end to end: activations and their gradients are bf16 tensors between the kernels
+        storage = 'bf16'
     cfg = make_cfg(args.batch)
     dp, grad_dtype = make_dp(math)
     use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
@@ -329,7 +334,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': math, 'data': 'synthetic',
            'config': {'workload': 'wgancls 64x64 batch=%d/GPU ' % args.batch + ('fp32' if math == 'f32' else
-                                  'bf16-MFMA operands / fp32 accumulate + master weights (BASELINE config 3)') + ', synthetic images + random 1024-d text embeddings, '
+                                  'bf16 MFMA, %s activation tensors, fp32 accumulate + master weights (BASELINE config 3)' % ('bf16' if storage == 'bf16' else 'fp32')) + ', synthetic images + random 1024-d text embeddings, '
                                   'D step (+kt) then G step, Adam(b1=0,b2=0.9)',
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                       'gradient_exchange': (grad_dtype + ' buckets over RCCL' + (' (fp32 accumulation)' if grad_dtype == 'bf16' else '')) if use_dp else None,
@@ -402,6 +407,8 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     gc.collect()
     torch.cuda.synchronize()
     K.filter_cache_reset()
+    K.set_storage('f32')
+    K.set_math('f32')
     torch.cuda.empty_cache()
     return out
 
@@ -419,6 +426,9 @@ def main():
     ap.add_argument('--math', choices=['f32', 'bf16'], default='f32',
                     help="conv arithmetic: f32 = BASELINE config 2 (the headline metric); bf16 = config 3 (bf16 MFMA "
                          "operands, fp32 accumulation and fp32 tensors) -- reported with dtype 'bf16', never the default")
+    ap.add_argument('--storage', choices=['f32', 'bf16'], default=os.environ.get('T2I_STORAGE', 'bf16'),
+                    help="with --math bf16 (and for the config3_bf16 block): 'bf16' = activation tensors are bf16 in HBM end to end "
+                         "(ABI v6, default); 'f32' = fp32 tensors with bf16 operand images beside them (round 2)")
     ap.add_argument('--side-stream', type=int, default=int(os.environ.get('T2I_SIDE_STREAM', '0')),
                     help='1: sunk filter gradients run on a second HIP stream, concurrently with the bwd-data chain')
     ap.add_argument('--repeats', type=int, default=3,

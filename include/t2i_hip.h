@@ -45,6 +45,15 @@ extern "C" {
 
 typedef void* t2i_stream_t; /* a hipStream_t */
 
+/* Element type of the ACTIVATION tensors of a call (v6).  T2I_DT_F32: dense fp32, the reference's dtype and the default everywhere.
+ * T2I_DT_BF16: the tensors are bf16 in memory (BASELINE config 3 end to end: activations and activation gradients travel between
+ * kernels as bf16; weights, biases, optimizer state, batch-norm statistics, every reduction result and all accumulators stay
+ * fp32).  Entry points with a `dtype` argument read AND write all their activation tensors in that type (pointers are void* for
+ * that reason); bf16 tensors need 16-byte aligned pointers and a channel / element count that is a multiple of 4, and there is no
+ * separate bf16 twin then (the y_h arguments must be NULL).  Arithmetic is fp32 either way: a bf16 tensor is widened exactly on load
+ * and rounded to nearest even on store. */
+enum { T2I_DT_F32 = 0, T2I_DT_BF16 = 1 };
+
 /* Geometry of one 2-D convolution, already resolved from the TF padding string (SAME/VALID -> pad_t/pad_l, Ho/Wo):
  * y[b,oh,ow,co] = sum_{kh,kw,ci} x[b, oh*SH-pad_t+kh, ow*SW-pad_l+kw, ci] * w[kh,kw,ci,co]. */
 typedef struct t2i_conv_desc {
@@ -63,9 +72,11 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 5 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 6 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
-                                   * and explicit image arguments instead of thread-local one-shot hand-overs) */
+                                   * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
+                                   * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
+                                   * out_dtype) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
@@ -94,7 +105,11 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fw
  *                       per tile, 4x resp. 2.25x the size of x).  T2I_XFORM_KEEP on t2i_conv2d_fwd / _fwd_stats leaves V in
  *                       `xform` (>= t2i_conv2d_input_transform_bytes(d) bytes; xform_kept tells whether the call took a path
  *                       that has one); T2I_XFORM_HAVE on t2i_conv2d_bwd_filter (same d, same unchanged x) reads V from there
- *                       instead of transforming x again. */
+ *                       instead of transforming x again.
+ *   in_dtype, out_dtype bf16 STORAGE: the activation tensors of the call are bf16 in memory.  The bf16-operand GEMMs and the
+ *                       3 -> 128 stem read and write them directly (no cast, no fp32 copy anywhere); the remaining paths (thin /
+ *                       head kernels, the generic kernel for channel counts that are not multiples of 64) run on fp32 staging copies
+ *                       carved from the workspace — t2i_conv2d_workspace_bytes includes the room for them. */
 enum { T2I_XFORM_NONE = 0, T2I_XFORM_KEEP = 1, T2I_XFORM_HAVE = 2 };
 typedef struct t2i_conv_opts {
   const void* a_image;
@@ -105,13 +120,16 @@ typedef struct t2i_conv_opts {
   int32_t xform_mode;
   int32_t out_image_written; /* out */
   int32_t xform_kept;        /* out */
+  int32_t in_dtype;          /* bf16 storage (needs math = T2I_MATH_BF16): bit 0 / bit 1 set = the call's first / second ACTIVATION operand
+                              * (the pointer argument itself) is a bf16 tensor; a_image / b_image are then not consulted for it */
+  int32_t out_dtype;         /* T2I_DT_BF16: the output pointer (y / dx) is a bf16 tensor and is the only thing written */
   int32_t reserved;
 } t2i_conv_opts;
 size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);   /* > 0: fwd and bwd_filter of `d` both take a Winograd path */
 
 /* y = act(conv(x, w) + bias).  bias may be NULL.  Serves ops.conv2d (utils/ops.py:58-63), ops.fc as a 1x1 conv on
  * [B,1,1,in] (utils/ops.py:84-87), and the double-backward term adj_gy = conv(ggx, w) of the gradient penalty. */
-int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+int t2i_conv2d_fwd(const t2i_conv_desc* d, const void* x, const float* w, const float* bias, void* y, int act,
                    float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* t2i_conv2d_fwd that also hands the batch norm behind it its statistics: if the launch takes the unsplit path,
@@ -120,19 +138,19 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const
  * tile_rows, B*Ho*Wo, Cout, sum, m2, ...)); otherwise *chunks = 0 and the caller computes the statistics itself
  * (t2i_bn_stats).  stats must hold t2i_conv2d_stats_bytes(d). */
 size_t t2i_conv2d_stats_bytes(const t2i_conv_desc* d);
-int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const void* x, const float* w, const float* bias, void* y, int act,
                          float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, t2i_conv_opts* opts,
                          void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* dx = conv^T(dy, w) (+ bias over Cin if non-NULL, then act).  This IS ops.conv2d_transpose (utils/ops.py:66-71):
  * TF stores the deconv filter as [KH,KW,Cout_deconv,Cin_deconv], i.e. the HWIO filter of the adjoint conv, so the
  * descriptor is that adjoint conv's (d->Cin = deconv output channels) and no re-layout is needed. */
-int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx,
+int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const void* dy, const float* w, const float* bias, void* dx,
                         int act, float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* dw = x (*) dy over all B*Ho*Wo positions (tf.gradients wrt `weights`, reference models/wgancls/model.py:94-106);
  * accumulate != 0: dw += x (*) dy in the epilogue, i.e. the gradient is summed straight into the optimizer's arena. */
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                           t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
 
 /* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
@@ -140,8 +158,9 @@ size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);
 /* out0[c] = sum_r a[r,c];  out1[c] = sum_r a[r,c]*(b[r,c] - center[c])  (b == NULL -> a*a; center == NULL -> 0;
  * out1 == NULL -> skipped).  Bias gradients (db = colsum(dy)) and the batch-norm backward sums (sum dy, sum dy*(x - mean):
  * centred inside the reduction — sum(dy*x) - mean*sum(dy) would cancel). */
-int t2i_col_reduce(const float* a, const float* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
-                   int accumulate, void* ws, size_t ws_bytes, t2i_stream_t stream); /* accumulate != 0: out += (gradient arena) */
+int t2i_col_reduce(const void* a, const void* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
+                   int accumulate, void* ws, size_t ws_bytes, int32_t dtype /* of a and b */,
+                   t2i_stream_t stream); /* accumulate != 0: out += (gradient arena) */
 
 /* ---- batch norm, training mode: reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm fused, scale=True) --- */
 /* Second stage alone: out0[c] = sum_k part0[k*C + c] (k < chunks, fixed order), same for part1/out1 when given. */
@@ -157,10 +176,10 @@ int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chun
 /* Statistics AND the finalize step in one chain (stage 1 + one stage-2 launch): exactly one of x (the tensor, [rows, C];
  * workspace as t2i_col_reduce) or the tile partials of t2i_conv2d_fwd_stats (part_sum / part_m2 / chunks / tile_rows).
  * Outputs as t2i_bn_finalize.  What the training-mode batch norm of utils/ops.py:7-29 launches in front of t2i_bn_apply. */
-int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
+int t2i_bn_train_fwd_stats(const void* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
                            int32_t C, const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd,
                            float* scale, float* shift, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes,
-                           t2i_stream_t stream);
+                           int32_t dtype /* of x */, t2i_stream_t stream);
 /* From sum and the centred second moment m2 over n rows: mean, rstd = 1/sqrt(m2/n + eps) (biased variance);
  * scale = gamma*rstd, shift = beta-mean*scale; and, if moving_mean != NULL,
  * moving = decay*moving + (1-decay)*{mean, var_biased*n/(n-1)} in place. */
@@ -173,8 +192,8 @@ int t2i_bn_finalize(const float* sum, const float* m2, int64_t n, int32_t C, con
  * tensor next takes as its operand image (t2i_conv_opts.a_image), so that no cast launch is needed.  Requires the vectorised
  * path: every tensor and y_h 16-byte aligned and C % 4 == 0 (n % 4 == 0); otherwise the call fails with T2I_ERR_INVALID
  * instead of silently not writing it. */
-int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act,
-                 float alpha, float* y, void* y_h, t2i_stream_t stream);
+int t2i_bn_apply(const void* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act,
+                 float alpha, void* y, void* y_h, int32_t dtype, t2i_stream_t stream);
 /* dx = gamma*rstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n), xhat = (x-mean)*rstd, sum_dy_xhat = rstd * sum_dy_x with
  * sum_dy_x = sum dy*(x - mean) (t2i_col_reduce / t2i_act_bwd_colsum with center = mean).  Also emits dgamma, dbeta. */
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -186,44 +205,44 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
  * stage 1] -> [stage 2 + dgamma/dbeta + the coefficients of dx] -> [dx = k_dy*g + k_x*x + k_0].  y == NULL: no activation
  * behind the batch norm (g = dy, gmask unused).  gmask: caller's [rows, C] buffer for g.  C % 4 == 0, 16-byte alignment. */
 size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C);
-int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
-                     int32_t C, int act, float alpha, float* gmask, float* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
-                     size_t ws_bytes, t2i_stream_t stream);
+int t2i_bn_bwd_fused(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
+                     int32_t C, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     size_t ws_bytes, int32_t dtype /* of dy, y, x, gmask, dx */, t2i_stream_t stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------------- */
 /* y = act(x) */
-int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream);
+int t2i_act_fwd(const void* x, int64_t n, int act, float alpha, void* y, void* y_h, int32_t dtype, t2i_stream_t stream);
 /* dx = dy * act'(.) with the derivative taken from the OUTPUT y (lrelu/relu are sign preserving, tanh' = 1-y^2). */
-int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, void* dx_h, t2i_stream_t stream);
+int t2i_act_bwd(const void* dy, const void* y, int64_t n, int act, float alpha, void* dx, void* dx_h, int32_t dtype, t2i_stream_t stream);
 /* Fused activation backward + column sums: dx = dy * act'(y), colsum[c] = sum_r dx[r,c] and, if x2 != NULL,
  * colsum_x2[c] = sum_r dx[r,c]*(x2[r,c] - center[c]) (center NULL = 0), in ONE pass over a [rows, C] view (C % 4 == 0,
  * 16-byte aligned).  Serves the bias gradient of a conv layer and the two reductions of the batch-norm backward (x2 = the
  * layer input, center = its batch mean).  accumulate: sums are added to the outputs.  Workspace as t2i_col_reduce. */
-int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
-                       float alpha, float* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
-                       t2i_stream_t stream);
+int t2i_act_bwd_colsum(const void* dy, const void* y, const void* x2, const float* center, int64_t rows, int32_t C, int act,
+                       float alpha, void* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       int32_t dtype, t2i_stream_t stream);
 /* y = act(a + b): residual joins (reference models/wgancls/model.py:145-146, 190-191, 206-207). */
-int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream);
+int t2i_add_act(const void* a, const void* b, int64_t n, int act, float alpha, void* y, void* y_h, int32_t dtype, t2i_stream_t stream);
 /* y = alpha*a + beta*b (b may be NULL). */
-int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream);
+int t2i_axpby(const void* a, float alpha, const void* b, float beta, int64_t n, void* y, int32_t dtype, t2i_stream_t stream);
 /* x_hat[b,:] = eps[b]*g[b,:] + (1-eps[b])*x[b,:]   (reference models/wgancls/model.py:53). */
 int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int64_t per_sample, float* xhat,
                t2i_stream_t stream);
 /* out[b,p,:] = concat(feat[b,p,:Cf], emb[b,:Ce]) for p < P: tile the compressed text embedding over the 4x4 map
  * and concatenate on channels (reference models/wgancls/model.py:153-155).  bwd splits the gradient back. */
-int t2i_concat_tile_fwd(const float* feat, const float* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce,
-                        float* out, t2i_stream_t stream);
-int t2i_concat_tile_bwd(const float* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* dfeat, float* demb,
-                        t2i_stream_t stream);
+int t2i_concat_tile_fwd(const void* feat, const void* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce,
+                        void* out, int32_t dtype, t2i_stream_t stream);
+int t2i_concat_tile_bwd(const void* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, void* dfeat, void* demb,
+                        int32_t dtype, t2i_stream_t stream);
 /* NCHW <-> NHWC physical transposes: reference utils/ops.py:129-134 (to_nchw / to_nhwc) and the dense_2 reshape. */
-int t2i_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream);
-int t2i_nhwc_to_nchw(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream);
+int t2i_nchw_to_nhwc(const void* x, int32_t B, int32_t C, int32_t HW, void* y, int32_t dtype, t2i_stream_t stream);
+int t2i_nhwc_to_nchw(const void* x, int32_t B, int32_t C, int32_t HW, void* y, int32_t dtype, t2i_stream_t stream);
 
 /* ---- gradient penalty: reference models/wgancls/model.py:62-70 -------------------------------------------------- */
 /* slopes[b] = sqrt(sum_j g[b,j]^2); one wavefront-shuffle reduction per sample. */
-int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, t2i_stream_t stream);
+int t2i_gp_slopes(const void* g, int32_t B, int64_t per_sample, float* slopes, int32_t dtype, t2i_stream_t stream);
 /* out[b,:] = coef[b] * g[b,:]  (per-sample scaling: backward of the slope norm, and its own double backward). */
-int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream);
+int t2i_row_scale(const void* g, const float* coef, int32_t B, int64_t per_sample, void* out, int32_t dtype, t2i_stream_t stream);
 
 /* ---- loss heads: reference models/wgancls/model.py:72-92 (critic losses) and :117-127 (conditioning augmentation) --- */
 /* From the critic's 3B logits (fake | real | mismatch, each B) and the two per-sample slope vectors: the loss scalars
@@ -324,6 +343,8 @@ int t2i_filter_cache_refresh(const void* ptr, size_t bytes, t2i_stream_t stream)
  * out[i] = bf16(x[i]), round to nearest even; n % 8 == 0, both buffers 16-byte aligned.  The image of an activation tensor
  * is handed to the convs that read it through t2i_conv_opts.a_image / b_image. */
 int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream);
+/* out[i] = float(x[i]) for a bf16 tensor x (exact widening; any n and alignment): a bf16 activation handed to fp32 code. */
+int t2i_cast_f32(const void* x_bf16, int64_t n, float* out, t2i_stream_t stream);
 /* 0 for an eager stream, else a number unique to the capture active on `stream`: a caller that keeps bf16 images (or any
  * derived buffer) across calls must not let a capture reuse one made outside it — the graph would not contain its producer. */
 uint64_t t2i_capture_id(t2i_stream_t stream);

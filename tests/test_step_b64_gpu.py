@@ -207,9 +207,12 @@ def test_b64_generator_step_mask_pinned(setup):
             _check_grad_kinks(m.g_arena.grad_of(n), free['grads'][n].numpy(), n, 0.0)
 
 
-def test_b64_bf16_steps_mask_pinned(setup):
-    """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate, fp32 tensors and master weights) at the metric's
-    own size, mask-pinned like the fp32 tests above.  At bf16 the forward differs from float64 by ~1e-2, which flips ~0.4 % of
+@pytest.mark.parametrize('storage', ['f32', 'bf16'])
+def test_b64_bf16_steps_mask_pinned(setup, storage):
+    """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate, master weights in fp32) at the metric's own size,
+    mask-pinned like the fp32 tests above; storage = 'f32': fp32 activation tensors with bf16 operand images (round 2),
+    'bf16': bf16 activation tensors end to end (ABI v6 — every activation and activation gradient with a multiple of 64 channels is
+    rounded once more, where its producer stores it; measured values for both in brackets below).  At bf16 the forward differs from float64 by ~1e-2, which flips ~0.4 % of
     the lrelu branches per layer; un-pinned, those flips dominate every gradient comparison (tests/test_step_gpu.py can only
     ask for a cosine there).  With the oracle replaying the HIP run's branches both sides differentiate the same
     piecewise-linear function, and what is left is the operand rounding itself: every product carries 2^-8 relative error with
@@ -235,6 +238,7 @@ def test_b64_bf16_steps_mask_pinned(setup):
         if not err <= tol:
             bad.append((name, err, tol))
     K.set_math('bf16')
+    K.set_storage(storage)
     try:
         rec = []
         with record_branches(rec):
@@ -273,5 +277,6 @@ def test_b64_bf16_steps_mask_pinned(setup):
                 continue
             chk('grad ' + n, rel_l2(m.g_arena.grad_of(n), r), 1.2e-1)
     finally:
+        K.set_storage('f32')
         K.set_math('f32')
     assert not bad, bad

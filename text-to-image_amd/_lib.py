@@ -17,10 +17,11 @@ class ConvOpts(ctypes.Structure):
     """t2i_conv_opts: optional side inputs / outputs of one conv call (include/t2i_hip.h)"""
     _fields_ = [('a_image', ctypes.c_void_p), ('b_image', ctypes.c_void_p), ('out_image', ctypes.c_void_p), ('xform', ctypes.c_void_p),
                 ('xform_bytes', ctypes.c_size_t), ('xform_mode', ctypes.c_int32), ('out_image_written', ctypes.c_int32),
-                ('xform_kept', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('xform_kept', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 XFORM_NONE, XFORM_KEEP, XFORM_HAVE = 0, 1, 2
+DT_F32, DT_BF16 = 0, 1           # t2i_dtype: element type of the activation tensors of a call
 
 _p = ctypes.c_void_p
 _i32, _i64, _f, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
@@ -37,27 +38,27 @@ SIGNATURES = {
     't2i_conv2d_bwd_data': (ctypes.c_int, [_dp, _p, _p, _p, _p, ctypes.c_int, _f, _op, _p, _sz, _p]),
     't2i_conv2d_bwd_filter': (ctypes.c_int, [_dp, _p, _p, _p, ctypes.c_int, _op, _p, _sz, _p]),
     't2i_col_reduce_workspace_bytes': (_sz, [_i64, _i32]),
-    't2i_col_reduce': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_col_reduce': (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, ctypes.c_int, _p, _sz, _i32, _p]),
     't2i_bn_stats': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
     't2i_bn_stats_tiles': (ctypes.c_int, [_p, _p, _i32, _i32, _i64, _i32, _p, _p, _p]),
-    't2i_bn_train_fwd_stats': (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    't2i_bn_train_fwd_stats': (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
     't2i_bn_bwd_fused_workspace_bytes': (_sz, [_i64, _i32]),
-    't2i_bn_bwd_fused': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
+    't2i_bn_bwd_fused': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _i32, _p]),
     't2i_bn_finalize': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p]),
+    't2i_bn_apply': (ctypes.c_int, [_p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _i32, _p]),
     't2i_bn_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
-    't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p, _p]),
-    't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _p]),
-    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _p]),
-    't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _p]),
-    't2i_axpby': (ctypes.c_int, [_p, _f, _p, _f, _i64, _p, _p]),
+    't2i_act_fwd': (ctypes.c_int, [_p, _i64, ctypes.c_int, _f, _p, _p, _i32, _p]),
+    't2i_act_bwd': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _i32, _p]),
+    't2i_act_bwd_colsum': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, ctypes.c_int, _f, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _i32, _p]),
+    't2i_add_act': (ctypes.c_int, [_p, _p, _i64, ctypes.c_int, _f, _p, _p, _i32, _p]),
+    't2i_axpby': (ctypes.c_int, [_p, _f, _p, _f, _i64, _p, _i32, _p]),
     't2i_interp': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
-    't2i_concat_tile_fwd': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
-    't2i_concat_tile_bwd': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p]),
-    't2i_nchw_to_nhwc': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
-    't2i_nhwc_to_nchw': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
-    't2i_gp_slopes': (ctypes.c_int, [_p, _i32, _i64, _p, _p]),
-    't2i_row_scale': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _p]),
+    't2i_concat_tile_fwd': (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    't2i_concat_tile_bwd': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    't2i_nchw_to_nhwc': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
+    't2i_nhwc_to_nchw': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
+    't2i_gp_slopes': (ctypes.c_int, [_p, _i32, _i64, _p, _i32, _p]),
+    't2i_row_scale': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _i32, _p]),
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),
     't2i_filter_cache_refresh': (ctypes.c_int, [_p, _sz, _p]),
     't2i_cast_bf16': (ctypes.c_int, [_p, _i64, _p, _p]),
+    't2i_cast_f32': (ctypes.c_int, [_p, _i64, _p, _p]),
     't2i_conv2d_input_transform_bytes': (ctypes.c_size_t, [_dp]),
     't2i_capture_id': (ctypes.c_uint64, [_p]),
     't2i_conv2d_stats_bytes': (ctypes.c_size_t, [_dp]),

@@ -156,27 +156,29 @@ class ColSumFn(Function):
 
     @staticmethod
     def forward(ctx, a):
-        ctx.shape = a.shape
+        ctx.shape, ctx.dtype = a.shape, a.dtype
         return K.col_reduce(_c(a))[0]
 
     @staticmethod
     def backward(ctx, g):
-        return g.expand(ctx.shape)
+        return g.to(ctx.dtype).expand(ctx.shape)
 
 
 class Conv2dFn(Function):
     """y = act(conv(x, w) + b): reference utils/ops.py:58-63.  geom = (ConvDesc, workspace_bytes)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, geom, act, alpha, want_stats=False):
+    def forward(ctx, x, w, b, geom, act, alpha, want_stats=False, out_dtype=None):
+        """out_dtype: None = the storage mode's rule (kernels._act_dtype); a gradient piece passes the dtype of the tensor it is the
+        gradient of, so that autograd never has to cast (bf16 storage)."""
         d, ws = geom
         x = _c(x)
         ctx.set_materialize_grads(False)   # an undefined upstream gradient must not become a zero-filled conv launch
         # want_stats: a batch norm consumes this output next; the GEMM epilogue leaves it the per-tile column sums
         # the filter gradient of this layer transforms the same x (fp32 Winograd): keep the transform if a gradient will be asked for
         keep = bool(ctx.needs_input_grad[1]) and not _INPUTS_ONLY[0]
-        y = (K.conv_fwd_stats(x, w, b, d, ws, act, alpha, keep_xform=keep) if want_stats
-             else K.conv_fwd(x, w, b, d, ws, act, alpha, keep_xform=keep))
+        y = (K.conv_fwd_stats(x, w, b, d, ws, act, alpha, keep_xform=keep, out_dtype=out_dtype) if want_stats
+             else K.conv_fwd(x, w, b, d, ws, act, alpha, keep_xform=keep, out_dtype=out_dtype))
         ctx.xform = K.LAST_XFORM[0] if keep else None
         K.LAST_XFORM[0] = None
         ctx.save_for_backward(x, w, y if act != K.ACT_NONE else None)
@@ -187,7 +189,7 @@ class Conv2dFn(Function):
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
         params = not _INPUTS_ONLY[0]
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and params
@@ -206,10 +208,10 @@ class Conv2dFn(Function):
                 _notify(ctx.bias_ref)
             elif want_b:
                 gb = ColSumFn.apply(gpre)
-        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
         gw = _filter_grad(x, gpre, ctx.geom, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
         ctx.xform = None
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class ConvBwdDataFn(Function):
@@ -217,11 +219,11 @@ class ConvBwdDataFn(Function):
     tf conv2d_transpose (reference utils/ops.py:66-71) — same kernel, TF deconv filters are already HWIO of the adjoint."""
 
     @staticmethod
-    def forward(ctx, dy, w, b, geom, act, alpha):
+    def forward(ctx, dy, w, b, geom, act, alpha, out_dtype=None):
         d, ws = geom
         dy = _c(dy)
         ctx.set_materialize_grads(False)
-        out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha)
+        out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha, out_dtype=out_dtype)
         ctx.save_for_backward(dy, w, out if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
         ctx.bias_ref = b
@@ -230,11 +232,11 @@ class ConvBwdDataFn(Function):
     @staticmethod
     def backward(ctx, gg):
         if gg is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dy, w, out = ctx.saved_tensors
         gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
         params = not _INPUTS_ONLY[0]
-        g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
         g_w = _filter_grad(gpre, dy, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
         g_b = None
         if ctx.has_bias and ctx.needs_input_grad[2] and params:
@@ -244,7 +246,7 @@ class ConvBwdDataFn(Function):
                 _notify(ctx.bias_ref)
             else:
                 g_b = ColSumFn.apply(gpre)
-        return g_dy, g_w, g_b, None, None, None
+        return g_dy, g_w, g_b, None, None, None, None
 
 
 class ConvBwdFilterFn(Function):
@@ -262,8 +264,8 @@ class ConvBwdFilterFn(Function):
     def backward(ctx, ggw):
         x, dy = ctx.saved_tensors
         ggw = _c(ggw)
-        g_x = ConvBwdDataFn.apply(dy, ggw, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
-        g_dy = Conv2dFn.apply(x, ggw, None, ctx.geom, K.ACT_NONE, 0.0) if ctx.needs_input_grad[1] else None
+        g_x = ConvBwdDataFn.apply(dy, ggw, None, ctx.geom, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
+        g_dy = Conv2dFn.apply(x, ggw, None, ctx.geom, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[1] else None
         return g_x, g_dy, None
 
 

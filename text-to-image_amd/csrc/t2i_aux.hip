@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "t2i_internal.h"
 
 namespace t2i {
@@ -136,11 +138,34 @@ __global__ __launch_bounds__(256) void col_reduce_stage2(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 STORAGE (BASELINE config 3, ABI v6): activation tensors may live in HBM as bf16 (t2i_dtype T2I_DT_BF16).  The vectorised
+// kernels below are templated on H = "the activation inputs are bf16" and take every activation OUTPUT as a pair
+// (fp32 pointer, bf16 pointer), either of which may be NULL: fp32 only (the fp32 path), both (fp32 tensor + bf16 twin, the
+// round-2 "operand image" mode) or bf16 only (bf16 storage).  All arithmetic, statistics and partial sums stay fp32.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned aux_pk2(float lo, float hi);
+template <bool H>
+__device__ __forceinline__ float4 ld4(const void* p, size_t i4) {        // 4 consecutive elements starting at element 4 * i4
+  if (H) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+  }
+  return reinterpret_cast<const float4*>(p)[i4];
+}
+__device__ __forceinline__ void st4(float* y, void* yh, size_t i4, const float4 v);
+template <bool H>
+__device__ __forceinline__ float ld1(const void* p, size_t i) {
+  if (H) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+  return reinterpret_cast<const float*>(p)[i];
+}
+
 // 16-byte variants (C % 4 == 0, 16-byte aligned operands): a lane owns 4 adjacent columns, 16 lanes = 64 columns, 16 row
 // lanes per workgroup; the row loop is unrolled so that several independent 16-byte loads are in flight per lane.
 // (The scalar stage 1 above streamed 67 MB at 1.5 TB/s; this one is bound by HBM like the other elementwise kernels.)
-template <bool WANT1, bool HAS_B>
-__global__ __launch_bounds__(256) void col_reduce_stage1_v4(const float* __restrict__ a, const float* __restrict__ b,
+template <bool WANT1, bool HAS_B, bool H = false>
+__global__ __launch_bounds__(256) void col_reduce_stage1_v4(const void* __restrict__ a, const void* __restrict__ b,
                                                             int64_t rows, int C, int64_t rows_per_chunk,
                                                             float* __restrict__ part0, float* __restrict__ part1, int shift,
                                                             const float* __restrict__ center) {
@@ -153,16 +178,16 @@ __global__ __launch_bounds__(256) void col_reduce_stage1_v4(const float* __restr
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
-    const float4 sh = shift ? *reinterpret_cast<const float4*>(a + rbeg * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 sh = shift ? ld4<H>(a, (size_t)(rbeg * C + c) >> 2) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 ce = (HAS_B && center) ? *reinterpret_cast<const float4*>(center + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
-      float4 v = *reinterpret_cast<const float4*>(a + r * C + c);
+      float4 v = ld4<H>(a, (size_t)(r * C + c) >> 2);
       v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       if (WANT1) {
         float4 w = v;
-        if (HAS_B) { w = *reinterpret_cast<const float4*>(b + r * C + c); w.x -= ce.x; w.y -= ce.y; w.z -= ce.z; w.w -= ce.w; }
+        if (HAS_B) { w = ld4<H>(b, (size_t)(r * C + c) >> 2); w.x -= ce.x; w.y -= ce.y; w.z -= ce.z; w.w -= ce.w; }
         acc1.x += v.x * w.x; acc1.y += v.y * w.y; acc1.z += v.z * w.z; acc1.w += v.w * w.w;
       }
     }
@@ -251,17 +276,26 @@ size_t col_reduce_ws(int64_t rows, int C) {
 }
 
 // stage 1 of a column reduction into the workspace partials; shared by col_reduce_launch and bn_stats_launch
-static void col_reduce_stage1_launch(const float* a, const float* b, int64_t rows, int C, bool want1, int shift, const float* center,
-                                     int ct, int nc, int64_t rpc, float* part0, float* part1, hipStream_t stream) {
+static void col_reduce_stage1_launch(const void* av, const void* bv, int64_t rows, int C, bool want1, int shift, const float* center,
+                                     int ct, int nc, int64_t rpc, float* part0, float* part1, hipStream_t stream, bool in_bf16 = false) {
+  const float* a = reinterpret_cast<const float*>(av);
+  const float* b = reinterpret_cast<const float*>(bv);
   const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(part0) |
                                      reinterpret_cast<uintptr_t>(center)) & 15) == 0;
-  if (v4) {
+  if (in_bf16) {                 // bf16 storage: the C API guarantees C % 4 == 0 and alignment
     if (!want1)
-      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
-    else if (b)
-      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
+      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false, true>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
+    else if (bv)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, true>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
     else
-      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false>), dim3(ct, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, shift, center);
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, true>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
+  } else if (v4) {
+    if (!want1)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<false, false, false>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
+    else if (b)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, false>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
+    else
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, nc), dim3(256), 0, stream, av, bv, rows, C, rpc, part0, part1, shift, center);
   } else if (C <= 4) {
     hipLaunchKernelGGL(col_reduce_stage1_small, dim3(1, nc), dim3(256), 0, stream, a, b, rows, C, rpc, part0, part1, want1, shift, center);
   } else {
@@ -269,13 +303,13 @@ static void col_reduce_stage1_launch(const float* a, const float* b, int64_t row
   }
 }
 
-hipError_t col_reduce_launch(const float* a, const float* b, const float* center, int64_t rows, int C, float* out0, float* out1,
-                             int accumulate, void* ws, hipStream_t stream) {
+hipError_t col_reduce_launch(const void* a, const void* b, const float* center, int64_t rows, int C, float* out0, float* out1,
+                             int accumulate, void* ws, hipStream_t stream, bool in_bf16) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
-  col_reduce_stage1_launch(a, b, rows, C, out1 != nullptr, 0, center, ct, nc, rpc, part0, part1, stream);
+  col_reduce_stage1_launch(a, b, rows, C, out1 != nullptr, 0, center, ct, nc, rpc, part0, part1, stream, in_bf16);
   const bool v4 = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
   if (v4)
     hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part0, (const float*)(out1 ? part1 : nullptr), nc, C,
@@ -394,9 +428,9 @@ __device__ __forceinline__ Agg4 agg4_merge(const Agg4& a, const Agg4& b) {
 // aggregates are merged 4 : 1 three times through LDS — a dependent chain of ~12 Chan merges (each a division) instead of the 28 of
 // the first version (16 chunk lanes x 12 chunks, then 16 serial merges by one thread: 13 us per launch, 20 launches per iteration).
 // The merge order is fixed, so results are repeatable; they differ from the first version's in the last bits.
-template <bool TILES>
+template <bool TILES, bool H = false>
 __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restrict__ part0, const float* __restrict__ part1,
-                                                          const float* __restrict__ x, int nchunks, int64_t rows,
+                                                          const void* __restrict__ x, int nchunks, int64_t rows,
                                                           int64_t rows_per_chunk, int C, float* __restrict__ sum, float* __restrict__ m2,
                                                           BnFin fin) {
   __shared__ float sn[64][4];
@@ -419,7 +453,7 @@ __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restric
         b.mean = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
         b.m2 = p1;
       } else {
-        const float4 s = *reinterpret_cast<const float4*>(x + rbeg * C + c);
+        const float4 s = ld4<H>(x, (size_t)(rbeg * C + c) >> 2);
         const float4 d = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
         b.mean = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
         b.m2 = make_float4(fmaxf(p1.x - p0.x * d.x, 0.f), fmaxf(p1.y - p0.y * d.y, 0.f), fmaxf(p1.z - p0.z * d.z, 0.f),
@@ -457,11 +491,14 @@ __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restric
 }
 
 template <bool TILES>
-static void bn_stats_stage2_launch(const float* part0, const float* part1, const float* x, int nc, int64_t rows, int64_t rpc, int C,
-                                   float* sum, float* m2, const BnFin& fin, hipStream_t stream) {
+static void bn_stats_stage2_launch(const float* part0, const float* part1, const void* xv, int nc, int64_t rows, int64_t rpc, int C,
+                                   float* sum, float* m2, const BnFin& fin, hipStream_t stream, bool x_bf16 = false) {
+  const float* x = reinterpret_cast<const float*>(xv);
   const bool v4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(part0) | reinterpret_cast<uintptr_t>(part1) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-  if (v4)
-    hipLaunchKernelGGL(bn_stats_stage2_v4<TILES>, dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
+  if (x_bf16)
+    hipLaunchKernelGGL((bn_stats_stage2_v4<TILES, true>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, xv, nc, rows, rpc, C, sum, m2, fin);
+  else if (v4)
+    hipLaunchKernelGGL((bn_stats_stage2_v4<TILES, false>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, xv, nc, rows, rpc, C, sum, m2, fin);
   else
     hipLaunchKernelGGL(bn_stats_stage2<TILES>, dim3((C + 63) / 64), dim3(256), 0, stream, part0, part1, x, nc, rows, rpc, C, sum, m2, fin);
 }
@@ -475,16 +512,16 @@ static BnFin make_fin(const float* gamma, const float* beta, float eps, float de
 }
 
 // gamma == nullptr: statistics only (sum, m2); else the batch norm's mean / rstd / scale / shift (+ moving averages) as well
-hipError_t bn_stats_launch(const float* x, int64_t rows, int C, float* sum, float* m2, const float* gamma, const float* beta, float eps,
+hipError_t bn_stats_launch(const void* x, int64_t rows, int C, float* sum, float* m2, const float* gamma, const float* beta, float eps,
                            float decay, float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, void* ws,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool x_bf16) {
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part0 = reinterpret_cast<float*>(ws);
   float* part1 = part0 + (size_t)nc * C;
-  col_reduce_stage1_launch(x, nullptr, rows, C, true, 1, nullptr, ct, nc, rpc, part0, part1, stream);
+  col_reduce_stage1_launch(x, nullptr, rows, C, true, 1, nullptr, ct, nc, rpc, part0, part1, stream, x_bf16);
   bn_stats_stage2_launch<false>(part0, part1, x, nc, rows, rpc, C, sum, m2, make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv),
-                                stream);
+                                stream, x_bf16);
   return hipGetLastError();
 }
 
@@ -528,24 +565,28 @@ __device__ __forceinline__ unsigned aux_pk2(float lo, float hi) {
   f2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
 }
+__device__ __forceinline__ void st4(float* y, void* yh, size_t i4, const float4 v) {     // fp32 and / or bf16 (RNE) copy of 4 elements
+  if (y) reinterpret_cast<float4*>(y)[i4] = v;
+  if (yh) reinterpret_cast<uint2*>(yh)[i4] = make_uint2(aux_pk2(v.x, v.y), aux_pk2(v.z, v.w));
+}
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool VEC, bool H = false>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ xv, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, size_t n, int C, int act,
                                                        float alpha, float* __restrict__ y, uint2* __restrict__ yh) {
+  const float* x = reinterpret_cast<const float*>(xv);
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
       const int c = (int)((i * 4) % (size_t)C);
-      float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 v = ld4<H>(xv, i);
       const float4 sc = *reinterpret_cast<const float4*>(scale + c);
       const float4 sh = *reinterpret_cast<const float4*>(shift + c);
       v.x = apply_act(v.x * sc.x + sh.x, act, alpha);
       v.y = apply_act(v.y * sc.y + sh.y, act, alpha);
       v.z = apply_act(v.z * sc.z + sh.z, act, alpha);
       v.w = apply_act(v.w * sc.w + sh.w, act, alpha);
-      reinterpret_cast<float4*>(y)[i] = v;
-      if (yh) yh[i] = make_uint2(aux_pk2(v.x, v.y), aux_pk2(v.z, v.w));
+      st4(y, yh, i, v);
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -619,17 +660,20 @@ __global__ __launch_bounds__(256) void bn_bwd_stage2_coef_v4(const float* __rest
   }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// HD / HX: dy resp. x is bf16 (in bf16 storage the masked gradient g of bn_bwd_fused is a bf16 tensor like everything else)
+template <bool VEC, bool HD = false, bool HX = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dyv, const void* __restrict__ xv,
                                                            const float* __restrict__ k_dy, const float* __restrict__ k_x,
                                                            const float* __restrict__ k_0, size_t n, int C,
                                                            float* __restrict__ dx, uint2* __restrict__ dxh) {
+  const float* dy = reinterpret_cast<const float*>(dyv);
+  const float* x = reinterpret_cast<const float*>(xv);
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
       const int c = (int)((i * 4) % (size_t)C);
-      const float4 d = reinterpret_cast<const float4*>(dy)[i];
-      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 d = ld4<HD>(dyv, i);
+      const float4 v = ld4<HX>(xv, i);
       const float4 a = *reinterpret_cast<const float4*>(k_dy + c);
       const float4 b = *reinterpret_cast<const float4*>(k_x + c);
       const float4 e = *reinterpret_cast<const float4*>(k_0 + c);
@@ -638,8 +682,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o.y = a.y * d.y + b.y * v.y + e.y;
       o.z = a.z * d.z + b.z * v.z + e.z;
       o.w = a.w * d.w + b.w * v.w + e.w;
-      reinterpret_cast<float4*>(dx)[i] = o;
-      if (dxh) dxh[i] = make_uint2(aux_pk2(o.x, o.y), aux_pk2(o.z, o.w));
+      st4(dx, dxh, i, o);
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -657,16 +700,19 @@ hipError_t bn_finalize_launch(const float* sum, const float* sumsq, int64_t n, i
   return hipGetLastError();
 }
 
-hipError_t bn_apply_launch(const float* x, const float* scale, const float* shift, int64_t rows, int C, int act,
-                           float alpha, float* y, hipStream_t stream, void* y_h) {
+hipError_t bn_apply_launch(const void* x, const float* scale, const float* shift, int64_t rows, int C, int act,
+                           float alpha, float* y, hipStream_t stream, void* y_h, bool x_bf16) {
   const bool al = C > 0;          // the C API passes -C when some pointer is not 16-byte aligned
   if (C < 0) C = -C;
   const size_t n = (size_t)rows * C;
-  if (al && (C & 3) == 0)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act,
+  if (x_bf16)                     // bf16 storage (the C API has checked alignment and C % 4)
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act,
+                       alpha, y, reinterpret_cast<uint2*>(y_h));
+  else if (al && (C & 3) == 0)
+    hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act,
                        alpha, y, reinterpret_cast<uint2*>(y_h));
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, x, scale, shift, n, C, act,
+    hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(ew_blocks(n)), dim3(256), 0, stream, x, scale, shift, n, C, act,
                        alpha, y, (uint2*)nullptr);
   return hipGetLastError();
 }
@@ -682,10 +728,10 @@ hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, con
                      sum_dy_x, (float)rows, C, dgamma, dbeta, k_dy, k_x, k_0, accumulate);
   const size_t n = (size_t)rows * C;
   if (al && (C & 3) == 0)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0,
                        n, C, dx, (uint2*)nullptr);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0, n,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false>), dim3(ew_blocks(n)), dim3(256), 0, stream, dy, x, k_dy, k_x, k_0, n,
                        C, dx, (uint2*)nullptr);
   return hipGetLastError();
 }
@@ -693,9 +739,9 @@ hipError_t bn_bwd_launch(const float* dy, const float* x, const float* mean, con
 // Whole batch-norm backward in three launches (C % 4 == 0, 16-byte aligned): [activation backward + the two reductions,
 // stage 1] -> [stage 2 + coefficients] -> [dx].  y == nullptr: no activation in front (gy is used as it is).  gmask: the
 // masked gradient dy*act'(y), written by stage 1 and read by the last launch (caller's buffer, may alias nothing else).
-hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
-                               int64_t rows, int C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta,
-                               int accumulate, void* ws, hipStream_t stream);
+hipError_t bn_bwd_fused_launch(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               int64_t rows, int C, int act, float alpha, void* gmask, float* dx, float* dgamma, float* dbeta,
+                               int accumulate, void* ws, hipStream_t stream, void* dx_h, bool in_bf16);
 
 // ---------------------------------------------------------------------------------------------------------------
 // elementwise (float4 body + scalar tail handled by the same kernel)
@@ -719,32 +765,34 @@ __device__ __forceinline__ float ew_op(float a, float b, int act, float alpha, f
   return alpha * a + beta * b;                                            // EW_AXPBY
 }
 
-template <int OP, bool HAS_B>
-__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+template <int OP, bool HAS_B, bool H = false>
+__global__ __launch_bounds__(256) void ew_kernel(const void* __restrict__ av, const void* __restrict__ bv, size_t n,
                                                  size_t n4, int act, float alpha, float beta, float* __restrict__ y,
                                                  uint2* __restrict__ yh) {
+  const float* a = reinterpret_cast<const float*>(av);
+  const float* b = reinterpret_cast<const float*>(bv);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (size_t i = t; i < n4; i += stride) {
-    const float4 va = reinterpret_cast<const float4*>(a)[i];
+    const float4 va = ld4<H>(av, i);
     float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (HAS_B) vb = reinterpret_cast<const float4*>(b)[i];
+    if (HAS_B) vb = ld4<H>(bv, i);
     float4 o;
     o.x = ew_op<OP>(va.x, vb.x, act, alpha, beta);
     o.y = ew_op<OP>(va.y, vb.y, act, alpha, beta);
     o.z = ew_op<OP>(va.z, vb.z, act, alpha, beta);
     o.w = ew_op<OP>(va.w, vb.w, act, alpha, beta);
-    reinterpret_cast<float4*>(y)[i] = o;
-    if (yh) yh[i] = make_uint2(aux_pk2(o.x, o.y), aux_pk2(o.z, o.w));
+    st4(y, yh, i, o);
   }
-  for (size_t i = (n4 << 2) + t; i < n; i += stride) y[i] = ew_op<OP>(a[i], HAS_B ? b[i] : 0.f, act, alpha, beta);
+  if (!H)      // scalar tail: fp32 tensors only (bf16 storage requires n % 4 == 0)
+    for (size_t i = (n4 << 2) + t; i < n; i += stride) y[i] = ew_op<OP>(a[i], HAS_B ? b[i] : 0.f, act, alpha, beta);
 }
 
 // fused: dx = dy * act'(y)  AND  colsum[c] = sum_r dx[r,c]  — the activation backward and the bias gradient of a conv layer
 // read the same tensor; one pass instead of two (float4 per lane, 16 lanes = 64 columns, 16 row lanes per workgroup).
-template <bool SECOND>   // SECOND: also part1[c] = sum_r dx[r,c] * x2[r,c]  (batch-norm backward needs sum dy and sum dy*x)
-__global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ x2, const float* __restrict__ center,
+template <bool SECOND, bool H = false>   // SECOND: also part1[c] = sum_r dx[r,c] * x2[r,c]  (batch-norm backward needs sum dy and sum dy*x)
+__global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const void* __restrict__ dy, const void* __restrict__ y,
+                                                             const void* __restrict__ x2, const float* __restrict__ center,
                                                              int64_t rows, int C, int64_t rows_per_chunk, int act, float alpha,
                                                              float* __restrict__ dx, float* __restrict__ part,
                                                              float* __restrict__ part1, unsigned short* __restrict__ dxh) {
@@ -760,16 +808,16 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
     const float4 ce = (SECOND && center) ? *reinterpret_cast<const float4*>(center + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
     for (int64_t r = rbeg + ty; r < rend; r += 16) {
-      const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
-      const float4 o = *reinterpret_cast<const float4*>(y + r * C + c);
+      const size_t e4 = (size_t)(r * C + c) >> 2;
+      const float4 g = ld4<H>(dy, e4);
+      const float4 o = ld4<H>(y, e4);
       float4 d;
       d.x = g.x * act_grad_from_output(o.x, act, alpha); d.y = g.y * act_grad_from_output(o.y, act, alpha);
       d.z = g.z * act_grad_from_output(o.z, act, alpha); d.w = g.w * act_grad_from_output(o.w, act, alpha);
-      *reinterpret_cast<float4*>(dx + r * C + c) = d;
-      if (dxh) *reinterpret_cast<uint2*>(dxh + r * C + c) = make_uint2(aux_pk2(d.x, d.y), aux_pk2(d.z, d.w));
+      st4(dx, dxh, e4, d);
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
       if (SECOND) {
-        const float4 v = *reinterpret_cast<const float4*>(x2 + r * C + c);
+        const float4 v = ld4<H>(x2, e4);
         acc1.x += d.x * (v.x - ce.x); acc1.y += d.y * (v.y - ce.y); acc1.z += d.z * (v.z - ce.z); acc1.w += d.w * (v.w - ce.w);
       }
     }
@@ -791,66 +839,90 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const float* __rest
   }
 }
 
-hipError_t act_bwd_colsum_launch(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int C, int act,
-                                 float alpha, float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream, void* dx_h) {
+hipError_t act_bwd_colsum_launch(const void* dy, const void* y, const void* x2, const float* center, int64_t rows, int C, int act,
+                                 float alpha, float* dx, float* sum0, float* sum1, int accumulate, void* ws, hipStream_t stream, void* dx_h,
+                                 bool in_bf16) {
   unsigned short* dxh = reinterpret_cast<unsigned short*>(dx_h);
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
   float* part1 = part + (size_t)nc * C;
   const bool second = x2 != nullptr && sum1 != nullptr;
-  if (second)
-    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
+  if (second && in_bf16)
+    hipLaunchKernelGGL((act_bwd_colsum_stage1<true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
+                       dx, part, part1, dxh);
+  else if (second)
+    hipLaunchKernelGGL((act_bwd_colsum_stage1<true, false>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
+                       dx, part, part1, dxh);
+  else if (in_bf16)
+    hipLaunchKernelGGL((act_bwd_colsum_stage1<false, true>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
                        dx, part, part1, dxh);
   else
-    hipLaunchKernelGGL(act_bwd_colsum_stage1<false>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
+    hipLaunchKernelGGL((act_bwd_colsum_stage1<false, false>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x2, center, rows, C, rpc, act, alpha,
                        dx, part, part1, dxh);
   hipLaunchKernelGGL(col_reduce_stage2_v4, dim3(ct), dim3(256), 0, stream, part, (const float*)(second ? part1 : nullptr), nc, C,
                      sum0, second ? sum1 : (float*)nullptr, accumulate);
   return hipGetLastError();
 }
 
-hipError_t bn_bwd_fused_launch(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
-                               int64_t rows, int C, int act, float alpha, float* gmask, float* dx, float* dgamma, float* dbeta,
-                               int accumulate, void* ws, hipStream_t stream, void* dx_h) {
+hipError_t bn_bwd_fused_launch(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               int64_t rows, int C, int act, float alpha, void* gmask, float* dx, float* dgamma, float* dbeta,
+                               int accumulate, void* ws, hipStream_t stream, void* dx_h, bool in_bf16) {
+  // in_bf16 (bf16 storage): dy, y, x and the masked-gradient buffer gmask are bf16 tensors; dx is then written as bf16 only (dx NULL)
   int ct, nc; int64_t rpc;
   col_reduce_plan(rows, C, &ct, &nc, &rpc);
   float* part = reinterpret_cast<float*>(ws);
   float* part1 = part + (size_t)nc * C;
   float* coef = part1 + (size_t)nc * C;              // 3*C floats behind the partials
-  const float* g = dy;
+  const void* g = dy;
   if (y) {
-    hipLaunchKernelGGL(act_bwd_colsum_stage1<true>, dim3(ct, nc), dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha, gmask, part,
-                       part1, (unsigned short*)nullptr);
+    if (in_bf16)
+      hipLaunchKernelGGL((act_bwd_colsum_stage1<true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha,
+                         (float*)nullptr, part, part1, reinterpret_cast<unsigned short*>(gmask));
+    else
+      hipLaunchKernelGGL((act_bwd_colsum_stage1<true, false>), dim3(ct, nc), dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha,
+                         reinterpret_cast<float*>(gmask), part, part1, (unsigned short*)nullptr);
     g = gmask;
+  } else if (in_bf16) {
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean);
   } else {
-    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true>), dim3(ct, nc), dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean);
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, false>), dim3(ct, nc), dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean);
   }
   float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
   hipLaunchKernelGGL(bn_bwd_stage2_coef_v4, dim3(ct), dim3(256), 0, stream, part, part1, nc, C, mean, rstd, gamma, (float)rows, dgamma, dbeta,
                      k_dy, k_x, k_0, accumulate);
   const size_t n = (size_t)rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
-                     reinterpret_cast<uint2*>(dx_h));
+  if (in_bf16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
+                       reinterpret_cast<uint2*>(dx_h));
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
+                       reinterpret_cast<uint2*>(dx_h));
   return hipGetLastError();
 }
 
-hipError_t ew_launch(int op, const float* a, const float* b, size_t n_flag, int act, float alpha, float beta, float* y,
-                     hipStream_t stream, void* y_h) {
-  uint2* yh = reinterpret_cast<uint2*>(y_h);          // bf16 twin of y (only with the float4 body: n % 4 == 0, aligned)
+hipError_t ew_launch(int op, const void* a, const void* b, size_t n_flag, int act, float alpha, float beta, float* y,
+                     hipStream_t stream, void* y_h, bool in_bf16) {
+  uint2* yh = reinterpret_cast<uint2*>(y_h);          // bf16 copy of y (only with the float4 body: n % 4 == 0, aligned)
   // bit 63 of n_flag set => some pointer is not 16-byte aligned: no float4 body, everything through the scalar tail
   const bool al = (n_flag >> 63) == 0;
   const size_t n = n_flag & ~(1ull << 63);
   const size_t n4 = al ? (n >> 2) : 0;
   dim3 g(ew_blocks(al ? ((n + 3) >> 2) : n)), blk(256);
+#define T2I_EW(OPC, HASB)                                                                                                        \
+  do {                                                                                                                           \
+    if (in_bf16) hipLaunchKernelGGL((ew_kernel<OPC, HASB, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);      \
+    else hipLaunchKernelGGL((ew_kernel<OPC, HASB, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);             \
+  } while (0)
   switch (op) {
-    case EW_ACT_FWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_FWD, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
-    case EW_ACT_BWD: hipLaunchKernelGGL((ew_kernel<EW_ACT_BWD, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
-    case EW_ADD_ACT: hipLaunchKernelGGL((ew_kernel<EW_ADD_ACT, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh); break;
+    case EW_ACT_FWD: T2I_EW(EW_ACT_FWD, false); break;
+    case EW_ACT_BWD: T2I_EW(EW_ACT_BWD, true); break;
+    case EW_ADD_ACT: T2I_EW(EW_ADD_ACT, true); break;
     default:
-      if (b) hipLaunchKernelGGL((ew_kernel<EW_AXPBY, true>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);
-      else hipLaunchKernelGGL((ew_kernel<EW_AXPBY, false>), g, blk, 0, stream, a, b, n, n4, act, alpha, beta, y, yh);
+      if (b) T2I_EW(EW_AXPBY, true);
+      else T2I_EW(EW_AXPBY, false);
   }
+#undef T2I_EW
   return hipGetLastError();
 }
 
@@ -864,9 +936,10 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ e
   }
 }
 
-// out[b,p,:] = [feat[b,p,:Cf] | emb[b,:Ce]]
-__global__ __launch_bounds__(256) void concat_tile_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ emb,
-                                                              size_t n, int P, int Cf, int Ce, float* __restrict__ out) {
+// out[b,p,:] = [feat[b,p,:Cf] | emb[b,:Ce]].  T = float or unsigned short (bf16 storage: a pure copy, 2-byte elements)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_tile_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ emb,
+                                                              size_t n, int P, int Cf, int Ce, T* __restrict__ out) {
   const int Ct = Cf + Ce;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t pix = i / Ct;
@@ -875,37 +948,42 @@ __global__ __launch_bounds__(256) void concat_tile_fwd_kernel(const float* __res
   }
 }
 
-// dfeat = dout[..., :Cf]; demb[b,:] = sum_p dout[b,p,Cf:]
-__global__ __launch_bounds__(256) void concat_tile_bwd_kernel(const float* __restrict__ dout, size_t nfeat, size_t nemb,
-                                                              int P, int Cf, int Ce, float* __restrict__ dfeat,
-                                                              float* __restrict__ demb) {
+// dfeat = dout[..., :Cf]; demb[b,:] = sum_p dout[b,p,Cf:]  (H: bf16 tensors; the sum over the P positions is taken in fp32)
+__device__ __forceinline__ void st1(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st1(unsigned short* p, size_t i, float v) { p[i] = (unsigned short)(aux_pk2(v, 0.f) & 0xFFFFu); }
+template <bool H>
+__global__ __launch_bounds__(256) void concat_tile_bwd_kernel(const void* __restrict__ dout, size_t nfeat, size_t nemb,
+                                                              int P, int Cf, int Ce, void* __restrict__ dfeat,
+                                                              void* __restrict__ demb) {
+  typedef typename std::conditional<H, unsigned short, float>::type T;
   const int Ct = Cf + Ce;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfeat + nemb; i += (size_t)gridDim.x * blockDim.x) {
     if (i < nfeat) {
       const size_t pix = i / Cf;
       const int c = (int)(i - pix * Cf);
-      dfeat[i] = dout[pix * Ct + c];
+      reinterpret_cast<T*>(dfeat)[i] = reinterpret_cast<const T*>(dout)[pix * Ct + c];
     } else {
       const size_t j = i - nfeat;
       const size_t b = j / Ce;
       const int c = (int)(j - b * Ce);
       float s = 0.f;
-      for (int p = 0; p < P; ++p) s += dout[(b * P + p) * Ct + Cf + c];
-      demb[j] = s;
+      for (int p = 0; p < P; ++p) s += ld1<H>(dout, (b * P + p) * Ct + Cf + c);
+      st1(reinterpret_cast<T*>(demb), j, s);
     }
   }
 }
 
 // [B,C,HW] <-> [B,HW,C] through a 32x32 LDS tile (+1 pad) so both sides are coalesced
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+template <typename T>            // float, or unsigned short for bf16 tensors (a pure copy)
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, int R, int Cc, T* __restrict__ y) {
   // per batch: x is [R, Cc] row-major -> y is [Cc, R]
-  __shared__ float tile[32][33];
+  __shared__ T tile[32][33];
   const size_t boff = (size_t)blockIdx.z * R * Cc;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     int r = r0 + j, c = c0 + tx;
-    tile[j][tx] = (r < R && c < Cc) ? x[boff + (size_t)r * Cc + c] : 0.f;
+    tile[j][tx] = (r < R && c < Cc) ? x[boff + (size_t)r * Cc + c] : (T)0;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
@@ -921,60 +999,76 @@ hipError_t interp_launch(const float* eps, const float* g, const float* x, int B
   return hipGetLastError();
 }
 
-hipError_t concat_tile_fwd_launch(const float* feat, const float* emb, int B, int P, int Cf, int Ce, float* out,
-                                  hipStream_t stream) {
+hipError_t concat_tile_fwd_launch(const void* feat, const void* emb, int B, int P, int Cf, int Ce, void* out,
+                                  hipStream_t stream, bool bf16) {
   const size_t n = (size_t)B * P * (Cf + Ce);
-  hipLaunchKernelGGL(concat_tile_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, feat, emb, n, P, Cf, Ce, out);
+  if (bf16)
+    hipLaunchKernelGGL(concat_tile_fwd_kernel<unsigned short>, dim3(ew_blocks(n)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(feat),
+                       reinterpret_cast<const unsigned short*>(emb), n, P, Cf, Ce, reinterpret_cast<unsigned short*>(out));
+  else
+    hipLaunchKernelGGL(concat_tile_fwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, stream, reinterpret_cast<const float*>(feat),
+                       reinterpret_cast<const float*>(emb), n, P, Cf, Ce, reinterpret_cast<float*>(out));
   return hipGetLastError();
 }
 
-hipError_t concat_tile_bwd_launch(const float* dout, int B, int P, int Cf, int Ce, float* dfeat, float* demb,
-                                  hipStream_t stream) {
+hipError_t concat_tile_bwd_launch(const void* dout, int B, int P, int Cf, int Ce, void* dfeat, void* demb,
+                                  hipStream_t stream, bool bf16) {
   const size_t nfeat = (size_t)B * P * Cf, nemb = (size_t)B * Ce;
-  hipLaunchKernelGGL(concat_tile_bwd_kernel, dim3(ew_blocks(nfeat + nemb)), dim3(256), 0, stream, dout, nfeat, nemb, P,
-                     Cf, Ce, dfeat, demb);
+  if (bf16)
+    hipLaunchKernelGGL(concat_tile_bwd_kernel<true>, dim3(ew_blocks(nfeat + nemb)), dim3(256), 0, stream, dout, nfeat, nemb, P, Cf, Ce, dfeat, demb);
+  else
+    hipLaunchKernelGGL(concat_tile_bwd_kernel<false>, dim3(ew_blocks(nfeat + nemb)), dim3(256), 0, stream, dout, nfeat, nemb, P, Cf, Ce, dfeat, demb);
   return hipGetLastError();
 }
 
-hipError_t transpose_launch(const float* x, int B, int R, int Cc, float* y, hipStream_t stream) {
+hipError_t transpose_launch(const void* x, int B, int R, int Cc, void* y, hipStream_t stream, bool bf16) {
   dim3 grid((Cc + 31) / 32, (R + 31) / 32, B);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, x, R, Cc, y);
+  if (bf16)
+    hipLaunchKernelGGL(transpose_kernel<unsigned short>, grid, dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(x), R, Cc,
+                       reinterpret_cast<unsigned short*>(y));
+  else
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(x), R, Cc, reinterpret_cast<float*>(y));
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // gradient penalty: per-sample L2 norm (one block per sample, wave64 shuffle + LDS across the 4 waves)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_slopes_kernel(const float* __restrict__ g, size_t per, float* __restrict__ slopes) {
+template <bool H>
+__global__ __launch_bounds__(256) void gp_slopes_kernel(const void* __restrict__ gv, size_t per, float* __restrict__ slopes) {
   __shared__ float red[4];
-  const float* row = g + (size_t)blockIdx.x * per;
+  const size_t base = (size_t)blockIdx.x * per;
   float acc = 0.f;
-  const size_t n4 = ((per & 3) == 0 && (((size_t)blockIdx.x * per) & 3) == 0) ? (per >> 2) : 0;
+  const size_t n4 = ((per & 3) == 0 && (base & 3) == 0) ? (per >> 2) : 0;
   for (size_t i = threadIdx.x; i < n4; i += 256) {
-    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    const float4 v = ld4<H>(gv, (base >> 2) + i);
     acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
-  for (size_t i = (n4 << 2) + threadIdx.x; i < per; i += 256) acc += row[i] * row[i];
+  for (size_t i = (n4 << 2) + threadIdx.x; i < per; i += 256) { const float v = ld1<H>(gv, base + i); acc += v * v; }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) slopes[blockIdx.x] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
 }
 
-__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ g, const float* __restrict__ coef,
-                                                        size_t n, size_t per, float* __restrict__ out) {
+template <bool H>
+__global__ __launch_bounds__(256) void row_scale_kernel(const void* __restrict__ g, const float* __restrict__ coef,
+                                                        size_t n, size_t per, void* __restrict__ out) {
+  typedef typename std::conditional<H, unsigned short, float>::type T;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = coef[i / per] * g[i];
+    st1(reinterpret_cast<T*>(out), i, coef[i / per] * ld1<H>(g, i));
 }
 
-hipError_t gp_slopes_launch(const float* g, int B, int64_t per, float* slopes, hipStream_t stream) {
-  hipLaunchKernelGGL(gp_slopes_kernel, dim3(B), dim3(256), 0, stream, g, (size_t)per, slopes);
+hipError_t gp_slopes_launch(const void* g, int B, int64_t per, float* slopes, hipStream_t stream, bool bf16) {
+  if (bf16) hipLaunchKernelGGL(gp_slopes_kernel<true>, dim3(B), dim3(256), 0, stream, g, (size_t)per, slopes);
+  else hipLaunchKernelGGL(gp_slopes_kernel<false>, dim3(B), dim3(256), 0, stream, g, (size_t)per, slopes);
   return hipGetLastError();
 }
 
-hipError_t row_scale_launch(const float* g, const float* coef, int B, int64_t per, float* out, hipStream_t stream) {
+hipError_t row_scale_launch(const void* g, const float* coef, int B, int64_t per, void* out, hipStream_t stream, bool bf16) {
   const size_t n = (size_t)B * per;
-  hipLaunchKernelGGL(row_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
+  if (bf16) hipLaunchKernelGGL(row_scale_kernel<true>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
+  else hipLaunchKernelGGL(row_scale_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
   return hipGetLastError();
 }
 

@@ -23,25 +23,25 @@ void set_error(const char* fmt, ...) {
 
 // launchers implemented in t2i_aux.hip
 size_t col_reduce_ws(int64_t rows, int C);
-hipError_t col_reduce_launch(const float*, const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
-hipError_t bn_stats_launch(const float*, int64_t, int, float*, float*, const float*, const float*, float, float, float*, float*, float*,
-                           float*, float*, float*, void*, hipStream_t);
+hipError_t col_reduce_launch(const void*, const void*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t, bool in_bf16 = false);
+hipError_t bn_stats_launch(const void*, int64_t, int, float*, float*, const float*, const float*, float, float, float*, float*, float*,
+                           float*, float*, float*, void*, hipStream_t, bool x_bf16 = false);
 hipError_t bn_stats_tiles_launch(const float*, const float*, int, int, int64_t, int, float*, float*, const float*, const float*, float, float,
                                  float*, float*, float*, float*, float*, float*, hipStream_t);
-hipError_t bn_bwd_fused_launch(const float*, const float*, const float*, const float*, const float*, const float*, int64_t, int, int, float,
-                               float*, float*, float*, float*, int, void*, hipStream_t, void* dx_h = nullptr);
+hipError_t bn_bwd_fused_launch(const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, int, float,
+                               void*, float*, float*, float*, int, void*, hipStream_t, void* dx_h, bool in_bf16);
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
-hipError_t bn_apply_launch(const float*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h = nullptr);
+hipError_t bn_apply_launch(const void*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h, bool x_bf16);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                          int64_t, int, float*, float*, float*, float*, int, hipStream_t);
-hipError_t ew_launch(int, const float*, const float*, size_t, int, float, float, float*, hipStream_t, void* y_h = nullptr);
+hipError_t ew_launch(int, const void*, const void*, size_t, int, float, float, float*, hipStream_t, void* y_h, bool in_bf16);
 hipError_t interp_launch(const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
-hipError_t concat_tile_fwd_launch(const float*, const float*, int, int, int, int, float*, hipStream_t);
-hipError_t concat_tile_bwd_launch(const float*, int, int, int, int, float*, float*, hipStream_t);
-hipError_t transpose_launch(const float*, int, int, int, float*, hipStream_t);
-hipError_t gp_slopes_launch(const float*, int, int64_t, float*, hipStream_t);
-hipError_t row_scale_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
+hipError_t concat_tile_fwd_launch(const void*, const void*, int, int, int, int, void*, hipStream_t, bool bf16);
+hipError_t concat_tile_bwd_launch(const void*, int, int, int, int, void*, void*, hipStream_t, bool bf16);
+hipError_t transpose_launch(const void*, int, int, int, void*, hipStream_t, bool bf16);
+hipError_t gp_slopes_launch(const void*, int, int64_t, float*, hipStream_t, bool bf16);
+hipError_t row_scale_launch(const void*, const float*, int, int64_t, void*, hipStream_t, bool bf16);
 hipError_t crop_flip_normalize_launch(const uint8_t*, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t gather_mean_launch(const float*, int, int, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t resample2_launch(bool, const float*, int, int, int, int, float, float*, hipStream_t);
@@ -56,8 +56,8 @@ hipError_t col_reduce_partials_launch(const float*, const float*, int, int, floa
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t kt_sgd_launch(float*, const float*, float, float, hipStream_t);
-hipError_t act_bwd_colsum_launch(const float*, const float*, const float*, const float*, int64_t, int, int, float, float*, float*,
-                                 float*, int, void*, hipStream_t, void* dx_h = nullptr);
+hipError_t act_bwd_colsum_launch(const void*, const void*, const void*, const float*, int64_t, int, int, float, float*, float*,
+                                 float*, int, void*, hipStream_t, void* dx_h, bool in_bf16);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
 hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -508,7 +508,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 5; }
+int t2i_version(void) { return 6; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -545,6 +545,9 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_ws(*d) > need) need = winograd_k4s2_ws(*d);
   if (winograd_k4s2_eligible(*d, true) && winograd_k4s2_bwd_ws(*d) > need) need = winograd_k4s2_bwd_ws(*d);
   if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_filter_grad_ws(*d) > need) need = winograd_k4s2_filter_grad_ws(*d);
+  // bf16 storage (t2i_conv_opts.in_dtype / out_dtype): a call whose path has no bf16-tensor loader (thin / head / generic kernels)
+  // stages fp32 copies of its two activation tensors in front of the path's own workspace
+  if (d->math == T2I_MATH_BF16) need += al256c(nx * 4) + al256c(ny * 4) + 512;
   return need;
 }
 
@@ -558,17 +561,75 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
                            float alpha, float* stats, int* stats_chunks, int* stats_tile_rows, t2i_conv_opts* opts, void* ws, size_t ws_bytes,
                            t2i_stream_t stream);
 
-int t2i_conv2d_fwd(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+// ---- bf16 storage around the three primitives ---------------------------------------------------------------------------
+// opts->in_dtype bit 0 / bit 1: the first / second ACTIVATION operand is a bf16 tensor; opts->out_dtype: the output is.  The
+// bf16-operand GEMMs (and the 3 -> 128 stem) read / write such tensors directly; every other path runs on fp32 staging copies
+// in the workspace (exact widening in front, one RNE rounding behind) — correct everywhere, fast where it matters.
+static inline bool in_h(const t2i_conv_opts* o, int which) { return o && ((o->in_dtype >> which) & 1); }
+static inline bool out_h(const t2i_conv_opts* o) { return o && o->out_dtype == T2I_DT_BF16; }
+static int storage_check(const t2i_conv_desc* d, const t2i_conv_opts* o, const char* what) {
+  if (o && (o->in_dtype & ~3)) { set_error("%s: in_dtype is a mask of bit 0 / bit 1", what); return T2I_ERR_INVALID; }
+  if (o && o->out_dtype != T2I_DT_F32 && o->out_dtype != T2I_DT_BF16) { set_error("%s: out_dtype must be T2I_DT_F32 or T2I_DT_BF16", what); return T2I_ERR_INVALID; }
+  if (d->math != T2I_MATH_BF16) { set_error("%s: bf16 tensors need t2i_conv_desc.math = T2I_MATH_BF16", what); return T2I_ERR_INVALID; }
+  return T2I_OK;
+}
+struct Staging {           // fp32 copies carved from the front of the workspace
+  char* base; size_t bytes, off;
+  float* take(size_t elems) {
+    const size_t need = al256c(elems * 4);
+    if (!base || off + need > bytes) return nullptr;
+    float* p = reinterpret_cast<float*>(base + off);
+    off += need;
+    return p;
+  }
+};
+
+int t2i_conv2d_fwd(const t2i_conv_desc* d, const void* xv, const float* w, const float* bias, void* yv, int act,
                    float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
-  return conv2d_fwd_impl(d, x, w, bias, y, act, alpha, nullptr, nullptr, nullptr, opts, ws, ws_bytes, stream);
+  const bool xh = in_h(opts, 0), yh = out_h(opts);
+  if (!xh && !yh)
+    return conv2d_fwd_impl(d, reinterpret_cast<const float*>(xv), w, bias, reinterpret_cast<float*>(yv), act, alpha, nullptr, nullptr, nullptr, opts,
+                           ws, ws_bytes, stream);
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if ((rc = storage_check(d, opts, "t2i_conv2d_fwd"))) return rc;
+  if (!xv || !w || !yv) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
+  opts->out_image_written = 0; opts->xform_kept = 0;
+  if (!tuning().no_thin && stem_fwd_eligible(*d) && aligned16(w) && !xh && yh)           // fp32 image in, bf16 activation out
+    return check(stem_fwd_launch(*d, reinterpret_cast<const float*>(xv), w, bias, nullptr, act, alpha, (hipStream_t)stream, yv), "t2i_conv2d_fwd(stem)");
+  const bool head = !tuning().no_thin && head_conv_eligible(*d);
+  if (!head && h_eligible(*d, false) && (d->Cout % 4) == 0 && aligned16(xv) && aligned16(w) && aligned16(yv))
+    return conv_h(MODE_FWD, d, xh ? nullptr : reinterpret_cast<const float*>(xv), xh ? xv : opts->a_image, w, bias,
+                  yh ? nullptr : reinterpret_cast<float*>(yv), yh ? yv : opts->out_image, yh ? nullptr : &opts->out_image_written, act, alpha, ws,
+                  ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+  Staging st{reinterpret_cast<char*>(ws), ws_bytes, 0};
+  const float* x32 = reinterpret_cast<const float*>(xv);
+  float* y32 = reinterpret_cast<float*>(yv);
+  if (xh) {
+    float* t = st.take(nx);
+    if (!t) { set_error("t2i_conv2d_fwd: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if ((rc = check(cast_f32_launch(xv, nx, t, (hipStream_t)stream), "t2i_conv2d_fwd(stage)"))) return rc;
+    x32 = t;
+  }
+  if (yh && !(y32 = st.take(ny))) { set_error("t2i_conv2d_fwd: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+  t2i_conv_opts o2 = *opts;
+  o2.in_dtype = 0; o2.out_dtype = T2I_DT_F32; o2.a_image = nullptr; o2.out_image = nullptr;
+  rc = conv2d_fwd_impl(d, x32, w, bias, y32, act, alpha, nullptr, nullptr, nullptr, &o2, st.base + st.off, ws_bytes - st.off, stream);
+  if (rc == T2I_OK && yh) rc = check(cast_bf16_any_launch(y32, ny, yv, (hipStream_t)stream), "t2i_conv2d_fwd(unstage)");
+  return rc;
 }
 
-int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const void* x, const float* w, const float* bias, void* y, int act,
                          float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, t2i_conv_opts* opts,
                          void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!stats || !chunks || !tile_rows || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
+  if (in_h(opts, 0) || out_h(opts)) {         // bf16 storage: the bf16-operand kernel has no statistics epilogue; the batch norm reduces y itself
+    *chunks = 0; *tile_rows = 0;
+    return t2i_conv2d_fwd(d, x, w, bias, y, act, alpha, opts, ws, ws_bytes, stream);
+  }
   int c = 0, tr = 0;          // number of M-tiles and their height, reported by the plan that launched (run_gemm)
-  const int rc = conv2d_fwd_impl(d, x, w, bias, y, act, alpha, stats, &c, &tr, opts, ws, ws_bytes, stream);
+  const int rc = conv2d_fwd_impl(d, reinterpret_cast<const float*>(x), w, bias, reinterpret_cast<float*>(y), act, alpha, stats, &c, &tr, opts, ws, ws_bytes, stream);
   *chunks = c;
   *tile_rows = tr;
   return rc;
@@ -625,8 +686,44 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
                   "t2i_conv2d_fwd", 0, stats_chunks, stats_tile_rows);
 }
 
-int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
+static int conv2d_bwd_data_impl(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
+                                float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
+int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const void* dyv, const float* w, const float* bias, void* dxv, int act,
                         float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  const bool gh = in_h(opts, 0), xh = out_h(opts);
+  if (!gh && !xh)
+    return conv2d_bwd_data_impl(d, reinterpret_cast<const float*>(dyv), w, bias, reinterpret_cast<float*>(dxv), act, alpha, opts, ws, ws_bytes, stream);
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if ((rc = storage_check(d, opts, "t2i_conv2d_bwd_data"))) return rc;
+  if (!dyv || !w || !dxv) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
+  opts->out_image_written = 0; opts->xform_kept = 0;
+  const bool direct = !tuning().no_thin && ((head_conv_eligible(*d) && !bias && act == T2I_ACT_NONE) || tiny_conv_eligible(*d, true) || thin_deconv_eligible(*d));
+  if (!direct && h_eligible(*d, true) && (d->Cin % 4) == 0 && aligned16(dyv) && aligned16(w) && aligned16(dxv))
+    return conv_h(MODE_BWD_DATA, d, gh ? nullptr : reinterpret_cast<const float*>(dyv), gh ? dyv : opts->a_image, w, bias,
+                  xh ? nullptr : reinterpret_cast<float*>(dxv), xh ? dxv : opts->out_image, xh ? nullptr : &opts->out_image_written, act, alpha, ws,
+                  ws_bytes, (hipStream_t)stream, "t2i_conv2d_bwd_data(bf16 operands)");
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+  Staging st{reinterpret_cast<char*>(ws), ws_bytes, 0};
+  const float* dy32 = reinterpret_cast<const float*>(dyv);
+  float* dx32 = reinterpret_cast<float*>(dxv);
+  if (gh) {
+    float* t = st.take(ny);
+    if (!t) { set_error("t2i_conv2d_bwd_data: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if ((rc = check(cast_f32_launch(dyv, ny, t, (hipStream_t)stream), "t2i_conv2d_bwd_data(stage)"))) return rc;
+    dy32 = t;
+  }
+  if (xh && !(dx32 = st.take(nx))) { set_error("t2i_conv2d_bwd_data: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+  t2i_conv_opts o2 = *opts;
+  o2.in_dtype = 0; o2.out_dtype = T2I_DT_F32; o2.a_image = nullptr; o2.out_image = nullptr;
+  rc = conv2d_bwd_data_impl(d, dy32, w, bias, dx32, act, alpha, &o2, st.base + st.off, ws_bytes - st.off, stream);
+  if (rc == T2I_OK && xh) rc = check(cast_bf16_any_launch(dx32, nx, dxv, (hipStream_t)stream), "t2i_conv2d_bwd_data(unstage)");
+  return rc;
+}
+
+static int conv2d_bwd_data_impl(const t2i_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, int act,
+                                float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   const void* dy_h = opts ? opts->a_image : nullptr;
   void* dx_h = opts ? opts->out_image : nullptr;
   if (opts) { opts->out_image_written = 0; opts->xform_kept = 0; }
@@ -662,8 +759,46 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const float* dy, const float* w,
                   (hipStream_t)stream, "t2i_conv2d_bwd_data");
 }
 
-int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                                  t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
+int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* xv, const void* dyv, float* dw, int accumulate,
                           t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  const bool xh = in_h(opts, 0), gh = in_h(opts, 1);
+  if (!xh && !gh)
+    return conv2d_bwd_filter_impl(d, reinterpret_cast<const float*>(xv), reinterpret_cast<const float*>(dyv), dw, accumulate, opts, ws, ws_bytes, stream);
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if ((rc = storage_check(d, opts, "t2i_conv2d_bwd_filter"))) return rc;
+  if (!xv || !dyv || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
+  opts->out_image_written = 0; opts->xform_kept = 0;
+  const bool direct = !tuning().no_thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d) || (stem_bwdf_eligible(*d) && aligned16(dw)));
+  if (!direct && h_filter_eligible(*d) && aligned16(xv) && aligned16(dyv) && aligned16(dw))
+    return conv_h_filter(d, xh ? nullptr : reinterpret_cast<const float*>(xv), gh ? nullptr : reinterpret_cast<const float*>(dyv),
+                         xh ? xv : opts->a_image, gh ? dyv : opts->b_image, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
+  const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
+  Staging st{reinterpret_cast<char*>(ws), ws_bytes, 0};
+  const float* x32 = reinterpret_cast<const float*>(xv);
+  const float* dy32 = reinterpret_cast<const float*>(dyv);
+  if (xh) {
+    float* t = st.take(nx);
+    if (!t) { set_error("t2i_conv2d_bwd_filter: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if ((rc = check(cast_f32_launch(xv, nx, t, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stage)"))) return rc;
+    x32 = t;
+  }
+  if (gh) {
+    float* t = st.take(ny);
+    if (!t) { set_error("t2i_conv2d_bwd_filter: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if ((rc = check(cast_f32_launch(dyv, ny, t, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stage)"))) return rc;
+    dy32 = t;
+  }
+  t2i_conv_opts o2 = *opts;
+  o2.in_dtype = 0; o2.out_dtype = T2I_DT_F32; o2.a_image = nullptr; o2.b_image = nullptr;
+  return conv2d_bwd_filter_impl(d, x32, dy32, dw, accumulate, &o2, st.base + st.off, ws_bytes - st.off, stream);
+}
+
+static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                                  t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (opts) { opts->out_image_written = 0; opts->xform_kept = 0; }
   int rc = validate_desc(d);
   if (rc) return rc;
@@ -709,16 +844,27 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const float* x, const float* d
                   (hipStream_t)stream, "t2i_conv2d_bwd_filter", accumulate ? 1 : 0);
 }
 
+// bf16 tensors (dtype == T2I_DT_BF16) run on the vectorised paths only: C (or n) a multiple of 4, 16-byte aligned pointers; no twin
+static int h_contract(int32_t dtype, bool aligned, int64_t quad, const void* twin, const char* what) {
+  if (dtype != T2I_DT_F32 && dtype != T2I_DT_BF16) { set_error("%s: dtype must be T2I_DT_F32 or T2I_DT_BF16", what); return T2I_ERR_INVALID; }
+  if (dtype == T2I_DT_BF16 && (!aligned || (quad & 3) != 0 || twin)) {
+    set_error("%s: bf16 tensors need 16-byte aligned pointers, a channel / element count that is a multiple of 4, and no twin argument", what);
+    return T2I_ERR_INVALID;
+  }
+  return T2I_OK;
+}
+
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
   return col_reduce_ws(rows, C);
 }
 
-int t2i_col_reduce(const float* a, const float* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
-                   int accumulate, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+int t2i_col_reduce(const void* a, const void* b, const float* center, int64_t rows, int32_t C, float* out0, float* out1,
+                   int accumulate, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
   if (!a || !out0 || rows <= 0 || C <= 0 || (center && !b)) { set_error("t2i_col_reduce: bad argument"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_col_reduce: workspace too small"); return T2I_ERR_WORKSPACE; }
-  return check(col_reduce_launch(a, b, center, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_col_reduce");
+  if (int rc = h_contract(dtype, aligned16(a) && aligned16(b) && aligned16(ws) && aligned16(center), C, nullptr, "t2i_col_reduce")) return rc;
+  return check(col_reduce_launch(a, b, center, rows, C, out0, out1, accumulate ? 1 : 0, ws, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_col_reduce");
 }
 
 int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2, void* ws, size_t ws_bytes, t2i_stream_t stream) {
@@ -728,10 +874,10 @@ int t2i_bn_stats(const float* x, int64_t rows, int32_t C, float* sum, float* m2,
                                (hipStream_t)stream), "t2i_bn_stats");
 }
 
-int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
+int t2i_bn_train_fwd_stats(const void* x, const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows,
                            int32_t C, const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd,
                            float* scale, float* shift, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes,
-                           t2i_stream_t stream) {
+                           int32_t dtype, t2i_stream_t stream) {
   if (!gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || ((moving_mean == nullptr) != (moving_var == nullptr)) ||
       ((x == nullptr) == (part_sum == nullptr)) || (part_sum && (!part_m2 || chunks <= 0 || tile_rows <= 0))) {
     set_error("t2i_bn_train_fwd_stats: bad argument (exactly one of x / tile partials)");
@@ -739,8 +885,9 @@ int t2i_bn_train_fwd_stats(const float* x, const float* part_sum, const float* p
   }
   if (x) {
     if (!ws || ws_bytes < col_reduce_ws(rows, C)) { set_error("t2i_bn_train_fwd_stats: workspace too small"); return T2I_ERR_WORKSPACE; }
+    if (int rc = h_contract(dtype, aligned16(x) && aligned16(ws), C, nullptr, "t2i_bn_train_fwd_stats")) return rc;
     return check(bn_stats_launch(x, rows, C, nullptr, nullptr, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, ws,
-                                 (hipStream_t)stream), "t2i_bn_train_fwd_stats");
+                                 (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_bn_train_fwd_stats");
   }
   return check(bn_stats_tiles_launch(part_sum, part_m2, chunks, tile_rows, rows, C, nullptr, nullptr, gamma, beta, eps, decay, mean, rstd, scale,
                                      shift, moving_mean, moving_var, (hipStream_t)stream), "t2i_bn_train_fwd_stats");
@@ -751,9 +898,9 @@ size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C) {
   return col_reduce_ws(rows, C) + (size_t)3 * C * sizeof(float);
 }
 
-int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
-                     int32_t C, int act, float alpha, float* gmask, float* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
-                     size_t ws_bytes, t2i_stream_t stream) {
+int t2i_bn_bwd_fused(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
+                     int32_t C, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
+                     size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || (y && !gmask)) {
     set_error("t2i_bn_bwd_fused: bad argument (C % 4 == 0 required; gmask needed with an activation)");
     return T2I_ERR_INVALID;
@@ -764,8 +911,10 @@ int t2i_bn_bwd_fused(const float* dy, const float* y, const float* x, const floa
   }
   if (!ws || ws_bytes < t2i_bn_bwd_fused_workspace_bytes(rows, C) || !aligned16(ws)) { set_error("t2i_bn_bwd_fused: workspace too small"); return T2I_ERR_WORKSPACE; }
   if (!aligned16(dx_h)) { set_error("t2i_bn_bwd_fused: dx_h must be 16-byte aligned"); return T2I_ERR_INVALID; }
-  return check(bn_bwd_fused_launch(dy, y, x, mean, rstd, gamma, rows, C, act, alpha, gmask, dx, dgamma, dbeta, accumulate ? 1 : 0, ws,
-                                   (hipStream_t)stream, dx_h), "t2i_bn_bwd_fused");
+  if (int rc = h_contract(dtype, true, C, dx_h, "t2i_bn_bwd_fused")) return rc;
+  const bool h = dtype == T2I_DT_BF16;       // bf16 storage: dy, y, x, gmask and dx are bf16 tensors
+  return check(bn_bwd_fused_launch(dy, y, x, mean, rstd, gamma, rows, C, act, alpha, gmask, h ? nullptr : reinterpret_cast<float*>(dx), dgamma, dbeta,
+                                   accumulate ? 1 : 0, ws, (hipStream_t)stream, h ? dx : dx_h, h), "t2i_bn_bwd_fused");
 }
 
 int t2i_bn_stats_tiles(const float* part_sum, const float* part_m2, int32_t chunks, int32_t tile_rows, int64_t rows, int32_t C,
@@ -798,12 +947,15 @@ int t2i_bn_finalize(const float* sum, const float* sumsq, int64_t n, int32_t C, 
                                   moving_var, (hipStream_t)stream), "t2i_bn_finalize");
 }
 
-int t2i_bn_apply(const float* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act, float alpha,
-                 float* y, void* y_h, t2i_stream_t stream) {
+int t2i_bn_apply(const void* x, const float* scale, const float* shift, int64_t rows, int32_t C, int act, float alpha,
+                 void* y, void* y_h, int32_t dtype, t2i_stream_t stream) {
   if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) { set_error("t2i_bn_apply: bad argument"); return T2I_ERR_INVALID; }
   const bool al = aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift);
   if (y_h && !(al && (C & 3) == 0 && aligned16(y_h))) { set_error("t2i_bn_apply: y_h needs 16-byte aligned tensors and C %% 4 == 0"); return T2I_ERR_INVALID; }
-  return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, y, (hipStream_t)stream, y_h), "t2i_bn_apply");
+  if (int rc = h_contract(dtype, al, C, y_h, "t2i_bn_apply")) return rc;
+  const bool h = dtype == T2I_DT_BF16;
+  return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, h ? nullptr : reinterpret_cast<float*>(y), (hipStream_t)stream,
+                               h ? y : y_h, h), "t2i_bn_apply");
 }
 
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -819,38 +971,43 @@ int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* 
                              reinterpret_cast<float*>(ws), accumulate ? 1 : 0, (hipStream_t)stream), "t2i_bn_bwd");
 }
 
-static int ew_call(int op, const float* a, const float* b, int64_t n, int act, float alpha, float beta, float* y, void* y_h,
+static int ew_call(int op, const void* a, const void* b, int64_t n, int act, float alpha, float beta, void* y, void* y_h, int32_t dtype,
                    t2i_stream_t stream, const char* what, bool need_b) {
   if (!a || !y || n <= 0 || (need_b && !b)) { set_error("%s: bad argument", what); return T2I_ERR_INVALID; }
   const bool al = aligned16(a) && aligned16(y) && (!b || aligned16(b));
   if (y_h && !(al && (n & 3) == 0 && aligned16(y_h))) { set_error("%s: the bf16 image needs 16-byte aligned tensors and n %% 4 == 0", what); return T2I_ERR_INVALID; }
+  if (int rc = h_contract(dtype, al, n, y_h, what)) return rc;
+  const bool h = dtype == T2I_DT_BF16;
   // unaligned views take the scalar tail path: tell the kernel there is no float4 body
-  return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, y, (hipStream_t)stream, y_h), what);
+  return check(ew_launch(op, a, b, al ? (size_t)n : ((size_t)n | (1ull << 63)), act, alpha, beta, h ? nullptr : reinterpret_cast<float*>(y),
+                         (hipStream_t)stream, h ? y : y_h, h), what);
 }
 
-int t2i_act_fwd(const float* x, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream) {
-  return ew_call(0, x, nullptr, n, act, alpha, 0.f, y, y_h, stream, "t2i_act_fwd", false);
+int t2i_act_fwd(const void* x, int64_t n, int act, float alpha, void* y, void* y_h, int32_t dtype, t2i_stream_t stream) {
+  return ew_call(0, x, nullptr, n, act, alpha, 0.f, y, y_h, dtype, stream, "t2i_act_fwd", false);
 }
-int t2i_act_bwd(const float* dy, const float* y, int64_t n, int act, float alpha, float* dx, void* dx_h, t2i_stream_t stream) {
-  return ew_call(1, dy, y, n, act, alpha, 0.f, dx, dx_h, stream, "t2i_act_bwd", true);
+int t2i_act_bwd(const void* dy, const void* y, int64_t n, int act, float alpha, void* dx, void* dx_h, int32_t dtype, t2i_stream_t stream) {
+  return ew_call(1, dy, y, n, act, alpha, 0.f, dx, dx_h, dtype, stream, "t2i_act_bwd", true);
 }
-int t2i_act_bwd_colsum(const float* dy, const float* y, const float* x2, const float* center, int64_t rows, int32_t C, int act,
-                       float alpha, float* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
-                       t2i_stream_t stream) {
+int t2i_act_bwd_colsum(const void* dy, const void* y, const void* x2, const float* center, int64_t rows, int32_t C, int act,
+                       float alpha, void* dx, void* dx_h, float* colsum, float* colsum_x2, int accumulate, void* ws, size_t ws_bytes,
+                       int32_t dtype, t2i_stream_t stream) {
   if (center && (!x2 || !aligned16(center))) { set_error("t2i_act_bwd_colsum: center needs x2 and 16-byte alignment"); return T2I_ERR_INVALID; }
   if ((x2 == nullptr) != (colsum_x2 == nullptr) || (x2 && !aligned16(x2))) { set_error("t2i_act_bwd_colsum: x2 / colsum_x2 must come together, 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!dy || !y || !dx || !colsum || rows <= 0 || C <= 0 || (C & 3)) { set_error("t2i_act_bwd_colsum: bad argument (C % 4 == 0 required)"); return T2I_ERR_INVALID; }
   if (!(aligned16(dy) && aligned16(y) && aligned16(dx))) { set_error("t2i_act_bwd_colsum: tensors must be 16-byte aligned"); return T2I_ERR_INVALID; }
   if (!ws || ws_bytes < col_reduce_ws(rows, C) || !aligned16(ws)) { set_error("t2i_act_bwd_colsum: workspace too small"); return T2I_ERR_WORKSPACE; }
   if (!aligned16(dx_h)) { set_error("t2i_act_bwd_colsum: dx_h must be 16-byte aligned"); return T2I_ERR_INVALID; }
-  return check(act_bwd_colsum_launch(dy, y, x2, center, rows, C, act, alpha, dx, colsum, colsum_x2, accumulate ? 1 : 0, ws,
-                                     (hipStream_t)stream, dx_h), "t2i_act_bwd_colsum");
+  if (int rc = h_contract(dtype, true, C, dx_h, "t2i_act_bwd_colsum")) return rc;
+  const bool h = dtype == T2I_DT_BF16;
+  return check(act_bwd_colsum_launch(dy, y, x2, center, rows, C, act, alpha, h ? nullptr : reinterpret_cast<float*>(dx), colsum, colsum_x2,
+                                     accumulate ? 1 : 0, ws, (hipStream_t)stream, h ? dx : dx_h, h), "t2i_act_bwd_colsum");
 }
-int t2i_add_act(const float* a, const float* b, int64_t n, int act, float alpha, float* y, void* y_h, t2i_stream_t stream) {
-  return ew_call(2, a, b, n, act, alpha, 0.f, y, y_h, stream, "t2i_add_act", true);
+int t2i_add_act(const void* a, const void* b, int64_t n, int act, float alpha, void* y, void* y_h, int32_t dtype, t2i_stream_t stream) {
+  return ew_call(2, a, b, n, act, alpha, 0.f, y, y_h, dtype, stream, "t2i_add_act", true);
 }
-int t2i_axpby(const float* a, float alpha, const float* b, float beta, int64_t n, float* y, t2i_stream_t stream) {
-  return ew_call(3, a, b, n, T2I_ACT_NONE, alpha, beta, y, nullptr, stream, "t2i_axpby", false);
+int t2i_axpby(const void* a, float alpha, const void* b, float beta, int64_t n, void* y, int32_t dtype, t2i_stream_t stream) {
+  return ew_call(3, a, b, n, T2I_ACT_NONE, alpha, beta, y, nullptr, dtype, stream, "t2i_axpby", false);
 }
 
 int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int64_t per_sample, float* xhat,
@@ -859,36 +1016,43 @@ int t2i_interp(const float* eps, const float* g, const float* x, int32_t B, int6
   return check(interp_launch(eps, g, x, B, per_sample, xhat, (hipStream_t)stream), "t2i_interp");
 }
 
-int t2i_concat_tile_fwd(const float* feat, const float* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* out,
-                        t2i_stream_t stream) {
-  if (!feat || !emb || !out || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0) { set_error("t2i_concat_tile_fwd: bad argument"); return T2I_ERR_INVALID; }
-  return check(concat_tile_fwd_launch(feat, emb, B, P, Cf, Ce, out, (hipStream_t)stream), "t2i_concat_tile_fwd");
+static bool dt_ok(int32_t dtype, const char* what) {
+  if (dtype == T2I_DT_F32 || dtype == T2I_DT_BF16) return true;
+  set_error("%s: dtype must be T2I_DT_F32 or T2I_DT_BF16", what);
+  return false;
 }
 
-int t2i_concat_tile_bwd(const float* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, float* dfeat, float* demb,
-                        t2i_stream_t stream) {
-  if (!dout || !dfeat || !demb || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0) { set_error("t2i_concat_tile_bwd: bad argument"); return T2I_ERR_INVALID; }
-  return check(concat_tile_bwd_launch(dout, B, P, Cf, Ce, dfeat, demb, (hipStream_t)stream), "t2i_concat_tile_bwd");
+int t2i_concat_tile_fwd(const void* feat, const void* emb, int32_t B, int32_t P, int32_t Cf, int32_t Ce, void* out,
+                        int32_t dtype, t2i_stream_t stream) {
+  if (!feat || !emb || !out || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0 || !dt_ok(dtype, "t2i_concat_tile_fwd")) { set_error("t2i_concat_tile_fwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(concat_tile_fwd_launch(feat, emb, B, P, Cf, Ce, out, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_concat_tile_fwd");
 }
 
-int t2i_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream) {
-  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) { set_error("t2i_nchw_to_nhwc: bad argument"); return T2I_ERR_INVALID; }
-  return check(transpose_launch(x, B, C, HW, y, (hipStream_t)stream), "t2i_nchw_to_nhwc");   // [C,HW] -> [HW,C]
+int t2i_concat_tile_bwd(const void* dout, int32_t B, int32_t P, int32_t Cf, int32_t Ce, void* dfeat, void* demb,
+                        int32_t dtype, t2i_stream_t stream) {
+  if (!dout || !dfeat || !demb || B <= 0 || P <= 0 || Cf <= 0 || Ce <= 0 || !dt_ok(dtype, "t2i_concat_tile_bwd")) { set_error("t2i_concat_tile_bwd: bad argument"); return T2I_ERR_INVALID; }
+  return check(concat_tile_bwd_launch(dout, B, P, Cf, Ce, dfeat, demb, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_concat_tile_bwd");
 }
 
-int t2i_nhwc_to_nchw(const float* x, int32_t B, int32_t C, int32_t HW, float* y, t2i_stream_t stream) {
-  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) { set_error("t2i_nhwc_to_nchw: bad argument"); return T2I_ERR_INVALID; }
-  return check(transpose_launch(x, B, HW, C, y, (hipStream_t)stream), "t2i_nhwc_to_nchw");   // [HW,C] -> [C,HW]
+int t2i_nchw_to_nhwc(const void* x, int32_t B, int32_t C, int32_t HW, void* y, int32_t dtype, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || !dt_ok(dtype, "t2i_nchw_to_nhwc")) { set_error("t2i_nchw_to_nhwc: bad argument"); return T2I_ERR_INVALID; }
+  return check(transpose_launch(x, B, C, HW, y, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_nchw_to_nhwc");   // [C,HW] -> [HW,C]
 }
 
-int t2i_gp_slopes(const float* g, int32_t B, int64_t per_sample, float* slopes, t2i_stream_t stream) {
-  if (!g || !slopes || B <= 0 || per_sample <= 0) { set_error("t2i_gp_slopes: bad argument"); return T2I_ERR_INVALID; }
-  return check(gp_slopes_launch(g, B, per_sample, slopes, (hipStream_t)stream), "t2i_gp_slopes");
+int t2i_nhwc_to_nchw(const void* x, int32_t B, int32_t C, int32_t HW, void* y, int32_t dtype, t2i_stream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0 || !dt_ok(dtype, "t2i_nhwc_to_nchw")) { set_error("t2i_nhwc_to_nchw: bad argument"); return T2I_ERR_INVALID; }
+  return check(transpose_launch(x, B, HW, C, y, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_nhwc_to_nchw");   // [HW,C] -> [C,HW]
 }
 
-int t2i_row_scale(const float* g, const float* coef, int32_t B, int64_t per_sample, float* out, t2i_stream_t stream) {
-  if (!g || !coef || !out || B <= 0 || per_sample <= 0) { set_error("t2i_row_scale: bad argument"); return T2I_ERR_INVALID; }
-  return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream), "t2i_row_scale");
+int t2i_gp_slopes(const void* g, int32_t B, int64_t per_sample, float* slopes, int32_t dtype, t2i_stream_t stream) {
+  if (!g || !slopes || B <= 0 || per_sample <= 0 || !dt_ok(dtype, "t2i_gp_slopes")) { set_error("t2i_gp_slopes: bad argument"); return T2I_ERR_INVALID; }
+  if (dtype == T2I_DT_BF16 && (per_sample & 3) != 0) { set_error("t2i_gp_slopes: bf16 rows need a multiple of 4 elements"); return T2I_ERR_INVALID; }
+  return check(gp_slopes_launch(g, B, per_sample, slopes, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_gp_slopes");
+}
+
+int t2i_row_scale(const void* g, const float* coef, int32_t B, int64_t per_sample, void* out, int32_t dtype, t2i_stream_t stream) {
+  if (!g || !coef || !out || B <= 0 || per_sample <= 0 || !dt_ok(dtype, "t2i_row_scale")) { set_error("t2i_row_scale: bad argument"); return T2I_ERR_INVALID; }
+  return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_row_scale");
 }
 
 int t2i_crop_flip_normalize(const uint8_t* src, int64_t N, int32_t S, const int32_t* ids, const int32_t* row0,
@@ -1037,6 +1201,11 @@ int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream) {
     return T2I_ERR_INVALID;
   }
   return check(cast_bf16_launch(x, (size_t)n, out, (hipStream_t)stream), "t2i_cast_bf16");
+}
+
+int t2i_cast_f32(const void* x_bf16, int64_t n, float* out, t2i_stream_t stream) {
+  if (!x_bf16 || !out || n <= 0) { set_error("t2i_cast_f32: bad argument"); return T2I_ERR_INVALID; }
+  return check(cast_f32_launch(x_bf16, (size_t)n, out, (hipStream_t)stream), "t2i_cast_f32");
 }
 
 uint64_t t2i_capture_id(t2i_stream_t stream) {

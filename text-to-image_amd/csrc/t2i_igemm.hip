@@ -744,8 +744,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       const float4 o = reinterpret_cast<const float4*>(out)[i];
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
-    reinterpret_cast<float4*>(out)[i] = s;
-    if (outh) {                     // bf16 twin of the finished output (t2i_output_image)
+    if (out) reinterpret_cast<float4*>(out)[i] = s;       // out == NULL: bf16 storage, only the bf16 tensor is written
+    if (outh) {                     // bf16 copy of the finished output (twin, or THE tensor under bf16 storage)
       typedef float f2 __attribute__((ext_vector_type(2)));
       typedef __bf16 h2 __attribute__((ext_vector_type(2)));
       f2 lo = {s.x, s.y}, hi = {s.z, s.w};
@@ -759,7 +759,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // slabs ty, ty+16, ... and the 16 partial sums are joined in lane order through LDS — still a fixed order.
 __global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(const float* __restrict__ slabs, int splitk,
                                                                  size_t out_elems, const float* __restrict__ bias, int N,
-                                                                 int act, float alpha, float* __restrict__ out, int accumulate) {
+                                                                 int act, float alpha, float* __restrict__ out, int accumulate,
+                                                                 uint2* __restrict__ outh) {
   __shared__ float4 red[16][16];
   const size_t n4 = out_elems >> 2;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -787,7 +788,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(const float* __
       const float4 o = reinterpret_cast<const float4*>(out)[i];
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
-    reinterpret_cast<float4*>(out)[i] = s;
+    if (out) reinterpret_cast<float4*>(out)[i] = s;
+    if (outh) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+      f2 lo = {s.x, s.y}, hi = {s.z, s.w};
+      outh[i] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2)));
+    }
   }
 }
 
@@ -861,7 +868,8 @@ hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems
     size_t n4 = out_elems >> 2;
     if (splitk >= 32 && n4 <= 65536) {           // few outputs, many slabs: parallelise over slabs too
       hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, stream, slabs, splitk, out_elems,
-                         bias, N, act, alpha, out, accumulate);
+                         bias, N, act, alpha, out, accumulate, reinterpret_cast<uint2*>(out_h));
+      if (wrote_h && out_h) *wrote_h = true;
       return hipGetLastError();
     }
     int blocks = (int)((n4 + 255) / 256);

@@ -56,6 +56,44 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 // (the filter copies — wcast_kernel, [tap][Cout][Cin] / [tap][Cin][Cout] bf16 — live with the filter cache in t2i_winograd.hip)
 
+hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream);
+
+// y[i] = float(x[i]) for bf16 x (exact): the staging copy for the few paths that have no bf16-tensor loader (bf16 storage)
+__global__ __launch_bounds__(256) void cast_f32_kernel(const uint4* __restrict__ x, size_t n8, float4* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 u = x[i];
+    y[2 * i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    y[2 * i + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xFFFF0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xFFFF0000u));
+  }
+}
+__global__ __launch_bounds__(256) void cast_f32_scalar_kernel(const unsigned short* __restrict__ x, size_t n, float* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = __uint_as_float((unsigned)x[i] << 16);
+}
+__global__ __launch_bounds__(256) void cast_bf16_scalar_kernel(const float* __restrict__ x, size_t n, __bf16* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];
+}
+
+hipError_t cast_f32_launch(const void* x, size_t n, float* y, hipStream_t stream) {
+  const bool vec = (n & 7) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  size_t items = vec ? (n >> 3) : n;
+  size_t blocks = (items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (vec) hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(x), n >> 3, reinterpret_cast<float4*>(y));
+  else hipLaunchKernelGGL(cast_f32_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(x), n, y);
+  return hipGetLastError();
+}
+
+// any n / alignment (the vectorised cast_bf16_launch below needs n % 8 == 0 and 16-byte alignment)
+hipError_t cast_bf16_any_launch(const float* x, size_t n, void* y, hipStream_t stream) {
+  if ((n & 7) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) return cast_bf16_launch(x, n, y, stream);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_bf16_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, reinterpret_cast<__bf16*>(y));
+  return hipGetLastError();
+}
+
 hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream) {
   const size_t n8 = n >> 3;
   size_t blocks = (n8 + 255) / 256;
@@ -256,7 +294,7 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
   }
 
   // ---- epilogue (fp32 output; same conventions as igemm_kernel) ----------------------------------------------------------
-  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);     // (never dereferenced when p.c is NULL: see below)
   const bool fused = (p.splitk == 1);
 #pragma unroll
   for (int i = 0; i < WMT; ++i) {
@@ -288,7 +326,7 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
             if (p.accumulate) v += out[rowoff + n];
             if (p.c_h) reinterpret_cast<__bf16*>(p.c_h)[rowoff + n] = (__bf16)v;
           }
-          out[rowoff + n] = v;
+          if (!fused || p.c) out[rowoff + n] = v;       // bf16 storage: an unsplit launch writes the bf16 tensor only (p.c == NULL)
         }
       }
     }

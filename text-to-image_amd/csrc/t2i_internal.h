@@ -110,6 +110,8 @@ hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int va
 hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
 hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
 hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream);
+hipError_t cast_bf16_any_launch(const float* x, size_t n, void* y, hipStream_t stream);      // any n / alignment
+hipError_t cast_f32_launch(const void* x_bf16, size_t n, float* y, hipStream_t stream);    // exact widening (staging copies, bf16 storage)
 hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream);
 // slot of the caller-owned filter-cache arena for (filter, kind) — nullptr when the cache cannot serve it (t2i_winograd.hip)
 float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill);

@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
         if (ow < Wo) {
           const float v = apply_act(acc[j][e] + bv, act, alpha);
           const size_t o = ((size_t)(b * Ho + oh) * Wo + ow) * Co + j * 32 + l31;
-          y[o] = v;
-          if (yh) yh[o] = (__bf16)v;             // bf16 twin for the conv that reads this tensor next (t2i_output_image)
+          if (y) y[o] = v;                       // y == NULL: bf16 storage, the bf16 tensor alone is written
+          if (yh) yh[o] = (__bf16)v;             // bf16 twin for the conv that reads this tensor next, or THE tensor
         }
       }
     }
@@ -413,7 +413,7 @@ hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* 
 namespace t2i {
 
 size_t col_reduce_ws(int64_t rows, int C);
-hipError_t col_reduce_launch(const float*, const float*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t);
+hipError_t col_reduce_launch(const void*, const void*, const float*, int64_t, int, float*, float*, int, void*, hipStream_t, bool in_bf16 = false);
 
 // ------------------------------------------------------------------------------------------------------------------
 // tiny filter gradient (Cin, Cout <= 3, k <= 3: the generator's 3 -> 3 output conv): 81 sums over B*H*W pixels.

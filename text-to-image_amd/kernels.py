@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import XFORM_HAVE, XFORM_KEEP, ConvDesc, ConvOpts, check, lib
+from ._lib import DT_BF16, DT_F32, XFORM_HAVE, XFORM_KEEP, ConvDesc, ConvOpts, check, lib
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -43,9 +43,11 @@ def _live(t):
     raise RuntimeError('text-to-image_amd kernels need a ROCm device tensor (got %s); there is no CPU path' % t.device)
 
 
-def _chk(t, name='tensor'):
-    if t.dtype != torch.float32:
-        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+def _chk(t, name='tensor', f32=False):
+    """Activation tensors are float32, or bfloat16 under bf16 storage (set_storage); parameters and reduction results (f32=True)
+    are always float32."""
+    if t.dtype != torch.float32 and (f32 or t.dtype != torch.bfloat16):
+        raise TypeError('%s must be float32%s, got %s' % (name, '' if f32 else ' or bfloat16', t.dtype))
     if not t.is_contiguous():
         raise ValueError('%s must be contiguous (shape %s, strides %s)' % (name, tuple(t.shape), t.stride()))
     return t
@@ -132,6 +134,72 @@ def set_math(mode):
 
 def get_math():
     return 'bf16' if _MATH[0] == MATH_BF16 else 'f32'
+
+
+# Storage of the activation tensors the wrappers allocate (ABI v6, BASELINE config 3 end to end): 'f32' (default), or 'bf16' —
+# every activation / activation-gradient tensor with a multiple of 64 channels is then a torch.bfloat16 tensor, written by the
+# producing kernel and read by the consuming kernel as bf16; the 3-channel image side, logits, losses, parameters, gradients of
+# parameters, optimizer state and batch-norm statistics stay float32.  Needs set_math('bf16').
+_STORE = [torch.float32]
+_FORCE_F32 = [0]
+
+
+def set_storage(mode):
+    mode = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}[str(mode).lower()]
+    if mode is torch.bfloat16 and _MATH[0] != MATH_BF16:
+        raise ValueError("set_storage('bf16') needs set_math('bf16') first (bf16 tensors feed the bf16 matrix pipe)")
+    _STORE[0] = mode
+
+
+def get_storage():
+    return 'bf16' if _STORE[0] is torch.bfloat16 else 'f32'
+
+
+@contextlib.contextmanager
+def f32_outputs():
+    """Inside, the wrappers allocate float32 outputs whatever the storage mode (small tensors that feed fp32-only kernels: the two
+    conditioning-augmentation heads in front of t2i_ca_kl_fwd)."""
+    _FORCE_F32[0] += 1
+    try:
+        yield
+    finally:
+        _FORCE_F32[0] -= 1
+
+
+def _act_dtype(shape, want=None):
+    """dtype of a freshly allocated activation tensor of `shape`; want: the caller's explicit choice (a gradient takes the dtype of
+    the tensor it is the gradient of)."""
+    if want is not None:
+        return want
+    if _STORE[0] is torch.bfloat16 and not _FORCE_F32[0] and _MATH[0] == MATH_BF16 and shape[-1] % 64 == 0:
+        n = 1
+        for k in shape:
+            n *= int(k)
+        if n % 8 == 0:
+            return torch.bfloat16
+    return torch.float32
+
+
+def _dt(t):
+    return DT_BF16 if t.dtype == torch.bfloat16 else DT_F32
+
+
+def _same_dt(*ts):
+    ts = [t for t in ts if t is not None]
+    if any(t.dtype != ts[0].dtype for t in ts):
+        raise TypeError('activation tensors of one call must share a dtype, got %s' % [str(t.dtype) for t in ts])
+    return _dt(ts[0])
+
+
+def cast_f32(t):
+    """bf16 activation -> float32 tensor (exact), through t2i_cast_f32."""
+    if t.dtype == torch.float32:
+        return t
+    _chk(t, 't')
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    if _live(t):
+        check(lib.t2i_cast_f32(_ptr(t), t.numel(), _ptr(out), _stream()), 't2i_cast_f32')
+    return out
 
 
 def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding, math=None):
@@ -237,6 +305,8 @@ def bf16_image(t):
     INVARIANT: the kernels of this package write through raw pointers and do not bump tensor._version, so every wrapper that
     overwrites an EXISTING tensor (the `out=` arguments of axpby, col_reduce, conv_bwd_filter) drops the cached image of that
     tensor itself (_drop_image); all other wrappers write freshly allocated outputs."""
+    if t.dtype == torch.bfloat16:
+        return t                       # bf16 storage: the tensor is its own image
     if t.numel() % 8 != 0 or t.data_ptr() % 16 != 0:
         return None
     h = _image_holder(t)
@@ -252,8 +322,8 @@ def bf16_image(t):
 def _operand_images(opts, a, b=None):
     """Put the bf16 images of the call's activation operands into its t2i_conv_opts; the returned tensors must stay alive until
     the conv call has been issued."""
-    ia = bf16_image(a) if a is not None else None
-    ib = bf16_image(b) if b is not None else None
+    ia = bf16_image(a) if (a is not None and a.dtype != torch.bfloat16) else None      # a bf16 tensor is passed as the operand itself
+    ib = bf16_image(b) if (b is not None and b.dtype != torch.bfloat16) else None
     opts.a_image = ia.data_ptr() if ia is not None else None
     opts.b_image = ib.data_ptr() if ib is not None else None
     return ia, ib
@@ -273,7 +343,7 @@ def bf16_twins(on):
 def _twin_for(out, *inputs):
     """A buffer for the bf16 twin of `out` (bf16 math, a multiple of 64 channels: a conv reads it next), or None.  The producers
     write it on their vectorised path only, so every tensor of the call must be 16-byte aligned (the entry points refuse otherwise)."""
-    if _MATH[0] != MATH_BF16 or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
+    if out.dtype != torch.float32 or _MATH[0] != MATH_BF16 or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
         return None
     if any(t is not None and t.data_ptr() % 16 for t in (out,) + inputs):
         return None
@@ -324,13 +394,19 @@ def _xform_taken(opts, V):
         LAST_XFORM[0] = V
 
 
-def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False):
-    _chk(x, 'x'); _chk(w, 'w')
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
+def _storage_flags(opts, a, b, out):
+    opts.in_dtype = (1 if a.dtype == torch.bfloat16 else 0) | (2 if (b is not None and b.dtype == torch.bfloat16) else 0)
+    opts.out_dtype = DT_BF16 if (out is not None and out.dtype == torch.bfloat16) else DT_F32
+
+
+def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False, out_dtype=None):
+    _chk(x, 'x'); _chk(w, 'w', f32=True)
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=_act_dtype((d.B, d.Ho, d.Wo, d.Cout), out_dtype), device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         opts = ConvOpts()          # every allocation happens BEFORE the call; nothing is armed on the library side
+        _storage_flags(opts, x, None, y)
         keep = _operand_images(opts, x) if _h_path(d, 'fwd') else None
         twin = _twin_for(y) if (act != ACT_NONE and d.math == MATH_BF16) else None     # conv + bias + lrelu feeds the next conv directly
         opts.out_image = twin.data_ptr() if twin is not None else None
@@ -380,12 +456,12 @@ def bn_train_stats(x, gamma, beta, eps, decay, moving_mean=None, moving_var=None
             part, chunks, tile_rows, _ = hit
             check(lib.t2i_bn_train_fwd_stats(None, _ptr(part), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks, tile_rows, rows, C,
                                              _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift),
-                                             _ptr(moving_mean), _ptr(moving_var), None, 0, _stream()), 't2i_bn_train_fwd_stats')
+                                             _ptr(moving_mean), _ptr(moving_var), None, 0, DT_F32, _stream()), 't2i_bn_train_fwd_stats')
         else:
             wsp, wsn = _ws_args(x, int(lib.t2i_col_reduce_workspace_bytes(rows, C)))
             check(lib.t2i_bn_train_fwd_stats(_ptr(x), None, None, 0, 0, rows, C, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(mean),
-                                             _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(moving_mean), _ptr(moving_var), wsp, wsn, _stream()),
-                  't2i_bn_train_fwd_stats')
+                                             _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(moving_mean), _ptr(moving_var), wsp, wsn, _dt(x),
+                                             _stream()), 't2i_bn_train_fwd_stats')
     return mean, rstd, scale, shift
 
 
@@ -406,7 +482,7 @@ def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, d
         twin = _twin_for(dx)                    # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
         check(lib.t2i_bn_bwd_fused(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
                                    rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(twin), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
-                                   _stream()), 't2i_bn_bwd_fused')
+                                   _same_dt(dy, y, x), _stream()), 't2i_bn_bwd_fused')
         _twin_keep(dx, twin)
     return dx, dgamma, dbeta
 
@@ -424,10 +500,10 @@ def bn_stats(x):
     return s0, s1
 
 
-def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False):
+def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False, out_dtype=None):
     """conv_fwd whose epilogue also leaves the per-tile column sums of y, y*y for the batch norm behind it (take_stats)."""
-    _chk(x, 'x'); _chk(w, 'w')
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32, device=x.device)
+    _chk(x, 'x'); _chk(w, 'w', f32=True)
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=_act_dtype((d.B, d.Ho, d.Wo, d.Cout), out_dtype), device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         nbytes = int(lib.t2i_conv2d_stats_bytes(ctypes.byref(d)))
@@ -435,6 +511,7 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=
         chunks, tile_rows = ctypes.c_int32(0), ctypes.c_int32(0)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
         opts = ConvOpts()
+        _storage_flags(opts, x, None, y)
         keep = _operand_images(opts, x) if _h_path(d, 'fwd') else None
         V = _xform_offer(opts, x, d, keep_xform)
         check(lib.t2i_conv2d_fwd_stats(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(_chk(bias, 'bias') if bias is not None else None),
@@ -450,13 +527,14 @@ def conv_fwd_stats(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=
     return y
 
 
-def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2):
-    _chk(dy, 'dy'); _chk(w, 'w')
-    dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dy.device)
+def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, out_dtype=None):
+    _chk(dy, 'dy'); _chk(w, 'w', f32=True)
+    dx = torch.empty((d.B, d.H, d.W, d.Cin), dtype=_act_dtype((d.B, d.H, d.W, d.Cin), out_dtype), device=dy.device)
     if _live(dy):
         wsp, wsn = _ws_args(dy, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_data')) if _TIMER[0] is not None else None
         opts = ConvOpts()
+        _storage_flags(opts, dy, None, dx)
         keep = _operand_images(opts, dy) if _h_path(d, 'bwd_data') else None
         twin = _twin_for(dx) if (act != ACT_NONE and d.math == MATH_BF16) else None
         opts.out_image = twin.data_ptr() if twin is not None else None
@@ -474,7 +552,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
     optimizer's gradient arena; returns it."""
     _chk(x, 'x'); _chk(dy, 'dy')
     if out is not None:
-        _chk(out, 'out')
+        _chk(out, 'out', f32=True)
         assert out.numel() == d.KH * d.KW * d.Cin * d.Cout
         _drop_image(out)
     dw = out if out is not None else torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
@@ -482,6 +560,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'bwd_filter')) if _TIMER[0] is not None else None
         opts = ConvOpts()
+        _storage_flags(opts, x, dy, None)
         keep = _operand_images(opts, x, dy) if _h_path(d, 'bwd_filter') else None
         if xform is not None and conv_xform_bytes(d):
             opts.xform, opts.xform_bytes, opts.xform_mode = xform.data_ptr(), xform.numel() * 4, XFORM_HAVE
@@ -510,7 +589,7 @@ def col_reduce(a, b=None, want_second=False, out=None, center=None):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(a, need)
         check(lib.t2i_col_reduce(_ptr(a), _ptr(b), _ptr(_chk(center, 'center') if center is not None else None), rows, C, _ptr(out0),
-                                 _ptr(out1), 1 if out is not None else 0, wsp, wsn, _stream()), 't2i_col_reduce')
+                                 _ptr(out1), 1 if out is not None else 0, wsp, wsn, _same_dt(a, b), _stream()), 't2i_col_reduce')
     return out0, out1
 
 
@@ -531,7 +610,7 @@ def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
     y = torch.empty_like(x)
     if _live(x):
         twin = _twin_for(y, x, scale, shift)
-        check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _ptr(twin), _stream()),
+        check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _ptr(twin), _dt(x), _stream()),
               't2i_bn_apply')
         _twin_keep(y, twin)
     return y
@@ -560,7 +639,7 @@ def act_fwd(x, act, alpha=0.2):
     y = torch.empty_like(x)
     if _live(x):
         twin = _twin_for(y, x)
-        check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _ptr(twin), _stream()), 't2i_act_fwd')
+        check(lib.t2i_act_fwd(_ptr(x), x.numel(), act, alpha, _ptr(y), _ptr(twin), _dt(x), _stream()), 't2i_act_fwd')
         _twin_keep(y, twin)
     return y
 
@@ -570,7 +649,7 @@ def act_bwd(dy, y, act, alpha=0.2):
     dx = torch.empty_like(dy)
     if _live(dy):
         twin = _twin_for(dx, dy, y)
-        check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _ptr(twin), _stream()), 't2i_act_bwd')
+        check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _ptr(twin), _same_dt(dy, y), _stream()), 't2i_act_bwd')
         _twin_keep(dx, twin)
     return dx
 
@@ -594,7 +673,7 @@ def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
         twin = _twin_for(dx) if x2 is None else None        # conv bias path: dx is the next input / filter gradient's operand
         check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), _ptr(_chk(center, 'center') if center is not None else None), rows, C,
                                      act, alpha, _ptr(dx), _ptr(twin), _ptr(s), _ptr(s2),
-                                     1 if out is not None else 0, wsp, wsn, _stream()), 't2i_act_bwd_colsum')
+                                     1 if out is not None else 0, wsp, wsn, _same_dt(dy, y, x2), _stream()), 't2i_act_bwd_colsum')
         _twin_keep(dx, twin)
     return (dx, s) if x2 is None else (dx, s, s2)
 
@@ -605,7 +684,7 @@ def add_act(a, b, act=ACT_NONE, alpha=0.2):
     y = torch.empty_like(a)
     if _live(a):
         twin = _twin_for(y, a, b)
-        check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _ptr(twin), _stream()), 't2i_add_act')
+        check(lib.t2i_add_act(_ptr(a), _ptr(b), a.numel(), act, alpha, _ptr(y), _ptr(twin), _same_dt(a, b), _stream()), 't2i_add_act')
         _twin_keep(y, twin)
     return y
 
@@ -625,13 +704,13 @@ def axpby(a, alpha, b=None, beta=0.0, out=None):
     _drop_image(out)
     if _live(a):
         check(lib.t2i_axpby(_ptr(a), alpha, _ptr(_chk(b, 'b') if b is not None else None), beta, a.numel(), _ptr(y),
-                            _stream()), 't2i_axpby')
+                            _same_dt(a, b, y), _stream()), 't2i_axpby')
     return y
 
 
 def interp(eps, g, x):
-    _chk(g, 'g'); _chk(x, 'x')
-    eps = _chk(eps.reshape(-1), 'eps')
+    _chk(g, 'g', f32=True); _chk(x, 'x', f32=True)           # the 3-channel image side is float32 in every storage mode
+    eps = _chk(eps.reshape(-1), 'eps', f32=True)
     B = g.shape[0]
     assert eps.numel() == B and g.shape == x.shape
     out = torch.empty_like(g)
@@ -645,9 +724,9 @@ def concat_tile_fwd(feat, emb):
     _chk(feat, 'feat'); _chk(emb, 'emb')
     B, H, W, Cf = feat.shape
     Ce = emb.shape[1]
-    out = torch.empty((B, H, W, Cf + Ce), dtype=torch.float32, device=feat.device)
+    out = torch.empty((B, H, W, Cf + Ce), dtype=feat.dtype, device=feat.device)
     if _live(feat):
-        check(lib.t2i_concat_tile_fwd(_ptr(feat), _ptr(emb), B, H * W, Cf, Ce, _ptr(out), _stream()), 't2i_concat_tile_fwd')
+        check(lib.t2i_concat_tile_fwd(_ptr(feat), _ptr(emb), B, H * W, Cf, Ce, _ptr(out), _same_dt(feat, emb), _stream()), 't2i_concat_tile_fwd')
     return out
 
 
@@ -655,10 +734,10 @@ def concat_tile_bwd(dout, Cf, Ce):
     _chk(dout, 'dout')
     B, H, W, Ct = dout.shape
     assert Ct == Cf + Ce
-    dfeat = torch.empty((B, H, W, Cf), dtype=torch.float32, device=dout.device)
-    demb = torch.empty((B, Ce), dtype=torch.float32, device=dout.device)
+    dfeat = torch.empty((B, H, W, Cf), dtype=dout.dtype, device=dout.device)
+    demb = torch.empty((B, Ce), dtype=dout.dtype, device=dout.device)
     if _live(dout):
-        check(lib.t2i_concat_tile_bwd(_ptr(dout), B, H * W, Cf, Ce, _ptr(dfeat), _ptr(demb), _stream()), 't2i_concat_tile_bwd')
+        check(lib.t2i_concat_tile_bwd(_ptr(dout), B, H * W, Cf, Ce, _ptr(dfeat), _ptr(demb), _dt(dout), _stream()), 't2i_concat_tile_bwd')
     return dfeat, demb
 
 
@@ -666,18 +745,18 @@ def nchw_to_nhwc(x):
     """x physically [B,C,H,W] contiguous -> physically [B,H,W,C] contiguous"""
     _chk(x, 'x')
     B, C, H, W = x.shape
-    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     if _live(x):
-        check(lib.t2i_nchw_to_nhwc(_ptr(x), B, C, H * W, _ptr(y), _stream()), 't2i_nchw_to_nhwc')
+        check(lib.t2i_nchw_to_nhwc(_ptr(x), B, C, H * W, _ptr(y), _dt(x), _stream()), 't2i_nchw_to_nhwc')
     return y
 
 
 def nhwc_to_nchw(x):
     _chk(x, 'x')
     B, H, W, C = x.shape
-    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
     if _live(x):
-        check(lib.t2i_nhwc_to_nchw(_ptr(x), B, C, H * W, _ptr(y), _stream()), 't2i_nhwc_to_nchw')
+        check(lib.t2i_nhwc_to_nchw(_ptr(x), B, C, H * W, _ptr(y), _dt(x), _stream()), 't2i_nhwc_to_nchw')
     return y
 
 
@@ -686,17 +765,17 @@ def gp_slopes(g):
     B = g.shape[0]
     s = torch.empty(B, dtype=torch.float32, device=g.device)
     if _live(g):
-        check(lib.t2i_gp_slopes(_ptr(g), B, g.numel() // B, _ptr(s), _stream()), 't2i_gp_slopes')
+        check(lib.t2i_gp_slopes(_ptr(g), B, g.numel() // B, _ptr(s), _dt(g), _stream()), 't2i_gp_slopes')
     return s
 
 
 def row_scale(g, coef):
-    _chk(g, 'g'); _chk(coef, 'coef')
+    _chk(g, 'g'); _chk(coef, 'coef', f32=True)
     B = g.shape[0]
     assert coef.numel() == B
     out = torch.empty_like(g)
     if _live(g):
-        check(lib.t2i_row_scale(_ptr(g), _ptr(coef), B, g.numel() // B, _ptr(out), _stream()), 't2i_row_scale')
+        check(lib.t2i_row_scale(_ptr(g), _ptr(coef), B, g.numel() // B, _ptr(out), _dt(g), _stream()), 't2i_row_scale')
     return out
 
 
@@ -814,7 +893,7 @@ def wgan_d_head(logits, slopes1, slopes2, kt, gp_coeff):
 
 
 def ca_kl_fwd(mean, log_sigma, eps):
-    _chk(mean, 'mean'); _chk(log_sigma, 'log_sigma'); _chk(eps, 'eps')
+    _chk(mean, 'mean', f32=True); _chk(log_sigma, 'log_sigma', f32=True); _chk(eps, 'eps', f32=True)      # [B, 128]: kernels.f32_outputs()
     code = torch.empty_like(mean)
     kl = torch.empty(1, dtype=torch.float32, device=mean.device)
     if _live(mean):

@@ -508,7 +508,8 @@ class WGanCls(object):
         layers, `g_net/dense` (mu) and `g_net/dense_1` (log sigma)."""
         act = lrelu_act(0.2)
         flat = embeddings.reshape(embeddings.shape[0], -1)
-        return fc(flat, self.compressed_embed_dim, act=act), fc(flat, self.compressed_embed_dim, act=act)
+        with K.f32_outputs():      # [B, 128] each, consumed by the fp32 conditioning-augmentation kernel (bf16 storage would round them for nothing)
+            return fc(flat, self.compressed_embed_dim, act=act), fc(flat, self.compressed_embed_dim, act=act)
 
     def sample_normal_conditional(self, mean, log_sigma, cond_noise=True):
         """c = mu + exp(log sigma) * eps, eps ~ truncated N(0,1) (reference model.py:117-122).  The draw comes from the
