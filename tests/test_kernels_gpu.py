@@ -666,16 +666,16 @@ def test_bf16_twins_are_the_rounded_outputs(K):
         # writes none whatever came before it, and one that cannot write it (unaligned tensor) fails loudly instead of skipping
         img = torch.full(shape, 7.0, dtype=torch.bfloat16, device='cuda')
         y = torch.empty_like(a)
-        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), None)
+        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), 0, None)
         torch.cuda.synchronize()
         assert rc == 0 and np.array_equal(img.float().cpu().numpy(), _rne_bf16(y.cpu().numpy()))
         img.fill_(7.0)
-        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), None, None)
+        rc = lib.t2i_act_fwd(ctypes_ptr(a), a.numel(), K.ACT_LRELU, 0.2, ctypes_ptr(y), None, 0, None)
         torch.cuda.synchronize()
         assert rc == 0 and float(img.float().min()) == 7.0 and float(img.float().max()) == 7.0
         import ctypes
         odd = ctypes.c_void_p(a.data_ptr() + 4)
-        assert lib.t2i_act_fwd(odd, a.numel() - 4, K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), None) != 0
+        assert lib.t2i_act_fwd(odd, a.numel() - 4, K.ACT_LRELU, 0.2, ctypes_ptr(y), ctypes_ptr(img), 0, None) != 0
         assert b'16-byte' in lib.t2i_last_error()
     finally:
         K.tuning_set('force_splitk', 0)
