@@ -60,7 +60,7 @@ hipError_t act_bwd_colsum_launch(const void*, const void*, const void*, const fl
                                  float*, int, void*, hipStream_t, void* dx_h, bool in_bf16);
 // direct kernels for the 3-channel layers (t2i_thin.hip)
 bool thin_deconv_eligible(const t2i_conv_desc& d);
-hipError_t thin_deconv_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t);
+hipError_t thin_deconv_launch(const t2i_conv_desc&, const void*, const float*, const float*, float*, int, float, hipStream_t, bool dy_bf16 = false);
 bool tiny_bwdw_eligible(const t2i_conv_desc& d);
 size_t tiny_bwdw_ws(const t2i_conv_desc& d);
 hipError_t tiny_bwdw_launch(const t2i_conv_desc&, const float*, const float*, float*, int, void*, hipStream_t);
@@ -71,7 +71,7 @@ hipError_t head_bwd_filter_launch(const t2i_conv_desc&, const float*, const floa
 bool stem_fwd_eligible(const t2i_conv_desc& d);
 bool stem_bwdf_eligible(const t2i_conv_desc& d);
 size_t stem_bwdf_ws(const t2i_conv_desc& d);
-hipError_t stem_bwdf_launch(const t2i_conv_desc&, const float*, const float*, float*, int, void*, hipStream_t);
+hipError_t stem_bwdf_launch(const t2i_conv_desc&, const float*, const void*, float*, int, void*, hipStream_t, bool dy_bf16 = false);
 hipError_t stem_fwd_launch(const t2i_conv_desc&, const float*, const float*, const float*, float*, int, float, hipStream_t, void* y_h = nullptr);
 bool tiny_conv_eligible(const t2i_conv_desc& d, bool bwd);
 hipError_t tiny_conv_launch(const t2i_conv_desc&, bool, const float*, const float*, const float*, float*, int, float, hipStream_t);
@@ -699,6 +699,9 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const void* dyv, const float* w,
   if ((rc = storage_check(d, opts, "t2i_conv2d_bwd_data"))) return rc;
   if (!dyv || !w || !dxv) { set_error("t2i_conv2d_bwd_data: null tensor"); return T2I_ERR_INVALID; }
   opts->out_image_written = 0; opts->xform_kept = 0;
+  if (!tuning().no_thin && thin_deconv_eligible(*d) && gh && !xh && aligned16(dyv) && aligned16(w) &&
+      !(head_conv_eligible(*d) && !bias && act == T2I_ACT_NONE) && !tiny_conv_eligible(*d, true))      // 128 -> 3: bf16 activation in, fp32 image side out
+    return check(thin_deconv_launch(*d, dyv, w, bias, reinterpret_cast<float*>(dxv), act, alpha, (hipStream_t)stream, true), "t2i_conv2d_bwd_data(thin)");
   const bool direct = !tuning().no_thin && ((head_conv_eligible(*d) && !bias && act == T2I_ACT_NONE) || tiny_conv_eligible(*d, true) || thin_deconv_eligible(*d));
   if (!direct && h_eligible(*d, true) && (d->Cin % 4) == 0 && aligned16(dyv) && aligned16(w) && aligned16(dxv))
     return conv_h(MODE_BWD_DATA, d, gh ? nullptr : reinterpret_cast<const float*>(dyv), gh ? dyv : opts->a_image, w, bias,
@@ -772,6 +775,11 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* xv, const void* dy
   if ((rc = storage_check(d, opts, "t2i_conv2d_bwd_filter"))) return rc;
   if (!xv || !dyv || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
   opts->out_image_written = 0; opts->xform_kept = 0;
+  if (!tuning().no_thin && !head_conv_eligible(*d) && !tiny_bwdw_eligible(*d) && stem_bwdf_eligible(*d) && aligned16(dw) && !xh && gh) {
+    const size_t need = stem_bwdf_ws(*d);            // 3 -> 128 stem: fp32 image side x, bf16 activation gradient dy
+    if (!ws || ws_bytes < need || !aligned16(ws)) { set_error("t2i_conv2d_bwd_filter: workspace %zu B < %zu B required", ws_bytes, need); return T2I_ERR_WORKSPACE; }
+    return check(stem_bwdf_launch(*d, reinterpret_cast<const float*>(xv), dyv, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream, true), "t2i_conv2d_bwd_filter(stem)");
+  }
   const bool direct = !tuning().no_thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d) || (stem_bwdf_eligible(*d) && aligned16(dw)));
   if (!direct && h_filter_eligible(*d) && aligned16(xv) && aligned16(dyv) && aligned16(dw))
     return conv_h_filter(d, xh ? nullptr : reinterpret_cast<const float*>(xv), gh ? nullptr : reinterpret_cast<const float*>(dyv),

@@ -19,8 +19,8 @@
 namespace t2i {
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int CI>
-__global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+template <int CI, bool DYH = false>      // DYH: dy is a bf16 tensor (bf16 storage); widened exactly while it is staged into LDS
+__global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const void* __restrict__ dyv, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ dx,
                                                                int H, int W, int Co, int CH, int act, float alpha) {
   // CH = channels staged per pass (Co or Co / 2): with half the channels in LDS at a time a workgroup needs half the LDS, twice
@@ -50,8 +50,15 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const float* __re
       const int r = pix / 10, c = pix - r * 10;
       const int oh = oh0 + r, ow = ow0 + c;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo)
-        v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * Co + cbase + c4 * 4);
+      if ((unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo) {
+        const size_t e = ((size_t)(b * Ho + oh) * Wo + ow) * Co + cbase + c4 * 4;
+        if (DYH) {
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dyv) + e);
+          v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+        } else {
+          v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dyv) + e);
+        }
+      }
       *reinterpret_cast<float4*>(&tile[pix * PS + c4 * 4]) = v;
     }
     for (int i = threadIdx.x; i < 16 * CI * c4n; i += 256) {          // [tap][ci][CH] <- w[tap][ci][cbase .. cbase+CH)
@@ -92,8 +99,8 @@ bool thin_deconv_eligible(const t2i_conv_desc& d) {
          d.Wo * 2 == d.W;
 }
 
-hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx,
-                              int act, float alpha, hipStream_t stream) {
+hipError_t thin_deconv_launch(const t2i_conv_desc& d, const void* dy, const float* w, const float* bias, float* dx,
+                              int act, float alpha, hipStream_t stream, bool dy_bf16) {
   int parts = tuning().thin_parts;                  // passes over the channels (1, 2 or 4): Co / parts are staged at a time
   if (parts < 1) parts = 1;
   while (parts > 1 && ((d.Cout % (4 * parts)) != 0 || d.Cout / parts < 32)) parts >>= 1;
@@ -102,7 +109,7 @@ hipError_t thin_deconv_launch(const t2i_conv_desc& d, const float* dy, const flo
   dim3 grid(d.W / 16, d.H / 16, d.B);
 #define T2I_THIN(CI)                                                                                              \
   case CI: {                                                                                                      \
-    auto k = thin_deconv_k4s2_kernel<CI>;                                                                         \
+    auto k = dy_bf16 ? thin_deconv_k4s2_kernel<CI, true> : thin_deconv_k4s2_kernel<CI, false>;                    \
     if (lds > 48 * 1024) {                                                                                        \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                              \
@@ -492,7 +499,8 @@ __global__ __launch_bounds__(256) void tiny_bwdw_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+template <bool DYH>           // DYH: dy is a bf16 tensor (bf16 storage): 2-byte buffer loads, widened exactly
+__global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __restrict__ x, const void* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Ho, int Wo, int pix_per_wave, FastDiv div_wo, FastDiv div_ho) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // 2 x [64][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
   // (the load returns 0), so nothing depends on a load's result until the MFMA that consumes it — a select on the loaded
   // value would put an s_waitcnt behind every load
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((size_t)B * H * W * 3 * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), (short)0, (int)((size_t)P * 128 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), (short)0, (int)((size_t)P * 128 * (DYH ? 2 : 4)), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   auto load = [&](int p, float (&a)[2], float (&b)[4]) __attribute__((always_inline)) {
     const int pix = p + lh;                           // k = lh
@@ -540,9 +548,13 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
       const bool in = ok & a_ok[blk] & ((unsigned)(ih0 + a_kh[blk]) < (unsigned)H) & ((unsigned)(iw0 + a_kw[blk]) < (unsigned)W);
       a[blk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (unsigned)(xbase + a_off[blk]) * 4u : OOB, 0, 0));
     }
-    const unsigned ybase = ok ? ((unsigned)pp * 128u + (unsigned)l31) * 4u : OOB;
+    constexpr unsigned ES = DYH ? 2u : 4u;             // bytes per element of dy
+    const unsigned ybase = ok ? ((unsigned)pp * 128u + (unsigned)l31) * ES : OOB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? ybase + j * 128u : OOB, 0, 0));
+    for (int j = 0; j < 4; ++j) {
+      if (DYH) b[j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ry, ok ? ybase + j * 32u * ES : OOB, 0, 0) << 16);
+      else b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? ybase + j * 32u * ES : OOB, 0, 0));
+    }
   };
 
   // 8 pixels (4 MFMA k-steps) per macro step; the 24 loads of the next macro step are issued before this one's 32 MFMAs,
@@ -626,12 +638,12 @@ size_t stem_bwdf_ws(const t2i_conv_desc& d) {
   return (size_t)stem_bwdf_groups(d, &ppw) * 48 * 128 * sizeof(float);
 }
 
-hipError_t stem_bwdf_launch(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, hipStream_t stream) {
+hipError_t stem_bwdf_launch(const t2i_conv_desc& d, const float* x, const void* dy, float* dw, int accumulate, void* ws, hipStream_t stream, bool dy_bf16) {
   int ppw;
   const int G = stem_bwdf_groups(d, &ppw);
   float* part = reinterpret_cast<float*>(ws);
   const size_t lds = (size_t)2 * 64 * 128 * sizeof(float);
-  auto k = stem_k4s2_bwdf_kernel;
+  auto k = dy_bf16 ? stem_k4s2_bwdf_kernel<true> : stem_k4s2_bwdf_kernel<false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   FastDiv dwo, dho;
