@@ -306,7 +306,8 @@ class PGGAN(object):
 
     def generate_conditionals(self, embeddings, units=None):
         units = units or self.compr_embed_dim
-        return fc(embeddings, units, act=lrelu_act()), fc(embeddings, units, act=lrelu_act())
+        with K.f32_outputs():          # conditioning statistics stay fp32 in every storage mode
+            return fc(embeddings, units, act=lrelu_act()), fc(embeddings, units, act=lrelu_act())
 
     def sample_normal_conditional(self, mean, log_sigma, cond_noise=True):
         if not cond_noise:

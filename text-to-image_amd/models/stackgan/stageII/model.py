@@ -67,8 +67,9 @@ class ConditionalGan(object):
     def generate_conditionals(self, embeddings):
         act = lrelu_act(0.2)
         embeddings = embeddings.reshape(embeddings.shape[0], -1)
-        mean = dense(embeddings, self.compressed_embed_dim, activation=act, kernel_initializer=self.w_init)
-        log_sigma = dense(embeddings, self.compressed_embed_dim, activation=act, kernel_initializer=self.w_init)
+        with K.f32_outputs():          # [B, 128] statistics of the conditioning augmentation: fp32 in every storage mode
+            mean = dense(embeddings, self.compressed_embed_dim, activation=act, kernel_initializer=self.w_init)
+            log_sigma = dense(embeddings, self.compressed_embed_dim, activation=act, kernel_initializer=self.w_init)
         return mean, log_sigma
 
     def sample_normal_conditional(self, mean, log_sigma, cond_noise, noise=None):
