@@ -122,6 +122,7 @@ static Tuning& tuning_mut() {
     v.force_splitk = env_int("T2I_FORCE_SPLITK", 0);
     v.debug_plan = env_int("T2I_DEBUG_PLAN", 0);
     v.group_n = env_int("T2I_GROUP_N", 8);
+    v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
     v.no_thin = env_int("T2I_NO_THIN", 0);
     v.winograd = env_int("T2I_WINOGRAD", 1);
@@ -468,7 +469,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
     p.M = gd.Cin; p.N = gd.Cout; p.K = gd.B;
     p.div_c.set(gd.Cin);
     p.walk_db = 32; p.walk_doh = 0;               // 1x1 maps: one K-tile = 32 consecutive "images"
-    p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
+    p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc; p.batch_lin = tuning().batch_lin;
     Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
     { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }
@@ -490,7 +491,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
   } else {
     p.div_c.set(gd.Cin);
   }
-  p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc;
+  p.nbatch = nbatch; p.batch_a = sa; p.batch_b = sb; p.batch_c = sc; p.batch_lin = tuning().batch_lin;
   Plan pl = make_plan(p.M, p.N, p.K, nbatch, (size_t)p.M * p.N, 1, gd.math, true);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   { const int g = tuning().group_n; p.group_n = pl.tiles_n < g ? pl.tiles_n : g; if (p.group_n < 1) p.group_n = 1; }

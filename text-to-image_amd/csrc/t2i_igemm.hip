@@ -195,6 +195,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // down, so the ~64-96 workgroups an XCD runs at once form a block of (8-12 M tiles) x (GROUP_N N tiles) and share BOTH
   // operand panels through that XCD's 4 MB L2 (M-fastest order shared only the filter panel: every A panel was
   // re-fetched from HBM once per N tile — 220 MB of HBM-side traffic per launch against ~20 MB of operands).
+  // Batched launches (Winograd's tile positions) with batch_lin: grid.x = nbatch * tiles and the XCD run above is cut
+  // POSITION-major — an XCD works through whole positions one after the other, so a position's V panel and filter plane
+  // (1-4 MB together) are fetched into ONE L2 once, instead of every XCD streaming a slice of all positions at the same
+  // time (16 positions x (its A rows + the whole filter plane) = 10-36 MB against the 4 MB L2: every filter plane was
+  // fetched by all eight XCDs).
+  int bz_lin = 0;
+  if (p.batch_lin) {
+    const int tiles = tiles_m * p.tiles_n;
+    bz_lin = bid / tiles;
+    bid -= bz_lin * tiles;
+  }
   int tile_m, tile_n;
   {
     const int g = p.group_n;                       // min(tiles_n, 8), host side
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   // FWD launches may carry several independent GEMMs of one shape (grid.z): operand and output bases step per batch
-  const int64_t bz = p.nbatch > 1 ? (int64_t)blockIdx.z : 0;
+  const int64_t bz = p.nbatch > 1 ? (p.batch_lin ? (int64_t)bz_lin : (int64_t)blockIdx.z) : 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + bz * p.batch_a), (short)0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + bz * p.batch_b), (short)0, (int)p.b_bytes, 0x00020000);
 
@@ -845,6 +856,7 @@ static hipError_t launch_mode(const IgemmParams& p, int wmt, int wnt, int var, d
 
 hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int var, hipStream_t stream) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 1 ? p.nbatch : (mode == MODE_BWD_DATA ? p.nphase : 1));
+  if (p.nbatch > 1 && p.batch_lin) { grid.x *= p.nbatch; grid.z = 1; }
   if (p.d.math == T2I_MATH_BF16) {
     switch (mode) {
       case MODE_FWD: return launch_mode<MODE_FWD, 1>(p, wmt, wnt, var, grid, stream);

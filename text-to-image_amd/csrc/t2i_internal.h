@@ -66,6 +66,7 @@ struct IgemmParams {
   int32_t accumulate;         // epilogue adds the existing contents of the output (dw += ...: gradient accumulation)
   int32_t nbatch;             // FWD: independent GEMMs of identical shape in one launch (grid.z; Winograd's 16 tile positions)
   int64_t batch_a, batch_b, batch_c;   // element strides between them
+  int32_t batch_lin;          // batched: grid.x = nbatch * tiles, positions assigned to XCDs in contiguous runs (see igemm_kernel)
   float* stats;               // FWD, unsplit: per-M-tile column partials [2][tiles_m][N] (sum, sum of squares) of the output
   PhaseInfo phase[16];
 };
@@ -125,7 +126,7 @@ void set_error(const char* fmt, ...);
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin;
   double split_cost;
 };
 const Tuning& tuning();

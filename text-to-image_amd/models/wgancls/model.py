@@ -424,6 +424,11 @@ class WGanCls(object):
                 buf.copy_(src.reshape(buf.shape))
         self._graphs['loaded'] = True
 
+    def static_inputs(self):
+        """The captured graphs' input buffers (None before enable_graphs).  A data pipeline that writes its batch straight into
+        them — or a feed that simply hands them back — makes `_load_static` a no-op: it copies only tensors that live elsewhere."""
+        return dict(self._graphs['static']) if self._graphs is not None else None
+
     def enable_graphs(self, feed):
         """Capture the device work of d_step and g_step into two hipGraphs and replay them from then on: the step's
         ~1000 launches become two graph launches (the host was within 25% of being the bottleneck: 15.9 ms to issue an
