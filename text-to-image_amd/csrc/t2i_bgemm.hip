@@ -1,0 +1,278 @@
+// t2i_bgemm.hip — batched plain GEMMs of the Winograd paths on the fp32 matrix pipe, PERSISTENT workgroups (gfx950 only).
+//
+// The Winograd convolutions (t2i_winograd.hip) spend their matrix time in 9-36 independent GEMMs of one shape per launch,
+// with K = the channel count only (256-1152): 8-36 K-tiles per output tile.  Launched through igemm_kernel (one workgroup
+// per 64x64 output tile, 2-4 rounds of workgroups per launch) a K sweep measured  t = 12.5 us + 4.8 us x K-tiles  for the
+// 2048-tile shape (profiles/r03_batched_gemm_ksweep.txt): the K loop itself runs at 72 % of the fp32 MFMA peak — what this
+// chip's exact-fp32 MFMA sustains (cdna_hip_programming.md quotes 122 of 157 TF/s at 4096^3) — and the fixed 12.5 us are
+// the launch ramp plus one PROLOGUE BUBBLE PER ROUND: the 4 workgroups sharing a CU start together, so they also finish
+// together, and the 4 that replace them all sit in their prologue (address set-up, two dependent operand fetches, first
+// LDS fill: ~2 us) at the same time with nothing to multiply.
+// Here a launch has at most as many workgroups as fit on the chip at once (4 per CU), and each walks through its share of
+// the output tiles WITHOUT leaving the K loop: the operand fetches of tile i+1's first two K-tiles are issued during the
+// last two K-tiles of tile i (the loader state is switched on the fly), tile i's accumulators are stored while tile
+// i+1's fragments are already in registers, and the matrix pipe never waits for a prologue again.
+//   C[z][M,N] = op(A[z]) * op(B[z])   for z < nbatch, three operand layouts (what the three conv primitives need):
+//     LAY 0  A [M][K] K-inner, B [K][N] N-inner      forward conv        (V [T,Cin]  x U [Cin,Cout])
+//     LAY 1  A [M][K] K-inner, B [N][K] K-inner      input gradient      (V [T,Cout] x U [Cin,Cout]^T)
+//     LAY 2  A [K][M] M-inner, B [K][N] N-inner      filter gradient     (V [T,Cin]^T x dY [T,Cout])
+// Tile 64x64, 4 waves (2x2) of one 32x32 accumulator, BK = 32, v_mfma_f32_32x32x2_f32: the LDS images, the k permutation of
+// the fragments and the one-barrier-per-K-tile schedule are igemm_kernel's (t2i_igemm.hip) — an output element is the same
+// fmaf chain over k in the same order, so results are bit-identical to the per-tile launch.
+// Work order: items w = z * tiles + tile (position-major); XCD x owns a contiguous run of items (a position's operands
+// meet in ONE 4 MB L2), its S workgroups take items run + s, run + s + S, ... so that at any time an XCD works on 1-2
+// positions.  Ragged edges (M, N not multiples of 64; K not a multiple of 32) read zeros through the buffer range check.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t2i_internal.h"
+
+namespace t2i {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BK = 32;
+constexpr int KSTRIDE = BK + 4;            // K-inner LDS row stride (36 dwords: conflict-free ds_read_b128)
+constexpr int BM = 64, BN = 64;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+template <int LAY>
+struct BSmem {
+  static constexpr bool A_KIN = LAY != 2, B_KIN = LAY == 1;
+  static constexpr int A_ELEMS = A_KIN ? BM * KSTRIDE : BK * BM;
+  static constexpr int B_ELEMS = B_KIN ? BN * KSTRIDE : BK * BN;
+  static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
+};
+
+__device__ __forceinline__ float4 bl4(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)elem_off * 4u : OOB, 0, 0);
+  return __builtin_bit_cast(float4, v);
+}
+}  // namespace
+
+template <int LAY>
+__global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
+  using S = BSmem<LAY>;
+  constexpr bool A_KIN = S::A_KIN, B_KIN = S::B_KIN;
+  extern __shared__ __attribute__((aligned(16))) float smem_b[];
+  float* As = smem_b;
+  float* Bs = smem_b + 2 * S::A_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- this workgroup's items -----------------------------------------------------------------------------------------
+  const int nslot = gridDim.x >> 3;                       // workgroups per XCD (gridDim.x is a multiple of 8)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = p.items >> 3, r = p.items & 7;
+  const int run0 = xcd * q + min(xcd, r), runlen = q + (xcd < r ? 1 : 0);
+  if (slot >= runlen) return;
+  const int n_items = (runlen - slot + nslot - 1) / nslot;
+  const int tiles = p.tiles_m * p.tiles_n;
+
+  auto coords = [&](int w, int& bz, int& bm, int& bn) __attribute__((always_inline)) {
+    bz = w / tiles;
+    const int t = w - bz * tiles;
+    const int g = p.group_n, per_group = g * p.tiles_m;   // grouped rasterisation inside a position (as igemm_kernel)
+    const int grp = t / per_group, rr = t - grp * per_group, n0 = grp * g;
+    const int width = min(g, p.tiles_n - n0);
+    const int tm = rr / width;
+    bm = tm * BM;
+    bn = (n0 + rr - tm * width) * BN;
+  };
+
+  // ---- loader state (switched per item) ----------------------------------------------------------------------------------
+  // K-inner image: thread -> (k quad kq, rows r0 + 32 i).   M/N-inner image: thread -> (column quad c4, k rows kr + 16 i).
+  const int kq = tid & 7, r0 = tid >> 3, c4 = tid & 15, kr = tid >> 4;
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int a_off[2], b_off[2];
+  bool a_ok[2], b_ok[2];
+  int l_item = -1, l_t = 0;            // the item being fetched, and its next K-tile
+
+  auto next_item = [&]() __attribute__((always_inline)) {
+    ++l_item;
+    l_t = 0;
+    if (l_item >= n_items) {           // past the last item: the pipeline's look-ahead fetches zeros
+      a_ok[0] = a_ok[1] = b_ok[0] = b_ok[1] = false;
+      return;
+    }
+    int bz, bm, bn;
+    coords(run0 + slot + l_item * nslot, bz, bm, bn);
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (int64_t)bz * p.sa), (short)0, (int)p.a_bytes, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (int64_t)bz * p.sb), (short)0, (int)p.b_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KIN) {
+        const int m = bm + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        a_off[i] = m * p.K + kq * 4;
+      } else {
+        const int m = bm + c4 * 4;
+        a_ok[i] = m < p.M;
+        a_off[i] = (kr + 16 * i) * p.M + m;
+      }
+      if (B_KIN) {
+        const int n = bn + r0 + 32 * i;
+        b_ok[i] = n < p.N;
+        b_off[i] = n * p.K + kq * 4;
+      } else {
+        const int n = bn + c4 * 4;
+        b_ok[i] = n < p.N;
+        b_off[i] = (kr + 16 * i) * p.N + n;
+      }
+    }
+  };
+
+  float4 areg[2], breg[2];
+  auto load_tile = [&]() __attribute__((always_inline)) {          // the next K-tile of the item sequence (next_item() is the K loop's business)
+    const int k0 = l_t * BK;
+    ++l_t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KIN) areg[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
+      else areg[i] = bl4(ra, a_off[i] + k0 * p.M, a_ok[i] & (k0 + kr + 16 * i < p.K));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (B_KIN) breg[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
+      else breg[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + kr + 16 * i < p.K));
+    }
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    float* as = As + buf * S::A_ELEMS;
+    float* bs = Bs + buf * S::B_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = areg[i];
+      else *reinterpret_cast<float4*>(&as[(kr + 16 * i) * BM + c4 * 4]) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = breg[i];
+      else *reinterpret_cast<float4*>(&bs[(kr + 16 * i) * BN + c4 * 4]) = breg[i];
+    }
+  };
+
+  // fragments of one 8-k chunk: MFMA j consumes k = 8c + j (lanes 0-31) and 8c + 4 + j (lanes 32-63)
+  struct Frag { float a[4]; float b[4]; };
+  auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) __attribute__((always_inline)) {
+    const int row = wm * 32 + l31, col = wn * 32 + l31;
+    if (A_KIN) {
+      const float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
+      f.a[0] = v.x; f.a[1] = v.y; f.a[2] = v.z; f.a[3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.a[j] = as[(c * 8 + j + 4 * lh) * BM + row];
+    }
+    if (B_KIN) {
+      const float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
+      f.b[0] = v.x; f.b[1] = v.y; f.b[2] = v.z; f.b[3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[j] = bs[(c * 8 + j + 4 * lh) * BN + col];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto mma_frag = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j], f.b[j], acc, 0, 0, 0);
+  };
+
+  // One K-tile (igemm_kernel's schedule): registers hold tile t+1, LDS buf[t&1] tile t; the barrier sits mid-tile right after
+  // the store of tile t+1, the first two fragment chunks of tile t+1 are fetched while the last two of tile t multiply.
+  auto k_tile = [&](int t, Frag& c0, Frag& c1, Frag& n0, Frag& n1) __attribute__((always_inline)) {
+    const float* as = As + (t & 1) * S::A_ELEMS;
+    const float* bs = Bs + (t & 1) * S::B_ELEMS;
+    const float* an = As + ((t + 1) & 1) * S::A_ELEMS;
+    const float* bn_ = Bs + ((t + 1) & 1) * S::B_ELEMS;
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c0);                                   // chunk 0
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c0, as, bs, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c1);                                   // chunk 1, with the LDS store of tile t+1 interleaved
+    store_tile((t + 1) & 1);
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c1, as, bs, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frag(n0, an, bn_, 0);                      // tile t+1, chunks 0 and 1
+    read_frag(n1, an, bn_, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile();                                    // tile t+2 (the next item's first tiles at an item's end)
+    mma_frag(c0);                                   // chunk 2
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(c1);                                   // chunk 3
+  };
+
+  next_item();
+  load_tile();
+  store_tile(0);
+  load_tile();
+  __syncthreads();
+  Frag fa0, fa1, fb0, fb1;
+  read_frag(fa0, As, Bs, 0);
+  read_frag(fa1, As, Bs, 1);
+  for (int it = 0; it < n_items; ++it) {
+    for (int t = 0; t < p.ntiles; t += 2) {          // ntiles is even (host side): buffer parity restarts at 0 for every item
+      // the loads run two K-tiles ahead: K-tiles t and t+1 are on their way, so from here on the loader belongs to the next
+      // item.  The switch sits HERE, between two K-tile pairs, and not inside load_tile: a branch in the middle of a K-tile
+      // splits the region the sched_barriers order (measured: -3..5 % on the long-K shapes).
+      if (t + 2 == p.ntiles) next_item();
+      k_tile(0, fa0, fa1, fb0, fb1);
+      k_tile(1, fb0, fb1, fa0, fa1);
+    }
+    // ---- this item's tile -> memory.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    int bz, bm, bn;
+    coords(run0 + slot + it * nslot, bz, bm, bn);
+    float* out = p.c + (int64_t)bz * p.sc;
+    const int n = bn + wn * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  }
+}
+
+template <int LAY>
+static hipError_t launch_b(const BgemmParams& p, int nblk, hipStream_t stream) {
+  using S = BSmem<LAY>;
+  hipLaunchKernelGGL(bgemm_kernel<LAY>, dim3(nblk), dim3(256), S::BYTES, stream, p);
+  return hipGetLastError();
+}
+
+// lay: 0 forward, 1 input gradient, 2 filter gradient (see the header).  p.items / p.ntiles / tiles are filled by the caller.
+hipError_t bgemm_launch(int lay, const BgemmParams& p, hipStream_t stream) {
+  const int per_xcd = (p.items + 7) / 8;
+  int nslot = per_xcd < 128 ? per_xcd : 128;       // 128 = 4 per CU; fewer, evenly loaded workgroups (e.g. 72 x 2 items for 144) lose to the
+  if (nslot < 1) nslot = 1;                        // CU granularity: 72 workgroups on 32 CUs leave some CUs with 3, some with 2
+  const int nblk = nslot * 8;
+  switch (lay) {
+    case 0: return launch_b<0>(p, nblk, stream);
+    case 1: return launch_b<1>(p, nblk, stream);
+    case 2: return launch_b<2>(p, nblk, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace t2i

@@ -122,6 +122,7 @@ static Tuning& tuning_mut() {
     v.force_splitk = env_int("T2I_FORCE_SPLITK", 0);
     v.debug_plan = env_int("T2I_DEBUG_PLAN", 0);
     v.group_n = env_int("T2I_GROUP_N", 8);
+    v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
     v.no_thin = env_int("T2I_NO_THIN", 0);
@@ -460,6 +461,33 @@ static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy
 //   flt: c[Cin, Cout] = a[T, Cin]^T * b[T, Cout]     (MODE_BWD_FILTER, reduction over the T "pixels")
 int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb,
                      int64_t sc, hipStream_t stream, const char* what) {
+  {   // fp32, 16-byte operands, an even number of K-tiles: persistent workgroups that never leave the K loop
+    const int M = gmode == MODE_BWD_FILTER ? gd.Cin : gd.B;
+    const int N = gmode == MODE_BWD_DATA ? gd.Cin : gd.Cout;
+    const int K = gmode == MODE_BWD_FILTER ? gd.B : (gmode == MODE_BWD_DATA ? gd.Cout : gd.Cin);
+    const int ntiles = (K + 31) / 32;
+    const int64_t a_elems = (int64_t)gd.B * (gmode == MODE_BWD_DATA ? gd.Cout : gd.Cin);
+    const int64_t b_elems = gmode == MODE_BWD_FILTER ? (int64_t)gd.B * gd.Cout : (int64_t)gd.Cin * gd.Cout;
+    if (tuning().bgemm && gd.math != T2I_MATH_BF16 && !tuning().force_tile && (ntiles & 1) == 0 && M % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
+        aligned16(a) && aligned16(b) && sa % 4 == 0 && sb % 4 == 0 && a_elems < (1LL << 30) && b_elems < (1LL << 30)) {
+      BgemmParams q;
+      memset(&q, 0, sizeof(q));
+      q.a = a; q.b = b; q.c = c;
+      q.M = M; q.N = N; q.K = K;
+      q.tiles_m = (M + 63) / 64; q.tiles_n = (N + 63) / 64;
+      { const int g = tuning().group_n; q.group_n = q.tiles_n < g ? q.tiles_n : g; if (q.group_n < 1) q.group_n = 1; }
+      q.ntiles = ntiles;
+      const int64_t items = (int64_t)nbatch * q.tiles_m * q.tiles_n;
+      if (items < (1LL << 30)) {
+        q.items = (int32_t)items;
+        q.sa = sa; q.sb = sb; q.sc = sc;
+        q.a_bytes = (uint32_t)(a_elems * 4); q.b_bytes = (uint32_t)(b_elems * 4);
+        if (tuning().debug_plan)
+          fprintf(stderr, "[t2i plan] batched x%d M=%d N=%d K=%d mode %d -> persistent 64x64, %lld items\n", nbatch, M, N, K, gmode, (long long)items);
+        return check(bgemm_launch(gmode == MODE_FWD ? 0 : (gmode == MODE_BWD_DATA ? 1 : 2), q, stream), what);
+      }
+    }
+  }
   IgemmParams p;
   fill_common(p, &gd);
   p.a = a; p.b = b;
@@ -1156,7 +1184,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

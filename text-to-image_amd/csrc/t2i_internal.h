@@ -123,10 +123,24 @@ void set_error(const char* fmt, ...);
 
 // Tuning / diagnostic switches, read from the T2I_* environment ONCE (first use) so that the planner never depends on the
 // environment at call time: two calls with the same descriptor always take the same path within a process.
+// batched plain GEMMs with persistent workgroups (t2i_bgemm.hip): C[z][M,N] = op(A[z]) * op(B[z])
+struct BgemmParams {
+  const float* a;
+  const float* b;
+  float* c;
+  int32_t M, N, K;
+  int32_t tiles_m, tiles_n, group_n;
+  int32_t ntiles;             // K-tiles of 32 (even)
+  int32_t items;              // nbatch * tiles_m * tiles_n
+  int64_t sa, sb, sc;         // element strides between the batch members
+  uint32_t a_bytes, b_bytes;  // extents of ONE member's operands (buffer-load range check)
+};
+hipError_t bgemm_launch(int lay, const BgemmParams& p, hipStream_t stream);
+
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm;
   double split_cost;
 };
 const Tuning& tuning();
