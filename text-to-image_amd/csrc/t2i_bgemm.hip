@@ -19,6 +19,12 @@
 // Tile 64x64, 4 waves (2x2) of one 32x32 accumulator, BK = 32, v_mfma_f32_32x32x2_f32: the LDS images, the k permutation of
 // the fragments and the one-barrier-per-K-tile schedule are igemm_kernel's (t2i_igemm.hip) — an output element is the same
 // fmaf chain over k in the same order, so results are bit-identical to the per-tile launch.
+// What bounds the K loop (timing-only ablations of this kernel, 2048 tiles, profiles/r03_bgemm_ablation.txt): dropping the barrier
+// changes nothing; a second accumulator per wave (no MFMA -> MFMA dependency) nothing; loads three K-tiles ahead through a
+// second register set nothing; direct-to-LDS DMA (buffer_load ... lds into an XOR-swizzled unpadded image, issued from inline
+// assembly so that hipcc does not wait for it before every ds_read) nothing — while dropping the operand fetches altogether is
+// worth 14 % and the LDS stores another 4 %: the loop is co-limited by the L2 -> CU operand stream itself (64 KB per CU per
+// K-tile round, ~12 B/clk/CU), not by latency, issue order or the staging path.
 // Work order: items w = z * tiles + tile (position-major); XCD x owns a contiguous run of items (a position's operands
 // meet in ONE 4 MB L2), its S workgroups take items run + s, run + s + S, ... so that at any time an XCD works on 1-2
 // positions.  Ragged edges (M, N not multiples of 64; K not a multiple of 32) read zeros through the buffer range check.
@@ -128,34 +134,36 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   };
 
   float4 areg[2], breg[2];
-  auto load_tile = [&]() __attribute__((always_inline)) {          // the next K-tile of the item sequence (next_item() is the K loop's business)
+  auto load_into = [&](float4* ar, float4* br) __attribute__((always_inline)) {   // the next K-tile of the item sequence (next_item() is the K loop's business)
     const int k0 = l_t * BK;
     ++l_t;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (A_KIN) areg[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
-      else areg[i] = bl4(ra, a_off[i] + k0 * p.M, a_ok[i] & (k0 + kr + 16 * i < p.K));
+      if (A_KIN) ar[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
+      else ar[i] = bl4(ra, a_off[i] + k0 * p.M, a_ok[i] & (k0 + kr + 16 * i < p.K));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (B_KIN) breg[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
-      else breg[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + kr + 16 * i < p.K));
+      if (B_KIN) br[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
+      else br[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + kr + 16 * i < p.K));
     }
   };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+  auto load_tile = [&]() __attribute__((always_inline)) { load_into(areg, breg); };
+  auto store_from = [&](int buf, const float4* ar, const float4* br) __attribute__((always_inline)) {
     float* as = As + buf * S::A_ELEMS;
     float* bs = Bs + buf * S::B_ELEMS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = areg[i];
-      else *reinterpret_cast<float4*>(&as[(kr + 16 * i) * BM + c4 * 4]) = areg[i];
+      if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = ar[i];
+      else *reinterpret_cast<float4*>(&as[(kr + 16 * i) * BM + c4 * 4]) = ar[i];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = breg[i];
-      else *reinterpret_cast<float4*>(&bs[(kr + 16 * i) * BN + c4 * 4]) = breg[i];
+      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = br[i];
+      else *reinterpret_cast<float4*>(&bs[(kr + 16 * i) * BN + c4 * 4]) = br[i];
     }
   };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) { store_from(buf, areg, breg); };
 
   // fragments of one 8-k chunk: MFMA j consumes k = 8c + j (lanes 0-31) and 8c + 4 + j (lanes 32-63)
   struct Frag { float a[4]; float b[4]; };
@@ -223,9 +231,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   };
 
   next_item();
-  load_tile();
-  store_tile(0);
-  load_tile();
+  {   // the only prologue of the launch: both first K-tiles are requested before the first is waited for
+    float4 a0[2], b0[2];
+    load_into(a0, b0);
+    load_tile();
+    store_from(0, a0, b0);
+  }
   __syncthreads();
   Frag fa0, fa1, fb0, fb1;
   read_frag(fa0, As, Bs, 0);
