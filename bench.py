@@ -384,7 +384,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
             break
         flop_per_step = s['flop'] / inst_steps
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> (all conv/deconv/dense launches)',
+            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel)',
             'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
             'frac': achieved / peak, 'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
             # the same algorithmic FLOPs against the driver-visible clock: the WHOLE iteration (everything that is not a

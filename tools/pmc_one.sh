@@ -7,7 +7,7 @@ python - "$(find $out -name '*counter_collection.csv' | head -1)" "$1 $2 $3 $4 $
 import csv, sys
 tot = 0.0; n = set(); dur = 0
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'igemm_kernel' in r['Kernel_Name']:
+    if 'igemm_kernel' in r['Kernel_Name'] or 'bgemm_kernel' in r['Kernel_Name']:
         tot += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in n:
             n.add(r['Dispatch_Id']); dur += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
