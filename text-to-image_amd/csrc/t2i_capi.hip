@@ -127,11 +127,11 @@ static Tuning& tuning_mut() {
     v.no_ut = env_int("T2I_NO_UT", 0);
     v.no_thin = env_int("T2I_NO_THIN", 0);
     v.winograd = env_int("T2I_WINOGRAD", 1);
-    v.winograd_minc = env_int("T2I_WINOGRAD_MINC", 256);
+    v.winograd_minc = env_int("T2I_WINOGRAD_MINC", 128);
     v.winograd_maxhw = env_int("T2I_WINOGRAD_MAXHW", 256);
     v.winograd_k4s2 = env_int("T2I_WINOGRAD_K4S2", 1);
     v.winograd_k4s2_minc = env_int("T2I_WINOGRAD_K4S2_MINC", 128);
-    v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 256);
+    v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 128);
     v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
     v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
     v.cache_refresh = env_int("T2I_CACHE_REFRESH", 0);     // 1: t2i_adam_tf itself regenerates the cached filter images of its arena (else the caller: t2i_filter_cache_refresh)
@@ -311,7 +311,7 @@ static inline size_t al256c(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // bytes of the input transform the forward conv of `d` and its filter gradient share (0: they do not both take a Winograd path)
 static size_t xform_bytes(const t2i_conv_desc& d) {
-  if (winograd_eligible(d, false)) return (size_t)16 * ((size_t)d.B * (d.H / 2) * (d.W / 2)) * d.Cin * 4;
+  if (winograd_filter_eligible(d)) return (size_t)16 * ((size_t)d.B * (d.H / 2) * (d.W / 2)) * d.Cin * 4;
   if (winograd_k4s2_eligible(d, false) && tuning().winograd_k4s2_bwdf) return (size_t)9 * ((size_t)d.B * (d.Ho / 2) * (d.Wo / 2)) * 4 * d.Cin * 4;
   return 0;
 }
@@ -570,7 +570,7 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (stem_bwdf_eligible(*d) && stem_bwdf_ws(*d) > need) need = stem_bwdf_ws(*d);
   if (winograd_eligible(*d, false) && winograd_ws(*d, false) > need) need = winograd_ws(*d, false);
   if (winograd_eligible(*d, true) && winograd_ws(*d, true) > need) need = winograd_ws(*d, true);
-  if (winograd_eligible(*d, false) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
+  if (winograd_filter_eligible(*d) && winograd_filter_grad_ws(*d) > need) need = winograd_filter_grad_ws(*d);
   if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_ws(*d) > need) need = winograd_k4s2_ws(*d);
   if (winograd_k4s2_eligible(*d, true) && winograd_k4s2_bwd_ws(*d) > need) need = winograd_k4s2_bwd_ws(*d);
   if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_filter_grad_ws(*d) > need) need = winograd_k4s2_filter_grad_ws(*d);
@@ -856,7 +856,7 @@ static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const 
       return check(stem_bwdf_launch(*d, x, dy, dw, accumulate ? 1 : 0, ws, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stem)");
     }
   }
-  if (winograd_eligible(*d, false) && aligned16(x) && aligned16(dy) && aligned16(dw))
+  if (winograd_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
@@ -1212,7 +1212,7 @@ int t2i_conv2d_algo(const t2i_conv_desc* d, int32_t which) {
     if (winograd_k4s2_eligible(*d, true)) return T2I_ALGO_WINOGRAD_F2X2_2X2;
   } else {
     if (thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d) || stem_bwdf_eligible(*d))) return T2I_ALGO_DIRECT_SMALL;
-    if (winograd_eligible(*d, false)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
+    if (winograd_filter_eligible(*d)) return T2I_ALGO_WINOGRAD_F2X2_3X3;
     if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf) return T2I_ALGO_WINOGRAD_F2X2_2X2;
     if (h_filter_eligible(*d)) return T2I_ALGO_IMPLICIT_GEMM_BF16_OPERANDS;
   }

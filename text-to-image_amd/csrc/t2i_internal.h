@@ -82,6 +82,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
 
 // Winograd F(2x2, 3x3) for 3x3 stride-1 SAME convolutions with many channels (t2i_winograd.hip)
 bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data);
+bool winograd_filter_eligible(const t2i_conv_desc& d);      // the filter gradient's own size rule on top of winograd_eligible(d, false)
 size_t winograd_ws(const t2i_conv_desc& d, bool bwd_data);
 int winograd_conv(const t2i_conv_desc& d, bool bwd_data, const float* in, const float* w, const float* bias, float* out, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t stream, float* Vkeep = nullptr);

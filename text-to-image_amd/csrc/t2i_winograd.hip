@@ -261,6 +261,13 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
   return T * d.Cin * d.Cout >= 50000000LL;
 }
 
+// The filter gradient's 16 GEMMs are [Cin, T] x [T, Cout]: their tile count does not grow with the batch, and 128 x 128
+// channels (64 tiles of 64x64 in all) leave the chip three quarters empty (8x8x128->128 at B=192: 85 us against 43 us for the
+// direct GEMM).  From 128 x 512 on (256 tiles) the Winograd form wins again (8x8x128->512: 52.6 -> 47.2 us at B=64).
+bool winograd_filter_eligible(const t2i_conv_desc& d) {
+  return winograd_eligible(d, false) && (int64_t)d.Cin * d.Cout >= 65536;
+}
+
 static void wino_dims(const t2i_conv_desc& d, bool bwd, size_t* T, int* K, int* N) {
   *T = (size_t)d.B * (d.H / 2) * (d.W / 2);
   *K = bwd ? d.Cout : d.Cin;
@@ -522,8 +529,9 @@ bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data) {
   if (!(d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1)) return false;
   if ((d.H & 3) || (d.W & 3) || d.Ho * 2 != d.H || d.Wo * 2 != d.W) return false;          // 2x2 output tiles, no ragged edge
   if (bwd_data ? ((d.Cout % 32) || (d.Cin % 32)) : ((d.Cin % 8) || (d.Cout % 32))) return false;
-  // the input-gradient form transforms dy once per output phase (9x its bytes through the workspace): it only pays
-  // from 256 channels up (32x32x128->256 measured 13 % slower, 16x16x256->512 11 % faster than the direct GEMM)
+  // the input-gradient form transforms dy once per output phase (9x its bytes through the workspace).  With one workgroup per
+  // GEMM tile it only paid from 256 channels up (32x32x128->256 measured 13 % slower than the direct GEMM); with the persistent
+  // batched GEMM (t2i_bgemm.hip) the 128-channel layers gain too (155 -> 143 us at B=64, 457 -> 422 us at B=192)
   const int minc_bwd = tuning().winograd_k4s2_bwd_minc;
   const int m = bwd_data ? minc_bwd : minc;
   return d.Cin >= m && d.Cout >= m;
