@@ -128,7 +128,8 @@ static Tuning& tuning_mut() {
     v.no_thin = env_int("T2I_NO_THIN", 0);
     v.winograd = env_int("T2I_WINOGRAD", 1);
     v.winograd_minc = env_int("T2I_WINOGRAD_MINC", 128);
-    v.winograd_maxhw = env_int("T2I_WINOGRAD_MAXHW", 256);
+    v.winograd_maxhw = env_int("T2I_WINOGRAD_MAXHW", 1024);
+    v.winograd_minwork = env_int("T2I_WINOGRAD_MINWORK", 50000000);   // T * Cin * Cout below which 16 GEMMs + transforms lose to one direct GEMM
     v.winograd_k4s2 = env_int("T2I_WINOGRAD_K4S2", 1);
     v.winograd_k4s2_minc = env_int("T2I_WINOGRAD_K4S2_MINC", 128);
     v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 128);
@@ -1184,7 +1185,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

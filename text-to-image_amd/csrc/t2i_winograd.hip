@@ -255,10 +255,13 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
   const int cmin = d.Cin < d.Cout ? d.Cin : d.Cout;
   const int maxhw = tuning().winograd_maxhw;
   if (cmin < wino_min_channels() || (int64_t)d.H * d.W > maxhw) return false;
-  // ... and the 16 GEMMs are big enough to fill the chip after the fixed cost of the filter transform (measured: the
-  // 4x4x256->512 critic layer at B=64, T*K*N = 3.4e7, loses 12%; 4x4x256->1024, 6.7e7, gains 10%)
+  // ... and the 16 GEMMs are big enough to fill the chip (winograd_minwork, 5e7).  Measured at B=64 with the filter images cached
+  // and the persistent batched GEMM: 4x4x256->512, T*K*N = 3.4e7, would gain 15 % (5 us) in all three primitives — but it is the
+  // critic layer the x_hat pass runs at B=64, and with it on the Winograd path D(x_hat) of the full-width step moves from 7e-6 to
+  // 1.1e-5 of the float64 oracle, past SURVEY 8(c)'s 1e-5: parity first, the threshold stays.  4x4x256->256 and 8x8x128->128
+  // (1.7e7) gain 5 % / lose 18 % forward and lose in the filter gradient.
   const int64_t T = (int64_t)d.B * (d.H / 2) * (d.W / 2);
-  return T * d.Cin * d.Cout >= 50000000LL;
+  return T * d.Cin * d.Cout >= (int64_t)tuning().winograd_minwork;
 }
 
 // The filter gradient's 16 GEMMs are [Cin, T] x [T, Cout]: their tile count does not grow with the batch, and 128 x 128

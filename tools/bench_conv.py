@@ -75,8 +75,11 @@ def main():
     ap.add_argument('--filter', default='')
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--cache', action='store_true', help='transformed-filter cache on, as in the training step (filter transforms leave the timed calls)')
     a = ap.parse_args()
     K.set_math(a.math)
+    if a.cache:
+        K.filter_cache(True)
     tot = {'fwd': [0, 0, 0], 'bwd_data': [0, 0, 0], 'bwd_filter': [0, 0, 0]}
     # TF/s = direct-convolution FLOPs / time (what bench.py's roofline block counts); algo: G = implicit GEMM, W3 = Winograd
     # F(2x2,3x3) (executes 1/2.25 of those FLOPs), W2 = Winograd F(2x2,2x2) on 4x4 stride 2 (9/16), S = small direct kernel
