@@ -177,7 +177,7 @@ def test_conv_algorithm_choice_on_the_benchmark_layers():
         (4, 4, 1152, 1024, 3, 1, 'SAME'): (W3, W3, W3),
         (8, 8, 512, 512, 3, 1, 'SAME'): (W3, W3, W3),
         (16, 16, 256, 256, 3, 1, 'SAME'): (W3, W3, W3),
-        (32, 32, 128, 128, 3, 1, 'SAME'): (G, G, G),          # 32x32 maps: the transforms (through HBM) outweigh the saved multiplies
+        (32, 32, 128, 128, 3, 1, 'SAME'): (W3, W3, G),        # 32x32 maps pay since the persistent batched GEMM; 128 x 128 filters: direct filter gradient
         (8, 8, 128, 512, 3, 1, 'SAME'): (W3, W3, W3),
         (8, 8, 128, 128, 3, 1, 'SAME'): (G, G, G),            # too little work for 16 GEMMs at B = 64
         (4, 4, 1024, 256, 1, 1, 'SAME'): (G, G, G),
