@@ -368,7 +368,8 @@ def test_conv_epilogue_batch_norm_statistics(K):
 @pytest.mark.parametrize('case', [(48, 4, 4, 512, 1024, 'critic 4x4 map'), (12, 8, 8, 512, 512, 'generator 8x8'), (13, 16, 16, 256, 256, '16x16'),
                                   (16, 4, 6, 1152, 1024, 'non-square, 1152 = features ++ text channels'),
                                   (64, 8, 8, 128, 512, '128 -> 512 channels: K = 128 one way, 512 the other'),
-                                  (200, 8, 8, 128, 128, '128 x 128 channels: the filter gradient stays on the direct GEMM')])
+                                  (200, 8, 8, 128, 128, '128 x 128 channels: the filter gradient stays on the direct GEMM'),
+                                  (10, 4, 4, 1152, 1152, 'T = 40 tiles: ragged M in fwd / bwd-data, a ragged K tail (2 K-tiles, 8 of 32 valid) in the filter gradient')])
 def test_winograd_3x3_matches_oracle(K, case):
     """3x3 stride-1 SAME convs with >= 128 channels on small maps take the Winograd F(2x2,3x3) path (transforms + 16 batched
     GEMMs in one launch) in conv_fwd, conv_bwd_data and conv_bwd_filter.  Against the float64 direct oracle: 2e-5 of the output scale (the
