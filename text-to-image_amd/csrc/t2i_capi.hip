@@ -122,6 +122,7 @@ static Tuning& tuning_mut() {
     v.force_splitk = env_int("T2I_FORCE_SPLITK", 0);
     v.debug_plan = env_int("T2I_DEBUG_PLAN", 0);
     v.group_n = env_int("T2I_GROUP_N", 8);
+    v.bf16_dma = env_int("T2I_BF16_DMA", 1);               // bf16-operand GEMM (fwd / input gradient): operand tiles by LDS DMA (igemm_hd_kernel)
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
@@ -1185,7 +1186,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

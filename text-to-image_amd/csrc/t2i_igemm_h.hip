@@ -334,6 +334,245 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same GEMM with the operand tiles moved by the LDS DMA (buffer_load_dwordx4 ... lds): global memory -> LDS without the
+// VGPR round trip and without ds_write_b128 (13 LDS-path cycles per wave instruction: with two 128x128 workgroups per CU the
+// staging stores alone took 830 of the 1024 MFMA cycles of a K-tile round; timing-only ablation, profiles/r03_bf16_gemm_ablation.txt:
+// the staging path costs 35 % of the kernel at B = 512).
+//   LDS image   [rows][64 bf16 = 128 B], NO padding (the DMA writes lane-linear: [wave-uniform base] + lane * 16), the eight
+//               16-byte k-chunks of a row XOR-swizzled: chunk position q of row r holds the row's chunk q ^ ((r >> 1) & 7).
+//               The loader applies the XOR to its SOURCE address, the fragment reads to the LDS address; each 16-lane group
+//               of a ds_read_b128 then touches 16 distinct 16-byte bank groups (conflict-free, like the padded image).
+//   pipeline    two LDS buffers, tile t in buf[t & 1].  Iteration t: all fragment reads of tile t, barrier (buf[t & 1] is free),
+//               DMA of tile t+2 into it, 16 MFMAs, s_waitcnt vmcnt(<pieces of one tile>) = tile t+1 has landed (loads complete
+//               in order), barrier.  Two barriers per K-tile instead of one, but two tiles in flight and no staging registers.
+//   The DMA is issued from inline assembly: through the builtin hipcc treats the LDS write as a dependency of every later
+//   ds_read and waits vmcnt(0) before the next fragment read.  Out-of-range lanes (padding taps, ragged rows, K tails) write zeros.
+// ------------------------------------------------------------------------------------------------------------------
+typedef int i32x4h __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_h;
+
+__device__ __forceinline__ i32x4h rsrc_words_h(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  i32x4h r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void dma16_h(i32x4h rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+template <int WMT, int WNT>
+struct SmemD {
+  static constexpr int BM = 64 * WMT, BN = 64 * WNT;
+  static constexpr int ROW = 32;                                // dwords per row, unpadded
+  static constexpr int A_DW = BM * ROW, B_DW = BN * ROW;
+  static constexpr int BYTES = 2 * (A_DW + B_DW) * 4;
+};
+
+template <int MODE, int WMT, int WNT>
+__global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
+  using S = SmemD<WMT, WNT>;
+  constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
+  unsigned* As = smem_h;
+  unsigned* Bs = smem_h + 2 * S::A_DW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  const int tiles_m = p.tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    const int g = p.group_n;
+    const int per_group = g * tiles_m;
+    const int grp = bid / per_group;
+    const int r = bid - grp * per_group;
+    const int n0 = grp * g;
+    const int width = min(g, p.tiles_n - n0);
+    tile_m = r / width;
+    tile_n = n0 + (r - tile_m * width);
+  }
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int split = blockIdx.y;
+  const PhaseInfo pi = load_phase_h(MODE == MODE_BWD_DATA ? blockIdx.z : 0);
+  const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(Kdim, kbeg + p.k_per_split);
+  const int ntiles = (kend - kbeg + HBK - 1) / HBK;
+
+  const i32x4h wa = rsrc_words_h(p.a, p.a_bytes), wb = rsrc_words_h(p.b, p.b_bytes);
+
+  // ---- loader state: thread -> (LDS chunk position kp of the 128-byte K-tile row, rows (tid >> 3) + 32 i); it FETCHES chunk kg ----
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;
+  const int kp = tid & 7, r0 = tid >> 3;
+  const int kg = kp ^ ((r0 >> 1) & 7);               // rows r0 and r0 + 32 i swizzle alike
+  const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;
+  const int Wsrc = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+  const unsigned Hs = (MODE == MODE_FWD) ? p.d.H : p.d.Ho, Ws = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
+  int a_rowoff[A_LD], a_h0[A_LD], a_w0[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = bm + r0 + 32 * i;
+    bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int base, h0, w0;
+    if (MODE == MODE_FWD) {
+      const int b = p.div_howo.div(mm);
+      const int rem = mm - b * p.howo;
+      const int oh = p.div_wo.div(rem);
+      const int ow = rem - oh * p.d.Wo;
+      base = b * p.d.H * p.d.W;
+      h0 = oh * p.d.SH - p.d.pad_t;
+      w0 = ow * p.d.SW - p.d.pad_l;
+    } else {
+      const int b = p.div_hqwq.div(mm);
+      const int rem = mm - b * p.hqwq;
+      const int ihq = p.div_wq.div(rem);
+      const int iwq = rem - ihq * p.Wq;
+      base = b * p.d.Ho * p.d.Wo;
+      h0 = ihq + pi.oh_off;
+      w0 = iwq + pi.ow_off;
+      ok = ok && (ihq * p.d.SH + pi.ph < p.d.H) && (iwq * p.d.SW + pi.pw < p.d.W);
+    }
+    a_ok[i] = ok; a_h0[i] = h0; a_w0[i] = w0;
+    a_rowoff[i] = (base + h0 * Wsrc + w0) * Csrc + kg * 8;
+  }
+  int b_rowoff[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int n = bn + r0 + 32 * i;
+    b_ok[i] = n < p.N;
+    b_rowoff[i] = n * Csrc + kg * 8;
+  }
+  const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr_h)(As + wave_u * 8 * ROW);   // this wave's 8 rows of row group 0, buffer 0
+  const unsigned lds_b0 = (unsigned)(size_t)(lds_ptr_h)(Bs + wave_u * 8 * ROW);
+
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int k0 = kbeg + t * HBK;
+    const int tap = p.div_c.div(k0);                   // wave-uniform
+    const int c0 = k0 - tap * Csrc;
+    const bool kok = (k0 + kg * 8) < kend;
+    int dh, dw, wtap;
+    if (MODE == MODE_FWD) {
+      dh = p.div_kw.div(tap);
+      dw = tap - dh * p.d.KW;
+      wtap = tap;
+    } else {
+      const int jh = pi.div_ntw.div(tap);
+      const int jw = tap - jh * pi.ntw;
+      dh = -jh; dw = -jw;
+      wtap = (pi.kh0 + jh * p.d.SH) * p.d.KW + (pi.kw0 + jw * p.d.SW);
+    }
+    const int sa = (dh * Wsrc + dw) * Csrc + c0;
+    const int sb = wtap * p.N * Csrc + c0;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const bool ok = a_ok[i] & kok & ((unsigned)(a_h0[i] + dh) < Hs) & ((unsigned)(a_w0[i] + dw) < Ws);
+      dma16_h(wa, ok ? (unsigned)(a_rowoff[i] + sa) * 2u : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + 32 * i * ROW) * 4u);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      dma16_h(wb, (b_ok[i] & kok) ? (unsigned)(b_rowoff[i] + sb) * 2u : HOOB, lds_b0 + (unsigned)(buf * S::B_DW + 32 * i * ROW) * 4u);
+  };
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  dma_tile(0, 0);
+  dma_tile(1, 1);
+  if constexpr (A_LD + B_LD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();                                     // tile 0 is in LDS
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned* as = As + (t & 1) * S::A_DW;
+    const unsigned* bs = Bs + (t & 1) * S::B_DW;
+    bf16x8 fa[WMT][4], fb[WNT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        const int row = wm * 32 * WMT + i * 32 + l31;
+        fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int row = wn * 32 * WNT + i * 32 + l31;
+        fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+      }
+    }
+    __syncthreads();                                   // every wave holds its fragments of tile t: buf[t & 1] is free
+    dma_tile(t + 2, t & 1);                            // past the end: zeros (k >= kend), never read
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int n = 0; n < WNT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+    // tile t+1 (issued an iteration ago) has landed when at most this iteration's pieces are outstanding
+    if constexpr (A_LD + B_LD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead DMAs of the last two iterations
+
+  // ---- epilogue: igemm_h_kernel's ---------------------------------------------------------------------------------------------
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  const bool fused = (p.splitk == 1);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      bool mok = m < p.M;
+      int rowoff;
+      if (MODE == MODE_BWD_DATA) {
+        const int mm = mok ? m : 0;
+        const int b = p.div_hqwq.div(mm);
+        const int rem = mm - b * p.hqwq;
+        const int ihq = p.div_wq.div(rem);
+        const int iwq = rem - ihq * p.Wq;
+        const int ih = ihq * p.d.SH + pi.ph, iw = iwq * p.d.SW + pi.pw;
+        mok = mok && ih < p.d.H && iw < p.d.W;
+        rowoff = ((b * p.d.H + ih) * p.d.W + iw) * p.N;
+      } else {
+        rowoff = m * p.N;
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int n = bn + wn * 32 * WNT + j * 32 + l31;
+        if (mok && n < p.N) {
+          float v = acc[i][j][e];
+          if (fused) {
+            if (p.bias) v += p.bias[n];
+            v = apply_act(v, p.act, p.alpha);
+            if (p.accumulate) v += out[rowoff + n];
+            if (p.c_h) reinterpret_cast<__bf16*>(p.c_h)[rowoff + n] = (__bf16)v;
+          }
+          if (!fused || p.c) out[rowoff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Filter gradient with bf16 operands in memory:
 //   dw[M = KH*KW*Cin, N = Cout] = sum over k = (b, oh, ow) of  x_h[b, oh*SH-pad_t+kh, ow*SW-pad_l+kw, ci] * dy_h[b, oh, ow, co]
 // Both operands are "N-inner" in memory (channels contiguous, the reduction index k is the pixel), while the MFMA wants 8
@@ -513,7 +752,22 @@ hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStre
 }
 
 template <int MODE, int WMT, int WNT>
+static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+  using S = SmemD<WMT, WNT>;
+  auto k = igemm_hd_kernel<MODE, WMT, WNT>;
+  static bool attr_done = false;   // benign race: idempotent
+  if (!attr_done && S::BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), S::BYTES, stream, p);
+  return hipGetLastError();
+}
+
+template <int MODE, int WMT, int WNT>
 static hipError_t launch_h(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+  if (tuning().bf16_dma) return launch_hd<MODE, WMT, WNT>(p, grid, stream);
   using S = SmemH<WMT, WNT>;
   auto k = igemm_h_kernel<MODE, WMT, WNT>;
   static bool attr_done = false;   // benign race: idempotent
