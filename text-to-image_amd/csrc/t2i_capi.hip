@@ -158,7 +158,8 @@ const Tuning& tuning() { return tuning_mut(); }
 // operand stream (measured ~16 TB/s chip-wide on 128x128 tiles): bytes per FLOP scale with 1/tile edge, which is what
 // rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
 static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false,
-                      int bk = 32, int m_unit = 0) {      // m_unit > 0: the M tile must divide it (tiles that stay inside one filter tap)
+                      int bk = 32, int m_unit = 0,        // m_unit > 0: the M tile must divide it (tiles that stay inside one filter tap)
+                      bool dma = false) {                 // the bf16-operand kernel that moves its tiles by LDS DMA (igemm_hd_kernel)
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
   // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
@@ -170,11 +171,18 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   // pipe idle during its barrier / LDS-fill phases (measured: 128x128 tiles, 256 vs 512 workgroups: 0.80 vs 0.95)
   static const double share_eff_f32[5] = {0.0, 0.80, 0.95, 1.0, 1.0};
   static const double share_eff_bf16[5] = {0.0, 0.62, 0.86, 1.0, 1.0};
-  const double* rel_eff = math ? rel_eff_bf16 : rel_eff_f32;
-  const int* max_resident = math ? max_resident_bf16 : max_resident_f32;
-  const double* share_eff = math ? share_eff_bf16 : share_eff_f32;
+  // igemm_hd_kernel (no staging registers, no ds_write pass): the small tiles lose less to the 128x128 one, a lone workgroup
+  // per CU loses less, and unsplit launches of 64x128 tiles beat split 128x128 ones on most B = 64 layers.  Fitted on a sweep of
+  // every tile x split over 56 forward / input-gradient cases (profiles/r03_bf16_planner_fit.txt): regret against the per-case
+  // optimum 7.4 % with the constants above, 1.0 % with these.
+  static const double rel_eff_dma[4] = {1.0, 0.82, 0.83, 0.64};
+  static const int max_resident_dma[4] = {3, 3, 3, 6};
+  static const double share_eff_dma[7] = {0.0, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0};
+  const double* rel_eff = dma ? rel_eff_dma : (math ? rel_eff_bf16 : rel_eff_f32);
+  const int* max_resident = dma ? max_resident_dma : (math ? max_resident_bf16 : max_resident_f32);
+  const double* share_eff = dma ? share_eff_dma : (math ? share_eff_bf16 : share_eff_f32);
   const double unit_us = math ? 0.135 : 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
-  const double overhead_tiles = math ? 8.0 : 3.0;   // prologue + epilogue of a workgroup, in K-tile steps
+  const double overhead_tiles = dma ? 12.0 : (math ? 8.0 : 3.0);   // prologue + epilogue of a workgroup, in K-tile steps
   const int64_t ktiles = (K + bk - 1) / bk;        // K-tiles of the kernel that will run (32; 64 for the bf16-operand kernel)
   const double tile_w = bk / 32.0;                 // ... in units of the 32-wide tile-step the cost constants are quoted for
   int64_t maxsplit = ktiles / 4;
@@ -214,7 +222,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       double t = (double)rounds * ((double)per * tile_w + overhead_tiles) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * share_eff[resident]);
       const double split_cost = tuning().split_cost;
-      if (sk_eff > 1) t += (math ? 2.0 : split_cost) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (math ? 6.0e6 : 4.0e6);   // slabs out + in
+      if (sk_eff > 1) t += (dma ? 2.9 : (math ? 2.0 : split_cost)) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (dma ? 5.5e6 : (math ? 6.0e6 : 4.0e6));   // slabs out + in
       if (t < best_t) {
         best_t = t;
         best.wmt = wmt; best.wnt = wnt;
@@ -343,7 +351,7 @@ static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
   IgemmParams p;
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
-  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64);
+  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64, 0, tuning().bf16_dma != 0);
   return al256c(n_in * 2) + al256c((size_t)d->KH * d->KW * d->Cin * d->Cout * 2) + pl.ws_bytes;
 }
 
@@ -353,7 +361,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
   const size_t nw = (size_t)d->KH * d->KW * d->Cin * d->Cout;
-  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64);
+  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64, 0, tuning().bf16_dma != 0);
   const size_t off_w = al256c(n_in * 2), off_s = off_w + al256c(nw * 2), need = off_s + pl.ws_bytes;
   if (!ws || ws_bytes < need || !aligned16(ws)) {
     set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, need);
