@@ -123,6 +123,8 @@ static Tuning& tuning_mut() {
     v.debug_plan = env_int("T2I_DEBUG_PLAN", 0);
     v.group_n = env_int("T2I_GROUP_N", 8);
     v.bf16_dma = env_int("T2I_BF16_DMA", 1);               // bf16-operand GEMM (fwd / input gradient): operand tiles by LDS DMA (igemm_hd_kernel)
+    v.hft_boost = env_int("T2I_HFT_BOOST", 130);           // x0.01: planner efficiency of igemm_hft_kernel's 128x128 tile against igemm_h_filter_kernel's
+    v.hft_ovh = env_int("T2I_HFT_OVH", 80);                // x0.1 K-tile steps: its fixed cost per workgroup
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
@@ -178,6 +180,10 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   static const double rel_eff_dma[4] = {1.0, 0.82, 0.83, 0.64};
   static const int max_resident_dma[4] = {3, 3, 3, 6};
   static const double share_eff_dma[7] = {0.0, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0};
+  // the filter gradient (m_unit > 0) runs igemm_hft_kernel on 128x128 tiles when the tile fits a tap (m_unit % 128 == 0) and the
+  // register-transposing kernel on the other shapes: the 128x128 entry of rel_eff is raised by hft_boost for it
+  const bool hft = math && m_unit > 0 && (m_unit % 128) == 0 && tuning().bf16_dma;
+  const double hft_boost = hft ? tuning().hft_boost * 0.01 : 1.0;
   const double* rel_eff = dma ? rel_eff_dma : (math ? rel_eff_bf16 : rel_eff_f32);
   const int* max_resident = dma ? max_resident_dma : (math ? max_resident_bf16 : max_resident_f32);
   const double* share_eff = dma ? share_eff_dma : (math ? share_eff_bf16 : share_eff_f32);
@@ -219,8 +225,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       const int64_t blocks = tiles * sk_eff;
       const int64_t rounds = (blocks + 255) / 256;
       const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
-      double t = (double)rounds * ((double)per * tile_w + overhead_tiles) * (wmt * wnt) * unit_us /
-                 (rel_eff[c] * share_eff[resident]);
+      const double ovh_t = (hft && c == 0) ? tuning().hft_ovh * 0.1 : overhead_tiles;
+      double t = (double)rounds * ((double)per * tile_w + ovh_t) * (wmt * wnt) * unit_us /
+                 (rel_eff[c] * (c == 0 ? hft_boost : 1.0) * share_eff[resident]);
       const double split_cost = tuning().split_cost;
       if (sk_eff > 1) t += (dma ? 2.9 : (math ? 2.0 : split_cost)) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (dma ? 5.5e6 : (math ? 6.0e6 : 4.0e6));   // slabs out + in
       if (t < best_t) {
@@ -1194,7 +1201,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -729,6 +729,156 @@ __global__ __launch_bounds__(256) void igemm_h_filter_kernel(IgemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The filter gradient with NO register transpose: operand tiles by LDS DMA in their memory order ([k = pixel][channel], channel
+// contiguous), fragments by ds_read_b64_tr_b16 — gfx950's transposing LDS read.
+// Why: a timing-only ablation of igemm_h_filter_kernel (profiles/r03_bf16_gemm_ablation.txt) showed the transposing staging pass
+// (16 v_perm + 16 ds_write_b64 per thread and K-tile) costing 42-55 % of the kernel (4x4x1152->1024 at B = 192: 120 -> 55 us
+// without it).
+// ds_read_b64_tr_b16 (semantics measured with tools/probe/tr_probe.hip): inside each 16-lane group, lane j passes the address
+// of a 4-element chunk C_j; rows R_r = C_4r ++ C_4r+1 ++ C_4r+2 ++ C_4r+3 (r = 0..3) form a 4 x 16 matrix, and lane i receives
+// COLUMN i: (R_0[i], R_1[i], R_2[i], R_3[i]).  With chunk C_(4r+q) = tile[k0 + r][m0 + 4q .. 4q+3] lane i therefore gets
+// tile[k0 .. k0+3][m0 + i]: four consecutive k of one channel — half an MFMA operand.  Lane groups 0/1 take m0 = 0 / 16 and
+// k-half 0, groups 2/3 the same channels at k-half 1: exactly v_mfma_f32_32x32x16_bf16's A/B layout (row = lane & 31, k = 8 *
+// (lane >> 5) + 0..7) after two reads (k0 and k0 + 4).
+// LDS image: [64 k][128 channels] bf16 = 256-byte rows, unpadded (the DMA writes lane-linear); the sixteen 16-byte slots of a
+// row are XOR-swizzled with (k & 3) << 2: the four rows a lane group reads at once would otherwise sit on the same banks
+// (a 256-byte row is exactly one bank row); with the XOR the 32 lanes of a half-wave touch 32 distinct 8-byte bank pairs.
+// Tile 128 x 128 only (the shape that carries the filter-gradient time); other shapes keep igemm_h_filter_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+typedef short s16x4h __attribute__((ext_vector_type(4)));
+typedef short s16x8h __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int TILE_B = HBK * 256;                       // bytes of one operand tile: 64 k-rows of 256 bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
+  char* As = reinterpret_cast<char*>(smem_h);             // 2 buffers
+  char* Bs = As + 2 * TILE_B;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int ntiles = (kend - kbeg + HBK - 1) / HBK;
+
+  const i32x4h wa = rsrc_words_h(p.a, p.a_bytes), wb = rsrc_words_h(p.b, p.b_bytes);
+
+  // tile constants: the filter tap and first input channel of this M tile (Cin % 128 == 0: the tile lies inside one tap)
+  const int tap = p.div_c.div(bm);
+  const int ci0 = bm - tap * p.d.Cin;
+  const int kh = p.div_kw.div(tap), kw = tap - kh * p.d.KW;
+
+  // ---- loader: DMA instruction i of wave w covers k-rows 16 i + 4 w + (lane >> 4); lane -> LDS slot position (lane & 15), it
+  // FETCHES channel slot sg = position ^ ((row & 3) << 2) (row & 3 == lane >> 4) ---------------------------------------------
+  const int rloc = wave * 4 + (lane >> 4);               // + 16 i
+  const int sg = (lane & 15) ^ ((lane >> 4) << 2);
+  const bool b_nok = (bn + sg * 8) < p.N;
+  const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr_h)(As + wave_u * 1024);      // + i * 4096 + buf * TILE_B
+  const unsigned lds_b0 = (unsigned)(size_t)(lds_ptr_h)(Bs + wave_u * 1024);
+
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const int kt = kbeg + t * HBK + rloc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt + 16 * i;
+      const bool kok = k < kend;
+      const int kk = kok ? k : 0;
+      const int b = p.div_howo.div(kk);
+      const int rem = kk - b * p.howo;
+      const int oh = p.div_wo.div(rem);
+      const int ow = rem - oh * p.d.Wo;
+      const int ih = oh * p.d.SH - p.d.pad_t + kh, iw = ow * p.d.SW - p.d.pad_l + kw;
+      const bool ok = kok & ((unsigned)ih < (unsigned)p.d.H) & ((unsigned)iw < (unsigned)p.d.W);
+      dma16_h(wa, ok ? (unsigned)(((b * p.d.H + ih) * p.d.W + iw) * p.d.Cin + ci0 + sg * 8) * 2u : HOOB,
+              lds_a0 + (unsigned)(buf * TILE_B + i * 4096));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt + 16 * i;
+      dma16_h(wb, (b_nok & (k < kend)) ? (unsigned)(k * p.N + bn + sg * 8) * 2u : HOOB, lds_b0 + (unsigned)(buf * TILE_B + i * 4096));
+    }
+  };
+
+  // ---- fragment addresses: lane = (group g = lane >> 4: channel half gb = g & 1, k half = g >> 1; r = (lane & 15) >> 2; q = lane & 3)
+  // reads the chunk at k-row 16 s + 8 (g >> 1) + r (+ 4), channel chunk c = blk * 8 + gb * 4 + q, stored at chunk c ^ (r << 3)
+  const int g = lane >> 4, gb = g & 1, r4 = (lane & 15) >> 2, q = lane & 3;
+  int fa_off[2], fb_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fa_off[i] = (8 * (g >> 1) + r4) * 256 + ((((wm * 2 + i) * 8 + gb * 4 + q) ^ (r4 << 3)) << 3);
+    fb_off[i] = (8 * (g >> 1) + r4) * 256 + ((((wn * 2 + i) * 8 + gb * 4 + q) ^ (r4 << 3)) << 3);
+  }
+  auto frag = [&](const char* tile, int off, int s) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) s16x4h* lp;
+    const s16x4h lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(tile + off + s * 4096));
+    const s16x4h hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(tile + off + s * 4096 + 1024));
+    const s16x8h v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  dma_tile(0, 0);
+  dma_tile(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const char* as = As + (t & 1) * TILE_B;
+    const char* bs = Bs + (t & 1) * TILE_B;
+    bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i][s] = frag(as, fa_off[i], s);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[i][s] = frag(bs, fb_off[i], s);
+    }
+    __syncthreads();                                   // every wave holds its fragments of tile t: buf[t & 1] is free
+    dma_tile(t + 2, t & 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t+1 has landed
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  const bool fused = (p.splitk == 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][e];
+          if (fused && p.accumulate) v += out[(size_t)m * p.N + n];
+          out[(size_t)m * p.N + n] = v;
+        }
+      }
+    }
+}
+
 template <int WMT, int WNT>
 static hipError_t launch_hf(const IgemmParams& p, hipStream_t stream) {
   using S = SmemH<WMT, WNT>;
@@ -744,6 +894,17 @@ static hipError_t launch_hf(const IgemmParams& p, hipStream_t stream) {
 }
 
 hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStream_t stream) {
+  if (wmt == 2 && wnt == 2 && tuning().bf16_dma && (p.d.Cin % 128) == 0) {
+    constexpr int bytes = 4 * HBK * 256;               // 2 operands x 2 buffers of [64][128] bf16
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_hft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(igemm_hft_kernel, dim3(p.tiles_m * p.tiles_n, p.splitk), dim3(256), bytes, stream, p);
+    return hipGetLastError();
+  }
   if (wmt == 2 && wnt == 2) return launch_hf<2, 2>(p, stream);
   if (wmt == 2 && wnt == 1) return launch_hf<2, 1>(p, stream);
   if (wmt == 1 && wnt == 2) return launch_hf<1, 2>(p, stream);
