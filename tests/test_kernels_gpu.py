@@ -547,6 +547,35 @@ def test_bf16_operand_gemm_matches_rounded_oracle(K, case):
             K.tuning_set('force_splitk', 0)
 
 
+@pytest.mark.parametrize('case', [(4, 8, 8, 256, 160, 3, 3, 1, 'SAME'), (3, 16, 16, 128, 128, 4, 4, 2, 'SAME'), (9, 4, 4, 384, 256, 3, 3, 1, 'SAME'),
+                                  (2, 8, 4, 128, 72, 1, 1, 1, 'VALID')])
+def test_bf16_filter_gradient_dma_and_transposing_reads(K, case):
+    """igemm_hft_kernel (128 x 128 tiles, Cin % 128 == 0): operand tiles by LDS DMA in memory order, fragments through
+    ds_read_b64_tr_b16.  Forced onto that tile shape, unsplit and split, on shapes with a ragged N tile (160, 72 output channels),
+    a strided gather (4x4 stride 2), and a ragged K tail (9 * 16 = 144 pixels = 2.25 K-tiles): against the float64 oracle on the
+    bf16-rounded operands at the fp32 gradient tolerance, plain and accumulating into an arena slot."""
+    from oracle import np_ops as O
+    B, H, W, Ci, Co, KH, KW, s, pad = case
+    rng = np.random.default_rng(B * 1000 + Ci + Co)
+    x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
+    d, _ = K.conv_desc(B, H, W, Ci, Co, KH, KW, s, s, pad, math=K.MATH_BF16)
+    dy = rng.standard_normal((B, d.Ho, d.Wo, Co)).astype(np.float32)
+    assert d.Wo % 4 == 0 and Ci % 128 == 0
+    dw_ref = O.conv2d_bwd_filter(_bf16_round(x), _bf16_round(dy), (KH, KW, Ci, Co), (s, s), pad)
+    ws = 256 << 20
+    for splitk in (0, 2):
+        K.tuning_set('force_tile', 22); K.tuning_set('force_splitk', splitk)
+        try:
+            assert K.conv_algo(d, 'bwd_filter') == 'implicit_gemm_bf16_operands'
+            assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= GRAD_TOL, (case, splitk)
+            base = rng.standard_normal(dw_ref.shape).astype(np.float32)
+            acc = dev(base)
+            K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc)
+            assert relerr(acc, base + dw_ref) <= GRAD_TOL, (case, splitk)
+        finally:
+            K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0)
+
+
 @pytest.mark.parametrize('rows,C,offset', [(2, 16384, 300.0), (32, 512, 1000.0), (64 * 16, 256, 50.0), (192 * 32 * 32, 128, 20.0), (7, 3, 100.0)])
 def test_bn_stats_are_stable_against_a_large_mean(K, rows, C, offset):
     """t2i_bn_stats: (sum, sum (x - mean)^2) by shifted per-chunk moments + Chan merging.  x = offset + unit noise: the
