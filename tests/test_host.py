@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol(t2i):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(_lib.lib, name), name
-    assert _lib.lib.t2i_version() == 6
+    assert _lib.lib.t2i_version() == _lib.ABI_VERSION
     assert _lib.lib.t2i_last_error() is not None
 
 

@@ -93,7 +93,17 @@ if not os.path.exists(LIB_PATH):
     raise ImportError('libt2i_hip.so not found at %s — build it with text-to-image_amd/csrc/build.sh '
                       '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback' % LIB_PATH)
 
+ABI_VERSION = 6          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
+
 lib = ctypes.CDLL(LIB_PATH)
+try:
+    lib.t2i_version.restype = ctypes.c_int
+    _got = lib.t2i_version()
+except AttributeError:
+    _got = None
+if _got != ABI_VERSION:
+    raise ImportError('%s reports ABI version %r, this package binds version %d: a stale build would be called with shifted '
+                      'arguments — rebuild with text-to-image_amd/csrc/build.sh' % (LIB_PATH, _got, ABI_VERSION))
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == ABI mismatch: fail loudly
     _fn.restype = _res

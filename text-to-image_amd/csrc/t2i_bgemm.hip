@@ -16,9 +16,12 @@
 //     LAY 0  A [M][K] K-inner, B [K][N] N-inner      forward conv        (V [T,Cin]  x U [Cin,Cout])
 //     LAY 1  A [M][K] K-inner, B [N][K] K-inner      input gradient      (V [T,Cout] x U [Cin,Cout]^T)
 //     LAY 2  A [K][M] M-inner, B [K][N] N-inner      filter gradient     (V [T,Cin]^T x dY [T,Cout])
-// Tile 64x64, 4 waves (2x2) of one 32x32 accumulator, BK = 32, v_mfma_f32_32x32x2_f32: the LDS images, the k permutation of
-// the fragments and the one-barrier-per-K-tile schedule are igemm_kernel's (t2i_igemm.hip) — an output element is the same
-// fmaf chain over k in the same order, so results are bit-identical to the per-tile launch.
+// Tile 64 WM x 64 WN (round 4: WM, WN in {1, 2}; rounds 1-3: 64x64 only), 4 waves (2x2) of WM x WN 32x32 accumulators, BK = 32,
+// v_mfma_f32_32x32x2_f32: the LDS images, the k permutation of the fragments and the one-barrier-per-K-tile schedule are
+// igemm_kernel's (t2i_igemm.hip) — an output element is the same fmaf chain over k in the same order whatever the tile, so
+// results are bit-identical to the per-tile launch and across tile shapes.  Per multiply-add a 128x128 tile streams half the operand bytes of a 64x64 one into the CU (32 instead of 16 FLOP per L2
+// byte) — the K loop is co-limited by exactly that stream (below) — at the price of 4x coarser work items, so bgemm_launch's
+// caller picks the tile by item count (t2i_capi.hip: run_batched_gemm).
 // What bounds the K loop (timing-only ablations of this kernel, 2048 tiles, profiles/r03_bgemm_ablation.txt): dropping the barrier
 // changes nothing; a second accumulator per wave (no MFMA -> MFMA dependency) nothing; loads three K-tiles ahead through a
 // second register set nothing; direct-to-LDS DMA (buffer_load ... lds into an XOR-swizzled unpadded image, issued from inline
@@ -41,12 +44,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int BK = 32;
 constexpr int KSTRIDE = BK + 4;            // K-inner LDS row stride (36 dwords: conflict-free ds_read_b128)
-constexpr int BM = 64, BN = 64;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-template <int LAY>
+template <int LAY, int WM, int WN>
 struct BSmem {
   static constexpr bool A_KIN = LAY != 2, B_KIN = LAY == 1;
+  static constexpr int BM = 64 * WM, BN = 64 * WN;
   static constexpr int A_ELEMS = A_KIN ? BM * KSTRIDE : BK * BM;
   static constexpr int B_ELEMS = B_KIN ? BN * KSTRIDE : BK * BN;
   static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
@@ -58,10 +61,14 @@ __device__ __forceinline__ float4 bl4(__amdgpu_buffer_rsrc_t r, int elem_off, bo
 }
 }  // namespace
 
-template <int LAY>
+template <int LAY, int WM, int WN>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
-  using S = BSmem<LAY>;
+  using S = BSmem<LAY, WM, WN>;
   constexpr bool A_KIN = S::A_KIN, B_KIN = S::B_KIN;
+  constexpr int BM = S::BM, BN = S::BN;
+  constexpr int A_LD = 2 * WM, B_LD = 2 * WN;              // 16-byte pieces per thread and K-tile
+  // M/N-inner image [32 k][64 W cols]: 16 W threads per k-row, 16 / W k-rows per pass, 2 W passes
+  constexpr int A_C4 = BM / 4, A_KR = 256 / A_C4, B_C4 = BN / 4, B_KR = 256 / B_C4;
   extern __shared__ __attribute__((aligned(16))) float smem_b[];
   float* As = smem_b;
   float* Bs = smem_b + 2 * S::A_ELEMS;
@@ -93,17 +100,21 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
 
   // ---- loader state (switched per item) ----------------------------------------------------------------------------------
   // K-inner image: thread -> (k quad kq, rows r0 + 32 i).   M/N-inner image: thread -> (column quad c4, k rows kr + 16 i).
-  const int kq = tid & 7, r0 = tid >> 3, c4 = tid & 15, kr = tid >> 4;
+  const int kq = tid & 7, r0 = tid >> 3;
+  const int a_c4 = tid % A_C4, a_kr = tid / A_C4, b_c4 = tid % B_C4, b_kr = tid / B_C4;
   __amdgpu_buffer_rsrc_t ra, rb;
-  int a_off[2], b_off[2];
-  bool a_ok[2], b_ok[2];
+  int a_off[A_LD], b_off[B_LD];
+  bool a_ok[A_LD], b_ok[B_LD];
   int l_item = -1, l_t = 0;            // the item being fetched, and its next K-tile
 
   auto next_item = [&]() __attribute__((always_inline)) {
     ++l_item;
     l_t = 0;
     if (l_item >= n_items) {           // past the last item: the pipeline's look-ahead fetches zeros
-      a_ok[0] = a_ok[1] = b_ok[0] = b_ok[1] = false;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) a_ok[i] = false;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) b_ok[i] = false;
       return;
     }
     int bz, bm, bn;
@@ -111,41 +122,44 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (int64_t)bz * p.sa), (short)0, (int)p.a_bytes, 0x00020000);
     rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (int64_t)bz * p.sb), (short)0, (int)p.b_bytes, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_LD; ++i) {
       if (A_KIN) {
         const int m = bm + r0 + 32 * i;
         a_ok[i] = m < p.M;
         a_off[i] = m * p.K + kq * 4;
       } else {
-        const int m = bm + c4 * 4;
+        const int m = bm + a_c4 * 4;
         a_ok[i] = m < p.M;
-        a_off[i] = (kr + 16 * i) * p.M + m;
+        a_off[i] = (a_kr + A_KR * i) * p.M + m;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
       if (B_KIN) {
         const int n = bn + r0 + 32 * i;
         b_ok[i] = n < p.N;
         b_off[i] = n * p.K + kq * 4;
       } else {
-        const int n = bn + c4 * 4;
+        const int n = bn + b_c4 * 4;
         b_ok[i] = n < p.N;
-        b_off[i] = (kr + 16 * i) * p.N + n;
+        b_off[i] = (b_kr + B_KR * i) * p.N + n;
       }
     }
   };
 
-  float4 areg[2], breg[2];
+  float4 areg[A_LD], breg[B_LD];
   auto load_into = [&](float4* ar, float4* br) __attribute__((always_inline)) {   // the next K-tile of the item sequence (next_item() is the K loop's business)
     const int k0 = l_t * BK;
     ++l_t;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_LD; ++i) {
       if (A_KIN) ar[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
-      else ar[i] = bl4(ra, a_off[i] + k0 * p.M, a_ok[i] & (k0 + kr + 16 * i < p.K));
+      else ar[i] = bl4(ra, a_off[i] + k0 * p.M, a_ok[i] & (k0 + a_kr + A_KR * i < p.K));
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_LD; ++i) {
       if (B_KIN) br[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
-      else br[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + kr + 16 * i < p.K));
+      else br[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + b_kr + B_KR * i < p.K));
     }
   };
   auto load_tile = [&]() __attribute__((always_inline)) { load_into(areg, breg); };
@@ -153,45 +167,64 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     float* as = As + buf * S::A_ELEMS;
     float* bs = Bs + buf * S::B_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_LD; ++i) {
       if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = ar[i];
-      else *reinterpret_cast<float4*>(&as[(kr + 16 * i) * BM + c4 * 4]) = ar[i];
+      else *reinterpret_cast<float4*>(&as[(a_kr + A_KR * i) * BM + a_c4 * 4]) = ar[i];
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_LD; ++i) {
       if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = br[i];
-      else *reinterpret_cast<float4*>(&bs[(kr + 16 * i) * BN + c4 * 4]) = br[i];
+      else *reinterpret_cast<float4*>(&bs[(b_kr + B_KR * i) * BN + b_c4 * 4]) = br[i];
     }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) { store_from(buf, areg, breg); };
 
   // fragments of one 8-k chunk: MFMA j consumes k = 8c + j (lanes 0-31) and 8c + 4 + j (lanes 32-63)
-  struct Frag { float a[4]; float b[4]; };
+  struct Frag { float a[WM][4]; float b[WN][4]; };
   auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) __attribute__((always_inline)) {
-    const int row = wm * 32 + l31, col = wn * 32 + l31;
-    if (A_KIN) {
-      const float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
-      f.a[0] = v.x; f.a[1] = v.y; f.a[2] = v.z; f.a[3] = v.w;
-    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.a[j] = as[(c * 8 + j + 4 * lh) * BM + row];
+    for (int i = 0; i < WM; ++i) {
+      const int row = (wm * WM + i) * 32 + l31;
+      if (A_KIN) {
+        const float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
+        f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.a[i][j] = as[(c * 8 + j + 4 * lh) * BM + row];
+      }
     }
-    if (B_KIN) {
-      const float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
-      f.b[0] = v.x; f.b[1] = v.y; f.b[2] = v.z; f.b[3] = v.w;
-    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.b[j] = bs[(c * 8 + j + 4 * lh) * BN + col];
+    for (int i = 0; i < WN; ++i) {
+      const int col = (wn * WN + i) * 32 + l31;
+      if (B_KIN) {
+        const float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
+        f.b[i][0] = v.x; f.b[i][1] = v.y; f.b[i][2] = v.z; f.b[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[i][j] = bs[(c * 8 + j + 4 * lh) * BN + col];
+      }
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+  // j outermost: with more than one accumulator consecutive MFMAs never depend on each other; every accumulator still sees
+  // its k in the order j = 0..3 of chunk 0, 1, 2, 3 — the 64x64 kernel's chain
   auto mma_frag = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j], f.b[j], acc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][j], f.b[n][j], acc[i][n], 0, 0, 0);
   };
+  constexpr int N_MMA = 4 * WM * WN, N_PIECE = A_LD + B_LD, MMA_PER_PIECE = N_MMA / N_PIECE > 0 ? N_MMA / N_PIECE : 1;
 
   // One K-tile (igemm_kernel's schedule): registers hold tile t+1, LDS buf[t&1] tile t; the barrier sits mid-tile right after
   // the store of tile t+1, the first two fragment chunks of tile t+1 are fetched while the last two of tile t multiply.
@@ -208,9 +241,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     mma_frag(c1);                                   // chunk 1, with the LDS store of tile t+1 interleaved
     store_tile((t + 1) & 1);
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+    for (int q2 = 0; q2 < N_PIECE; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MMA_PER_PIECE, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // DS write
     }
     __builtin_amdgcn_sched_barrier(0);
     read_frag(c1, as, bs, 3);
@@ -222,9 +255,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     load_tile();                                    // tile t+2 (the next item's first tiles at an item's end)
     mma_frag(c0);                                   // chunk 2
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+    for (int q2 = 0; q2 < N_PIECE; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MMA_PER_PIECE, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // VMEM read
     }
     __builtin_amdgcn_sched_barrier(0);
     mma_frag(c1);                                   // chunk 3
@@ -232,7 +265,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
 
   next_item();
   {   // the only prologue of the launch: both first K-tiles are requested before the first is waited for
-    float4 a0[2], b0[2];
+    float4 a0[A_LD], b0[B_LD];
     load_into(a0, b0);
     load_tile();
     store_from(0, a0, b0);
@@ -254,35 +287,49 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     int bz, bm, bn;
     coords(run0 + slot + it * nslot, bz, bm, bn);
     float* out = p.c + (int64_t)bz * p.sc;
-    const int n = bn + wn * 32 + l31;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[e];
-    }
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int j = 0; j < WN; ++j) {
+        const int n = bn + (wn * WN + j) * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = bm + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[i][j][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      }
   }
 }
 
-template <int LAY>
-static hipError_t launch_b(const BgemmParams& p, int nblk, hipStream_t stream) {
-  using S = BSmem<LAY>;
-  hipLaunchKernelGGL(bgemm_kernel<LAY>, dim3(nblk), dim3(256), S::BYTES, stream, p);
+template <int LAY, int WM, int WN>
+static hipError_t launch_b(const BgemmParams& p, hipStream_t stream) {
+  using S = BSmem<LAY, WM, WN>;
+  auto k = bgemm_kernel<LAY, WM, WN>;
+  static bool attr_done = false;   // benign race: idempotent
+  if (!attr_done && S::BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  // workgroups resident per CU: 4 of the 64x64 tile (its registers and LDS), 2 of the larger ones
+  const int per_cu = (WM * WN == 1) ? 4 : 2;
+  const int per_xcd = (p.items + 7) / 8;
+  int nslot = per_xcd < 32 * per_cu ? per_xcd : 32 * per_cu;   // fewer, evenly loaded workgroups (e.g. 72 x 2 items for 144) lose to the
+  if (nslot < 1) nslot = 1;                                    // CU granularity: 72 workgroups on 32 CUs leave some CUs with 3, some with 2
+  hipLaunchKernelGGL(k, dim3(nslot * 8), dim3(256), S::BYTES, stream, p);
   return hipGetLastError();
 }
 
-// lay: 0 forward, 1 input gradient, 2 filter gradient (see the header).  p.items / p.ntiles / tiles are filled by the caller.
-hipError_t bgemm_launch(int lay, const BgemmParams& p, hipStream_t stream) {
-  const int per_xcd = (p.items + 7) / 8;
-  int nslot = per_xcd < 128 ? per_xcd : 128;       // 128 = 4 per CU; fewer, evenly loaded workgroups (e.g. 72 x 2 items for 144) lose to the
-  if (nslot < 1) nslot = 1;                        // CU granularity: 72 workgroups on 32 CUs leave some CUs with 3, some with 2
-  const int nblk = nslot * 8;
-  switch (lay) {
-    case 0: return launch_b<0>(p, nblk, stream);
-    case 1: return launch_b<1>(p, nblk, stream);
-    case 2: return launch_b<2>(p, nblk, stream);
-  }
+// lay: 0 forward, 1 input gradient, 2 filter gradient (see the header); wm, wn in {1, 2}: tile 64 wm x 64 wn.
+// p.items / p.ntiles / tiles_m / tiles_n are filled by the caller FOR THAT TILE.
+hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream_t stream) {
+#define T2I_B(L, a, b) if (lay == L && wm == a && wn == b) return launch_b<L, a, b>(p, stream);
+  T2I_B(0, 1, 1) T2I_B(0, 2, 1) T2I_B(0, 1, 2) T2I_B(0, 2, 2)
+  T2I_B(1, 1, 1) T2I_B(1, 2, 1) T2I_B(1, 1, 2) T2I_B(1, 2, 2)
+  T2I_B(2, 1, 1) T2I_B(2, 2, 1) T2I_B(2, 1, 2) T2I_B(2, 2, 2)
+#undef T2I_B
   return hipErrorInvalidValue;
 }
 

@@ -126,6 +126,9 @@ static Tuning& tuning_mut() {
     v.hft_boost = env_int("T2I_HFT_BOOST", 130);           // x0.01: planner efficiency of igemm_hft_kernel's 128x128 tile against igemm_h_filter_kernel's
     v.hft_ovh = env_int("T2I_HFT_OVH", 80);                // x0.1 K-tile steps: its fixed cost per workgroup
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
+    v.bgemm_tile = env_int("T2I_BGEMM_TILE", 0);           // persistent batched GEMM tile: 0 = by item count, 11 / 21 / 12 / 22 = 64 a x 64 b forced
+    v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
+    v.vec_epi = env_int("T2I_VEC_EPI", 1);                 // bf16-operand GEMMs: epilogue through LDS, 16-byte stores (0: one store per element)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
     v.no_thin = env_int("T2I_NO_THIN", 0);
@@ -258,6 +261,7 @@ static void fill_common(IgemmParams& p, const t2i_conv_desc* d) {
   p.div_hqwq.set(p.hqwq);
   p.div_wq.set(p.Wq);
   p.nphase = 1;
+  p.vec_epi = tuning().vec_epi;
 }
 
 // stride phases of the transposed conv: dx pixels with (ih % SH, iw % SW) == (ph, pw) see taps kh = kh0 + SH*jh
@@ -491,7 +495,20 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
       memset(&q, 0, sizeof(q));
       q.a = a; q.b = b; q.c = c;
       q.M = M; q.N = N; q.K = K;
-      q.tiles_m = (M + 63) / 64; q.tiles_n = (N + 63) / 64;
+      // Tile: the K loop is co-limited by the L2 -> CU operand stream (t2i_bgemm.hip), which a 128x128 tile halves per multiply-add —
+      // but its work items are 4x coarser and only two of its workgroups fit a CU, so it is taken when the launch still has
+      // enough items to keep 512 resident workgroups evenly busy; 128x64 / 64x128 in between; 64x64 (4 per CU) otherwise.
+      int wm = 1, wn = 1;
+      {
+        auto items_of = [&](int a_, int b_) { return (int64_t)nbatch * ((M + 64 * a_ - 1) / (64 * a_)) * ((N + 64 * b_ - 1) / (64 * b_)); };
+        const int ft = tuning().bgemm_tile;
+        const int64_t big = tuning().bgemm_big_items;
+        if (ft == 22 || ft == 21 || ft == 12 || ft == 11) { wm = ft / 10; wn = ft % 10; }
+        else if (M >= 128 && N >= 128 && items_of(2, 2) >= big) { wm = 2; wn = 2; }
+        else if (M >= 128 && items_of(2, 1) >= big) { wm = 2; wn = 1; }
+        else if (N >= 128 && items_of(1, 2) >= big) { wm = 1; wn = 2; }
+      }
+      q.tiles_m = (M + 64 * wm - 1) / (64 * wm); q.tiles_n = (N + 64 * wn - 1) / (64 * wn);
       { const int g = tuning().group_n; q.group_n = q.tiles_n < g ? q.tiles_n : g; if (q.group_n < 1) q.group_n = 1; }
       q.ntiles = ntiles;
       const int64_t items = (int64_t)nbatch * q.tiles_m * q.tiles_n;
@@ -500,8 +517,8 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
         q.sa = sa; q.sb = sb; q.sc = sc;
         q.a_bytes = (uint32_t)(a_elems * 4); q.b_bytes = (uint32_t)(b_elems * 4);
         if (tuning().debug_plan)
-          fprintf(stderr, "[t2i plan] batched x%d M=%d N=%d K=%d mode %d -> persistent 64x64, %lld items\n", nbatch, M, N, K, gmode, (long long)items);
-        return check(bgemm_launch(gmode == MODE_FWD ? 0 : (gmode == MODE_BWD_DATA ? 1 : 2), q, stream), what);
+          fprintf(stderr, "[t2i plan] batched x%d M=%d N=%d K=%d mode %d -> persistent %dx%d, %lld items\n", nbatch, M, N, K, gmode, 64 * wm, 64 * wn, (long long)items);
+        return check(bgemm_launch(gmode == MODE_FWD ? 0 : (gmode == MODE_BWD_DATA ? 1 : 2), wm, wn, q, stream), what);
       }
     }
   }
@@ -593,7 +610,10 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d) {
   if (winograd_k4s2_eligible(*d, false) && winograd_k4s2_filter_grad_ws(*d) > need) need = winograd_k4s2_filter_grad_ws(*d);
   // bf16 storage (t2i_conv_opts.in_dtype / out_dtype): a call whose path has no bf16-tensor loader (thin / head / generic kernels)
   // stages fp32 copies of its two activation tensors in front of the path's own workspace
-  if (d->math == T2I_MATH_BF16) need += al256c(nx * 4) + al256c(ny * 4) + 512;
+  // — room for them only where such a call can happen: a descriptor whose three primitives all have bf16-tensor loaders
+  // (every 64-channel-multiple layer: the bulk of the bytes) never stages
+  if (d->math == T2I_MATH_BF16 && !(h_eligible(*d, false) && h_eligible(*d, true) && h_filter_eligible(*d) && !head_conv_eligible(*d)))
+    need += al256c(nx * 4) + al256c(ny * 4) + 512;
   return need;
 }
 
@@ -1201,7 +1221,8 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
-      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh}};
+      {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -122,6 +122,97 @@ __device__ __forceinline__ PhaseInfo load_phase_h(int idx) {
   return r;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue through LDS (round 4).  The MFMA leaves a lane with ONE output column and 16 rows of each 32x32 block, so the direct
+// epilogue issued 16 WMT WNT stores of 2 or 4 bytes per thread (64 at 128x128) — and a launch-level ablation showed those stores
+// costing 7 us of EVERY launch whatever its K (15.4 -> 8.4 us for a one-K-tile GEMM on 256 tiles, profiles/r04_bf16_gemm_fixed_cost.txt):
+// the epilogue is store-ISSUE-bound (256 store instructions per CU through one address pipe), not bandwidth-bound.  Here every
+// wave passes its sub-tile through a private LDS patch, 32 rows at a time (ds_write_b32 by column, ds_read_b128 by row — LDS
+// operations of one wave execute in order, no barrier), and a lane then owns 8 consecutive columns of a row: one 16-byte store
+// for a bf16 output (8 per thread at 128x128), two for an fp32 one; bias is added from two 16-byte loads, the accumulate form
+// reads its old values the same way.  Element arithmetic (bias, activation, accumulate, RNE to bf16) is the direct epilogue's:
+// results are bit-identical.  Needs N % 8 == 0 and 16-byte aligned bases (else: direct epilogue).
+// lds: >= 4 * 32 * (32 WNT + 4) floats, no longer read or written by anybody (the caller synchronises).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE, int WMT, int WNT>
+__device__ __forceinline__ void store_tile_h(const IgemmParams& p, const PhaseInfo& pi, const f32x16 (&acc)[WMT][WNT], float* lds, int bm, int bn,
+                                             int split) {
+  constexpr int SROW = 32 * WNT + 4, CH = 4 * WNT;          // staging row stride (floats); 8-column chunks per row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  float* st = lds + wave * (32 * SROW);
+  float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
+  const bool fused = (p.splitk == 1);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * lh) * SROW + j * 32 + l31] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2 * WNT; ++it) {
+      const int idx = it * 64 + lane, row = idx / CH, c8 = idx % CH;
+      const float4 v0 = *reinterpret_cast<const float4*>(&st[row * SROW + c8 * 8]);
+      const float4 v1 = *reinterpret_cast<const float4*>(&st[row * SROW + c8 * 8 + 4]);
+      const int m = bm + (wm * WMT + i) * 32 + row;
+      const int n = bn + wn * 32 * WNT + c8 * 8;
+      bool mok = m < p.M;
+      int rowoff;
+      if (MODE == MODE_BWD_DATA) {
+        const int mm = mok ? m : 0;
+        const int b = p.div_hqwq.div(mm);
+        const int rem = mm - b * p.hqwq;
+        const int ihq = p.div_wq.div(rem);
+        const int iwq = rem - ihq * p.Wq;
+        const int ih = ihq * p.d.SH + pi.ph, iw = iwq * p.d.SW + pi.pw;
+        mok = mok && ih < p.d.H && iw < p.d.W;
+        rowoff = ((b * p.d.H + ih) * p.d.W + iw) * p.N;
+      } else {
+        rowoff = m * p.N;
+      }
+#if defined(T2I_HEXP) && (T2I_HEXP & 1)
+      if (mok && n < p.N && v0.x == 1.2345e38f) {
+#else
+      if (mok && n < p.N) {
+#endif
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (fused) {
+          if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], p.act, p.alpha);
+          if (p.accumulate) {
+            const float4 o0 = *reinterpret_cast<const float4*>(out + rowoff + n), o1 = *reinterpret_cast<const float4*>(out + rowoff + n + 4);
+            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+          }
+          if (p.c_h) {
+            const uint4 h = {pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])};
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.c_h) + rowoff + n) = h;
+          }
+        }
+        if (!fused || p.c) {       // bf16 storage: an unsplit launch writes the bf16 tensor only (p.c == NULL)
+          *reinterpret_cast<float4*>(out + rowoff + n) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(out + rowoff + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+__device__ __forceinline__ bool vec_epilogue_ok(const IgemmParams& p) {
+  return p.vec_epi && (p.N & 7) == 0 &&
+         ((reinterpret_cast<uintptr_t>(p.c) | reinterpret_cast<uintptr_t>(p.c_h) | reinterpret_cast<uintptr_t>(p.bias) | (uintptr_t)(p.out_elems & 3)) & 15) == 0;
+}
+
 template <int WMT, int WNT>
 struct SmemH {
   static constexpr int BM = 64 * WMT, BN = 64 * WNT;
@@ -293,7 +384,11 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue (fp32 output; same conventions as igemm_kernel) ----------------------------------------------------------
+  // ---- epilogue (same conventions as igemm_kernel) ------------------------------------------------------------------------
+  if (vec_epilogue_ok(p)) {       // launch-uniform; the K loop's last barrier has freed the LDS
+    store_tile_h<MODE, WMT, WNT>(p, pi, acc, reinterpret_cast<float*>(smem_h), bm, bn, split);
+    return;
+  }
   float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);     // (never dereferenced when p.c is NULL: see below)
   const bool fused = (p.splitk == 1);
 #pragma unroll
@@ -318,7 +413,11 @@ __global__ __launch_bounds__(256) void igemm_h_kernel(IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
         const int n = bn + wn * 32 * WNT + j * 32 + l31;
+#if defined(T2I_HEXP) && (T2I_HEXP & 1)
+        if (mok && n < p.N && acc[i][j][e] == 1.2345e38f) {
+#else
         if (mok && n < p.N) {
+#endif
           float v = acc[i][j][e];
           if (fused) {
             if (p.bias) v += p.bias[n];
@@ -368,7 +467,7 @@ struct SmemD {
   static constexpr int BYTES = 2 * (A_DW + B_DW) * 4;
 };
 
-template <int MODE, int WMT, int WNT>
+template <int MODE, int WMT, int WNT, int PIPE>
 __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   using S = SmemD<WMT, WNT>;
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
@@ -405,7 +504,11 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
   const int kbeg = split * p.k_per_split;
   const int kend = min(Kdim, kbeg + p.k_per_split);
+#if defined(T2I_HEXP) && (T2I_HEXP & 2)
+  const int ntiles = 0;
+#else
   const int ntiles = (kend - kbeg + HBK - 1) / HBK;
+#endif
 
   const i32x4h wa = rsrc_words_h(p.a, p.a_bytes), wb = rsrc_words_h(p.b, p.b_bytes);
 
@@ -498,6 +601,62 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();                                     // tile 0 is in LDS
+  if constexpr (PIPE) {
+    // Software-pipelined K loop (round 4).  With ONE workgroup on a CU (<= 256 tiles: every large layer at B = 64) nothing hides a
+    // phase in which all four waves only read fragments, so the fragments of 16-k step s+1 are read while step s multiplies, and
+    // ONE barrier per K-tile sits between steps 2 and 3: there every wave holds the last fragments of tile t (buf[t & 1] is free
+    // for the DMA of tile t+2) and has seen its own pieces of tile t+1 land (vmcnt(0): only they are outstanding), so behind the
+    // barrier tile t+1 is complete and its step-0 fragments are fetched under the step-3 MFMAs of tile t.
+    auto read_step = [&](const unsigned* as, const unsigned* bs, int s, bf16x8 (&fa)[WMT], bf16x8 (&fb)[WNT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        const int row = wm * 32 * WMT + i * 32 + l31;
+        fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
+        const int row = wn * 32 * WNT + i * 32 + l31;
+        fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+      }
+    };
+    auto mma_step = [&](const bf16x8 (&fa)[WMT], const bf16x8 (&fb)[WNT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int n = 0; n < WNT; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    };
+    bf16x8 ca[WMT], cb[WNT];
+    read_step(As, Bs, 0, ca, cb);
+    for (int t = 0; t < ntiles; ++t) {
+      const unsigned* as = As + (t & 1) * S::A_DW;
+      const unsigned* bs = Bs + (t & 1) * S::B_DW;
+      const unsigned* nas = As + ((t + 1) & 1) * S::A_DW;
+      const unsigned* nbs = Bs + ((t + 1) & 1) * S::B_DW;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        bf16x8 na[WMT], nb[WNT];
+        read_step(as, bs, s + 1, na, nb);
+        mma_step(ca, cb);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) ca[i] = na[i];
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) cb[i] = nb[i];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 (the only ones outstanding) have landed
+      __syncthreads();                                   // ... everybody's have, and everybody holds the step-3 fragments of tile t
+      dma_tile(t + 2, t & 1);                            // past the end: zeros (k >= kend)
+      {
+        bf16x8 na[WMT], nb[WNT];
+        read_step(nas, nbs, 0, na, nb);                  // past the end: the zeros of the look-ahead DMA, never multiplied
+        mma_step(ca, cb);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) ca[i] = na[i];
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) cb[i] = nb[i];
+      }
+    }
+  } else {
   for (int t = 0; t < ntiles; ++t) {
     const unsigned* as = As + (t & 1) * S::A_DW;
     const unsigned* bs = Bs + (t & 1) * S::B_DW;
@@ -530,9 +689,15 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
   }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead DMAs of the last two iterations
 
   // ---- epilogue: igemm_h_kernel's ---------------------------------------------------------------------------------------------
+  if (vec_epilogue_ok(p)) {
+    __syncthreads();              // every wave's look-ahead DMAs have landed and nobody reads fragments any more: the LDS is free
+    store_tile_h<MODE, WMT, WNT>(p, pi, acc, reinterpret_cast<float*>(smem_h), bm, bn, split);
+    return;
+  }
   float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
   const bool fused = (p.splitk == 1);
 #pragma unroll
@@ -557,7 +722,11 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
         const int n = bn + wn * 32 * WNT + j * 32 + l31;
+#if defined(T2I_HEXP) && (T2I_HEXP & 1)
+        if (mok && n < p.N && acc[i][j][e] == 1.2345e38f) {
+#else
         if (mok && n < p.N) {
+#endif
           float v = acc[i][j][e];
           if (fused) {
             if (p.bias) v += p.bias[n];
@@ -749,6 +918,7 @@ __global__ __launch_bounds__(256) void igemm_h_filter_kernel(IgemmParams p) {
 typedef short s16x4h __attribute__((ext_vector_type(4)));
 typedef short s16x8h __attribute__((ext_vector_type(8)));
 
+template <int PIPE>
 __global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
   constexpr int BM = 128, BN = 128;
   constexpr int TILE_B = HBK * 256;                       // bytes of one operand tile: 64 k-rows of 256 bytes
@@ -835,6 +1005,46 @@ __global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
   dma_tile(1, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __syncthreads();
+  if constexpr (PIPE) {
+    // the software-pipelined loop of igemm_hd_kernel<.., PIPE = 1>: fragments of step s+1 are read under the MFMAs of step s, one
+    // barrier per K-tile between steps 2 and 3
+    auto mma_step = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    };
+    bf16x8 ca[2], cb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ca[i] = frag(As, fa_off[i], 0); cb[i] = frag(Bs, fb_off[i], 0); }
+    for (int t = 0; t < ntiles; ++t) {
+      const char* as = As + (t & 1) * TILE_B;
+      const char* bs = Bs + (t & 1) * TILE_B;
+      const char* nas = As + ((t + 1) & 1) * TILE_B;
+      const char* nbs = Bs + ((t + 1) & 1) * TILE_B;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        bf16x8 na[2], nb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { na[i] = frag(as, fa_off[i], s + 1); nb[i] = frag(bs, fb_off[i], s + 1); }
+        mma_step(ca, cb);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
+      __syncthreads();
+      dma_tile(t + 2, t & 1);
+      {
+        bf16x8 na[2], nb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { na[i] = frag(nas, fa_off[i], 0); nb[i] = frag(nbs, fb_off[i], 0); }
+        mma_step(ca, cb);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+      }
+    }
+  } else {
   for (int t = 0; t < ntiles; ++t) {
     const char* as = As + (t & 1) * TILE_B;
     const char* bs = Bs + (t & 1) * TILE_B;
@@ -858,8 +1068,15 @@ __global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t+1 has landed
     __syncthreads();
   }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if (vec_epilogue_ok(p)) {       // dw[M][N] fp32, plain / accumulate / split-K slab: igemm_h_kernel's forward conventions without bias
+    __syncthreads();
+    PhaseInfo none;
+    store_tile_h<MODE_FWD, 2, 2>(p, none, acc, reinterpret_cast<float*>(smem_h), bm, bn, split);
+    return;
+  }
   float* out = p.c + (p.splitk > 1 ? (size_t)split * p.out_elems : 0);
   const bool fused = (p.splitk == 1);
 #pragma unroll
@@ -898,11 +1115,13 @@ hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStre
     constexpr int bytes = 4 * HBK * 256;               // 2 operands x 2 buffers of [64][128] bf16
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_hft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_hft_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_hft_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
       if (e != hipSuccess) return e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(igemm_hft_kernel, dim3(p.tiles_m * p.tiles_n, p.splitk), dim3(256), bytes, stream, p);
+    if (tuning().bf16_dma >= 2) hipLaunchKernelGGL(igemm_hft_kernel<1>, dim3(p.tiles_m * p.tiles_n, p.splitk), dim3(256), bytes, stream, p);
+    else hipLaunchKernelGGL(igemm_hft_kernel<0>, dim3(p.tiles_m * p.tiles_n, p.splitk), dim3(256), bytes, stream, p);
     return hipGetLastError();
   }
   if (wmt == 2 && wnt == 2) return launch_hf<2, 2>(p, stream);
@@ -912,10 +1131,10 @@ hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStre
   return hipErrorInvalidValue;
 }
 
-template <int MODE, int WMT, int WNT>
-static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+template <int MODE, int WMT, int WNT, int PIPE>
+static hipError_t launch_hd1(const IgemmParams& p, dim3 grid, hipStream_t stream) {
   using S = SmemD<WMT, WNT>;
-  auto k = igemm_hd_kernel<MODE, WMT, WNT>;
+  auto k = igemm_hd_kernel<MODE, WMT, WNT, PIPE>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
@@ -924,6 +1143,10 @@ static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream)
   }
   hipLaunchKernelGGL(k, grid, dim3(256), S::BYTES, stream, p);
   return hipGetLastError();
+}
+template <int MODE, int WMT, int WNT>
+static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+  return tuning().bf16_dma >= 2 ? launch_hd1<MODE, WMT, WNT, 1>(p, grid, stream) : launch_hd1<MODE, WMT, WNT, 0>(p, grid, stream);
 }
 
 template <int MODE, int WMT, int WNT>

@@ -67,6 +67,7 @@ struct IgemmParams {
   int32_t nbatch;             // FWD: independent GEMMs of identical shape in one launch (grid.z; Winograd's 16 tile positions)
   int64_t batch_a, batch_b, batch_c;   // element strides between them
   int32_t batch_lin;          // batched: grid.x = nbatch * tiles, positions assigned to XCDs in contiguous runs (see igemm_kernel)
+  int32_t vec_epi;            // bf16-operand kernels: epilogue through LDS with 16-byte stores (store_tile_h) when N % 8 == 0
   float* stats;               // FWD, unsplit: per-M-tile column partials [2][tiles_m][N] (sum, sum of squares) of the output
   PhaseInfo phase[16];
 };
@@ -136,12 +137,12 @@ struct BgemmParams {
   int64_t sa, sb, sc;         // element strides between the batch members
   uint32_t a_bytes, b_bytes;  // extents of ONE member's operands (buffer-load range check)
 };
-hipError_t bgemm_launch(int lay, const BgemmParams& p, hipStream_t stream);
+hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream_t stream);   // tile 64 wm x 64 wn
 
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi;
   double split_cost;
 };
 const Tuning& tuning();

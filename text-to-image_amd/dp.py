@@ -48,7 +48,10 @@ class DataParallel(object):
             raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (grad_dtype,))
         self.grad_dtype = grad_dtype
         self._stage = {}                      # id(arena) -> (send, recv, [offset]) bf16 staging buffers
-        self._a2a = None                      # does the backend have all-to-all on this device?  (None: not tried yet)
+        # bf16 buckets: all-to-all + all-gather (RCCL) or the all-gather-everything fallback (gloo, test transports).  Decided
+        # ONCE per device type from the backend's name — never by catching an exception around a collective: an OOM or a transient
+        # RCCL error on one rank would otherwise switch that rank alone to a collective its peers are not in.
+        self._a2a = {}
         # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
         self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
 
@@ -193,23 +196,35 @@ class DataParallel(object):
         if N == 1:
             buf.copy_(send[:n])
             return
-        if self._a2a is not False:
-            try:
-                dist.all_to_all_single(recv, send, group=self.group)            # recv[j] = rank j's chunk number `rank`
-                mine = recv.view(N, chunk).float().sum(0).to(torch.bfloat16)   # the sum in fp32, rounded once
-                dist.all_gather_into_tensor(send, mine, group=self.group)       # send now holds every rank's reduced chunk
-                self._a2a = True
-                buf.copy_(send[:n])
-                return
-            except RuntimeError:
-                if self._a2a:                   # it worked before: a real failure, not a missing collective
-                    raise
-                self._a2a = False               # e.g. gloo with device tensors (the 2-ranks-on-1-GPU pre-flight): no all-to-all
+        if self._has_all_to_all(buf):
+            dist.all_to_all_single(recv, send, group=self.group)            # recv[j] = rank j's chunk number `rank`
+            mine = recv.view(N, chunk).float().sum(0).to(torch.bfloat16)   # the sum in fp32, rounded once
+            dist.all_gather_into_tensor(send, mine, group=self.group)       # send now holds every rank's reduced chunk
+            buf.copy_(send[:n])
+            return
         # same arithmetic without all-to-all: everybody gathers everybody's bf16 bucket and sums all of it in fp32 (N times the
         # bytes — test transports only; RCCL takes the branch above)
         parts = [torch.empty_like(send) for _ in range(N)]
         dist.all_gather(parts, send, group=self.group)
         buf.copy_(torch.stack(parts).float().sum(0).to(torch.bfloat16)[:n])
+
+    def _has_all_to_all(self, buf):
+        """Does the process group's backend for this tensor's device have all_to_all_single / all_gather_into_tensor?  RCCL
+        ('nccl') does; gloo does not (neither on device tensors — the 2-ranks-on-1-GPU pre-flight — nor, for all_to_all, on the
+        CPU).  A pure function of (backend name, device type), so every rank decides alike; the choice is logged once."""
+        kind = buf.device.type
+        got = self._a2a.get(kind)
+        if got is None:
+            backend = str(dist.get_backend(self.group)).lower()
+            config = str(dist.get_backend_config(self.group)).lower() if hasattr(dist, 'get_backend_config') else backend
+            if ':' in config:                             # "cpu:gloo,cuda:nccl": the entry of this device type
+                per = dict(item.split(':', 1) for item in config.split(',') if ':' in item)
+                backend = per.get('cuda' if kind == 'cuda' else 'cpu', backend)
+            got = self._a2a[kind] = backend in ('nccl', 'rccl')
+            if not got and self.rank == 0 and os.environ.get('T2I_QUIET') != '1':
+                print('[t2i dp] bf16 buckets on backend %r (%s tensors): no all-to-all, gathering whole buckets instead '
+                      '(test transport; N x the bytes)' % (backend, kind), flush=True)
+        return got
 
     def _launch_range(self, st, start, end):
         buf = st['arena'].grad[start:end]
@@ -244,6 +259,10 @@ class DataParallel(object):
         of the arena whose gradients are final NOW — the part of a backward that has been cut in two; the caller issues the
         remaining ranges with another call before finish_allreduce."""
         st = self.attach(arena)
+        if ranges is not None and st['armed']:
+            raise RuntimeError('start_allreduce(ranges=...) belongs to the cut (un-armed) schedule: this arena is armed for the '
+                               'bucket-overlap schedule, which would exchange every bucket now — including the ones the cut says '
+                               'are not final yet')
         if st.get('snap'):                      # ... and compare with what the backward finally left there
             torch.cuda.synchronize()
             for bi, snap in st['snap'].items():

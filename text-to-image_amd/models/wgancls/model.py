@@ -143,12 +143,20 @@ class WGanCls(object):
 
     def _cut_ranges(self, arena, first_var):
         """([(start, end)] of the part that is final after the first half of the cut backward, [(start, end)] of the rest)."""
+        if first_var not in arena.offsets:
+            raise KeyError('cut schedule: %r is not a variable of this arena (a model variant needs its own _CUT_D / _CUT_G)' % first_var)
+        # the cut is "everything created from first_var on": only valid when arena order == creation order
+        offs = [arena.offsets[n][0] for n in arena.names]
+        if any(b <= a for a, b in zip(offs, offs[1:])):
+            raise RuntimeError('cut schedule: arena offsets are not monotone in creation order; use the uncut schedule')
         o = arena.offsets[first_var][0]
         return [(o, arena.numel)], [(0, o)]
 
     @staticmethod
     def _split_vars(variables, first_var):
         names = list(variables)
+        if first_var not in variables:
+            raise KeyError('cut schedule: %r is not among the variables %s...' % (first_var, names[:3]))
         i = names.index(first_var)
         return [variables[n] for n in names[i:]], [variables[n] for n in names[:i]]
 
