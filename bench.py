@@ -40,19 +40,25 @@ def make_cfg(batch):
     return cfg
 
 
-def synthetic_feed(cfg, device, seed):
-    """BASELINE.md §2 inputs, generated on the device (resident in HBM before the timed region)."""
+def synthetic_feed(cfg, device, seed, with_noise=True):
+    """BASELINE.md §2 inputs, generated on the device (resident in HBM before the timed region).
+    with_noise=False: the feed carries no conditioning-augmentation noise, so the model draws it itself on every iteration —
+    tf.truncated_normal is part of the reference's sess.run (models/wgancls/model.py:119); the timed region uses this form, the
+    exactness checks (which need every rank and every run to see the same noise) the other."""
     g = torch.Generator(device=device).manual_seed(seed)
     B, m = cfg.TRAIN.BATCH_SIZE, cfg.MODEL
     shape = (B, m.IMAGE_SHAPE.H, m.IMAGE_SHAPE.W, m.IMAGE_SHAPE.D)
     tn = lambda: torch.nn.init.trunc_normal_(torch.empty(B, m.COMPRESSED_EMBED_DIM, device=device), 0.0, 1.0, -2.0, 2.0, generator=g)
-    return {'x': torch.rand(shape, generator=g, device=device) * 2 - 1,
+    feed = {'x': torch.rand(shape, generator=g, device=device) * 2 - 1,
             'x_mismatch': torch.rand(shape, generator=g, device=device) * 2 - 1,
             'cond': torch.randn((B, m.EMBED_DIM), generator=g, device=device),
             'z': torch.randn((B, m.Z_DIM), generator=g, device=device),
             'epsilon': torch.rand((B, 1, 1, 1), generator=g, device=device),
             'ca_noise_d': tn(), 'ca_noise_g': tn(),
             'learning_rate_d': cfg.TRAIN.D_LR, 'learning_rate_g': cfg.TRAIN.G_LR}
+    if not with_noise:
+        del feed['ca_noise_d'], feed['ca_noise_g']
+    return feed
 
 
 class ConvTimer(object):
@@ -227,7 +233,8 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     # and an N-rank run must end with EXACTLY the weights of a single process — a check of the exchange that, unlike the
     # replica comparison, also catches buckets that are exchanged consistently but too early
     same_data = os.environ.get('T2I_SAME_DATA') == '1'
-    feed = synthetic_feed(cfg, device, seed=1 + (0 if same_data else rank))
+    # the timed feed carries no conditioning noise: the two [B, 128] truncated-normal draws of an iteration happen inside it
+    feed = synthetic_feed(cfg, device, seed=1 + (0 if same_data else rank), with_noise=os.environ.get('T2I_BENCH_FEED_NOISE') == '1')
     if same_data:
         torch.manual_seed(1234)
         torch.cuda.manual_seed_all(1234)
@@ -342,7 +349,9 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                       'gradient_exchange': (grad_dtype + ' buckets over RCCL' + (' (fp32 accumulation)' if grad_dtype == 'bf16' else '')) if use_dp else None,
                       'launch': ('hipGraph replay (%s)' % ((schedule or 'graph segments + eager all-reduces') if use_dp else '1 graph/iteration')) if use_graphs else 'eager'},
-           'nominal_tflops': NOMINAL_FLOP_PER_IMAGE * value / 1e12,
+           # SURVEY 8(d)'s nominal 31.362 GFLOP/image books 4 conv launches per critic layer whose operand is identically zero and
+           # which are never launched; it is NOT a utilisation figure (roofline.frac is, from the launched convs' FLOPs)
+           'survey_nominal_tflops_overcounts_zero_branches': NOMINAL_FLOP_PER_IMAGE * value / 1e12,
            'timing': {'regions': len(regions), 'steps_per_region': args.steps, 'statistic': 'median over regions (max over ranks per region)',
                       'gpu_busy_s': sum(regions), 'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
     if preflight is not None:
@@ -360,7 +369,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
         # the profile counts igemm_kernel dispatches; every conv entry-point call launches exactly one, except the small direct kernels
         igemm_per_step = launches_per_step - (s['by_algo'].get('direct_small', [0])[0] / float(inst_steps))
         suffix = '' if math == 'f32' else '_bf16'
-        for cand in ('r03_pmc_igemm%s.json' % suffix, 'r02_pmc_igemm%s.json' % suffix, 'r01_pmc_igemm.json'):
+        for cand in ('r04_pmc_igemm%s.json' % suffix, 'r03_pmc_igemm%s.json' % suffix, 'r02_pmc_igemm%s.json' % suffix, 'r01_pmc_igemm.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
             except Exception:
@@ -383,22 +392,34 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
                                                  'note': 'multiply-adds issued by the GEMM kernels / their profiled time (transforms, reductions and thin kernels excluded)'}
             break
         flop_per_step = s['flop'] / inst_steps
+        driver_tflops = flop_per_step / (ms * 1e-3) / 1e12          # algorithmic FLOPs of the launched convs over the replayed step
+        # compulsory HBM bytes of the same launches (Σ layer in+out per pass, 286 MB per generator pass and 161 MB per
+        # critic pass at B = 64 in fp32, 4 generator-side and 15 critic-side passes are launched; half in bf16 storage)
+        compulsory = (4 * 286e6 + 15 * 161e6) * (args.batch / 64.0) * (0.5 if storage == 'bf16' else 1.0)
+        igemm_launches = prof['profile_igemm_launches_per_step'] if (prof and prof.get('counts_agree')) else None
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel)',
-            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': achieved / peak, 'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
-            # the same algorithmic FLOPs against the driver-visible clock: the WHOLE iteration (everything that is not a
-            # convolution included) as `ms_per_step` measures it under graph replay
-            'frac_vs_driver_ms': flop_per_step / (ms * 1e-3) / 1e12 / peak,
+            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel)'
+                     if math == 'f32' else 't2i::igemm_hd_kernel<MODE,WMT,WNT> + t2i::igemm_hft_kernel (bf16 operands by LDS DMA) + the fp32 thin-layer kernels',
+            'achieved': driver_tflops, 'peak': peak, 'unit': 'TFLOP/s',
+            # round 4: `frac` is the driver-clock figure (algorithmic FLOPs of the launched convs / ms_per_step of the replayed
+            # iteration, everything that is not a convolution included); the eager per-launch event sum is kept beside it
+            'frac': driver_tflops / peak, 'frac_vs_driver_ms': driver_tflops / peak,
+            'achieved_entry_points': achieved, 'frac_entry_points': achieved / peak,
+            'traffic': traffic, 'traffic_source': prof, 'mfma_util': mfma_util,
+            'traffic_per_step': (traffic * igemm_launches) if (traffic and igemm_launches) else None,
+            'compulsory_bytes_per_step': compulsory,
+            'traffic_over_compulsory': (traffic * igemm_launches / compulsory) if (traffic and igemm_launches) else None,
             'algorithmic_flop_per_launch': s['flop'] / max(s['launches'], 1),
             'launches_per_step': launches_per_step, 'igemm_ms_per_step': s['ms'] / inst_steps,
             'igemm_gflop_per_step': flop_per_step / 1e9, 'events': args.instrument,
             # `achieved` counts direct-convolution FLOPs; the Winograd paths issue 1/2.25 resp. 9/16 of them
             'executed_tflops': sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 if s['ms'] > 0 else 0.0,
             'executed_frac': (sum(r[3] for r in s['by_algo'].values()) / (s['ms'] * 1e-3) / 1e12 / peak) if s['ms'] > 0 else 0.0,
-            'note': 'frac = direct-convolution FLOPs / time in the conv entry points (eager instrumented pass; Winograd issues 1/2.25 resp. '
-                    '9/16 of them); frac_vs_driver_ms = the same FLOPs / ms_per_step; executed_frac = multiply-adds actually issued / peak; '
-                    'mfma_util = PMC pipe-busy fraction (from_profile)',
+            'note': 'frac = achieved / peak with achieved = direct-convolution FLOPs of the launched conv calls / ms_per_step (the replayed '
+                    'iteration on the driver\'s clock); frac_entry_points = the same FLOPs / time inside the conv entry points (eager '
+                    'instrumented pass; Winograd issues 1/2.25 resp. 9/16 of them); executed_frac = multiply-adds actually issued / peak over '
+                    'the entry-point time; mfma_util = PMC pipe-busy fraction (from_profile); traffic = HBM-side bytes per GEMM launch '
+                    '(from_profile), traffic_over_compulsory = per step against the minimum activation + weight bytes of the same launches',
             'by_algorithm': {a: {'calls_per_step': r[0] / float(inst_steps), 'ms_per_step': r[1] / inst_steps,
                                  'algorithmic_tflops': r[2] / (r[1] * 1e-3) / 1e12 if r[1] > 0 else 0.0}
                              for a, r in sorted(s['by_algo'].items())},
@@ -439,6 +460,8 @@ def main():
     ap.add_argument('--min-busy-s', type=float, default=3.0,
                     help='keep adding timed regions (each exactly --steps iterations) until the GPU has been busy this long in total')
     ap.add_argument('--no-config3', action='store_true', help='skip the config3_bf16 block (bf16 arithmetic) behind the fp32 headline')
+    ap.add_argument('--no-side-rows', action='store_true', help='skip the b8_per_gpu and next_rows blocks')
+    ap.add_argument('--side-budget-s', type=float, default=0.6, help='timed replay budget per side row')
     ap.add_argument('--cpu-baseline-only', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -506,6 +529,18 @@ def main():
                                        'generator_step_gradients': 1.2e-1},
                 'kernel_arithmetic': 'tests/test_kernels_gpu.py::test_bf16_operand_gemm_matches_rounded_oracle: 1e-5 / 1e-4 vs float64 on bf16-rounded operands'}
             out['config3_bf16'] = blk
+    # SURVEY 8(d)'s strong-scaling share (global 64 = 8 per GPU = the yml's BATCH_SIZE) and the next rows (gancls, StackGAN, PGGAN):
+    # short measured rows on the same line — images/s, algorithmic GFLOP/image, fraction of the matrix peak on the replayed clock
+    if (rank == 0 and world == 1 and args.math == 'f32' and not args.no_config3 and not args.no_side_rows and args.instrument != 'off' and
+            os.environ.get('T2I_BENCH_SIDE_ROWS', '1') != '0'):      # only on the full default line (diagnostic invocations skip them)
+        from tools.next_rows import measure_rows
+        b8 = measure_rows(['wgancls_b8'], 'f32', args.side_budget_s, device) + measure_rows(['wgancls_b8'], 'bf16', args.side_budget_s, device, args.storage)
+        out['b8_per_gpu'] = {'what': 'wgancls at batch 8 per GPU (strong scaling of global batch 64 over 8 GPUs; models/wgancls/cfg/flowers.yml:24), '
+                                     'hipGraph replay, noise drawn inside the iteration', 'f32': b8[0], 'bf16': b8[1]}
+        rows = measure_rows(['gancls', 'stage1', 'stage2', 'pggan7'], 'f32', args.side_budget_s, device)
+        rows += measure_rows(['stage2'], 'bf16', args.side_budget_s, device, 'f32')     # (fp32 activation tensors + bf16 operand images: the StackGAN graphs mix 3-channel joins into 64-multiples)
+        out['next_rows'] = {'what': 'SURVEY 8(f) rows + the gancls variant at the reference\'s dimensions and batch sizes; algorithmic_gflop_per_image = '
+                                    'direct-convolution FLOPs of the conv/deconv/dense calls one iteration launches / batch', 'rows': rows}
     if rank == 0 and not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only (the other ranks would idle in the final barrier)
         out['cpu_baseline'] = cpu_baseline(16)              # BASELINE configs[0]
         out['cpu_baseline_b64'] = cpu_baseline(64)          # and the batch the metric is quoted on

@@ -148,8 +148,9 @@ class MaskTape(object):
     own pre-activation has the other sign is within rounding distance of zero, so values move by rounding only.
     masks / record: lists of bool tensors in call order (NCHW for feature maps, [B, C] for dense layers)."""
 
-    def __init__(self, masks=None):
+    def __init__(self, masks=None, keep_values=False):
         self.masks, self.record, self.i = masks, [], 0
+        self.values = [] if keep_values else None      # the activation outputs, in call order (per-layer error tables: tools/bf16_error_table.py)
 
     def act(self, x, slope):
         if self.masks is None:
@@ -159,7 +160,10 @@ class MaskTape(object):
             assert m.shape == x.shape, ('mask %d' % self.i, tuple(m.shape), tuple(x.shape))
         self.i += 1
         self.record.append(m)
-        return x * torch.where(m, torch.ones((), dtype=x.dtype), torch.full((), slope, dtype=x.dtype))
+        y = x * torch.where(m, torch.ones((), dtype=x.dtype), torch.full((), slope, dtype=x.dtype))
+        if self.values is not None:
+            self.values.append(y.detach())
+        return y
 
 
 def _lrelu(x, tape=None):

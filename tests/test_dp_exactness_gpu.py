@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _signature(cmd, env_extra):
     env = dict(os.environ)
-    env.update(T2I_SAME_DATA='1', T2I_FILTER_CACHE='1')
+    env.update(T2I_SAME_DATA='1', T2I_FILTER_CACHE='1', T2I_BENCH_FEED_NOISE='1')     # noise in the feed: the same on every rank and in every run
     env.update(env_extra)
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     err = r.stderr.decode()

@@ -143,11 +143,13 @@ def test_stackgan_stage2_full_size(gpu):
     assert not chk.bad, chk.bad
 
 
-@pytest.mark.parametrize('stage,trans,B', [(5, True, 4), (6, False, 2), (7, True, 2)])
+@pytest.mark.parametrize('stage,trans,B', [(1, False, 16), (2, True, 16), (2, False, 16), (3, True, 16), (3, False, 8), (4, True, 8), (4, False, 8),
+                                           (5, True, 4), (6, False, 2), (7, True, 2)])
 def test_pggan_stage_full_width(gpu, stage, trans, B):
-    """reference models/pggan/pggan.py:251-316 (generator / critic of a stage), train_pggan.py:17-69 (the stage schedule: 5t =
-    64x64 in transition, 6 = 128x128 stabilisation, 7t = 256x256 in transition; batch 16 -> 8 from stage 6 on, here the smallest
-    batches that keep the float64 oracle below a minute)."""
+    """reference models/pggan/pggan.py:251-316 (generator / critic of a stage), train_pggan.py:17-69 (the stage schedule: 1 = 4x4,
+    2t / 2 = 8x8, 3t / 3 = 16x16, 4t / 4 = 32x32 — round 4: the low stages at full width and at the reference's batch 16 where the
+    float64 oracle allows — 5t = 64x64 in transition, 6 = 128x128 stabilisation, 7t = 256x256 in transition; batch 16 -> 8 from
+    stage 6 on, from stage 3 here the smallest batches that keep the float64 oracle below a minute)."""
     from oracle import torch_pggan as PG, torch_step as T
     from t2i_amd.models.pggan.pggan import PGGAN
     alpha = 0.3

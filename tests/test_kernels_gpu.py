@@ -34,6 +34,26 @@ def relerr(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+class Bounds(object):
+    """Per-check error bounds of one parametrised case: every check is held to `default` unless the case states its own bound for
+    it (with the measured value beside it).  All measured values are printed (pytest -s) and all failures reported together."""
+
+    def __init__(self, case, default, stated=None):
+        self.case, self.default, self.stated, self.bad, self.seen = case, default, dict(stated or {}), [], []
+
+    def check(self, name, err):
+        tol = self.stated.get(name, self.default)
+        self.seen.append((name, err, tol))
+        if not err <= tol:
+            self.bad.append((name, err, tol))
+
+    def done(self):
+        print('  case %s: %s' % (self.case, ', '.join('%s %.2e/%.0e' % t for t in self.seen)))
+        unused = set(self.stated) - set(n for n, _, _ in self.seen)
+        assert not unused, ('stated bounds for checks that do not exist', unused)
+        assert not self.bad, (self.case, self.bad)
+
+
 CONV_CASES = {  # name -> (stride, padding); geometry comes from the arrays
     'k4s2_same': (2, 'SAME'), 'k4s2_same_c3': (2, 'SAME'), 'k4s2_same_odd': (2, 'SAME'), 'k3s1_same': (1, 'SAME'),
     'k3s1_same_c3': (1, 'SAME'), 'k1s1_valid': (1, 'VALID'), 'k4s4_valid': (4, 'VALID'), 'k4s1_same': (1, 'SAME'),
@@ -365,6 +385,11 @@ def test_conv_epilogue_batch_norm_statistics(K):
         K.tuning_set('force_splitk', 0)
 
 
+# checks of the Winograd tests that do not meet 1e-5: case -> {check: bound}   (measured value in the comment; K = reduction length)
+WINO3_STATED = {}
+WINO4_STATED = {}
+
+
 @pytest.mark.parametrize('case', [(48, 4, 4, 512, 1024, 'critic 4x4 map'), (12, 8, 8, 512, 512, 'generator 8x8'), (13, 16, 16, 256, 256, '16x16'),
                                   (16, 4, 6, 1152, 1024, 'non-square, 1152 = features ++ text channels'),
                                   (64, 8, 8, 128, 512, '128 -> 512 channels: K = 128 one way, 512 the other'),
@@ -372,11 +397,14 @@ def test_conv_epilogue_batch_norm_statistics(K):
                                   (10, 4, 4, 1152, 1152, 'T = 40 tiles: ragged M in fwd / bwd-data, a ragged K tail (2 K-tiles, 8 of 32 valid) in the filter gradient')])
 def test_winograd_3x3_matches_oracle(K, case):
     """3x3 stride-1 SAME convs with >= 128 channels on small maps take the Winograd F(2x2,3x3) path (transforms + 16 batched
-    GEMMs in one launch) in conv_fwd, conv_bwd_data and conv_bwd_filter.  Against the float64 direct oracle: 2e-5 of the output scale (the
-    transforms add a few ulps to the 1e-5 of the direct kernel); bias + activation in the output transform; and the same
-    call with T2I_WINOGRAD=0 semantics is covered by the other conv tests (smaller channel counts never take this path)."""
+    GEMMs in one launch) in conv_fwd, conv_bwd_data and conv_bwd_filter.  Against the float64 direct oracle every check is held to
+    SURVEY 8(c)'s 1e-5 of the output scale, except the checks listed per case in WINO3_STATED with the bound they get and the
+    value measured for them (the transforms add a few ulps per element, the reduction is K = 9 Cin resp. B H W long); bias +
+    activation in the output transform; the same call with T2I_WINOGRAD=0 semantics is covered by the other conv tests (smaller
+    channel counts never take this path)."""
     from oracle import np_ops as O
     B, H, W, Ci, Co, _ = case
+    bd = Bounds(case[:5], 1e-5, WINO3_STATED.get(case[:5]))
     rng = np.random.default_rng(B * 1000 + H * 10 + Ci)
     x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
     w = (rng.standard_normal((3, 3, Ci, Co)) / np.sqrt(9 * Ci)).astype(np.float32)
@@ -385,30 +413,33 @@ def test_winograd_3x3_matches_oracle(K, case):
     assert [K.conv_algo(d, m) for m in ('fwd', 'bwd_data', 'bwd_filter')] == \
         ['winograd_f2x2_3x3'] * 2 + ['winograd_f2x2_3x3' if Ci * Co >= 65536 else 'implicit_gemm']     # this IS the path under test
     y_ref = O.conv2d(x, w, b, (1, 1), 'SAME')
-    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
-    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
-    assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (1, 1), 'SAME')) <= 2e-5
+    bd.check('fwd', relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref))
+    bd.check('fwd_lrelu', relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)))
+    bd.check('fwd_nobias', relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (1, 1), 'SAME')))
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (1, 1), 'SAME')) <= 2e-5
+    bd.check('bwd_data', relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), O.conv2d_bwd_data(dy, w, x.shape, (1, 1), 'SAME')))
     dw_ref = O.conv2d_bwd_filter(x, dy, w.shape, (1, 1), 'SAME')
-    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= 2e-5
+    bd.check('bwd_filter', relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref))
     acc = dev(w.copy())
     K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1))               # accumulate form (gradient sink)
-    assert relerr(acc, w.astype(np.float64) + dw_ref) <= 2e-5
+    bd.check('bwd_filter_acc', relerr(acc, w.astype(np.float64) + dw_ref))
     # adjoint identity between the two Winograd paths: <conv(x), dy> == <x, conv^T(dy)>
     yk = K.conv_fwd(dev(x), dev(w), None, d, ws).double()
     lhs = float((yk * dev(dy).double()).sum())
     rhs = float((dev(x).double() * K.conv_bwd_data(dev(dy), dev(w), None, d, ws).double()).sum())
-    assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())      # on the scale of the two vectors
+    bd.check('adjoint', abs(lhs - rhs) / float(yk.norm() * dev(dy).double().norm()))      # on the scale of the two vectors
+    bd.done()
 
 
 @pytest.mark.parametrize('case', [(2, 8, 8, 128, 160), (3, 16, 16, 256, 128), (1, 4, 12, 136, 128), (2, 32, 32, 128, 256),
                                   (1, 8, 8, 256, 288), (3, 4, 8, 320, 256), (16, 32, 32, 128, 128)])
 def test_winograd_k4s2_matches_oracle(K, case):
     """4x4 stride-2 SAME convs with >= 128 channels take the F(2x2,2x2) path in conv_fwd (space-to-depth phases, 9 batched
-    GEMMs).  Against the float64 direct oracle: 2e-5 of the output scale, with bias and activation."""
+    GEMMs).  Against the float64 direct oracle every check is held to SURVEY 8(c)'s 1e-5 of the output scale unless WINO4_STATED
+    lists the check for the case with its own bound and the measured value; with bias and activation."""
     from oracle import np_ops as O
     B, H, W, Ci, Co = case
+    bd = Bounds(case, 1e-5, WINO4_STATED.get(case))
     rng = np.random.default_rng(B * 100 + H + Ci)
     x = rng.standard_normal((B, H, W, Ci)).astype(np.float32)
     w = (rng.standard_normal((4, 4, Ci, Co)) / np.sqrt(16 * Ci)).astype(np.float32)
@@ -417,25 +448,26 @@ def test_winograd_k4s2_matches_oracle(K, case):
     assert K.conv_algo(d, 'fwd') == K.conv_algo(d, 'bwd_filter') == 'winograd_f2x2_2x2'
     assert K.conv_algo(d, 'bwd_data') == ('winograd_f2x2_2x2' if min(Ci, Co) >= 128 and Ci % 32 == 0 and Co % 32 == 0 else 'implicit_gemm')
     y_ref = O.conv2d(x, w, b, (2, 2), 'SAME')
-    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref) <= 2e-5
-    assert relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)) <= 2e-5
-    assert relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (2, 2), 'SAME')) <= 2e-5
+    bd.check('fwd', relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws), y_ref))
+    bd.check('fwd_lrelu', relerr(K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2), O.lrelu(y_ref)))
+    bd.check('fwd_nobias', relerr(K.conv_fwd(dev(x), dev(w), None, d, ws), O.conv2d(x, w, None, (2, 2), 'SAME')))
     # input gradient / tf conv2d_transpose forward: 4 output phases x 9 batched GEMMs when Cin % 32 == 0 as well
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     bi = rng.standard_normal(Ci).astype(np.float32)
     dx_ref = O.conv2d_bwd_data(dy, w, x.shape, (2, 2), 'SAME')
-    assert relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), dx_ref) <= 2e-5
-    assert relerr(K.conv_bwd_data(dev(dy), dev(w), dev(bi), d, ws, K.ACT_RELU), np.maximum(dx_ref + bi, 0)) <= 2e-5
+    bd.check('bwd_data', relerr(K.conv_bwd_data(dev(dy), dev(w), None, d, ws), dx_ref))
+    bd.check('bwd_data_bias_relu', relerr(K.conv_bwd_data(dev(dy), dev(w), dev(bi), d, ws, K.ACT_RELU), np.maximum(dx_ref + bi, 0)))
     yk = K.conv_fwd(dev(x), dev(w), None, d, ws).double()
     lhs = float((yk * dev(dy).double()).sum())
     rhs = float((dev(x).double() * K.conv_bwd_data(dev(dy), dev(w), None, d, ws).double()).sum())
-    assert abs(lhs - rhs) <= 1e-5 * float(yk.norm() * dev(dy).double().norm())
+    bd.check('adjoint', abs(lhs - rhs) / float(yk.norm() * dev(dy).double().norm()))
     # filter gradient (adjoint of the forward identity; tile chunks in the batch dimension when 9 GEMMs leave CUs idle)
     dw_ref = O.conv2d_bwd_filter(x, dy, w.shape, (2, 2), 'SAME')
-    assert relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref) <= 2e-5
+    bd.check('bwd_filter', relerr(K.conv_bwd_filter(dev(x), dev(dy), d, ws), dw_ref))
     acc = dev(w.copy())
     K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc.view(-1))
-    assert relerr(acc, w.astype(np.float64) + dw_ref) <= 2e-5
+    bd.check('bwd_filter_acc', relerr(acc, w.astype(np.float64) + dw_ref))
+    bd.done()
 
 
 def test_filter_cache_reuse_and_invalidate(K):

@@ -71,15 +71,18 @@ def relerr(got, ref, scale=None):
     return float(np.abs(got - ref).max() / max(s, 1e-30))
 
 
-@pytest.fixture(scope='module')
-def setup():
+@pytest.fixture(scope='module', params=[64, 16], ids=['B64', 'B16'])
+def setup(request):
+    """B = 64: the metric's batch (BASELINE configs[1]).  B = 16 (round 4): BASELINE configs[0]'s batch on the HIP path at full
+    width, held to the same mask-pinned bounds — so that the kink-tolerant criterion of tests/test_step_gpu.py is never the only
+    full-width check at a batch size the configs name."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import bench
     import t2i_amd  # noqa: F401
     from oracle import torch_step as T
     from t2i_amd.models.wgancls.model import WGanCls
-    B = 64
+    B = request.param
     dev = torch.device('cuda')
     ocfg = T.Cfg(batch=B)
     P = {n: v.double() for n, v in T.init_variables(ocfg, seed=0).items()}
@@ -225,6 +228,8 @@ def test_b64_bf16_steps_mask_pinned(setup, storage):
         relative error is ~2 |logit| d(logit) for the nearly saturated pixels that carry most of the gradient.
     For comparison the un-pinned bf16 check (tests/test_step_gpu.py) can only ask for a cosine >= 0.95."""
     T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
+    if B != 64:
+        pytest.skip('config 3 is quoted at B = 64')
     from t2i_amd import kernels as K
 
     def rel_l2(got, ref):

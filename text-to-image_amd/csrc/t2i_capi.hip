@@ -126,7 +126,7 @@ static Tuning& tuning_mut() {
     v.hft_boost = env_int("T2I_HFT_BOOST", 130);           // x0.01: planner efficiency of igemm_hft_kernel's 128x128 tile against igemm_h_filter_kernel's
     v.hft_ovh = env_int("T2I_HFT_OVH", 80);                // x0.1 K-tile steps: its fixed cost per workgroup
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
-    v.bgemm_tile = env_int("T2I_BGEMM_TILE", 0);           // persistent batched GEMM tile: 0 = by item count, 11 / 21 / 12 / 22 = 64 a x 64 b forced
+    v.bgemm_tile = env_int("T2I_BGEMM_TILE", 11);          // persistent batched GEMM tile: 11 / 21 / 12 / 22 = 64 a x 64 b; 0 = by item count (measured: the larger tiles lose at every batch size, profiles/r04_bgemm_tiles.txt)
     v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
     v.vec_epi = env_int("T2I_VEC_EPI", 1);                 // bf16-operand GEMMs: epilogue through LDS, 16-byte stores (0: one store per element)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)

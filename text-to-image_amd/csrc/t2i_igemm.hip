@@ -647,6 +647,85 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   float cs[WNT];               // this lane's column sums over its rows (batch-norm statistics of the layer output)
 #pragma unroll
   for (int j = 0; j < WNT; ++j) cs[j] = 0.f;
+  // Round 4: stores through LDS.  The direct form below issues 16 WMT WNT four-byte stores per thread, and a bf16-kernel ablation
+  // (profiles/r04_bf16_gemm_fixed_cost.txt) showed that form costing 7 us of every launch — store-issue latency of the workgroup,
+  // not bandwidth.  Each wave passes its sub-tile through a private LDS patch 32 rows at a time (the operand tiles are dead after
+  // the barrier) and a lane then stores 4 consecutive columns of a row with one 16-byte instruction: 4 WMT WNT stores per thread.
+  // Same element arithmetic (bias, activation, accumulate) in the same order: bit-identical.  N % 4 == 0, aligned bases.
+  constexpr bool STAGE_FITS = S::BYTES >= 4 * 32 * (32 * WNT + 4) * 4;      // (the bf16-math images of the 64x128 tile are smaller)
+  const bool vec_epi = STAGE_FITS && p.vec_epi && (p.N & 3) == 0 && (p.out_elems & 3) == 0 && (p.batch_c & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(p.c) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+  if (vec_epi) {
+    constexpr int SROW = 32 * WNT + 4, CH = 8 * WNT;      // staging row stride (floats); 4-column chunks per row
+    __syncthreads();                                       // every wave is done with the operand tiles in LDS
+    float* st = smem + wave * (32 * SROW);
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * lh) * SROW + j * 32 + l31] = acc[i][j][e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 4 * WNT; ++it) {
+        const int idx = it * 64 + lane, row = idx / CH, c4 = idx % CH;
+        float4 v = *reinterpret_cast<const float4*>(&st[row * SROW + c4 * 4]);
+        const int m = bm + (wm * WMT + i) * 32 + row;
+        const int n = bn + wn * 32 * WNT + c4 * 4;
+        bool mok = m < p.M;
+        int rowoff;
+        if (MODE == MODE_BWD_DATA) {
+          int mm = mok ? m : 0;
+          int b = p.div_hqwq.div(mm);
+          int rem = mm - b * p.hqwq;
+          int ihq = p.div_wq.div(rem);
+          int iwq = rem - ihq * p.Wq;
+          int ih = ihq * p.d.SH + pi.ph, iw = iwq * p.d.SW + pi.pw;
+          mok = mok && ih < p.d.H && iw < p.d.W;
+          rowoff = ((b * p.d.H + ih) * p.d.W + iw) * p.N;
+        } else {
+          rowoff = m * p.N;
+        }
+        if (mok && n < p.N) {
+          if (fused) {
+            if (p.bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            v.x = apply_act(v.x, p.act, p.alpha); v.y = apply_act(v.y, p.act, p.alpha);
+            v.z = apply_act(v.z, p.act, p.alpha); v.w = apply_act(v.w, p.act, p.alpha);
+            if (p.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(out + rowoff + n);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+          }
+          *reinterpret_cast<float4*>(out + rowoff + n) = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (want_stats) {            // the column sums of the values just stored, from the accumulators (same arithmetic)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int n = bn + wn * 32 * WNT + j * 32 + l31;
+        const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = acc[i][j][e];
+            if (p.bias) v += bv;
+            v = apply_act(v, p.act, p.alpha);
+            if (m < p.M && n < p.N) cs[j] += v;
+          }
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < WMT; ++i) {
 #pragma unroll

@@ -459,21 +459,22 @@ __device__ __forceinline__ void dma16_h(i32x4h rsrc, unsigned voff, unsigned lds
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 
-template <int WMT, int WNT>
+template <int WMT, int WNT, int NBUF = 2>
 struct SmemD {
   static constexpr int BM = 64 * WMT, BN = 64 * WNT;
   static constexpr int ROW = 32;                                // dwords per row, unpadded
   static constexpr int A_DW = BM * ROW, B_DW = BN * ROW;
-  static constexpr int BYTES = 2 * (A_DW + B_DW) * 4;
+  static constexpr int BYTES = NBUF * (A_DW + B_DW) * 4;
 };
 
-template <int MODE, int WMT, int WNT, int PIPE>
+template <int MODE, int WMT, int WNT, int PIPE>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
 __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
-  using S = SmemD<WMT, WNT>;
+  constexpr int NBUF = PIPE > 2 ? PIPE : 2;
+  using S = SmemD<WMT, WNT, NBUF>;
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
   extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
   unsigned* As = smem_h;
-  unsigned* Bs = smem_h + 2 * S::A_DW;
+  unsigned* Bs = smem_h + NBUF * S::A_DW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -595,11 +596,10 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  dma_tile(0, 0);
-  dma_tile(1, 1);
-  if constexpr (A_LD + B_LD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  constexpr int PIECES = A_LD + B_LD;
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b) dma_tile(b, b);
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES * (NBUF - 1)) : "memory");
   __syncthreads();                                     // tile 0 is in LDS
   if constexpr (PIPE) {
     // Software-pipelined K loop (round 4).  With ONE workgroup on a CU (<= 256 tiles: every large layer at B = 64) nothing hides a
@@ -628,11 +628,13 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
     };
     bf16x8 ca[WMT], cb[WNT];
     read_step(As, Bs, 0, ca, cb);
+    int cur = 0;                                         // t % NBUF
     for (int t = 0; t < ntiles; ++t) {
-      const unsigned* as = As + (t & 1) * S::A_DW;
-      const unsigned* bs = Bs + (t & 1) * S::B_DW;
-      const unsigned* nas = As + ((t + 1) & 1) * S::A_DW;
-      const unsigned* nbs = Bs + ((t + 1) & 1) * S::B_DW;
+      const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
+      const unsigned* as = As + cur * S::A_DW;
+      const unsigned* bs = Bs + cur * S::B_DW;
+      const unsigned* nas = As + nxt * S::A_DW;
+      const unsigned* nbs = Bs + nxt * S::B_DW;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         bf16x8 na[WMT], nb[WNT];
@@ -643,9 +645,10 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < WNT; ++i) cb[i] = nb[i];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 (the only ones outstanding) have landed
+      // this wave's pieces of tile t+1 have landed (loads complete in order; tiles t+2 .. t+NBUF-1 may still be in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES * (NBUF - 2)) : "memory");
       __syncthreads();                                   // ... everybody's have, and everybody holds the step-3 fragments of tile t
-      dma_tile(t + 2, t & 1);                            // past the end: zeros (k >= kend)
+      dma_tile(t + NBUF, cur);                           // past the end: zeros (k >= kend)
       {
         bf16x8 na[WMT], nb[WNT];
         read_step(nas, nbs, 0, na, nb);                  // past the end: the zeros of the look-ahead DMA, never multiplied
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < WNT; ++i) cb[i] = nb[i];
       }
+      cur = nxt;
     }
   } else {
   for (int t = 0; t < ntiles; ++t) {
@@ -1133,7 +1137,7 @@ hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStre
 
 template <int MODE, int WMT, int WNT, int PIPE>
 static hipError_t launch_hd1(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = SmemD<WMT, WNT>;
+  using S = SmemD<WMT, WNT, (PIPE > 2 ? PIPE : 2)>;
   auto k = igemm_hd_kernel<MODE, WMT, WNT, PIPE>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
@@ -1146,7 +1150,12 @@ static hipError_t launch_hd1(const IgemmParams& p, dim3 grid, hipStream_t stream
 }
 template <int MODE, int WMT, int WNT>
 static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  return tuning().bf16_dma >= 2 ? launch_hd1<MODE, WMT, WNT, 1>(p, grid, stream) : launch_hd1<MODE, WMT, WNT, 0>(p, grid, stream);
+  const int v = tuning().bf16_dma;
+  if constexpr (WMT == 2 && WNT == 2) {       // deeper LDS rings (experiment): 96 / 128 KB, one workgroup per CU
+    if (v == 3) return launch_hd1<MODE, WMT, WNT, 3>(p, grid, stream);
+    if (v == 4) return launch_hd1<MODE, WMT, WNT, 4>(p, grid, stream);
+  }
+  return v >= 2 ? launch_hd1<MODE, WMT, WNT, 2>(p, grid, stream) : launch_hd1<MODE, WMT, WNT, 0>(p, grid, stream);
 }
 
 template <int MODE, int WMT, int WNT>

@@ -378,8 +378,63 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ws[k * Co + j * 32 + l31], acc[j], 0, 0, 0);
   }
   // ---- epilogue: C/D layout col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*lh (output column) -------------------------
+  // Round 4: through LDS.  A lane holds ONE channel of 16 pixels per block, so the direct form issued 64 stores of 2-4 bytes per
+  // thread — store-issue-bound like the GEMM epilogues (profiles/r04_bf16_gemm_fixed_cost.txt).  The staged input / filter are dead
+  // after the barrier; each wave passes its 32 pixels x 128 channels through a private patch, 64 channels at a time, and a lane
+  // then owns 8 consecutive channels of a pixel: one 16-byte store for the bf16 tensor, two for the fp32 one.  Same arithmetic.
   const int oh = oh0 + wave;
-  if (oh < Ho) {
+  if constexpr (NB == 4) {
+    constexpr int SROW = 68;                    // 64 channels + 4 floats of padding
+    __syncthreads();                            // xs / ws are no longer read
+    float* st = lds_stem + wave * (32 * SROW);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * lh) * SROW + jj * 32 + l31] = acc[half * 2 + jj][e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 3, c8 = idx & 7;
+        const float4 v0 = *reinterpret_cast<const float4*>(&st[row * SROW + c8 * 8]);
+        const float4 v1 = *reinterpret_cast<const float4*>(&st[row * SROW + c8 * 8 + 4]);
+        const int ow = ow0 + row, ch = half * 64 + c8 * 8;
+        if (oh < Ho && ow < Wo) {
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + ch), b1 = *reinterpret_cast<const float4*>(bias + ch + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += 0.f;          // the direct form adds bv = 0: keeps -0 -> +0 identical
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], act, alpha);
+          const size_t o = ((size_t)(b * Ho + oh) * Wo + ow) * Co + ch;
+          if (y) {                                // y == NULL: bf16 storage, the bf16 tensor alone is written
+            *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+          if (yh) {                               // bf16 twin for the conv that reads this tensor next, or THE tensor
+            typedef float f2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 h2_t __attribute__((ext_vector_type(2)));
+            uint4 h;
+            { f2_t t = {v[0], v[1]}; h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2_t)); }
+            { f2_t t = {v[2], v[3]}; h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2_t)); }
+            { f2_t t = {v[4], v[5]}; h.z = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2_t)); }
+            { f2_t t = {v[6], v[7]}; h.w = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2_t)); }
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(yh) + o) = h;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else if (oh < Ho) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float bv = bias ? bias[j * 32 + l31] : 0.f;
@@ -404,7 +459,8 @@ bool stem_fwd_eligible(const t2i_conv_desc& d) {
 
 hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
                            hipStream_t stream, void* y_h) {
-  const size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * 128) * sizeof(float);
+  size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * 128) * sizeof(float);
+  if (lds < (size_t)4 * 32 * 68 * sizeof(float)) lds = (size_t)4 * 32 * 68 * sizeof(float);      // the epilogue's staging patches
   auto k = stem_k4s2_fwd_kernel<3, 4>;
   dim3 grid((d.Wo + 31) / 32, (d.Ho + 3) / 4, d.B);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, x, w, bias, y, d.H, d.W, act, alpha, reinterpret_cast<__bf16*>(y_h));

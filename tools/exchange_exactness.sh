@@ -1,6 +1,7 @@
 #!/bin/bash
 # N-rank data parallelism on identical data must reproduce the single-process weights exactly (T2I_SAME_DATA=1, bench.py).
 # Runs on a 1-GPU box: both ranks on device 0, gloo in place of RCCL.  Prints one signature line per schedule.
+export T2I_BENCH_FEED_NOISE=1   # conditioning noise travels in the feed: identical on every rank and in every run
 run2() {  # env, bench args
   port=$((29700 + RANDOM % 200))
   env T2I_SAME_DEVICE=1 T2I_DIST_BACKEND=gloo T2I_SAME_DATA=1 T2I_CHECK_SYNC=1 $1 timeout 800 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
