@@ -72,12 +72,13 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 6 (v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 7 (v7: t2i_conv2d_bwd_pair added, nothing else changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
                                    * out_dtype) */
 const char* t2i_last_error(void); /* thread-local, never NULL */
+long long t2i_stat(const char* key); /* process-wide counters for tests / diagnostics: "pair_fused" = t2i_conv2d_bwd_pair calls issued as one launch; -1: unknown key */
 /* CU count, clock (kHz) and gcnArchName of `device` into caller buffers; used by bench.py to re-derive peaks. */
 int t2i_device_info(int device, int32_t* cu_count, int32_t* clock_khz, char* arch, size_t arch_len);
 
@@ -152,6 +153,20 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const void* dy, const float* w, 
  * accumulate != 0: dw += x (*) dy in the epilogue, i.e. the gradient is summed straight into the optimizer's arena. */
 int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                           t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream);
+
+/* One layer's backward on bf16 tensors in (possibly) ONE launch (v7).  In tf.gradients' walk of the reference graph
+ * (models/wgancls/model.py:94-106) every conv2d (utils/ops.py:58-63) contributes an input gradient conv^T(g, w) AND a filter
+ * gradient x (*) g, every conv2d_transpose (utils/ops.py:66-71) contributes conv(g, w) AND a filter gradient g (*) saved dy: two
+ * independent GEMMs on the same incoming gradient.  first = T2I_PAIR_BWD_DATA: out1 = conv^T(g, w);  T2I_PAIR_FWD: out1 = conv(g, w)
+ * (no bias, no activation);  then dw = fx (*) fdy (accumulate != 0: dw += ...).  The results are bit for bit those of
+ * t2i_conv2d_bwd_data / t2i_conv2d_fwd followed by t2i_conv2d_bwd_filter with the same opts; where both GEMMs run on the
+ * bf16-operand kernels they share one launch (a B = 64 layer leaves each of them one workgroup per CU; two streams of a captured
+ * graph do not overlap on this stack).  opts1 (in_dtype bit 0: g, out_dtype: out1) and opts2 (bit 0: fx, bit 1: fdy) are
+ * required; ws1 / ws2 (each t2i_conv2d_workspace_bytes(d)) are in use at the same time and must not overlap. */
+enum { T2I_PAIR_FWD = 0, T2I_PAIR_BWD_DATA = 1 };
+int t2i_conv2d_bwd_pair(const t2i_conv_desc* d, int first, const void* g, const float* w, void* out1, t2i_conv_opts* opts1,
+                        const void* fx, const void* fdy, float* dw, int accumulate, t2i_conv_opts* opts2,
+                        void* ws1, size_t ws1_bytes, void* ws2, size_t ws2_bytes, t2i_stream_t stream);
 
 /* ---- column reductions over a [rows, C] view ------------------------------------------------------------------ */
 size_t t2i_col_reduce_workspace_bytes(int64_t rows, int32_t C);

@@ -124,6 +124,80 @@ def test_convs_on_bf16_tensors_equal_the_rounded_fp32_tensor_path(K, splitk):
         K.tuning_set('force_splitk', 0)
 
 
+@pytest.mark.parametrize('case', [
+    (8, 16, 16, 256, 512, 4, 2, 0, 22, 'D3-like k4s2: input gradient in 4 stride phases + 128x128 filter-gradient tiles'),
+    (16, 8, 8, 512, 512, 3, 1, 0, 22, '3x3 stride 1'),
+    (16, 8, 8, 512, 512, 3, 1, 4, 22, '3x3, both GEMMs split-K by 4: two reductions behind the one launch'),
+    (64, 4, 4, 1152, 1024, 3, 1, 0, 0, 'critic 4x4 map, K = 10368, the planner\'s own tiles (fused iff it takes 128x128 for the filter gradient)'),
+    (64, 16, 16, 256, 256, 3, 1, 0, 0, 'generator 16x16 layer at the benchmark batch, the planner\'s own tiles'),
+    (4, 8, 8, 192, 256, 3, 1, 0, 0, 'Cin = 192: the filter gradient is not the 128x128 DMA kernel -> the pair falls back to two launches'),
+    (3, 8, 8, 128, 136, 3, 1, 0, 22, 'ragged N (136) and M')])
+def test_bwd_pair_is_bit_identical_to_the_two_calls(K, case):
+    """t2i_conv2d_bwd_pair (round 4): a layer's input gradient (PAIR_BWD_DATA; PAIR_FWD for the layer behind a transposed conv) and its
+    sunk filter gradient in one launch.  Same tiles and arithmetic as the two entry points it replaces: every output bit for bit,
+    including the accumulate-into-arena form; the fused launch is confirmed by the library's counter."""
+    from t2i_amd._lib import lib
+    B, H, W, Ci, Co, k, s, splitk, tile, _ = case
+    g = torch.Generator(device='cuda').manual_seed(B * 7 + Ci)
+    K.set_storage('bf16')
+    K.tuning_set('force_splitk', splitk)
+    K.tuning_set('force_tile', tile)
+    # for the bit-for-bit comparison every layer may share a launch and both GEMMs keep the plan of their own entry point
+    # (by default only small maps are fused, each GEMM planned for half the chip: another split-K grouping of the same sums)
+    K.tuning_set('pair_max_px', 1 << 30)
+    K.tuning_set('pair_cus', 256)
+    try:
+        d, ws = K.conv_desc(B, H, W, Ci, Co, k, k, s, s, 'SAME')
+        ws = max(ws, 128 << 20)
+        x = bf(torch.randn(B, H, W, Ci, generator=g, device='cuda'))
+        dy = bf(torch.randn(B, d.Ho, d.Wo, Co, generator=g, device='cuda'))
+        w = torch.randn(k, k, Ci, Co, generator=g, device='cuda') * 0.05
+        arena0 = torch.randn(k * k * Ci * Co, generator=g, device='cuda')
+        # conv backward: dx = conv^T(dy, w), dw += x (*) dy
+        ref_dx = K.conv_bwd_data(dy, w, None, d, ws, out_dtype=torch.bfloat16)
+        ref_dw = K.conv_bwd_filter(x, dy, d, ws, out=arena0.clone())
+        n0 = lib.t2i_stat(b'pair_fused')
+        got_dw = arena0.clone()
+        got_dx = K.conv_bwd_pair(K.PAIR_BWD_DATA, dy, w, x, dy, d, ws, got_dw, out_dtype=torch.bfloat16)
+        fused = lib.t2i_stat(b'pair_fused') - n0
+        assert fused == 1 if (tile == 22 and Ci % 128 == 0 and Co % 64 == 0) else fused in ((0,) if Ci % 128 else (0, 1)), (fused, case)
+        print('  %s: fused = %d' % (case[-1], fused))
+        assert got_dx.dtype == torch.bfloat16 and torch.equal(got_dx, ref_dx)
+        assert torch.equal(got_dw, ref_dw)
+        # transposed-conv backward: g_dy = conv(gx, w), dw += gx (*) dy   (the incoming gradient has the conv's INPUT shape)
+        if s == 1 or True:
+            gx = bf(torch.randn(B, H, W, Ci, generator=g, device='cuda'))
+            ref_y = K.conv_fwd(gx, w, None, d, ws, out_dtype=torch.bfloat16)
+            ref_dw2 = K.conv_bwd_filter(gx, dy, d, ws, out=arena0.clone())
+            got_dw2 = arena0.clone()
+            got_y = K.conv_bwd_pair(K.PAIR_FWD, gx, w, gx, dy, d, ws, got_dw2, out_dtype=torch.bfloat16)
+            assert torch.equal(got_y, ref_y) and torch.equal(got_dw2, ref_dw2)
+        # the switch: two launches, same bits
+        K.tuning_set('pair', 0)
+        n1 = lib.t2i_stat(b'pair_fused')
+        off_dw = arena0.clone()
+        off_dx = K.conv_bwd_pair(K.PAIR_BWD_DATA, dy, w, x, dy, d, ws, off_dw, out_dtype=torch.bfloat16)
+        assert lib.t2i_stat(b'pair_fused') == n1 and torch.equal(off_dx, ref_dx) and torch.equal(off_dw, ref_dw)
+        # the default planning of a shared launch (half the chip each): same sums in another split-K grouping — fp32 rounding apart
+        K.tuning_set('pair', 1); K.tuning_set('pair_cus', 128)
+        if not splitk:
+            K.tuning_set('force_tile', 0)
+            d_dw = arena0.clone()
+            d_dx = K.conv_bwd_pair(K.PAIR_BWD_DATA, dy, w, x, dy, d, ws, d_dw, out_dtype=torch.bfloat16)
+            K.tuning_set('force_tile', 0)
+            r_dx = K.conv_bwd_data(dy, w, None, d, ws, out_dtype=torch.bfloat16).float()
+            r_dw = K.conv_bwd_filter(x, dy, d, ws, out=arena0.clone())
+            assert float((d_dx.float() - r_dx).abs().max()) <= 2.0 ** -7 * float(r_dx.abs().max())          # one bf16 ulp of the largest element
+            assert float((d_dw - r_dw).abs().max()) <= 1e-5 * float(r_dw.abs().max())
+    finally:
+        K.tuning_set('pair_cus', 128)
+        K.tuning_set('pair_max_px', 49152)
+        K.tuning_set('pair', 1)
+        K.tuning_set('force_splitk', 0)
+        K.tuning_set('force_tile', 0)
+        K.set_storage('f32')
+
+
 def test_boundary_layers_with_bf16_tensors(K):
     """3 -> 128 stem (fp32 image in, bf16 out, native), its filter gradient and the 128 -> 3 transposed conv (bf16 in, staged), the
     logit head (bf16 in, fp32 out and back)."""

@@ -65,6 +65,8 @@ SIGNATURES = {
     't2i_ca_kl_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     't2i_lerp_dev': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
     't2i_conv2d_algo': (ctypes.c_int, [_p, _i32]),
+    't2i_stat': (ctypes.c_longlong, [ctypes.c_char_p]),
+    't2i_conv2d_bwd_pair': (ctypes.c_int, [_dp, ctypes.c_int, _p, _p, _p, _op, _p, _p, _p, ctypes.c_int, _op, _p, _sz, _p, _sz, _p]),
     't2i_filter_cache_attach': (ctypes.c_int, [_p, _sz]),
     't2i_filter_cache_enable': (ctypes.c_int, [ctypes.c_int]),
     't2i_tuning_set': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_double]),
@@ -93,7 +95,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError('libt2i_hip.so not found at %s — build it with text-to-image_amd/csrc/build.sh '
                       '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback' % LIB_PATH)
 
-ABI_VERSION = 6          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
+ABI_VERSION = 7          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
 
 lib = ctypes.CDLL(LIB_PATH)
 try:

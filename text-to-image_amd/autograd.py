@@ -114,6 +114,13 @@ def _filter_grad(x, gpre, geom, w, xform=None):
     return ConvBwdFilterFn.apply(x, gpre, geom)
 
 
+def _pair_ok(g, other, w):
+    """Final (first-order) backward, sunk filter gradient, bf16 tensors on one stream: the layer's two backward GEMMs may share a
+    launch (kernels.conv_bwd_pair).  Everything else keeps the two differentiable Functions."""
+    return (not torch.is_grad_enabled() and SIDE.stream is None and K.pair_calls() and g.dtype == torch.bfloat16 and
+            other.dtype == torch.bfloat16 and g.is_cuda and sink_at(w.data_ptr()) is not None)
+
+
 @contextlib.contextmanager
 def input_grads_only():
     prev = _INPUTS_ONLY[0]
@@ -208,6 +215,12 @@ class Conv2dFn(Function):
                 _notify(ctx.bias_ref)
             elif want_b:
                 gb = ColSumFn.apply(gpre)
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, x, w):
+            # final backward on bf16 tensors: the input gradient and the (sunk) filter gradient in one launch
+            gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), ctx.geom[0], ctx.geom[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
+            _notify(w)
+            ctx.xform = None
+            return gx, None, gb, None, None, None, None, None
         gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
         gw = _filter_grad(x, gpre, ctx.geom, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
         ctx.xform = None
@@ -236,8 +249,13 @@ class ConvBwdDataFn(Function):
         dy, w, out = ctx.saved_tensors
         gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
         params = not _INPUTS_ONLY[0]
-        g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
-        g_w = _filter_grad(gpre, dy, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, dy, w):
+            g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), ctx.geom[0], ctx.geom[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
+            _notify(w)
+            g_w = None
+        else:
+            g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
+            g_w = _filter_grad(gpre, dy, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
         g_b = None
         if ctx.has_bias and ctx.needs_input_grad[2] and params:
             bsink = _sink_of(ctx.bias_ref)

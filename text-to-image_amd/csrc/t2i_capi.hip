@@ -3,6 +3,7 @@
 // synchronisation: every entry point only enqueues kernels on the caller's stream, so a whole training step can be
 // captured into a hipGraph.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -128,6 +129,9 @@ static Tuning& tuning_mut() {
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
     v.bgemm_tile = env_int("T2I_BGEMM_TILE", 11);          // persistent batched GEMM tile: 11 / 21 / 12 / 22 = 64 a x 64 b; 0 = by item count (measured: the larger tiles lose at every batch size, profiles/r04_bgemm_tiles.txt)
     v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
+    v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
+    v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
+    v.pair = env_int("T2I_PAIR", 1);                       // t2i_conv2d_bwd_pair: the two GEMMs in one launch where both are bf16-operand DMA kernels (0: two launches)
     v.vec_epi = env_int("T2I_VEC_EPI", 1);                 // bf16-operand GEMMs: epilogue through LDS, 16-byte stores (0: one store per element)
     v.batch_lin = env_int("T2I_BATCH_LIN", 1);             // batched (Winograd) GEMMs: positions in XCD-contiguous runs (0: grid.z = position)
     v.no_ut = env_int("T2I_NO_UT", 0);
@@ -164,7 +168,8 @@ const Tuning& tuning() { return tuning_mut(); }
 // rel_eff_bf16 encodes (sweep: profiles/r01_bf16_tile_split_sweep.txt; 128x128 wins almost everywhere).
 static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_elems, int split_cap = 32, int math = 0, bool batched = false,
                       int bk = 32, int m_unit = 0,        // m_unit > 0: the M tile must divide it (tiles that stay inside one filter tap)
-                      bool dma = false) {                 // the bf16-operand kernel that moves its tiles by LDS DMA (igemm_hd_kernel)
+                      bool dma = false,                   // the bf16-operand kernel that moves its tiles by LDS DMA (igemm_hd_kernel)
+                      int cus = 256) {                    // CUs this GEMM can count on: 256, or fewer when a sibling GEMM shares the launch (t2i_conv2d_bwd_pair)
   static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
   // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
@@ -226,8 +231,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       // 128x128 tile its second resident workgroup: 228 of 256 registers are taken).
       if (!math && !batched && per * bk > tuning().max_chain && sk < maxsplit && !fs) continue;
       const int64_t blocks = tiles * sk_eff;
-      const int64_t rounds = (blocks + 255) / 256;
-      const int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
+      const int64_t rounds = (blocks + cus - 1) / cus;
+      int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
+      if (cus < 256 && resident < 2) resident = 2;      // the sibling's workgroups are co-resident: nobody is alone on a CU
       const double ovh_t = (hft && c == 0) ? tuning().hft_ovh * 0.1 : overhead_tiles;
       double t = (double)rounds * ((double)per * tile_w + ovh_t) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * (c == 0 ? hft_boost : 1.0) * share_eff[resident]);
@@ -366,14 +372,40 @@ static size_t conv_h_ws(const t2i_conv_desc* d, int mode) {
   return al256c(n_in * 2) + al256c((size_t)d->KH * d->KW * d->Cin * d->Cout * 2) + pl.ws_bytes;
 }
 
+static std::atomic<long long> g_stat_pair_fused{0};     // t2i_stat("pair_fused"): pairs that went out as ONE launch
+
+// t2i_conv2d_bwd_pair: the two GEMMs of one layer's backward are prepared by conv_h / conv_h_filter as usual (staging, filter
+// images, plan, workspace) but their GEMM launches and split-K reductions are handed back in this record instead of being
+// issued, so that the caller can put both GEMMs into ONE launch (igemm_pair_kernel) and issue the reductions behind it.
+struct PendingGemm {
+  bool set = false;
+  int mode = 0, wmt = 0, wnt = 0;
+  IgemmParams p;
+  // the split-K reduction that follows (splitk > 1)
+  const float* slabs = nullptr; const float* bias = nullptr; int act = 0; float alpha = 0.f; float* out = nullptr; int accumulate = 0;
+  void* out_h = nullptr; int32_t* out_h_written = nullptr;
+};
+
+static int finish_pending(const PendingGemm& g, hipStream_t stream, const char* what) {
+  if (g.p.splitk <= 1) return T2I_OK;
+  bool wrote = false;
+  const int rc = check(splitk_reduce_launch(g.slabs, g.p.splitk, g.p.out_elems, g.bias, g.p.N, g.act, g.alpha, g.out, g.accumulate, stream, g.out_h, &wrote), what);
+  if (wrote && g.out_h_written) *g.out_h_written = 1;
+  return rc;
+}
+
 static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, void* out_h,
-                  int32_t* out_h_written, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+                  int32_t* out_h_written, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what,
+                  PendingGemm* defer = nullptr, int cus = 256) {
   IgemmParams p;
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
   const size_t nw = (size_t)d->KH * d->KW * d->Cin * d->Cout;
-  const Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64, 0, tuning().bf16_dma != 0);
-  const size_t off_w = al256c(n_in * 2), off_s = off_w + al256c(nw * 2), need = off_s + pl.ws_bytes;
+  Plan pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64, 0, tuning().bf16_dma != 0, cus);
+  const size_t off_w = al256c(n_in * 2), off_s = off_w + al256c(nw * 2);
+  if (cus != 256 && off_s + pl.ws_bytes > ws_bytes) // the shared-launch plan must fit the workspace sized for the plain one
+    pl = make_plan(p.M, p.N, p.K, p.nphase, out_elems, 32, 1, false, 64, 0, tuning().bf16_dma != 0);
+  const size_t need = off_s + pl.ws_bytes;
   if (!ws || ws_bytes < need || !aligned16(ws)) {
     set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, need);
     return T2I_ERR_WORKSPACE;
@@ -405,6 +437,12 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = 0;
     if (out_h && aligned16(out_h)) { p.c_h = out_h; if (out_h_written) *out_h_written = 1; }
   }
+  if (defer) {
+    defer->set = true; defer->mode = mode; defer->wmt = pl.wmt; defer->wnt = pl.wnt; defer->p = p;
+    defer->slabs = reinterpret_cast<const float*>(base + off_s); defer->bias = bias; defer->act = act; defer->alpha = alpha; defer->out = out;
+    defer->accumulate = 0; defer->out_h = (out_h && aligned16(out_h)) ? out_h : nullptr; defer->out_h_written = out_h_written;
+    return T2I_OK;
+  }
   rc = check(igemm_h_launch(mode, p, pl.wmt, pl.wnt, stream), what);
   if (rc != T2I_OK) return rc;
   if (pl.splitk > 1) {
@@ -422,9 +460,9 @@ static bool h_filter_eligible(const t2i_conv_desc& d) {
          (!tuning().force_tile || (d.Cin % (64 * (tuning().force_tile / 10))) == 0);
 }
 
-static Plan h_filter_plan(const t2i_conv_desc* d) {
+static Plan h_filter_plan(const t2i_conv_desc* d, int cus = 256) {
   const int64_t M = (int64_t)d->KH * d->KW * d->Cin, N = d->Cout, K = (int64_t)d->B * d->Ho * d->Wo;
-  return make_plan(M, N, K, 1, (size_t)(M * N), split_cap_for(MODE_BWD_FILTER), 1, false, 64, d->Cin);
+  return make_plan(M, N, K, 1, (size_t)(M * N), split_cap_for(MODE_BWD_FILTER), 1, false, 64, d->Cin, false, cus);
 }
 
 static size_t conv_h_filter_ws(const t2i_conv_desc* d) {
@@ -433,7 +471,7 @@ static size_t conv_h_filter_ws(const t2i_conv_desc* d) {
 }
 
 static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy, const void* x_h, const void* dy_h, float* dw, int accumulate,
-                         void* ws, size_t ws_bytes, hipStream_t stream) {
+                         void* ws, size_t ws_bytes, hipStream_t stream, PendingGemm* defer = nullptr, int cus = 256) {
   const char* what = "t2i_conv2d_bwd_filter(bf16 operands)";
   IgemmParams p;
   fill_common(p, d);
@@ -441,8 +479,10 @@ static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy
   p.M = d->KH * d->KW * d->Cin; p.N = d->Cout; p.K = d->B * d->Ho * d->Wo;
   p.div_c.set(d->Cin);
   const size_t out_elems = (size_t)p.M * p.N;
-  const Plan pl = h_filter_plan(d);
-  const size_t off_y = al256c(nx * 2), off_s = off_y + al256c(ny * 2), need = off_s + pl.ws_bytes;
+  Plan pl = h_filter_plan(d, cus);
+  const size_t off_y = al256c(nx * 2), off_s = off_y + al256c(ny * 2);
+  if (cus != 256 && off_s + pl.ws_bytes > ws_bytes) pl = h_filter_plan(d);
+  const size_t need = off_s + pl.ws_bytes;
   if (!ws || ws_bytes < need || !aligned16(ws)) {
     set_error("%s: workspace %zu B < %zu B required (or misaligned)", what, ws_bytes, need);
     return T2I_ERR_WORKSPACE;
@@ -467,6 +507,12 @@ static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy
   p.bias = nullptr; p.act = T2I_ACT_NONE; p.alpha = 0.f;
   if (pl.splitk > 1) { p.c = reinterpret_cast<float*>(base + off_s); p.accumulate = 0; }
   else { p.c = dw; p.accumulate = accumulate; }
+  if (defer) {
+    defer->set = true; defer->mode = MODE_BWD_FILTER; defer->wmt = pl.wmt; defer->wnt = pl.wnt; defer->p = p;
+    defer->slabs = reinterpret_cast<const float*>(base + off_s); defer->bias = nullptr; defer->act = T2I_ACT_NONE; defer->alpha = 0.f; defer->out = dw;
+    defer->accumulate = accumulate; defer->out_h = nullptr; defer->out_h_written = nullptr;
+    return T2I_OK;
+  }
   rc = check(igemm_h_filter_launch(p, pl.wmt, pl.wnt, stream), what);
   if (rc != T2I_OK) return rc;
   if (pl.splitk > 1)
@@ -571,7 +617,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 6; }
+int t2i_version(void) { return 7; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -869,6 +915,70 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* xv, const void* dy
   t2i_conv_opts o2 = *opts;
   o2.in_dtype = 0; o2.out_dtype = T2I_DT_F32; o2.a_image = nullptr; o2.b_image = nullptr;
   return conv2d_bwd_filter_impl(d, x32, dy32, dw, accumulate, &o2, st.base + st.off, ws_bytes - st.off, stream);
+}
+
+// One layer's backward pair on bf16 tensors (round 4): `first` = T2I_PAIR_BWD_DATA: dx = conv^T(g, w) (the input gradient of a
+// conv) or T2I_PAIR_FWD: y = conv(g, w) (the input gradient of a transposed conv), together with the filter gradient dw (+)= fx (*) fdy.
+// Exactly t2i_conv2d_bwd_data / t2i_conv2d_fwd (no bias, no activation) followed by t2i_conv2d_bwd_filter — same tiles, same
+// arithmetic, same bits — except that, where both run on the bf16-operand DMA kernels, the two GEMMs share ONE launch
+// (igemm_pair_kernel).  The two calls need their workspaces at the same time: ws1 / ws2 must not overlap.
+int t2i_conv2d_bwd_pair(const t2i_conv_desc* d, int first, const void* g, const float* w, void* out1, t2i_conv_opts* opts1,
+                        const void* fx, const void* fdy, float* dw, int accumulate, t2i_conv_opts* opts2,
+                        void* ws1, size_t ws1_bytes, void* ws2, size_t ws2_bytes, t2i_stream_t stream) {
+  if (first != T2I_PAIR_FWD && first != T2I_PAIR_BWD_DATA) { set_error("t2i_conv2d_bwd_pair: first must be T2I_PAIR_FWD or T2I_PAIR_BWD_DATA"); return T2I_ERR_INVALID; }
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  if (!opts1 || !opts2) { set_error("t2i_conv2d_bwd_pair: opts1 / opts2 are required (they carry the tensor dtypes)"); return T2I_ERR_INVALID; }
+  const int mode = first == T2I_PAIR_FWD ? MODE_FWD : MODE_BWD_DATA;
+  const bool all_h = in_h(opts1, 0) && out_h(opts1) && in_h(opts2, 0) && in_h(opts2, 1);
+  const bool thin1 = !tuning().no_thin && (head_conv_eligible(*d) || tiny_conv_eligible(*d, mode == MODE_BWD_DATA) ||
+                                           (mode == MODE_FWD ? stem_fwd_eligible(*d) : thin_deconv_eligible(*d)));
+  const bool thin2 = !tuning().no_thin && (head_conv_eligible(*d) || tiny_bwdw_eligible(*d) || stem_bwdf_eligible(*d));
+  const int Cout1 = mode == MODE_FWD ? d->Cout : d->Cin;
+  // Measured (profiles/r04_bf16_pair_launch.txt): sharing the launch pays on the small maps (4x4, 8x8: each GEMM alone is a handful of
+  // K-deep tiles per CU plus split-K slabs; planned for half the chip each they need half the slabs and hide each other's stalls:
+  // -8..-23 %), and loses on the 16x16 / 32x32 maps, whose GEMMs already fill the chip two workgroups deep on their own.
+  const bool small_map = (int64_t)d->B * d->H * d->W <= (int64_t)tuning().pair_max_px;
+  const bool fuse = tuning().pair && small_map && all_h && d->math == T2I_MATH_BF16 && !thin1 && !thin2 && h_eligible(*d, mode == MODE_BWD_DATA) && (Cout1 % 4) == 0 &&
+                    h_filter_eligible(*d) && g && w && out1 && fx && fdy && dw && aligned16(g) && aligned16(w) && aligned16(out1) && aligned16(fx) &&
+                    aligned16(fdy) && aligned16(dw) && ws1 && ws2 &&
+                    (reinterpret_cast<char*>(ws1) + ws1_bytes <= reinterpret_cast<char*>(ws2) || reinterpret_cast<char*>(ws2) + ws2_bytes <= reinterpret_cast<char*>(ws1));
+  if (fuse) {
+    if ((rc = storage_check(d, opts1, "t2i_conv2d_bwd_pair")) || (rc = storage_check(d, opts2, "t2i_conv2d_bwd_pair"))) return rc;
+    opts1->out_image_written = 0; opts1->xform_kept = 0; opts2->out_image_written = 0; opts2->xform_kept = 0;
+    PendingGemm ga, gb;
+    const char* what = "t2i_conv2d_bwd_pair";
+    // the filter gradient first, planned for its share of the chip: only igemm_hft_kernel's 128x128 case can share a launch
+    int cus = tuning().pair_cus;
+    if (cus < 32 || cus > 256) cus = 256;
+    rc = conv_h_filter(d, nullptr, nullptr, fx, fdy, dw, accumulate ? 1 : 0, ws2, ws2_bytes, (hipStream_t)stream, &gb, cus);
+    if (rc != T2I_OK) return rc;
+    bool one = igemm_pair_fusable(gb.p, gb.wmt, gb.wnt);
+    if (!one && cus != 256) {                      // two launches after all: each gets the whole chip, plan for that
+      cus = 256;
+      rc = conv_h_filter(d, nullptr, nullptr, fx, fdy, dw, accumulate ? 1 : 0, ws2, ws2_bytes, (hipStream_t)stream, &gb, cus);
+      if (rc != T2I_OK) return rc;
+      one = igemm_pair_fusable(gb.p, gb.wmt, gb.wnt);
+    }
+    rc = conv_h(mode, d, nullptr, g, w, nullptr, nullptr, out1, nullptr, T2I_ACT_NONE, 0.f, ws1, ws1_bytes, (hipStream_t)stream, what, &ga, one ? cus : 256);
+    if (rc != T2I_OK) return rc;
+    if (one) {
+      if (tuning().debug_plan) fprintf(stderr, "[t2i plan] pair: one launch, %d + %d workgroups\n",
+                                       ga.p.tiles_m * ga.p.tiles_n * ga.p.splitk * (mode == MODE_BWD_DATA ? ga.p.nphase : 1), gb.p.tiles_m * gb.p.tiles_n * gb.p.splitk);
+      rc = check(igemm_pair_launch(mode, ga.p, ga.wmt, ga.wnt, gb.p, (hipStream_t)stream), what);
+      ++g_stat_pair_fused;
+    } else {
+      rc = check(igemm_h_launch(mode, ga.p, ga.wmt, ga.wnt, (hipStream_t)stream), what);
+      if (rc == T2I_OK) rc = check(igemm_h_filter_launch(gb.p, gb.wmt, gb.wnt, (hipStream_t)stream), what);
+    }
+    if (rc != T2I_OK) return rc;
+    if ((rc = finish_pending(ga, (hipStream_t)stream, what))) return rc;
+    return finish_pending(gb, (hipStream_t)stream, what);
+  }
+  rc = mode == MODE_FWD ? t2i_conv2d_fwd(d, g, w, nullptr, out1, T2I_ACT_NONE, 0.f, opts1, ws1, ws1_bytes, stream)
+                        : t2i_conv2d_bwd_data(d, g, w, nullptr, out1, T2I_ACT_NONE, 0.f, opts1, ws1, ws1_bytes, stream);
+  if (rc != T2I_OK) return rc;
+  return t2i_conv2d_bwd_filter(d, fx, fdy, dw, accumulate, opts2, ws2, ws2_bytes, stream);
 }
 
 static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
@@ -1212,6 +1322,11 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
   return filter_cache_refresh(w, (size_t)n * 4, (hipStream_t)stream);   // ... and regenerated behind the update, all in one launch
 }
 
+long long t2i_stat(const char* key) {
+  if (key && !strcmp(key, "pair_fused")) return g_stat_pair_fused.load();
+  return -1;
+}
+
 int t2i_tuning_set(const char* key, double value) {
   if (!key) { set_error("t2i_tuning_set: null key"); return T2I_ERR_INVALID; }
   Tuning& t = tuning_mut();
@@ -1222,7 +1337,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

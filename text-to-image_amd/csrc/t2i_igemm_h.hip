@@ -467,8 +467,11 @@ struct SmemD {
   static constexpr int BYTES = NBUF * (A_DW + B_DW) * 4;
 };
 
+// The body is a device function of (params, block coordinates) so that TWO independent GEMMs can share one launch
+// (igemm_pair_kernel below); igemm_hd_kernel is the plain one-GEMM launch.  bx / nbx: tile block and their number, by: K split,
+// bz: stride phase (input gradient).  `p` must sit at kernarg offset 0 (load_phase_h).
 template <int MODE, int WMT, int WNT, int PIPE>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
-__global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
+__device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, const int nbx, const int by, const int bz) {
   constexpr int NBUF = PIPE > 2 ? PIPE : 2;
   using S = SmemD<WMT, WNT, NBUF>;
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
@@ -483,9 +486,9 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   const int tiles_m = p.tiles_m;
-  int bid = blockIdx.x;
+  int bid = bx;
   {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nblk = nbx, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   int tile_m, tile_n;
@@ -500,8 +503,8 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
     tile_n = n0 + (r - tile_m * width);
   }
   const int bm = tile_m * BM, bn = tile_n * BN;
-  const int split = blockIdx.y;
-  const PhaseInfo pi = load_phase_h(MODE == MODE_BWD_DATA ? blockIdx.z : 0);
+  const int split = by;
+  const PhaseInfo pi = load_phase_h(MODE == MODE_BWD_DATA ? bz : 0);
   const int Kdim = (MODE == MODE_BWD_DATA) ? pi.K : p.K;
   const int kbeg = split * p.k_per_split;
   const int kend = min(Kdim, kbeg + p.k_per_split);
@@ -745,6 +748,11 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   }
 }
 
+template <int MODE, int WMT, int WNT, int PIPE>
+__global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
+  hd_body<MODE, WMT, WNT, PIPE>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Filter gradient with bf16 operands in memory:
 //   dw[M = KH*KW*Cin, N = Cout] = sum over k = (b, oh, ow) of  x_h[b, oh*SH-pad_t+kh, ow*SW-pad_l+kw, ci] * dy_h[b, oh, ow, co]
@@ -923,7 +931,7 @@ typedef short s16x4h __attribute__((ext_vector_type(4)));
 typedef short s16x8h __attribute__((ext_vector_type(8)));
 
 template <int PIPE>
-__global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
+__device__ __forceinline__ void hft_body(const IgemmParams& p, const int bx, const int by) {
   constexpr int BM = 128, BN = 128;
   constexpr int TILE_B = HBK * 256;                       // bytes of one operand tile: 64 k-rows of 256 bytes
   extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
@@ -935,9 +943,9 @@ __global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int tile_m = bx % p.tiles_m, tile_n = bx / p.tiles_m;
   const int bm = tile_m * BM, bn = tile_n * BN;
-  const int split = blockIdx.y;
+  const int split = by;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int ntiles = (kend - kbeg + HBK - 1) / HBK;
@@ -1100,6 +1108,38 @@ __global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
     }
 }
 
+template <int PIPE>
+__global__ __launch_bounds__(256) void igemm_hft_kernel(IgemmParams p) {
+  hft_body<PIPE>(p, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two independent GEMMs of one layer's backward in ONE launch (round 4): the input gradient (or, behind a transposed conv, the
+// forward-type conv of the incoming gradient) and the filter gradient read the same incoming gradient and write different tensors.
+// At B = 64 each has <= 256 workgroups — one per CU, nothing to hide its barriers, DMA waits, prologue and epilogue — and two
+// streams of a captured graph do NOT run them side by side on this stack (tools/probe/pair_overlap.py: pair on two streams =
+// pair on one).  Here the first n1 workgroups run hd_body on `a`, the rest hft_body on `b`: the dispatcher puts one of each on
+// a CU (64 KB of LDS each), and one launch ramp / drain is paid instead of two.  Same tiles, same arithmetic: bit-identical to
+// the two launches.  `a` first: hd_body reads its stride-phase table at kernarg offset 0.
+// ------------------------------------------------------------------------------------------------------------------
+struct PairParams {
+  IgemmParams a, b;
+  int32_t n1, tiles1, splitk1;       // blocks of the first GEMM = tiles1 x splitk1 x phases; of the second = tiles_m tiles_n x splitk
+  int32_t tiles2;
+};
+
+template <int MODE, int WMT, int WNT>
+__global__ __launch_bounds__(256) void igemm_pair_kernel(PairParams pp) {
+  const int b = blockIdx.x;
+  if (b < pp.n1) {
+    const int bx = b % pp.tiles1, r = b / pp.tiles1;
+    hd_body<MODE, WMT, WNT, 0>(pp.a, bx, pp.tiles1, r % pp.splitk1, r / pp.splitk1);
+  } else {
+    const int b2 = b - pp.n1;
+    hft_body<0>(pp.b, b2 % pp.tiles2, b2 / pp.tiles2);
+  }
+}
+
 template <int WMT, int WNT>
 static hipError_t launch_hf(const IgemmParams& p, hipStream_t stream) {
   using S = SmemH<WMT, WNT>;
@@ -1171,6 +1211,40 @@ static hipError_t launch_h(const IgemmParams& p, dim3 grid, hipStream_t stream) 
   }
   hipLaunchKernelGGL(k, grid, dim3(256), S::BYTES, stream, p);
   return hipGetLastError();
+}
+
+bool igemm_pair_fusable(const IgemmParams& pb, int wmt_b, int wnt_b) {       // the filter gradient must be igemm_hft_kernel's case
+  return tuning().bf16_dma == 1 && wmt_b == 2 && wnt_b == 2 && (pb.d.Cin % 128) == 0;
+}
+
+template <int MODE, int WMT, int WNT>
+static hipError_t launch_pair(const PairParams& pp, int nblk, hipStream_t stream) {
+  constexpr int bytes = 4 * HBK * 256;               // igemm_hft_kernel's 64 KB (>= every SmemD<WMT, WNT>)
+  static_assert(SmemD<WMT, WNT>::BYTES <= bytes, "pair LDS");
+  auto k = igemm_pair_kernel<MODE, WMT, WNT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nblk), dim3(256), bytes, stream, pp);
+  return hipGetLastError();
+}
+
+// first GEMM: mode FWD / BWD_DATA on tile (wmt, wnt); second: the filter gradient on igemm_hft_kernel's 128x128 tile
+hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, const IgemmParams& pb, hipStream_t stream) {
+  PairParams pp;
+  pp.a = pa; pp.b = pb;
+  pp.tiles1 = pa.tiles_m * pa.tiles_n; pp.splitk1 = pa.splitk;
+  pp.n1 = pp.tiles1 * pa.splitk * (mode == MODE_BWD_DATA ? pa.nphase : 1);
+  pp.tiles2 = pb.tiles_m * pb.tiles_n;
+  const int nblk = pp.n1 + pp.tiles2 * pb.splitk;
+#define T2I_P(M_, a, b) if (mode == M_ && wmt == a && wnt == b) return launch_pair<M_, a, b>(pp, nblk, stream);
+  T2I_P(MODE_FWD, 2, 2) T2I_P(MODE_FWD, 2, 1) T2I_P(MODE_FWD, 1, 2) T2I_P(MODE_FWD, 1, 1)
+  T2I_P(MODE_BWD_DATA, 2, 2) T2I_P(MODE_BWD_DATA, 2, 1) T2I_P(MODE_BWD_DATA, 1, 2) T2I_P(MODE_BWD_DATA, 1, 1)
+#undef T2I_P
+  return hipErrorInvalidValue;
 }
 
 // tiles: (wmt, wnt) in {(2,2), (2,1), (1,2), (1,1)}

@@ -112,6 +112,9 @@ hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int va
 // bf16 operands in memory (t2i_igemm_h.hip): staging kernels + the GEMM
 hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
 hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStream_t stream);
+// one launch for a layer's input gradient (or forward-type conv) AND its filter gradient (igemm_pair_kernel)
+bool igemm_pair_fusable(const IgemmParams& pb, int wmt_b, int wnt_b);
+hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, const IgemmParams& pb, hipStream_t stream);
 hipError_t cast_bf16_launch(const float* x, size_t n, void* y, hipStream_t stream);
 hipError_t cast_bf16_any_launch(const float* x, size_t n, void* y, hipStream_t stream);      // any n / alignment
 hipError_t cast_f32_launch(const void* x_bf16, size_t n, float* y, hipStream_t stream);    // exact widening (staging copies, bf16 storage)
@@ -142,7 +145,7 @@ hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px;
   double split_cost;
 };
 const Tuning& tuning();

@@ -71,6 +71,9 @@ _WS_CAPTURED = set()     # lanes whose CURRENT buffer has been handed to a kerne
 _WS_RETIRED = []         # outgrown buffers that captured graphs still point at: kept alive for the life of the process
 
 
+PAIR_LANE = 1000          # lane + PAIR_LANE: the second workspace of a fused backward pair (kernels.conv_bwd_pair)
+
+
 def workspace(device, nbytes):
     """The lane's scratch buffer, grown on demand.  A hipGraph captured while a buffer was current has that buffer's
     address baked into its kernel arguments, so once a capture has used a buffer it is never freed: a later eager call
@@ -106,10 +109,11 @@ def stream_lane(stream, device=None):
         dev = torch.device('cuda', torch.cuda.current_device())
     main = _WS.get((dev.type, dev.index, 0))
     key = (dev.type, dev.index, lane)
-    if main is not None and (_WS.get(key) is None or _WS[key].numel() < main.numel()):
-        if _WS.get(key) is not None and key in _WS_CAPTURED:
-            _WS_RETIRED.append(_WS[key]); _WS_CAPTURED.discard(key)
-        _WS[key] = torch.empty(main.numel(), dtype=torch.uint8, device=dev)
+    for key in (key, (dev.type, dev.index, PAIR_LANE + lane)):       # ... and the lane of conv_bwd_pair's second workspace
+        if main is not None and (_WS.get(key) is None or _WS[key].numel() < main.numel()):
+            if _WS.get(key) is not None and key in _WS_CAPTURED:
+                _WS_RETIRED.append(_WS[key]); _WS_CAPTURED.discard(key)
+            _WS[key] = torch.empty(main.numel(), dtype=torch.uint8, device=dev)
 
 
 # ---- convolution geometry (TF padding rules; reference utils/ops.py:58-71 passes the string through to TF) -------------
@@ -569,6 +573,49 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
         if ev is not None:
             ev.record()
     return dw
+
+
+PAIR_FWD, PAIR_BWD_DATA = 0, 1
+_PAIR = [os.environ.get('T2I_PAIR_CALLS', '1') != '0']
+
+
+def pair_calls(on=None):
+    """Should a layer's backward hand its two GEMMs to conv_bwd_pair (one launch where the library can fuse them)?"""
+    if on is not None:
+        _PAIR[0] = bool(on)
+    return _PAIR[0]
+
+
+def conv_bwd_pair(first, g, w, fx, fdy, d, ws_bytes, dw_out, out_dtype=None):
+    """One layer's backward pair: out1 = conv^T(g, w) (first = PAIR_BWD_DATA) or conv(g, w) (PAIR_FWD), and dw_out += fx (*) fdy
+    (the gradient sink).  Same results as conv_bwd_data / conv_fwd followed by conv_bwd_filter(out=dw_out); on bf16 tensors the
+    two GEMMs share one launch (t2i_conv2d_bwd_pair).  Returns out1."""
+    _chk(g, 'g'); _chk(w, 'w', f32=True); _chk(fx, 'fx'); _chk(fdy, 'fdy'); _chk(dw_out, 'dw_out', f32=True)
+    assert dw_out.numel() == d.KH * d.KW * d.Cin * d.Cout
+    _drop_image(dw_out)
+    shape = (d.B, d.H, d.W, d.Cin) if first == PAIR_BWD_DATA else (d.B, d.Ho, d.Wo, d.Cout)
+    out1 = torch.empty(shape, dtype=_act_dtype(shape, out_dtype), device=g.device)
+    if _live(g):
+        which = 'bwd_data' if first == PAIR_BWD_DATA else 'fwd'
+        ws1p, ws1n = _ws_args(g, ws_bytes)
+        lane0 = WS_LANE[0]
+        WS_LANE[0] = PAIR_LANE + (lane0 if lane0 else (_STREAM_LANE.get(torch.cuda.current_stream(g.device).cuda_stream, 0) if _STREAM_LANE else 0))
+        try:
+            ws2p, ws2n = _ws_args(g, ws_bytes)            # the pair's second workspace: both GEMMs are in flight together
+        finally:
+            WS_LANE[0] = lane0
+        ev = _TIMER[0].begin(2 * conv_flops(d), conv_algo(d, which)) if _TIMER[0] is not None else None
+        o1, o2 = ConvOpts(), ConvOpts()
+        _storage_flags(o1, g, None, out1)
+        keep1 = _operand_images(o1, g) if _h_path(d, which) else None
+        _storage_flags(o2, fx, fdy, None)
+        keep2 = _operand_images(o2, fx, fdy) if _h_path(d, 'bwd_filter') else None
+        check(lib.t2i_conv2d_bwd_pair(ctypes.byref(d), first, _ptr(g), _ptr(w), _ptr(out1), ctypes.byref(o1), _ptr(fx), _ptr(fdy), _ptr(dw_out), 1,
+                                      ctypes.byref(o2), ws1p, ws1n, ws2p, ws2n, _stream()), 't2i_conv2d_bwd_pair')
+        del keep1, keep2
+        if ev is not None:
+            ev.record()
+    return out1
 
 
 def col_reduce(a, b=None, want_second=False, out=None, center=None):
