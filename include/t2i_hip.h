@@ -258,6 +258,9 @@ int t2i_nhwc_to_nchw(const void* x, int32_t B, int32_t C, int32_t HW, void* y, i
 int t2i_gp_slopes(const void* g, int32_t B, int64_t per_sample, float* slopes, int32_t dtype, t2i_stream_t stream);
 /* out[b,:] = coef[b] * g[b,:]  (per-sample scaling: backward of the slope norm, and its own double backward). */
 int t2i_row_scale(const void* g, const float* coef, int32_t B, int64_t per_sample, void* out, int32_t dtype, t2i_stream_t stream);
+/* out[b,:] = (den[b] > 0 ? num[b] / max(den[b], 1e-30) : 0) * g[b,:]: the slope norm's backward with its coefficient d / ||g_b|| formed
+ * in the kernel (v7; tf.gradients of tf.sqrt(tf.reduce_sum(tf.square(.))), model.py:64,69). */
+int t2i_row_scale_div(const void* g, const float* num, const float* den, int32_t B, int64_t per_sample, void* out, int32_t dtype, t2i_stream_t stream);
 
 /* ---- loss heads: reference models/wgancls/model.py:72-92 (critic losses) and :117-127 (conditioning augmentation) --- */
 /* From the critic's 3B logits (fake | real | mismatch, each B) and the two per-sample slope vectors: the loss scalars

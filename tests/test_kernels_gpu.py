@@ -147,6 +147,13 @@ def test_gp_golden(K, golden_ops):
     B = gr.shape[0]
     coef = torch.where(s > 1, 2 * (s - 1) / (B * s), torch.zeros_like(s))
     assert relerr(K.row_scale(gr, coef), golden_ops['gp/dg']) <= FWD_TOL
+    # the slope norm's backward with the coefficient formed in the kernel == the tensor-library expression it replaced, bit for bit
+    # (incl. a sample with zero slope: coefficient 0, not inf)
+    g2 = gr.clone(); g2[0].zero_()
+    s2 = K.gp_slopes(g2)
+    ds = torch.linspace(-1.0, 2.0, B, device='cuda')
+    want = K.row_scale(g2, torch.where(s2 > 0, ds / s2.clamp_min(1e-30), torch.zeros_like(s2)))
+    assert float(s2[0]) == 0.0 and torch.equal(K.row_scale_div(g2, ds, s2), want)
 
 
 @pytest.mark.parametrize('shape', [(3, 4, 4, 8), (24, 8, 8, 512), (6, 32, 32, 128), (1000, 36)])

@@ -59,6 +59,7 @@ SIGNATURES = {
     't2i_nhwc_to_nchw': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p]),
     't2i_gp_slopes': (ctypes.c_int, [_p, _i32, _i64, _p, _i32, _p]),
     't2i_row_scale': (ctypes.c_int, [_p, _p, _i32, _i64, _p, _i32, _p]),
+    't2i_row_scale_div': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _i32, _p]),
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),

@@ -437,8 +437,8 @@ class GpSlopesFn(Function):
     @once_differentiable
     def backward(ctx, ds):
         g, s = ctx.saved_tensors
-        coef = torch.where(s > 0, ds / s.clamp_min(1e-30), torch.zeros_like(s))   # [B] scalars per sample
-        return K.row_scale(g, _c(coef))
+        # coef_b = where(s > 0, ds / clamp_min(s, 1e-30), 0), formed inside the kernel (five tensor-library launches per term before)
+        return K.row_scale_div(g, _c(ds), s)
 
 
 # ---- PGGAN operators (reference utils/ops.py:74-81,100-101,109-111) ------------------------------------------------------

@@ -1053,10 +1053,15 @@ __global__ __launch_bounds__(256) void gp_slopes_kernel(const void* __restrict__
 
 template <bool H>
 __global__ __launch_bounds__(256) void row_scale_kernel(const void* __restrict__ g, const float* __restrict__ coef,
-                                                        size_t n, size_t per, void* __restrict__ out) {
+                                                        size_t n, size_t per, void* __restrict__ out, const float* __restrict__ den) {
   typedef typename std::conditional<H, unsigned short, float>::type T;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    st1(reinterpret_cast<T*>(out), i, coef[i / per] * ld1<H>(g, i));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per;
+    // den != NULL: the backward of the slope norm, coef_b = d / ||g_b|| with the guard of the tensor-library expression it replaces
+    // (where(s > 0, d / clamp_min(s, 1e-30), 0): five launches per gradient-penalty term before)
+    const float c = den ? (den[b] > 0.f ? coef[b] / fmaxf(den[b], 1e-30f) : 0.f) : coef[b];
+    st1(reinterpret_cast<T*>(out), i, c * ld1<H>(g, i));
+  }
 }
 
 hipError_t gp_slopes_launch(const void* g, int B, int64_t per, float* slopes, hipStream_t stream, bool bf16) {
@@ -1065,10 +1070,10 @@ hipError_t gp_slopes_launch(const void* g, int B, int64_t per, float* slopes, hi
   return hipGetLastError();
 }
 
-hipError_t row_scale_launch(const void* g, const float* coef, int B, int64_t per, void* out, hipStream_t stream, bool bf16) {
+hipError_t row_scale_launch(const void* g, const float* coef, int B, int64_t per, void* out, hipStream_t stream, bool bf16, const float* den) {
   const size_t n = (size_t)B * per;
-  if (bf16) hipLaunchKernelGGL(row_scale_kernel<true>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
-  else hipLaunchKernelGGL(row_scale_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out);
+  if (bf16) hipLaunchKernelGGL(row_scale_kernel<true>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out, den);
+  else hipLaunchKernelGGL(row_scale_kernel<false>, dim3(ew_blocks(n)), dim3(256), 0, stream, g, coef, n, (size_t)per, out, den);
   return hipGetLastError();
 }
 

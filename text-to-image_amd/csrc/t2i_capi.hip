@@ -42,7 +42,7 @@ hipError_t concat_tile_fwd_launch(const void*, const void*, int, int, int, int, 
 hipError_t concat_tile_bwd_launch(const void*, int, int, int, int, void*, void*, hipStream_t, bool bf16);
 hipError_t transpose_launch(const void*, int, int, int, void*, hipStream_t, bool bf16);
 hipError_t gp_slopes_launch(const void*, int, int64_t, float*, hipStream_t, bool bf16);
-hipError_t row_scale_launch(const void*, const float*, int, int64_t, void*, hipStream_t, bool bf16);
+hipError_t row_scale_launch(const void*, const float*, int, int64_t, void*, hipStream_t, bool bf16 = false, const float* den = nullptr);
 hipError_t crop_flip_normalize_launch(const uint8_t*, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t gather_mean_launch(const float*, int, int, const int32_t*, const int32_t*, int, int, float*, hipStream_t);
 hipError_t resample2_launch(bool, const float*, int, int, int, int, float, float*, hipStream_t);
@@ -129,6 +129,8 @@ static Tuning& tuning_mut() {
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
     v.bgemm_tile = env_int("T2I_BGEMM_TILE", 11);          // persistent batched GEMM tile: 11 / 21 / 12 / 22 = 64 a x 64 b; 0 = by item count (measured: the larger tiles lose at every batch size, profiles/r04_bgemm_tiles.txt)
     v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
+    v.dma_ovh = env_int("T2I_DMA_OVH", 120);               // x0.1 K-tile steps: prologue + epilogue of an igemm_hd_kernel workgroup in the planner's model
+    v.dma_split_us = env_int("T2I_DMA_SPLIT_US", 29);      // x0.1 us: fixed cost of its split-K reduction launch
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
     v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
     v.pair = env_int("T2I_PAIR", 1);                       // t2i_conv2d_bwd_pair: the two GEMMs in one launch where both are bf16-operand DMA kernels (0: two launches)
@@ -196,7 +198,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   const int* max_resident = dma ? max_resident_dma : (math ? max_resident_bf16 : max_resident_f32);
   const double* share_eff = dma ? share_eff_dma : (math ? share_eff_bf16 : share_eff_f32);
   const double unit_us = math ? 0.135 : 0.52;       // one 64x64x32 tile-step on one CU at the sustained rate
-  const double overhead_tiles = dma ? 12.0 : (math ? 8.0 : 3.0);   // prologue + epilogue of a workgroup, in K-tile steps
+  const double overhead_tiles = dma ? tuning().dma_ovh * 0.1 : (math ? 8.0 : 3.0);   // prologue + epilogue of a workgroup, in K-tile steps
   const int64_t ktiles = (K + bk - 1) / bk;        // K-tiles of the kernel that will run (32; 64 for the bf16-operand kernel)
   const double tile_w = bk / 32.0;                 // ... in units of the 32-wide tile-step the cost constants are quoted for
   int64_t maxsplit = ktiles / 4;
@@ -238,7 +240,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       double t = (double)rounds * ((double)per * tile_w + ovh_t) * (wmt * wnt) * unit_us /
                  (rel_eff[c] * (c == 0 ? hft_boost : 1.0) * share_eff[resident]);
       const double split_cost = tuning().split_cost;
-      if (sk_eff > 1) t += (dma ? 2.9 : (math ? 2.0 : split_cost)) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (dma ? 5.5e6 : (math ? 6.0e6 : 4.0e6));   // slabs out + in
+      if (sk_eff > 1) t += (dma ? tuning().dma_split_us * 0.1 : (math ? 2.0 : split_cost)) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (dma ? 5.5e6 : (math ? 6.0e6 : 4.0e6));   // slabs out + in
       if (t < best_t) {
         best_t = t;
         best.wmt = wmt; best.wnt = wnt;
@@ -1239,6 +1241,11 @@ int t2i_row_scale(const void* g, const float* coef, int32_t B, int64_t per_sampl
   return check(row_scale_launch(g, coef, B, per_sample, out, (hipStream_t)stream, dtype == T2I_DT_BF16), "t2i_row_scale");
 }
 
+int t2i_row_scale_div(const void* g, const float* num, const float* den, int32_t B, int64_t per_sample, void* out, int32_t dtype, t2i_stream_t stream) {
+  if (!g || !num || !den || !out || B <= 0 || per_sample <= 0 || !dt_ok(dtype, "t2i_row_scale_div")) { set_error("t2i_row_scale_div: bad argument"); return T2I_ERR_INVALID; }
+  return check(row_scale_launch(g, num, B, per_sample, out, (hipStream_t)stream, dtype == T2I_DT_BF16, den), "t2i_row_scale_div");
+}
+
 int t2i_crop_flip_normalize(const uint8_t* src, int64_t N, int32_t S, const int32_t* ids, const int32_t* row0,
                             const int32_t* col0, const int32_t* flip, int32_t B, int32_t out_size, float* out,
                             t2i_stream_t stream) {
@@ -1337,7 +1344,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const void* __res
   for (int ci = 0; ci < CI; ++ci) o[ci] = apply_act(acc[ci] + (bias ? bias[ci] : 0.f), act, alpha);
 }
 
+// Measured and dropped (round 4): a 2x2 block of same-phase output pixels per lane (32x32 tiles, the 18x18 patch staged 32 or 64
+// channels at a time: 0.11 instead of 0.33 LDS reads per FMA).  35 -> 47-48 us at B = 64, 88 -> 98-135 us at B = 192: the kernel is
+// bound by STAGING the dy patch (global -> registers -> LDS with per-element index arithmetic, one workgroup per CU, passes separated
+// by barriers), not by the LDS reads of the inner loop; four times fewer, four times larger workgroups made that worse.
 bool thin_deconv_eligible(const t2i_conv_desc& d) {
   return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin >= 1 && d.Cin <= 4 &&
          (d.Cout % 4) == 0 && d.Cout >= 16 && d.Cout <= 512 && (d.H % 16) == 0 && (d.W % 16) == 0 && d.Ho * 2 == d.H &&

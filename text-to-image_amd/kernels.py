@@ -826,6 +826,17 @@ def row_scale(g, coef):
     return out
 
 
+def row_scale_div(g, num, den):
+    """out[b] = (den[b] > 0 ? num[b] / max(den[b], 1e-30) : 0) * g[b]: the slope norm's backward, coefficient formed in the kernel."""
+    _chk(g, 'g'); _chk(num, 'num', f32=True); _chk(den, 'den', f32=True)
+    B = g.shape[0]
+    assert num.numel() == B and den.numel() == B
+    out = torch.empty_like(g)
+    if _live(g):
+        check(lib.t2i_row_scale_div(_ptr(g), _ptr(num), _ptr(den), B, g.numel() // B, _ptr(out), _dt(g), _stream()), 't2i_row_scale_div')
+    return out
+
+
 def adam_tf(w, g, m, v, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0, lr_t_dev=None):
     """In place on flat arenas.  lr_t_dev: optional device scalar that overrides lr_t (graph replay)."""
     for t in (w, g, m, v):
