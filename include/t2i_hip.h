@@ -283,7 +283,8 @@ int t2i_ca_kl_bwd(const float* mean, const float* log_sigma, const float* eps, c
 /* m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; w -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller (epsilon outside the bias correction).  One launch over a flat parameter arena. grad_scale multiplies g
  * first (1/world_size for summed data-parallel gradients).  If lr_t_dev != NULL the step size is read from that device
- * scalar instead of lr_t, so a hipGraph that captured the launch can be replayed with the next step's bias correction. */
+ * scalar instead of lr_t, so a hipGraph that captured the launch can be replayed with the next step's bias correction.
+ * m may be NULL when beta1 == 0 (v7): m_t = g_t * grad_scale whatever m_{t-1} was, so it is neither read nor written. */
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
                 float beta2, float eps, float grad_scale, t2i_stream_t stream);
 

@@ -3,6 +3,12 @@ missing or a symbol is absent, importing this module raises — the product path
 import ctypes
 import os
 
+# The HIP runtime must come into the process through PyTorch first: libt2i_hip.so links against libamdhip64.so.7 by SONAME, and
+# PyTorch ships its own copy.  Loaded in the other order (`from t2i_amd import _lib` before anything imported torch) the loader binds
+# torch to /opt/rocm's runtime as well, and torch's device enumeration and this library's launches then disagree about the device
+# ("no ROCm-capable device is detected" at the first launch: __graft_entry__.py run as a script did exactly that).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('T2I_HIP_LIB', os.path.join(_HERE, 'lib', 'libt2i_hip.so'))
 

@@ -1092,7 +1092,8 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
     float4 W = reinterpret_cast<float4*>(w)[i];
     const float4 G0 = reinterpret_cast<const float4*>(g)[i];
     // beta1 == 0 (the wgancls optimizers: Adam(0, 0.9)): m_t = g_t whatever m_{t-1} was — the old moment is not read
-    // (6 instead of 7 streams over the arena); it is still written, the checkpoint carries it
+    // (6 instead of 7 streams over the arena); m == NULL (round 4, only with beta1 == 0): it is not written either — m_t is
+    // grad * grad_scale, which the caller can form whenever a checkpoint wants it (5 streams)
     float4 M = b1 != 0.f ? reinterpret_cast<float4*>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 V = reinterpret_cast<float4*>(v)[i];
     float gx = G0.x * gscale, gy = G0.y * gscale, gz = G0.z * gscale, gw = G0.w * gscale;
@@ -1103,14 +1104,15 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ w, con
     W.x -= lr_t * M.x / (sqrtf(V.x) + eps); W.y -= lr_t * M.y / (sqrtf(V.y) + eps);
     W.z -= lr_t * M.z / (sqrtf(V.z) + eps); W.w -= lr_t * M.w / (sqrtf(V.w) + eps);
     reinterpret_cast<float4*>(w)[i] = W;
-    reinterpret_cast<float4*>(m)[i] = M;
+    if (m) reinterpret_cast<float4*>(m)[i] = M;
     reinterpret_cast<float4*>(v)[i] = V;
   }
   for (size_t i = (n4 << 2) + t; i < n; i += stride) {
     const float gg = g[i] * gscale;
     const float mm = b1 * (b1 != 0.f ? m[i] : 0.f) + (1.f - b1) * gg;
     const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-    m[i] = mm; v[i] = vv;
+    if (m) m[i] = mm;
+    v[i] = vv;
     w[i] -= lr_t * mm / (sqrtf(vv) + eps);
   }
 }

@@ -131,6 +131,7 @@ static Tuning& tuning_mut() {
     v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
     v.dma_ovh = env_int("T2I_DMA_OVH", 120);               // x0.1 K-tile steps: prologue + epilogue of an igemm_hd_kernel workgroup in the planner's model
     v.dma_split_us = env_int("T2I_DMA_SPLIT_US", 29);      // x0.1 us: fixed cost of its split-K reduction launch
+    v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
     v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
     v.pair = env_int("T2I_PAIR", 1);                       // t2i_conv2d_bwd_pair: the two GEMMs in one launch where both are bf16-operand DMA kernels (0: two launches)
@@ -172,7 +173,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
                       int bk = 32, int m_unit = 0,        // m_unit > 0: the M tile must divide it (tiles that stay inside one filter tap)
                       bool dma = false,                   // the bf16-operand kernel that moves its tiles by LDS DMA (igemm_hd_kernel)
                       int cus = 256) {                    // CUs this GEMM can count on: 256, or fewer when a sibling GEMM shares the launch (t2i_conv2d_bwd_pair)
-  static const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  static const int cand[5][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}, {4, 2}};      // {4, 2}: the 8-wave 256x128 tile of igemm_hd8_kernel (dma only)
   // MFMA efficiency relative to the 128x128 tile (re-fitted on the sweep taken with Winograd active: the 128x64 / 64x128
   // shapes lose to 128x128 on the 128-channel direct layers by 7-10 %, and to 64x64 when many workgroups are wanted)
   static const double rel_eff_f32[4] = {1.0, 0.93, 0.93, 0.94};
@@ -187,8 +188,8 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   // per CU loses less, and unsplit launches of 64x128 tiles beat split 128x128 ones on most B = 64 layers.  Fitted on a sweep of
   // every tile x split over 56 forward / input-gradient cases (profiles/r03_bf16_planner_fit.txt): regret against the per-case
   // optimum 7.4 % with the constants above, 1.0 % with these.
-  static const double rel_eff_dma[4] = {1.0, 0.82, 0.83, 0.64};
-  static const int max_resident_dma[4] = {3, 3, 3, 6};
+  const double rel_eff_dma[5] = {1.0, 0.82, 0.83, 0.64, tuning().tile8_eff * 0.01};   // [4]: measured by tools/bench_conv.py --math bf16 (profiles/r04_bf16_tile8.txt); 0 = never chosen
+  static const int max_resident_dma[5] = {3, 3, 3, 6, 1};
   static const double share_eff_dma[7] = {0.0, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0};
   // the filter gradient (m_unit > 0) runs igemm_hft_kernel on 128x128 tiles when the tile fits a tap (m_unit % 128 == 0) and the
   // register-transposing kernel on the other shapes: the 128x128 entry of rel_eff is raised by hft_boost for it
@@ -204,12 +205,14 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
   int64_t maxsplit = ktiles / 4;
   if (maxsplit < 1) maxsplit = 1;
   if (maxsplit > split_cap) maxsplit = split_cap;
-  const int ft = tuning().force_tile;
+  int ft = tuning().force_tile;
+  if (ft == 42 && (!dma || batched || m_unit > 0 || M < 256 || N <= 64)) ft = 22;      // the 8-wave tile exists for the LDS-DMA forward / input-gradient kernel only
   const int fs = tuning().force_splitk;
   Plan best;
   double best_t = 1e300;
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < 5; ++c) {
     const int wmt = cand[c][0], wnt = cand[c][1];
+    if (c == 4 && (!dma || batched || m_unit > 0 || (!ft && rel_eff_dma[4] <= 0.0) || M < 256 || N <= 64)) continue;
     if (m_unit > 0 && (m_unit % (64 * wmt)) != 0) continue;
     if (ft) { if (ft != wmt * 10 + wnt) continue; }
     else if (batched && !math) {
@@ -237,8 +240,9 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, int nphase, size_t out_el
       int resident = (int)(rounds < max_resident[c] ? rounds : max_resident[c]);
       if (cus < 256 && resident < 2) resident = 2;      // the sibling's workgroups are co-resident: nobody is alone on a CU
       const double ovh_t = (hft && c == 0) ? tuning().hft_ovh * 0.1 : overhead_tiles;
+      const double eff_c = (c == 4 && rel_eff[c] <= 0.0) ? 1.0 : rel_eff[c];       // (forced 8-wave tile without a fitted efficiency)
       double t = (double)rounds * ((double)per * tile_w + ovh_t) * (wmt * wnt) * unit_us /
-                 (rel_eff[c] * (c == 0 ? hft_boost : 1.0) * share_eff[resident]);
+                 (eff_c * (c == 0 ? hft_boost : 1.0) * (c == 4 ? 1.0 : share_eff[resident]));      // 8 waves: two per SIMD hide each other like two workgroups
       const double split_cost = tuning().split_cost;
       if (sk_eff > 1) t += (dma ? tuning().dma_split_us * 0.1 : (math ? 2.0 : split_cost)) + (double)out_elems * 4.0 * (double)(sk_eff + 1) / (dma ? 5.5e6 : (math ? 6.0e6 : 4.0e6));   // slabs out + in
       if (t < best_t) {
@@ -459,7 +463,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
 // filter gradient with bf16 operand copies: workspace = [x_h][dy_h][split-K slabs]
 static bool h_filter_eligible(const t2i_conv_desc& d) {
   return d.math == T2I_MATH_BF16 && tuning().bf16_operands && d.Cin >= 64 && (d.Cin % 64) == 0 && (d.Cout % 8) == 0 && (d.Wo % 4) == 0 &&
-         (!tuning().force_tile || (d.Cin % (64 * (tuning().force_tile / 10))) == 0);
+         (!tuning().force_tile || (d.Cin % (64 * (tuning().force_tile / 10 > 2 ? 2 : tuning().force_tile / 10))) == 0);
 }
 
 static Plan h_filter_plan(const t2i_conv_desc* d, int cus = 256) {
@@ -1321,8 +1325,9 @@ int t2i_lerp_dev(const float* a, const float* b, const float* t_dev, int32_t mod
 int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev, float beta1,
                 float beta2, float eps,
                 float grad_scale, t2i_stream_t stream) {
-  if (!w || !g || !m || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
-  if (!(aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
+  if (!w || !g || !v || n <= 0) { set_error("t2i_adam_tf: bad argument"); return T2I_ERR_INVALID; }
+  if (!m && beta1 != 0.f) { set_error("t2i_adam_tf: m may be NULL only with beta1 == 0 (the first moment is then grad * grad_scale)"); return T2I_ERR_INVALID; }
+  if (!(aligned16(w) && aligned16(g) && (!m || aligned16(m)) && aligned16(v))) { set_error("t2i_adam_tf: arena must be 16-byte aligned"); return T2I_ERR_INVALID; }
   filter_cache_invalidate(w, (size_t)n * 4);          // transformed filters of this arena are stale from here on
   const int rc = check(adam_tf_launch(w, g, m, v, n, lr_t, lr_t_dev, beta1, beta2, eps, grad_scale, (hipStream_t)stream), "t2i_adam_tf");
   if (rc != T2I_OK || !tuning().cache_refresh) return rc;
@@ -1344,7 +1349,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -470,10 +470,14 @@ struct SmemD {
 // The body is a device function of (params, block coordinates) so that TWO independent GEMMs can share one launch
 // (igemm_pair_kernel below); igemm_hd_kernel is the plain one-GEMM launch.  bx / nbx: tile block and their number, by: K split,
 // bz: stride phase (input gradient).  `p` must sit at kernarg offset 0 (load_phase_h).
-template <int MODE, int WMT, int WNT, int PIPE>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
+// NW: waves per workgroup, 4 (2 x 2: tile 64 WMT x 64 WNT) or 8 (4 x 2, round 4: tile 128 WMT x 64 WNT — 256 x 128 with 64 x 64 wave
+// tiles: per multiply-add 3/4 of the staged bytes and DMA instructions of the 128 x 128 tile, and two waves per SIMD, so that one
+// wave's DMA issue and fragment reads sit beside the other's MFMAs; for GEMMs with >= 256 such tiles: big maps, B >= 256).
+template <int MODE, int WMT, int WNT, int PIPE, int NW = 4>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
 __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, const int nbx, const int by, const int bz) {
   constexpr int NBUF = PIPE > 2 ? PIPE : 2;
-  using S = SmemD<WMT, WNT, NBUF>;
+  using S = SmemD<WMT * (NW / 4), WNT, NBUF>;
+  constexpr int RPP = NW * 8;                           // rows staged per pass: 8 threads per 128-byte row
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
   extern __shared__ __attribute__((aligned(16))) unsigned smem_h[];
   unsigned* As = smem_h;
@@ -516,8 +520,8 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 
   const i32x4h wa = rsrc_words_h(p.a, p.a_bytes), wb = rsrc_words_h(p.b, p.b_bytes);
 
-  // ---- loader state: thread -> (LDS chunk position kp of the 128-byte K-tile row, rows (tid >> 3) + 32 i); it FETCHES chunk kg ----
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;
+  // ---- loader state: thread -> (LDS chunk position kp of the 128-byte K-tile row, rows (tid >> 3) + RPP i); it FETCHES chunk kg ----
+  constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
   const int kp = tid & 7, r0 = tid >> 3;
   const int kg = kp ^ ((r0 >> 1) & 7);               // rows r0 and r0 + 32 i swizzle alike
   const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   bool a_ok[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int m = bm + r0 + 32 * i;
+    const int m = bm + r0 + RPP * i;
     bool ok = m < p.M;
     const int mm = ok ? m : 0;
     int base, h0, w0;
@@ -556,7 +560,7 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   bool b_ok[B_LD];
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
-    const int n = bn + r0 + 32 * i;
+    const int n = bn + r0 + RPP * i;
     b_ok[i] = n < p.N;
     b_rowoff[i] = n * Csrc + kg * 8;
   }
@@ -584,11 +588,11 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const bool ok = a_ok[i] & kok & ((unsigned)(a_h0[i] + dh) < Hs) & ((unsigned)(a_w0[i] + dw) < Ws);
-      dma16_h(wa, ok ? (unsigned)(a_rowoff[i] + sa) * 2u : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + 32 * i * ROW) * 4u);
+      dma16_h(wa, ok ? (unsigned)(a_rowoff[i] + sa) * 2u : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      dma16_h(wb, (b_ok[i] & kok) ? (unsigned)(b_rowoff[i] + sb) * 2u : HOOB, lds_b0 + (unsigned)(buf * S::B_DW + 32 * i * ROW) * 4u);
+      dma16_h(wb, (b_ok[i] & kok) ? (unsigned)(b_rowoff[i] + sb) * 2u : HOOB, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
   };
 
   f32x16 acc[WMT][WNT];
@@ -751,6 +755,12 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 template <int MODE, int WMT, int WNT, int PIPE>
 __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   hd_body<MODE, WMT, WNT, PIPE>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
+// 8 waves, tile 256 x 128 (see hd_body)
+template <int MODE, int PIPE>
+__global__ __launch_bounds__(512) void igemm_hd8_kernel(IgemmParams p) {
+  hd_body<MODE, 2, 2, PIPE, 8>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1247,9 +1257,30 @@ hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, 
   return hipErrorInvalidValue;
 }
 
-// tiles: (wmt, wnt) in {(2,2), (2,1), (1,2), (1,1)}
+template <int MODE, int PIPE>
+static hipError_t launch_hd8(const IgemmParams& p, dim3 grid, hipStream_t stream) {
+  using S = SmemD<4, 2, (PIPE > 2 ? PIPE : 2)>;
+  auto k = igemm_hd8_kernel<MODE, PIPE>;
+  static bool attr_done = false;   // benign race: idempotent
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(512), S::BYTES, stream, p);
+  return hipGetLastError();
+}
+
+// tiles: (wmt, wnt) in {(2,2), (2,1), (1,2), (1,1)}; (4,2) = the 8-wave 256 x 128 tile (LDS-DMA kernel only)
 hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipStream_t stream) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
+  if (wmt == 4 && wnt == 2) {
+    if (!tuning().bf16_dma) return hipErrorInvalidValue;
+    const bool pipe = tuning().bf16_dma >= 2;
+    if (mode == MODE_FWD) return pipe ? launch_hd8<MODE_FWD, 2>(p, grid, stream) : launch_hd8<MODE_FWD, 0>(p, grid, stream);
+    if (mode == MODE_BWD_DATA) return pipe ? launch_hd8<MODE_BWD_DATA, 2>(p, grid, stream) : launch_hd8<MODE_BWD_DATA, 0>(p, grid, stream);
+    return hipErrorInvalidValue;
+  }
 #define T2I_H(M_, a, b) if (mode == M_ && wmt == a && wnt == b) return launch_h<M_, a, b>(p, grid, stream);
   T2I_H(MODE_FWD, 2, 2) T2I_H(MODE_FWD, 2, 1) T2I_H(MODE_FWD, 1, 2) T2I_H(MODE_FWD, 1, 1)
   T2I_H(MODE_BWD_DATA, 2, 2) T2I_H(MODE_BWD_DATA, 2, 1) T2I_H(MODE_BWD_DATA, 1, 2) T2I_H(MODE_BWD_DATA, 1, 1)

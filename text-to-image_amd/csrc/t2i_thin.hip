@@ -45,6 +45,47 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const void* __res
   for (int cbase = 0; cbase < Co; cbase += CH) {
     if (cbase) __syncthreads();                // everyone is done reading the previous pass
     // ---- stage the dy patch (zero outside the image) and the filter slice --------------------------------------------
+    if (CH == 64) {
+      // round 4: every global load of the pass is issued BEFORE the first LDS store (7 + 3 per thread at 64 channels).  The generic loop
+      // below stores each value as it arrives: ~7 dependent HBM round trips per pass, and staging is what this kernel waits for
+      // (a blocked inner loop with 3x fewer LDS reads did not move it, see the end of this file).
+      constexpr int C4N = 16, XN = (100 * C4N + 255) / 256, WN = (16 * CI * C4N + 255) / 256;
+      float4 xv[XN], wv[WN];
+#pragma unroll
+      for (int u = 0; u < XN; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int pix = i >> 4, c4 = i & 15;
+        const int r = pix / 10, c = pix - r * 10;
+        const int oh = oh0 + r, ow = ow0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 100 * C4N && (unsigned)oh < (unsigned)Ho && (unsigned)ow < (unsigned)Wo) {
+          const size_t e = ((size_t)(b * Ho + oh) * Wo + ow) * Co + cbase + c4 * 4;
+          if (DYH) {
+            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dyv) + e);
+            v = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
+          } else {
+            v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dyv) + e);
+          }
+        }
+        xv[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < WN; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int row = i >> 4, c4 = i & 15;
+        wv[u] = i < 16 * CI * C4N ? *reinterpret_cast<const float4*>(w + (size_t)row * Co + cbase + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < XN; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < 100 * C4N) *reinterpret_cast<float4*>(&tile[(i >> 4) * PS + (i & 15) * 4]) = xv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < WN; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < 16 * CI * C4N) reinterpret_cast<float4*>(wlds)[i] = wv[u];
+      }
+    } else {
     for (int i = threadIdx.x; i < 100 * c4n; i += 256) {
       const int pix = i / c4n, c4 = i - pix * c4n;
       const int r = pix / 10, c = pix - r * 10;
@@ -64,6 +105,7 @@ __global__ __launch_bounds__(256) void thin_deconv_k4s2_kernel(const void* __res
     for (int i = threadIdx.x; i < 16 * CI * c4n; i += 256) {          // [tap][ci][CH] <- w[tap][ci][cbase .. cbase+CH)
       const int row = i / c4n, c4 = i - row * c4n;
       reinterpret_cast<float4*>(wlds)[i] = *reinterpret_cast<const float4*>(w + (size_t)row * Co + cbase + c4 * 4);
+    }
     }
     __syncthreads();
 #pragma unroll

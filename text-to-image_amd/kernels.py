@@ -839,9 +839,10 @@ def row_scale_div(g, num, den):
 
 def adam_tf(w, g, m, v, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0, lr_t_dev=None):
     """In place on flat arenas.  lr_t_dev: optional device scalar that overrides lr_t (graph replay)."""
-    for t in (w, g, m, v):
+    for t in (w, g, v) + ((m,) if m is not None else ()):
         _chk(t)
-    assert w.numel() == g.numel() == m.numel() == v.numel()
+    assert w.numel() == g.numel() == v.numel() and (m is None or m.numel() == w.numel())
+    assert m is not None or beta1 == 0.0, 'the first moment can be skipped only with beta1 == 0'
     if _live(w):
         check(lib.t2i_adam_tf(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), lr_t, _ptr(lr_t_dev), beta1, beta2, eps, grad_scale,
                               _stream()),

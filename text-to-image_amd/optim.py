@@ -5,6 +5,7 @@ gradients, first and second moments in three more buffers of the same shape.  A 
 over ~29 M (critic) / ~23 M (generator) floats instead of one launch per tensor, and data-parallel gradient exchange
 works on contiguous slices of the gradient arena (dp.py)."""
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -54,10 +55,28 @@ class AdamTF(object):
 
     def __init__(self, arena, beta1=0.9, beta2=0.999, eps=1e-8):
         self.arena, self.beta1, self.beta2, self.eps = arena, beta1, beta2, eps
-        self.m = torch.zeros_like(arena.flat)
+        self._m = torch.zeros_like(arena.flat)
         self.v = torch.zeros_like(arena.flat)
+        # beta1 == 0 (both wgancls optimizers, PGGAN): m_t = g_t * grad_scale whatever m_{t-1} was, so the step neither reads nor
+        # writes it (4 bytes per parameter less of the 24 the update streams); `m` is formed from the gradient arena when somebody
+        # asks for it — a checkpoint between two iterations — which is valid until the arena is zeroed for the next backward
+        self.skip_m = beta1 == 0.0 and os.environ.get('T2I_ADAM_SKIP_M', '1') != '0'
+        self._m_valid_t, self._last_scale = 0, 1.0      # the step count `_m` was last brought up to date at
         self.t = 0
         self.lr_t_dev = torch.zeros(4, dtype=torch.float32, device=arena.flat.device)   # [0] = this step's lr_t
+
+    @property
+    def m(self):
+        """First moment.  With the beta1 == 0 fast path it is (re)built from the gradient arena on access (see __init__)."""
+        if self.skip_m and self.t != self._m_valid_t:       # (t advances in prepare(), the host half of every step, replayed or not)
+            with torch.no_grad():
+                torch.mul(self.arena.grad, self._last_scale, out=self._m)
+            self._m_valid_t = self.t
+        return self._m
+
+    def moments_loaded(self):
+        """The caller has just written m (and t) from a checkpoint: keep those values until the next step."""
+        self._m_valid_t = self.t
 
     def prepare(self, lr):
         """Host half of a step: advance t and publish lr_t to the device scalar (outside any captured graph)."""
@@ -72,8 +91,10 @@ class AdamTF(object):
         (kernels.filter_cache_refresh).  Default: yes for eager launches; not inside a capture, whose successor graph starts
         with a refresh of everything — pass True where the same capture goes on to use these filters (the critic's update in
         a one-graph iteration)."""
-        K.adam_tf(self.arena.flat, self.arena.grad, self.m, self.v, 0.0, self.beta1, self.beta2, self.eps, grad_scale,
+        K.adam_tf(self.arena.flat, self.arena.grad, None if self.skip_m else self._m, self.v, 0.0, self.beta1, self.beta2, self.eps, grad_scale,
                   lr_t_dev=self.lr_t_dev)
+        if self.skip_m:
+            self._last_scale = float(grad_scale)
         if refresh is None:
             refresh = self.arena.flat.is_cuda and not torch.cuda.is_current_stream_capturing()
         if refresh and self.arena.flat.is_cuda:

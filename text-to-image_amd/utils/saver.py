@@ -57,6 +57,8 @@ class Saver(object):
                         opt.v[o:o + k].copy_(torch.from_numpy(z['%s/%s/Adam_1' % (oname, n)]).reshape(-1).to(opt.v.device))
                 if '%s/t' % oname in z.files:
                     opt.t = int(z['%s/t' % oname])
+                if hasattr(opt, 'moments_loaded'):
+                    opt.moments_loaded()
             for k, get in self.extra.items():
                 if k in z.files:
                     get[1](z[k])
