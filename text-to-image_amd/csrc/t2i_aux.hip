@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256) void col_reduce_stage2_v4(const float* __restr
 
 static void col_reduce_plan(int64_t rows, int C, int* ctiles, int* nchunks, int64_t* rows_per_chunk) {
   *ctiles = (C + 63) / 64;
-  int64_t want = 768 / *ctiles;               // ~3 workgroups per CU in flight
+  int64_t want = tuning().colred_wgs / *ctiles;   // workgroups in flight (768 = 3 per CU in rounds 1-3)
   if (want < 1) want = 1;
   int64_t maxchunks = (rows + 63) / 64;       // at least 64 rows per chunk
   if (want > maxchunks) want = maxchunks;
-  if (want > 192) want = 192;                 // keeps the second stage short
+  if (want > tuning().colred_cap) want = tuning().colred_cap;                 // keeps the second stage short
   if (want < 1) want = 1;
   *rows_per_chunk = (rows + want - 1) / want;
   *nchunks = (int)((rows + *rows_per_chunk - 1) / *rows_per_chunk);

@@ -132,6 +132,8 @@ static Tuning& tuning_mut() {
     v.dma_ovh = env_int("T2I_DMA_OVH", 120);               // x0.1 K-tile steps: prologue + epilogue of an igemm_hd_kernel workgroup in the planner's model
     v.dma_split_us = env_int("T2I_DMA_SPLIT_US", 29);      // x0.1 us: fixed cost of its split-K reduction launch
     v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
+    v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
+    v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
     v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
     v.pair = env_int("T2I_PAIR", 1);                       // t2i_conv2d_bwd_pair: the two GEMMs in one launch where both are bf16-operand DMA kernels (0: two launches)
@@ -1349,7 +1351,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

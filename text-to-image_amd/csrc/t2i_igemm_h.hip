@@ -475,7 +475,8 @@ struct SmemD {
 // wave's DMA issue and fragment reads sit beside the other's MFMAs; for GEMMs with >= 256 such tiles: big maps, B >= 256).
 template <int MODE, int WMT, int WNT, int PIPE, int NW = 4>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
 __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, const int nbx, const int by, const int bz) {
-  constexpr int NBUF = PIPE > 2 ? PIPE : 2;
+  constexpr bool PINGPONG = (PIPE == 8);                // 8 waves only: the two waves of a SIMD alternate between a load phase and a multiply phase
+  constexpr int NBUF = PINGPONG ? 3 : (PIPE > 2 ? PIPE : 2);
   using S = SmemD<WMT * (NW / 4), WNT, NBUF>;
   constexpr int RPP = NW * 8;                           // rows staged per pass: 8 threads per 128-byte row
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
@@ -608,6 +609,60 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   for (int b = 0; b < NBUF; ++b) dma_tile(b, b);
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES * (NBUF - 1)) : "memory");
   __syncthreads();                                     // tile 0 is in LDS
+  if constexpr (PINGPONG) {
+    // Ping-pong K loop (round 4, 8 waves).  Waves w and w + 4 share a SIMD.  Every K-tile is two phases separated by workgroup
+    // barriers; in each phase one half of the waves (a "group") reads its fragments of a tile from LDS and issues its DMA pieces
+    // of the tile two ahead — no MFMA — while the other half multiplies the tile it read a phase earlier:
+    //   phase 2t     group A: read(t), DMA(t+2), wait for its pieces of t+1        group B: MFMA(t-1)
+    //   phase 2t+1   group A: MFMA(t)                                              group B: read(t), DMA(t+2), wait for its pieces of t+1
+    // so the matrix pipe of a SIMD always has one wave feeding it while its partner pays for the DMA issue and the LDS reads
+    // (which is what bounds the lock-step loops above).  Three LDS buffers: tile t+2 is written while tile t is still being read by
+    // the lagging group and tile t+1 is landing.  Hazards: a buffer is re-filled two phases after its last read at the earliest (a
+    // barrier in between); a tile is read only after BOTH groups waited for their own pieces of it (vmcnt) in front of a barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prologue: tiles 0, 1 (and 2: zeros or data) issued by everybody, all landed
+    __syncthreads();
+    const bool lag = wave_u >= 4;                          // group B runs one phase behind
+    if (lag) __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const unsigned* as = As + cur * S::A_DW;
+      const unsigned* bs = Bs + cur * S::B_DW;
+      bf16x8 fa[WMT][4], fb[WNT][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+          const int row = wm * 32 * WMT + i * 32 + l31;
+          fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+        }
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) {
+          const int row = wn * 32 * WNT + i * 32 + l31;
+          fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
+        }
+      }
+      if (t > 0) {                                         // (t = 0: tile 2 went out with the prologue)
+        const int tgt = (cur == 0) ? 2 : cur - 1;          // (t + 2) % 3 == (t - 1) % 3: the buffer of tile t-1, read two phases ago at the latest
+        dma_tile(t + 2, tgt);
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES) : "memory");      // this wave's pieces of tile t+1 have landed
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                     // end of this group's load phase
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int n = 0; n < WNT; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                     // end of this group's multiply phase
+      __builtin_amdgcn_sched_barrier(0);
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
+    if (!lag) __syncthreads();                             // the leading group waits out the lagging group's last phase
+  } else
   if constexpr (PIPE) {
     // Software-pipelined K loop (round 4).  With ONE workgroup on a CU (<= 256 tiles: every large layer at B = 64) nothing hides a
     // phase in which all four waves only read fragments, so the fragments of 16-k step s+1 are read while step s multiplies, and
@@ -1259,7 +1314,7 @@ hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, 
 
 template <int MODE, int PIPE>
 static hipError_t launch_hd8(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = SmemD<4, 2, (PIPE > 2 ? PIPE : 2)>;
+  using S = SmemD<4, 2, (PIPE == 8 ? 3 : (PIPE > 2 ? PIPE : 2))>;
   auto k = igemm_hd8_kernel<MODE, PIPE>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done) {
@@ -1276,6 +1331,10 @@ hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipS
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, mode == MODE_BWD_DATA ? p.nphase : 1);
   if (wmt == 4 && wnt == 2) {
     if (!tuning().bf16_dma) return hipErrorInvalidValue;
+    if (tuning().bf16_dma == 8) {          // ping-pong loop (hd_body, PIPE = 8)
+      if (mode == MODE_FWD) return launch_hd8<MODE_FWD, 8>(p, grid, stream);
+      if (mode == MODE_BWD_DATA) return launch_hd8<MODE_BWD_DATA, 8>(p, grid, stream);
+    }
     const bool pipe = tuning().bf16_dma >= 2;
     if (mode == MODE_FWD) return pipe ? launch_hd8<MODE_FWD, 2>(p, grid, stream) : launch_hd8<MODE_FWD, 0>(p, grid, stream);
     if (mode == MODE_BWD_DATA) return pipe ? launch_hd8<MODE_BWD_DATA, 2>(p, grid, stream) : launch_hd8<MODE_BWD_DATA, 0>(p, grid, stream);

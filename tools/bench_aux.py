@@ -56,7 +56,8 @@ def main():
     w, gr, m, v = (torch.randn(N + 3, device=dev)[:N] for _ in range(4))
     w, gr, m, v = (torch.zeros((N + 3) // 4 * 4, device=dev) for _ in range(4))
     v.uniform_()
-    row('adam_tf critic arena (4r+3w)', 28 * w.numel(), lambda: K.adam_tf(w, gr, m, v, 1e-4, 0.0, 0.9, 1e-8, 1.0))
+    row('adam_tf critic arena, beta1 = 0 (w, g, v read; w, m, v written)', 24 * w.numel(), lambda: K.adam_tf(w, gr, m, v, 1e-4, 0.0, 0.9, 1e-8, 1.0))
+    row('adam_tf critic arena, beta1 = 0, m skipped (3r+2w): the product path', 20 * w.numel(), lambda: K.adam_tf(w, gr, None, v, 1e-4, 0.0, 0.9, 1e-8, 1.0))
     # PGGAN operators
     row('pool2 avg (r + w/4)', 5 * n, lambda: K.pool2_sum(x, 0.25))
     xs = torch.randn(B, 16, 16, 256, device=dev)
