@@ -354,6 +354,37 @@ def _every_tile_body(K, tile, splitk, math, rnd, mcode):
             assert 1e-4 < e < 2e-2, (case, e)
 
 
+@pytest.mark.parametrize('dma,tile', [(2, 22), (3, 22), (4, 22), (1, 42), (2, 42), (8, 42)])
+def test_bf16_gemm_loop_and_tile_variants(K, dma, tile):
+    """Round-4 variants of the bf16 LDS-DMA GEMM kept behind switches: the software-pipelined K loop (bf16_dma = 2), 3- and
+    4-buffer LDS rings (3, 4), the 8-wave 256x128 tile (force_tile = 42) in lock step (1, 2) and with the ping-pong loop (8).  Every
+    accumulator sees its K products in the same order whatever the loop, so each variant must return the default kernel's bits — and
+    the default is held to the float64 oracle on rounded operands by the tests above."""
+    rng = np.random.default_rng(7)
+    cases = [(5, 16, 16, 128, 200, 3, 1), (3, 16, 16, 64, 136, 4, 2), (9, 8, 8, 192, 256, 3, 1)]      # M = 1280 / 192.. / 576: ragged 256-row tiles, ragged N
+    K.set_math('bf16')
+    try:
+        for B, H, W, Ci, Co, k, s in cases:
+            x = dev(rng.standard_normal((B, H, W, Ci)).astype(np.float32))
+            w = dev((rng.standard_normal((k, k, Ci, Co)) / np.sqrt(k * k * Ci)).astype(np.float32))
+            b = dev(rng.standard_normal(Co).astype(np.float32))
+            d, _ = K.conv_desc(B, H, W, Ci, Co, k, k, s, s, 'SAME')
+            dy = dev(rng.standard_normal((B, d.Ho, d.Wo, Co)).astype(np.float32))
+            ws = 256 << 20
+            outs = {}
+            for name, (v_dma, v_tile) in (('default', (1, 22)), ('variant', (dma, tile))):
+                K.tuning_set('bf16_dma', v_dma); K.tuning_set('force_tile', v_tile)
+                for sk in (1, 2):
+                    K.tuning_set('force_splitk', sk)
+                    outs[name, sk] = (K.conv_fwd(x, w, b, d, ws, K.ACT_LRELU, 0.2), K.conv_bwd_data(dy, w, None, d, ws))
+            for sk in (1, 2):
+                assert torch.equal(outs['variant', sk][0], outs['default', sk][0]), (B, H, Ci, Co, sk, 'fwd')
+                assert torch.equal(outs['variant', sk][1], outs['default', sk][1]), (B, H, Ci, Co, sk, 'bwd_data')
+    finally:
+        K.tuning_set('bf16_dma', 1); K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0)
+        K.set_math('f32')
+
+
 def test_conv_epilogue_batch_norm_statistics(K):
     """conv_fwd_stats: the GEMM epilogue's per-tile column sums, finished by take_stats, == column sums of the output (1e-5 of
     their scale) for every tile shape; when the planner splits K the fused path declines and nothing is cached."""

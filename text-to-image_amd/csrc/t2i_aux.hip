@@ -815,6 +815,10 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const void* __restr
       d.x = g.x * act_grad_from_output(o.x, act, alpha); d.y = g.y * act_grad_from_output(o.y, act, alpha);
       d.z = g.z * act_grad_from_output(o.z, act, alpha); d.w = g.w * act_grad_from_output(o.w, act, alpha);
       st4(dx, dxh, e4, d);
+      // bf16 storage: the bias / gamma / beta partial sums below take the UNROUNDED fp32 d, while dx is stored rounded to bf16 and the
+      // convolutions behind it read the rounded values — the reductions are the more accurate of the two, and differ from
+      // reduce(stored dx) by at most 2^-9 relative per element (random sign): sqrt(rows) * 2^-9 of an element's magnitude per column,
+      // far inside config 3's tolerance.  tests/test_storage_gpu.py pins it (reductions bit-equal to the fp32-tensor path; dx one rounding).
       acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
       if (SECOND) {
         const float4 v = ld4<H>(x2, e4);

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh [round]).
 # Kernel trace and each PMC group are separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
-# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r03);
+# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r04);
 # copy what should be judged into profiles/ with the round prefix.
 set -u
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-ROUND="${1:-r03}"
+ROUND="${1:-r04}"
 OUT="$REPO/gpurun_out/$ROUND"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off --repeats 1 --min-busy-s 0 --no-config3 --no-side-rows"
@@ -33,12 +33,38 @@ timeout 300 python tools/bench_conv.py --batch 64 > "$OUT/conv_microbench_B64.tx
 timeout 300 python tools/bench_conv.py --batch 192 --filter D > "$OUT/conv_microbench_B192.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 64 --math bf16 > "$OUT/conv_microbench_bf16_B64.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 512 --math bf16 --reps 10 > "$OUT/conv_microbench_bf16_B512.txt" 2>&1
-T2I_SWEEP_MATH=bf16 timeout 600 python tools/sweep_conv.py D2:64 D3:64 D4:64 D7:64 D10:64 G5c:64 G7c:64 G8c:64 G4c:64 G6c:64 D2:192 D3:192 D4:192 D10:192 2>&1 | grep -v amdgpu > "$OUT/bf16_tile_split_sweep.txt"
+{ echo "== bf16 tensors in and out (config 3 as it runs: no cast launches inside the timed calls), B = 64"; timeout 300 python tools/bench_conv.py --batch 64 --math bf16 --storage bf16 --reps 10 2>&1 | grep -v amdgpu
+  echo "== B = 512"; timeout 300 python tools/bench_conv.py --batch 512 --math bf16 --storage bf16 --reps 10 2>&1 | grep -v amdgpu; } > "$OUT/conv_microbench_bf16_tensors.txt"
 timeout 300 python tools/bench_aux.py 2>&1 | grep -v amdgpu > "$OUT/hbm_kernels.txt"
-{ for b in 8 64; do timeout 200 python text-to-image_amd/models/stackgan/run.py --stage 1 --batch $b 2>&1 | tail -1; done
-  for b in 8 32; do timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch $b --steps 5 2>&1 | tail -1; done
-  timeout 300 python text-to-image_amd/models/stackgan/run.py --stage 2 --batch 32 --steps 5 --math bf16 2>&1 | tail -1
-  timeout 600 python text-to-image_amd/models/pggan/train_pggan.py --bench --iters 8 --first 6 --last 12 2>&1 | grep "^pggan"; } > "$OUT/next_rows_throughput.txt"
+{ timeout 900 python tools/next_rows.py --math f32 --budget-s 2.0 2>&1 | grep -v amdgpu
+  timeout 600 python tools/next_rows.py --math bf16 --budget-s 2.0 --rows gancls wgancls_b8 2>&1 | grep -v amdgpu
+  timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu
+import sys; sys.path.insert(0, '.')
+import t2i_amd
+from t2i_amd import kernels as K
+K.filter_cache(True)
+from tools.next_rows import measure_rows
+for r in measure_rows(['stage2'], 'bf16', 2.0, storage='f32'):
+    print('%-16s bf16 (fp32 tensors) B=%-3d %8.2f ms/iteration %9.1f img/s | %.2f GFLOP/img | %.3f of the bf16 matrix peak' % (r['row'], r['batch'], r['ms_per_iteration'], r['images_per_sec'], r['algorithmic_gflop_per_image'], r['frac_vs_driver_ms']) if 'error' not in r else r)
+PY
+} > "$OUT/next_rows_throughput.txt"
+# per-kernel statistics of the next rows (StackGAN Stage-II, PGGAN stage 7): one kernel-trace pass each
+cd /tmp
+for row in stage2 pggan7; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$row" -o r -- python $REPO/tools/next_rows.py --rows $row --budget-s 1.0 > "$OUT/kt_$row.log" 2>&1
+  python - "$OUT/kt_$row" > "$OUT/kernel_stats_summary_$row.txt" 2>&1 <<'PY'
+import csv, glob, sys
+d = sys.argv[1]
+f = (glob.glob(d + '/*/*kernel_stats.csv') + glob.glob(d + '/*kernel_stats.csv'))[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print('whole process (set-up iterations + capture warm-up + timed replays): kernel time %.1f ms; share per kernel' % (tot / 1e6))
+for r in rows[:40]:
+    print('%-90s %7s calls %6.2f%% avg %9.1f us' % (r['Name'][:90], r['Calls'], float(r['Percentage']), float(r['AverageNs']) / 1e3))
+PY
+  rm -rf "$OUT/kt_$row"
+done
+cd "$REPO"
 timeout 600 python bench.py 2>/dev/null | grep '"metric"' > "$OUT/bench_line.json"
 # drop the bulky raw traces, keep the per-pass counter csv of the MFMA pass for reference
 rm -rf "$OUT/ktrace" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES"
