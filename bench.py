@@ -378,7 +378,9 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
                 continue
             prof = {'source': 'from_profile', 'file': 'profiles/' + cand, 'counters': 'FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES',
                     'profile_igemm_launches_per_step': pmc.get('launches_per_iteration'), 'run_igemm_launches_per_step': igemm_per_step}
-            same = pmc.get('launches_per_iteration') is not None and abs(pmc['launches_per_iteration'] - igemm_per_step) <= 0.02 * igemm_per_step
+            # (bf16: the profile counts GEMM-kernel DISPATCHES — a pair launch is one, a staged boundary layer's generic GEMM is one more —
+            # while this run counts entry-point CALLS: the two differ by a handful of launches for the same algorithm mix, hence 8 %)
+            same = pmc.get('launches_per_iteration') is not None and abs(pmc['launches_per_iteration'] - igemm_per_step) <= (0.02 if math == 'f32' else 0.08) * igemm_per_step
             prof['counts_agree'] = bool(same)
             if same:
                 traffic, mfma_util = pmc.get('traffic_bytes_per_launch'), pmc.get('mfma_util')
@@ -396,7 +398,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
         # compulsory HBM bytes of the same launches (Σ layer in+out per pass, 286 MB per generator pass and 161 MB per
         # critic pass at B = 64 in fp32, 4 generator-side and 15 critic-side passes are launched; half in bf16 storage)
         compulsory = (4 * 286e6 + 15 * 161e6) * (args.batch / 64.0) * (0.5 if storage == 'bf16' else 1.0)
-        igemm_launches = prof['profile_igemm_launches_per_step'] if (prof and prof.get('counts_agree')) else None
+        igemm_launches = prof['profile_igemm_launches_per_step'] if (prof and prof.get('counts_agree')) else None      # per-launch figures x the PROFILE's launch count = its per-step totals
         out['roofline'] = {
             'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel)'
                      if math == 'f32' else 't2i::igemm_hd_kernel<MODE,WMT,WNT> + t2i::igemm_hft_kernel (bf16 operands by LDS DMA) + the fp32 thin-layer kernels',

@@ -198,6 +198,40 @@ def test_bwd_pair_is_bit_identical_to_the_two_calls(K, case):
         K.set_storage('f32')
 
 
+def test_conv_epilogue_batch_norm_statistics_on_bf16_tensors(K):
+    """Round 4: the bf16-operand forward GEMM leaves the batch norm the per-tile column sums / centred second moments of the bf16
+    tensor it writes (tile_stats_h) whenever the launch is unsplit; merged by t2i_bn_stats_tiles they equal the moments of the stored
+    tensor (fp32 summation-order accuracy), for every tile shape incl. ragged M (bf16 tensors have multiples of 64 channels); a split launch declines."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    K.set_storage('bf16')
+    try:
+        for tile, (B, H, W, Ci, Co, k) in ((22, (4, 16, 16, 64, 192, 3)), (21, (3, 8, 8, 128, 64, 3)), (12, (2, 32, 32, 64, 128, 1)), (11, (5, 4, 4, 64, 192, 3)),
+                                           (42, (5, 16, 16, 64, 128, 3)), (0, (64, 16, 16, 256, 256, 3))):
+            K.tuning_set('force_tile', tile); K.tuning_set('force_splitk', 1 if tile else 0)
+            d, ws = K.conv_desc(B, H, W, Ci, Co, k, k, 1, 1, 'SAME')
+            x = bf(torch.randn(B, H, W, Ci, generator=g, device='cuda'))
+            w = torch.randn(k, k, Ci, Co, generator=g, device='cuda') / (k * Ci ** 0.5)
+            b = torch.randn(Co, generator=g, device='cuda')
+            y = K.conv_fwd_stats(x, w, b, d, 256 << 20, K.ACT_NONE)
+            assert y.dtype == torch.bfloat16
+            got = K.take_stats(y)
+            assert got is not None or tile == 0, (tile, 'a forced unsplit launch must leave statistics')
+            assert torch.equal(y, K.conv_fwd(x, w, b, d, 256 << 20, K.ACT_NONE))
+            if got is not None:
+                ref = y.double().reshape(-1, Co)
+                scale = float((ref * ref).sum(0).sqrt().max())
+                assert float((got[0].double() - ref.sum(0)).abs().max()) <= 1e-5 * scale * ref.shape[0] ** 0.5, tile
+                m2 = ((ref - ref.mean(0, keepdim=True)) ** 2).sum(0)
+                assert float((got[1].double() - m2).abs().max()) <= 1e-5 * float(m2.max()), tile
+        K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 3)
+        d, ws = K.conv_desc(2, 4, 4, 512, 256, 3, 3, 1, 1, 'SAME')
+        y = K.conv_fwd_stats(bf(torch.randn(2, 4, 4, 512, generator=g, device='cuda')), torch.randn(3, 3, 512, 256, generator=g, device='cuda') * 0.02, None, d, 256 << 20)
+        assert K.take_stats(y) is None
+    finally:
+        K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0)
+        K.set_storage('f32')
+
+
 def test_boundary_layers_with_bf16_tensors(K):
     """3 -> 128 stem (fp32 image in, bf16 out, native), its filter gradient and the 128 -> 3 transposed conv (bf16 in, staged), the
     logit head (bf16 in, fp32 out and back)."""

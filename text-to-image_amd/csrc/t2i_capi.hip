@@ -134,6 +134,7 @@ static Tuning& tuning_mut() {
     v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
     v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
     v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
+    v.h_stats = env_int("T2I_H_STATS", 1);                 // bf16-operand forward GEMM: batch-norm statistics from the epilogue (0: the batch norm reduces the tensor itself)
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
     v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
     v.pair = env_int("T2I_PAIR", 1);                       // t2i_conv2d_bwd_pair: the two GEMMs in one launch where both are bf16-operand DMA kernels (0: two launches)
@@ -404,7 +405,7 @@ static int finish_pending(const PendingGemm& g, hipStream_t stream, const char* 
 
 static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void* in_h, const float* w, const float* bias, float* out, void* out_h,
                   int32_t* out_h_written, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t stream, const char* what,
-                  PendingGemm* defer = nullptr, int cus = 256) {
+                  PendingGemm* defer = nullptr, int cus = 256, float* stats = nullptr, int* stats_chunks = nullptr, int* stats_tile_rows = nullptr) {
   IgemmParams p;
   size_t n_in, out_elems;
   h_problem(p, d, mode, &n_in, &out_elems);
@@ -444,6 +445,13 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
   } else {
     p.c = out; p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = 0;
     if (out_h && aligned16(out_h)) { p.c_h = out_h; if (out_h_written) *out_h_written = 1; }
+    // batch-norm statistics from the epilogue (tile_stats_h): unsplit forward launches of the LDS-DMA kernel whose epilogue goes through LDS
+    if (stats && mode == MODE_FWD && !defer && tuning().h_stats && tuning().bf16_dma && tuning().vec_epi && (p.N % 8) == 0 && (p.out_elems % 4) == 0 &&
+        aligned16(p.c) && aligned16(p.c_h) && aligned16(bias)) {
+      p.stats = stats;
+      if (stats_chunks) *stats_chunks = pl.tiles_m;
+      if (stats_tile_rows) *stats_tile_rows = 64 * pl.wmt;
+    }
   }
   if (defer) {
     defer->set = true; defer->mode = mode; defer->wmt = pl.wmt; defer->wnt = pl.wnt; defer->p = p;
@@ -704,8 +712,18 @@ struct Staging {           // fp32 copies carved from the front of the workspace
   }
 };
 
+static int conv2d_fwd_storage(const t2i_conv_desc* d, const void* xv, const float* w, const float* bias, void* yv, int act,
+                              float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream,
+                              float* stats, int* stats_chunks, int* stats_tile_rows);
+
 int t2i_conv2d_fwd(const t2i_conv_desc* d, const void* xv, const float* w, const float* bias, void* yv, int act,
                    float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream) {
+  return conv2d_fwd_storage(d, xv, w, bias, yv, act, alpha, opts, ws, ws_bytes, stream, nullptr, nullptr, nullptr);
+}
+
+static int conv2d_fwd_storage(const t2i_conv_desc* d, const void* xv, const float* w, const float* bias, void* yv, int act,
+                              float alpha, t2i_conv_opts* opts, void* ws, size_t ws_bytes, t2i_stream_t stream,
+                              float* stats, int* stats_chunks, int* stats_tile_rows) {
   const bool xh = in_h(opts, 0), yh = out_h(opts);
   if (!xh && !yh)
     return conv2d_fwd_impl(d, reinterpret_cast<const float*>(xv), w, bias, reinterpret_cast<float*>(yv), act, alpha, nullptr, nullptr, nullptr, opts,
@@ -721,7 +739,7 @@ int t2i_conv2d_fwd(const t2i_conv_desc* d, const void* xv, const float* w, const
   if (!head && h_eligible(*d, false) && (d->Cout % 4) == 0 && aligned16(xv) && aligned16(w) && aligned16(yv))
     return conv_h(MODE_FWD, d, xh ? nullptr : reinterpret_cast<const float*>(xv), xh ? xv : opts->a_image, w, bias,
                   yh ? nullptr : reinterpret_cast<float*>(yv), yh ? yv : opts->out_image, yh ? nullptr : &opts->out_image_written, act, alpha, ws,
-                  ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)");
+                  ws_bytes, (hipStream_t)stream, "t2i_conv2d_fwd(bf16 operands)", nullptr, 256, stats, stats_chunks, stats_tile_rows);
   const size_t nx = (size_t)d->B * d->H * d->W * d->Cin, ny = (size_t)d->B * d->Ho * d->Wo * d->Cout;
   Staging st{reinterpret_cast<char*>(ws), ws_bytes, 0};
   const float* x32 = reinterpret_cast<const float*>(xv);
@@ -744,9 +762,12 @@ int t2i_conv2d_fwd_stats(const t2i_conv_desc* d, const void* x, const float* w, 
                          float alpha, float* stats, size_t stats_bytes, int32_t* chunks, int32_t* tile_rows, t2i_conv_opts* opts,
                          void* ws, size_t ws_bytes, t2i_stream_t stream) {
   if (!stats || !chunks || !tile_rows || stats_bytes < t2i_conv2d_stats_bytes(d)) { set_error("t2i_conv2d_fwd_stats: stats buffer missing or too small"); return T2I_ERR_INVALID; }
-  if (in_h(opts, 0) || out_h(opts)) {         // bf16 storage: the bf16-operand kernel has no statistics epilogue; the batch norm reduces y itself
+  if (in_h(opts, 0) || out_h(opts)) {         // bf16 storage: statistics from the bf16-operand kernel's epilogue where the launch is unsplit (round 4)
     *chunks = 0; *tile_rows = 0;
-    return t2i_conv2d_fwd(d, x, w, bias, y, act, alpha, opts, ws, ws_bytes, stream);
+    int c = 0, tr = 0;
+    const int rc = conv2d_fwd_storage(d, x, w, bias, y, act, alpha, opts, ws, ws_bytes, stream, stats, &c, &tr);
+    *chunks = c; *tile_rows = tr;
+    return rc;
   }
   int c = 0, tr = 0;          // number of M-tiles and their height, reported by the plan that launched (run_gemm)
   const int rc = conv2d_fwd_impl(d, reinterpret_cast<const float*>(x), w, bias, reinterpret_cast<float*>(y), act, alpha, stats, &c, &tr, opts, ws, ws_bytes, stream);
@@ -1351,7 +1372,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -208,6 +208,80 @@ __device__ __forceinline__ void store_tile_h(const IgemmParams& p, const PhaseIn
   }
 }
 
+// Batch-norm statistics from the epilogue of a bf16-operand forward GEMM (round 4; igemm_kernel's scheme, t2i_igemm.hip): per column
+// the tile's SUM and its second moment ABOUT THE TILE'S OWN MEAN of the values the batch norm will read — act(acc + bias), rounded
+// to bf16 when the output tensor is bf16 — written as p.stats[2][tiles_m][N]; the batch norm merges the tiles with Chan's update
+// (t2i_bn_train_fwd_stats) instead of reading the activation again.  Two passes over the accumulators (still in registers); lanes l and
+// l ^ 32 hold the same column, the NWM waves stacked along M meet in LDS.  lds: NWM * BN floats, free (the caller synchronises).
+template <int WMT, int WNT, int NWM>
+__device__ __forceinline__ void tile_stats_h(const IgemmParams& p, const f32x16 (&acc)[WMT][WNT], float* red, int bm, int bn, int tile_m, int tiles_m) {
+  constexpr int BM = 32 * WMT * NWM, BN = 64 * WNT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const bool round_h = p.c_h != nullptr && p.c == nullptr;       // the tensor the batch norm reads is the bf16 one
+  auto value = [&](float a, float bv) __attribute__((always_inline)) {
+    float v = apply_act(a + bv, p.act, p.alpha);
+    if (round_h) v = __uint_as_float(pk2(v, 0.f) << 16);
+    return v;
+  };
+  float bv[WNT], cs[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int n = bn + wn * 32 * WNT + j * 32 + l31;
+    bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        s += (m < p.M) ? value(acc[i][j][e], bv[j]) : 0.f;
+      }
+    cs[j] = s + __shfl_xor(s, 32, 64);
+    if (lh == 0) red[wm * BN + wn * 32 * WNT + j * 32 + l31] = cs[j];
+  }
+  __syncthreads();
+  const float rows_tile = (float)min(BM, p.M - bm);
+  float cq[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int col = wn * 32 * WNT + j * 32 + l31;
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < NWM; ++g) tot += red[g * BN + col];
+    const float mean = tot / rows_tile;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm + wm * 32 * WMT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float dlt = value(acc[i][j][e], bv[j]) - mean;
+        q += (m < p.M) ? dlt * dlt : 0.f;
+      }
+    cq[j] = q + __shfl_xor(q, 32, 64);
+  }
+  __syncthreads();                                   // the sums have been read by everyone
+  float tsum = 0.f;
+  if (tid < BN) {
+#pragma unroll
+    for (int g = 0; g < NWM; ++g) tsum += red[g * BN + tid];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < WNT; ++j)
+    if (lh == 0) red[wm * BN + wn * 32 * WNT + j * 32 + l31] = cq[j];
+  __syncthreads();
+  if (tid < BN && bn + tid < p.N) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < NWM; ++g) m2 += red[g * BN + tid];
+    p.stats[(size_t)tile_m * p.N + bn + tid] = tsum;
+    p.stats[((size_t)tiles_m + tile_m) * p.N + bn + tid] = m2;
+  }
+  __syncthreads();                                   // red is free again (the epilogue's staging patches overlap it)
+}
+
 __device__ __forceinline__ bool vec_epilogue_ok(const IgemmParams& p) {
   return p.vec_epi && (p.N & 7) == 0 &&
          ((reinterpret_cast<uintptr_t>(p.c) | reinterpret_cast<uintptr_t>(p.c_h) | reinterpret_cast<uintptr_t>(p.bias) | (uintptr_t)(p.out_elems & 3)) & 15) == 0;
@@ -761,6 +835,8 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   // ---- epilogue: igemm_h_kernel's ---------------------------------------------------------------------------------------------
   if (vec_epilogue_ok(p)) {
     __syncthreads();              // every wave's look-ahead DMAs have landed and nobody reads fragments any more: the LDS is free
+    if (MODE == MODE_FWD && p.stats != nullptr && p.splitk == 1)       // (the host asks for statistics only on this path)
+      tile_stats_h<WMT, WNT, NW / 2>(p, acc, reinterpret_cast<float*>(smem_h), bm, bn, tile_m, tiles_m);
     store_tile_h<MODE, WMT, WNT>(p, pi, acc, reinterpret_cast<float*>(smem_h), bm, bn, split);
     return;
   }
