@@ -357,6 +357,14 @@ size_t t2i_filter_cache_bytes(void);            /* bytes of the attached arena h
  * small fill per (filter, kind) at its first use — ~60 launches.  The bytes moved are the same as with lazy fills as long as
  * an image is not regenerated twice between two updates of its filter. */
 int t2i_filter_cache_refresh(const void* ptr, size_t bytes, t2i_stream_t stream);
+/* v7: marks every cached image whose filter lies inside [ptr, ptr + bytes) as filled for the launch context of `stream` WITHOUT
+ * regenerating it — the caller's promise that, whenever the work issued (or captured) after this call runs, the images in the
+ * cache arena are those of the current filters.  For a captured iteration that regenerates an arena's images behind its own
+ * t2i_adam_tf (mid-graph t2i_filter_cache_refresh): every replay then finds them as the previous replay left them, and the
+ * regeneration at the head of the graph (one read of every filter per iteration) is redundant.  The caller must regenerate
+ * them eagerly (t2i_filter_cache_refresh outside the capture, same stream as the replay) before the first replay and after any
+ * other writer touched the filters (the writers that must call t2i_filter_cache_invalidate).  Launches nothing. */
+int t2i_filter_cache_assume(const void* ptr, size_t bytes, t2i_stream_t stream);
 
 /* ---- bf16 operand images (T2I_MATH_BF16) --------------------------------------------------------------------------
  * out[i] = bf16(x[i]), round to nearest even; n % 8 == 0, both buffers 16-byte aligned.  The image of an activation tensor

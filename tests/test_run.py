@@ -101,6 +101,20 @@ def test_main_trains_with_side_effects(tmp_path, graphs):
         'train_00_0002.png', 'train_01_0004.png', 'train_02_0006.png'], samples
     from PIL import Image
     assert Image.open(str(tmp_path / 'samples' / 'train_00_0002.png')).size == (3 * 64, 3 * 64)
+    # the TensorBoard event file of reference trainer.py:20-47,104-107: version record + one merged summary at idx 2, 4, 6
+    from t2i_amd.utils import summary as S
+    logs_dir = str(tmp_path / 'logs')
+    ev_files = [f for f in os.listdir(logs_dir) if f.startswith('events.out.tfevents.')]
+    assert len(ev_files) == 1, ev_files
+    ev = S.read_events(os.path.join(logs_dir, ev_files[0]))
+    assert ev[0]['file_version'] == 'brain.Event:2' and [e['step'] for e in ev[1:]] == [2, 4, 6]
+    tags = [v['tag'] for v in ev[1]['values']]
+    assert tags[:6] == ['x/image/0', 'x/image/1', 'x/image/2', 'G_img/image/0', 'G_img/image/1', 'G_img/image/2'] and tags[6:8] == ['z', 'z_sample']
+    assert tags[8:] == ['G_loss_wass', 'kl_loss', 'G_loss', 'D_loss_real', 'D_loss_fake', 'real_gp', 'D_loss', 'reg_loss', 'wdist', 'wdist2',
+                        'd_loss_mismatch', 'real_gp2', 'kt', 'balance_loss'], tags
+    last = {v['tag']: v for v in ev[-1]['values']}
+    assert abs(last['D_loss']['simple_value'] - float(out['d']['D_loss'])) <= 1e-6 * max(1.0, abs(float(out['d']['D_loss'])))
+    assert S.decode_png(last['G_img/image/0']['image']['png']).shape == (64, 64, 3) and last['z']['histo']['num'] == 4 * 8
     ck = sorted(os.listdir(str(tmp_path / 'ckpt')))
     assert ck == ['checkpoint', 'model-2.npz'], ck
     z = np.load(str(tmp_path / 'ckpt' / 'model-2.npz'))

@@ -71,11 +71,12 @@ def relerr(got, ref, scale=None):
     return float(np.abs(got - ref).max() / max(s, 1e-30))
 
 
-@pytest.fixture(scope='module', params=[64, 16], ids=['B64', 'B16'])
+@pytest.fixture(scope='module', params=[64, 16, 8], ids=['B64', 'B16', 'B8'])
 def setup(request):
     """B = 64: the metric's batch (BASELINE configs[1]).  B = 16 (round 4): BASELINE configs[0]'s batch on the HIP path at full
     width, held to the same mask-pinned bounds — so that the kink-tolerant criterion of tests/test_step_gpu.py is never the only
-    full-width check at a batch size the configs name."""
+    full-width check at a batch size the configs name.  B = 8: the yml's BATCH_SIZE (models/wgancls/cfg/flowers.yml:24) = the
+    strong-scaling share of global batch 64 on 8 GPUs (bench.py's b8_per_gpu block), different GEMM plans throughout."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import bench

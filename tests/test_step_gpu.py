@@ -470,10 +470,13 @@ def test_shared_winograd_input_transform_bit_identical(gpu):
             assert torch.equal(got[0][n], base[0][n]), (variant, n)
 
 
-def test_filter_cache_full_width_bit_identical(gpu):
-    """Transformed-filter cache (include/t2i_hip.h) at the benchmark's widths, where the Winograd paths are live: three
-    iterations with the cache on — eager, and replayed from one hipGraph — leave exactly the weights, Adam state and kt of
-    the run without it; the cache held buffers, and checkpoint-style loads behind the optimizer's back are honoured."""
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_filter_cache_full_width_bit_identical(gpu, math):
+    """Transformed-filter cache (include/t2i_hip.h) at the benchmark's widths, where the Winograd paths (fp32) / the bf16 filter
+    images are live: three iterations with the cache on — eager, and replayed from one hipGraph — leave exactly the weights, Adam
+    state and kt of the run without it; the cache held buffers, and checkpoint-style loads behind the optimizer's back are honoured
+    (round 4: the one-graph iteration no longer regenerates the critic's images at its head — t2i_filter_cache_assume — and
+    dg_step regenerates them when kernels.filter_epoch() moved: the load below rewrites a critic and a generator filter)."""
     from t2i_amd import kernels as K
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
@@ -500,16 +503,23 @@ def test_filter_cache_full_width_bit_identical(gpu):
             for i in range(2):
                 tr.iteration(2 + i, feeds[1 + i])
             # a load behind the optimizer's back (ParamStore.load invalidates), then one more step
-            m.store.load({n: (v.detach() * 0.5).cpu().numpy() for n, v in m.store.vars.items() if n.endswith('conv2d_2/kernel')})
+            loaded = {n: (v.detach() * 0.5).cpu().numpy() for n, v in m.store.vars.items() if n.endswith('Conv_6/weights')}
+            assert sorted(loaded) == ['d_net/Conv_6/weights', 'g_net/Conv_6/weights']
+            m.store.load(loaded)
             tr.iteration(4, feeds[3])
+            tr.iteration(5, feeds[0])
             torch.cuda.synchronize()
             held = K.filter_cache_bytes()
             return ({n: v.detach().clone() for n, v in m.store.vars.items()}, m.D_optim.v.clone(), m.G_optim.m.clone(), float(m.kt)), held
         finally:
             K.filter_cache(prev)
 
-    (ref, _), (eager, held), (replay, _) = run(False, False), run(True, False), run(True, True)
-    assert held > 0                                         # the Winograd layers went through the cache
+    K.set_math(math)
+    try:
+        (ref, _), (eager, held), (replay, _) = run(False, False), run(True, False), run(True, True)
+    finally:
+        K.set_math('f32')
+    assert held > 0                                         # the Winograd layers / bf16 filter images went through the cache
     for other in (eager, replay):
         assert other[3] == ref[3]
         assert torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])

@@ -81,6 +81,7 @@ SIGNATURES = {
     't2i_filter_cache_invalidate': (None, [_p, ctypes.c_size_t]),
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),
     't2i_filter_cache_refresh': (ctypes.c_int, [_p, _sz, _p]),
+    't2i_filter_cache_assume': (ctypes.c_int, [_p, _sz, _p]),
     't2i_cast_bf16': (ctypes.c_int, [_p, _i64, _p, _p]),
     't2i_cast_f32': (ctypes.c_int, [_p, _i64, _p, _p]),
     't2i_conv2d_input_transform_bytes': (ctypes.c_size_t, [_dp]),

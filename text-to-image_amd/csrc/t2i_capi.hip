@@ -134,6 +134,7 @@ static Tuning& tuning_mut() {
     v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
     v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
     v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
+    v.pair_reduce = env_int("T2I_PAIR_REDUCE", 1);         // the split-K reductions of a pair launch's two GEMMs in one launch (splitk_reduce2_kernel)
     v.h_stats = env_int("T2I_H_STATS", 0);                 // bf16-operand forward GEMM: batch-norm statistics from the epilogue (0, default: the batch norm reduces the tensor itself; measured round 4: 10 871 vs 10 827 img/s, the reduce is cheaper than the longer epilogue)
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
     v.pair_max_px = env_int("T2I_PAIR_MAX_PX", 49152);     // ... only for layers with at most this many input pixels (B * H * W)
@@ -1001,6 +1002,23 @@ int t2i_conv2d_bwd_pair(const t2i_conv_desc* d, int first, const void* g, const 
       if (rc == T2I_OK) rc = check(igemm_h_filter_launch(gb.p, gb.wmt, gb.wnt, (hipStream_t)stream), what);
     }
     if (rc != T2I_OK) return rc;
+    if (tuning().pair_reduce && ga.p.splitk > 1 && gb.p.splitk > 1) {        // both split: their reductions share a launch too
+      auto job = [](const PendingGemm& q) {
+        ReduceJob j;
+        j.slabs = q.slabs; j.bias = q.bias; j.out = q.out; j.out_h = q.out_h; j.out_elems = q.p.out_elems; j.alpha = q.alpha;
+        j.splitk = q.p.splitk; j.N = q.p.N; j.act = q.act; j.accumulate = q.accumulate; j.blocks = 0;
+        return j;
+      };
+      const ReduceJob ja = job(ga), jb = job(gb);
+      if (splitk_reduce2_ok(ja, jb)) {
+        rc = check(splitk_reduce2_launch(ja, jb, (hipStream_t)stream), what);
+        if (rc == T2I_OK) {
+          if (ga.out_h && ga.out_h_written) *ga.out_h_written = 1;
+          if (gb.out_h && gb.out_h_written) *gb.out_h_written = 1;
+        }
+        return rc;
+      }
+    }
     if ((rc = finish_pending(ga, (hipStream_t)stream, what))) return rc;
     return finish_pending(gb, (hipStream_t)stream, what);
   }
@@ -1372,7 +1390,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }
@@ -1419,6 +1437,7 @@ void t2i_filter_cache_invalidate(const void* p, size_t bytes) { filter_cache_inv
 size_t t2i_filter_cache_bytes(void) { return filter_cache_bytes(); }
 
 int t2i_filter_cache_refresh(const void* p, size_t bytes, t2i_stream_t stream) { return filter_cache_refresh(p, bytes, (hipStream_t)stream); }
+int t2i_filter_cache_assume(const void* p, size_t bytes, t2i_stream_t stream) { return filter_cache_assume(p, bytes, (hipStream_t)stream); }
 
 int t2i_cast_bf16(const float* x, int64_t n, void* out, t2i_stream_t stream) {
   if (!x || !out || n <= 0 || (n % 8) != 0 || !aligned16(x) || !aligned16(out)) {

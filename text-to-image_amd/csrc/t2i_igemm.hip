@@ -813,12 +813,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 // Split-K reduction: out[i] = act(sum_s slab[s][i] + bias[i % N]); fixed summation order => deterministic.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splitk,
-                                                            size_t out_elems, const float* __restrict__ bias, int N,
-                                                            int act, float alpha, float* __restrict__ out, int accumulate,
-                                                            uint2* __restrict__ outh) {
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ slabs, int splitk, size_t out_elems,
+                                                   const float* __restrict__ bias, int N, int act, float alpha,
+                                                   float* __restrict__ out, int accumulate, uint2* __restrict__ outh,
+                                                   unsigned vb, unsigned nvb) {
   const size_t n4 = out_elems >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)vb * 256 + threadIdx.x; i < n4; i += (size_t)nvb * 256) {
     float4 s = reinterpret_cast<const float4*>(slabs)[i];
     for (int k = 1; k < splitk; ++k) {
       float4 v = reinterpret_cast<const float4*>(slabs + (size_t)k * out_elems)[i];
@@ -842,6 +842,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       outh[i] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2)));
     }
   }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splitk,
+                                                            size_t out_elems, const float* __restrict__ bias, int N,
+                                                            int act, float alpha, float* __restrict__ out, int accumulate,
+                                                            uint2* __restrict__ outh) {
+  splitk_reduce_body(slabs, splitk, out_elems, bias, N, act, alpha, out, accumulate, outh, blockIdx.x, gridDim.x);
+}
+
+// The reductions of the two GEMMs of one launch (igemm_pair_kernel) in one launch: blocks [0, a.blocks) sum a's slabs, the rest b's —
+// each exactly as splitk_reduce_kernel would (same order, same bits).
+__global__ __launch_bounds__(256) void splitk_reduce2_kernel(ReduceJob a, ReduceJob b) {
+  if (blockIdx.x < (unsigned)a.blocks)
+    splitk_reduce_body(a.slabs, a.splitk, a.out_elems, a.bias, a.N, a.act, a.alpha, a.out, a.accumulate, reinterpret_cast<uint2*>(a.out_h), blockIdx.x, a.blocks);
+  else
+    splitk_reduce_body(b.slabs, b.splitk, b.out_elems, b.bias, b.N, b.act, b.alpha, b.out, b.accumulate, reinterpret_cast<uint2*>(b.out_h),
+                       blockIdx.x - a.blocks, b.blocks);
 }
 
 // Deep splits of small outputs (the critic's first-layer filter gradient: 48x128 outputs, 128-256 slabs): one thread per
@@ -950,6 +967,24 @@ hipError_t igemm_launch(int mode, const IgemmParams& p, int wmt, int wnt, int va
     case MODE_BWD_FILTER: return launch_mode<MODE_BWD_FILTER, 0>(p, wmt, wnt, var, grid, stream);
   }
   return hipErrorInvalidValue;
+}
+
+// true: both jobs take splitk_reduce_kernel's vector path (not the deep or the scalar one), so one launch can serve both
+bool splitk_reduce2_ok(const ReduceJob& a, const ReduceJob& b) {
+  auto plain = [](const ReduceJob& j) {
+    return j.splitk > 1 && (j.out_elems & 3) == 0 && (j.N & 3) == 0 && !(j.splitk >= 32 && (j.out_elems >> 2) <= 65536);
+  };
+  return plain(a) && plain(b);
+}
+
+hipError_t splitk_reduce2_launch(ReduceJob a, ReduceJob b, hipStream_t stream) {
+  auto nblocks = [](const ReduceJob& j) {
+    int blocks = (int)(((j.out_elems >> 2) + 255) / 256);
+    return blocks > 4096 ? 4096 : blocks < 1 ? 1 : blocks;
+  };
+  a.blocks = nblocks(a); b.blocks = nblocks(b);
+  hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(a.blocks + b.blocks), dim3(256), 0, stream, a, b);
+  return hipGetLastError();
 }
 
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,

@@ -96,6 +96,7 @@ int filter_cache_attach(void* buf, size_t bytes);
 void filter_cache_invalidate(const void* p, size_t bytes);
 size_t filter_cache_bytes();
 int filter_cache_refresh(const void* p, size_t bytes, hipStream_t stream);
+int filter_cache_assume(const void* p, size_t bytes, hipStream_t stream);
 size_t winograd_k4s2_bwd_ws(const t2i_conv_desc& d);
 int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float* w, const float* bias, float* dx, int act, float alpha,
                            void* ws, size_t ws_bytes, hipStream_t stream);
@@ -121,6 +122,12 @@ hipError_t cast_f32_launch(const void* x_bf16, size_t n, float* y, hipStream_t s
 hipError_t wcast_launch(const float* w, int taps, int Ci, int Co, int transpose, void* out, hipStream_t stream);
 // slot of the caller-owned filter-cache arena for (filter, kind) — nullptr when the cache cannot serve it (t2i_winograd.hip)
 float* filter_cache_get(const float* w, int kind, int Cin, int Cout, size_t bytes, hipStream_t stream, bool* fill);
+// one split-K reduction as splitk_reduce_launch's arguments (the pair launch issues two in one kernel)
+struct ReduceJob {
+  const float* slabs; const float* bias; float* out; void* out_h; size_t out_elems; float alpha; int splitk, N, act, accumulate, blocks;
+};
+bool splitk_reduce2_ok(const ReduceJob& a, const ReduceJob& b);
+hipError_t splitk_reduce2_launch(ReduceJob a, ReduceJob b, hipStream_t stream);
 hipError_t splitk_reduce_launch(const float* slabs, int splitk, size_t out_elems, const float* bias, int N, int act,
                                 float alpha, float* out, int accumulate, hipStream_t stream, void* out_h = nullptr, bool* wrote_h = nullptr);
 
@@ -145,7 +152,7 @@ hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce;
   double split_cost;
 };
 const Tuning& tuning();

@@ -939,6 +939,27 @@ __global__ __launch_bounds__(256) void filter_refresh_kernel(RefreshBatch tb) {
   }
 }
 
+// Marks the entries refresh would regenerate as filled for the launch context, launching nothing: the caller vouches for the bytes
+// (include/t2i_hip.h: t2i_filter_cache_assume).
+int filter_cache_assume(const void* p, size_t bytes, hipStream_t stream) {
+  if (!g_fc_on) return T2I_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return T2I_OK; }
+  const unsigned long long cap = st == hipStreamCaptureStatusActive ? id + 1 : 0;
+  std::lock_guard<std::mutex> lk(g_fc_mu);
+  if (!g_fc_buf) return T2I_OK;
+  const char* lo = reinterpret_cast<const char*>(p);
+  for (auto& e : g_fc) {
+    const char* q = reinterpret_cast<const char*>(e.w);
+    const size_t wbytes = (size_t)(e.kind == 0 ? 9 : e.kind == 2 ? 16 : (int)(e.bytes / ((size_t)e.Cin * e.Cout * 2))) * e.Cin * e.Cout * 4;
+    if (p && !(q >= lo && q + wbytes <= lo + bytes)) continue;
+    if (!cap && e.stream != stream) continue;
+    e.valid = true; e.cap = cap; e.cap_fill = nullptr;
+  }
+  return T2I_OK;
+}
+
 // Regenerates every cache entry whose filter lies in [p, p + bytes) (p == NULL: every entry) and that this launch context may
 // use (same rules as filter_cache_get), marking it valid for the context: eager launches after it, or the rest of the capture
 // it was recorded into, find the images filled.

@@ -1027,8 +1027,21 @@ def kt_sgd(kt, wdist_sums, scale, lr):
         check(lib.t2i_kt_sgd(_ptr(kt), _ptr(wdist_sums), scale, lr, _stream()), 't2i_kt_sgd')
 
 
-def filter_cache_invalidate(t=None):
-    """Drop cached transforms of the filters inside tensor `t` (None: all)."""
+_FILTER_EPOCH = [0]
+
+
+def filter_epoch():
+    """Counts the filter writes announced from OUTSIDE a training step (checkpoint loads, broadcasts, new arenas ...): a captured
+    iteration that trusts the images its previous replay left (filter_cache_assume) regenerates them eagerly when this moved."""
+    return _FILTER_EPOCH[0]
+
+
+def filter_cache_invalidate(t=None, external=True):
+    """Drop cached transforms of the filters inside tensor `t` (None: all).  external=False: the caller is a training step's own
+    replay, which left the images of the arenas it regenerates behind its updates valid in memory (only the host's bookkeeping is
+    stale); every other writer of filter memory leaves the default, which also moves filter_epoch()."""
+    if external:
+        _FILTER_EPOCH[0] += 1
     if t is None:
         lib.t2i_filter_cache_invalidate(None, 0)
     elif t.is_cuda:
@@ -1047,6 +1060,12 @@ def filter_cache_refresh(t=None):
         check(lib.t2i_filter_cache_refresh(None, 0, _stream()), 't2i_filter_cache_refresh')
     else:
         check(lib.t2i_filter_cache_refresh(_ptr(t), t.numel() * t.element_size(), _stream()), 't2i_filter_cache_refresh')
+
+
+def filter_cache_assume(t):
+    """Mark the cached images of the filters inside tensor `t` as filled for the current launch context without regenerating them
+    (include/t2i_hip.h t2i_filter_cache_assume: the caller vouches that they will be current whenever the following work runs)."""
+    check(lib.t2i_filter_cache_assume(_ptr(t), t.numel() * t.element_size(), _stream()), 't2i_filter_cache_assume')
 
 
 def lerp_dev(a, b, t_dev, mode=0):

@@ -28,6 +28,9 @@ from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_tra
 _CAPTURE_MODE = os.environ.get('T2I_DP_CAPTURE_MODE', 'thread_local')
 # one-graph iteration (single GPU): issue the G step's generator forward on a second stream beside the critic step
 _OVERLAP_G_FORWARD = os.environ.get('T2I_OVERLAP_G_FORWARD', '1') != '0'
+# the one-graph iteration trusts the critic's filter images its previous replay regenerated behind the critic's Adam step instead
+# of regenerating them again at its head (dg_step keeps them current across outside writers): T2I_TRUST_IMAGES=0 restores the refresh
+_TRUST_IMAGES = os.environ.get('T2I_TRUST_IMAGES', '1') != '0'
 
 
 class WGanCls(object):
@@ -242,7 +245,7 @@ class WGanCls(object):
             if self.dp is not None:            # the exchange step runs between the two captured halves
                 self.dp.allreduce_arena(self.d_arena, extra=out['wd_sums'])
                 self._graphs['d_upd'].replay()
-            K.filter_cache_invalidate()        # the replay rewrote filters (and cached transforms) behind the host's back
+            K.filter_cache_invalidate(external=False)        # the replay rewrote filters (and cached transforms) behind the host's back
         else:
             out = self._d_body(feed)
         self.global_step += 1
@@ -345,7 +348,7 @@ class WGanCls(object):
             if self.dp is not None:
                 self.dp.allreduce_arena(self.g_arena)
                 self._graphs['g_upd'].replay()
-            K.filter_cache_invalidate()
+            K.filter_cache_invalidate(external=False)
             return self._graphs['g_out']
         return self._g_body(feed)
 
@@ -363,6 +366,11 @@ class WGanCls(object):
         self._load_static(feed)
         g['loaded'] = False
         if self.dp is None:
+            if g.get('trust') and g.get('epoch') != K.filter_epoch():
+                # the graph does not regenerate the critic's filter images at its head (enable_graphs): before the first replay, and
+                # whenever someone outside the training step wrote filters since the last one, they are regenerated here
+                g['dref'].replay()
+                g['epoch'] = K.filter_epoch()
             g['dg'].replay()
         else:
             # five graph launches, four collectives; each backward is cut once so that the bulk of its gradients is on the wire
@@ -380,7 +388,7 @@ class WGanCls(object):
             self.dp.start_allreduce(self.g_arena, ranges=gB)
             self.dp.finish_allreduce(self.g_arena)
             g['g_upd'].replay()
-        K.filter_cache_invalidate()
+        K.filter_cache_invalidate(external=False)
         self.global_step += 1
         return g['dg_out']
 
@@ -462,14 +470,24 @@ class WGanCls(object):
             with torch.cuda.graph(gg, pool=gd.pool()):
                 self._refresh_filters()
                 g_out = self._g_body(static)
+            gref = torch.cuda.CUDAGraph()                # the critic's filter images alone (dg_step: after an outside write); captured,
+            with torch.cuda.graph(gref, pool=gd.pool()): # because a capture regenerates every image the cache holds of the range
+                K.filter_cache_refresh(self.d_arena.flat)
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
             with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
-                self._refresh_filters()
+                if _TRUST_IMAGES:
+                    # the critic's images were regenerated behind its Adam step by the previous replay (_d_update: refresh=True) —
+                    # by whichever step function ran last, in fact: all of them leave the critic's images current — so only the
+                    # generator's are due here; dg_step vouches for the critic's (t2i_filter_cache_assume)
+                    K.filter_cache_assume(self.d_arena.flat)
+                    K.filter_cache_refresh(self.g_arena.flat)
+                else:
+                    self._refresh_filters()
                 ahead = self._g_forward_ahead(static) if _OVERLAP_G_FORWARD else None   # beside the critic step, not after it
                 d_out2 = self._d_body(static)
                 g_out2 = self._g_body(static, ahead)
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
-                            'static': static, 'loaded': False}
+                            'static': static, 'loaded': False, 'trust': _TRUST_IMAGES, 'epoch': None, 'dref': gref}
             return
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -69,11 +69,39 @@ class WGanClsTrainer(object):
                      {'kt': (lambda: m.kt.detach().cpu().numpy(), set_kt), 'global_step': (lambda: m.global_step, set_step)},
                      max_to_keep=int(getattr(self.cfg.TRAIN, 'CHECKPOINTS_TO_KEEP', 5)))
 
+    def define_summaries(self):
+        """reference trainer.py:20-47: a tf.summary.FileWriter on cfg.LOGS_DIR (utils/summary.py writes the same event-file
+        format without TensorFlow)."""
+        from ...utils.summary import FileWriter
+        self.writer = FileWriter(self.cfg.LOGS_DIR)
+
+    def write_summaries(self, idx, feed, out, sample_z=None):
+        """The merged summary of reference trainer.py:21-45 at step idx: images `x` and `G_img` (first 3 of the batch, normalised as
+        tf.summary.image does), histograms `z` / `z_sample`, and the fourteen scalars under the reference's tags.  The reference
+        re-evaluates these tensors in a third sess.run AFTER the updates (with a fresh noise draw); here they are the values the
+        iteration itself computed — the same quantities one update earlier — so that logging costs no extra forward pass."""
+        from ...utils import summary as S
+        d, g = out['d'], out.get('g')
+        np_ = lambda t: t.detach().float().cpu().numpy()
+        vals = [S.image('x', np_(feed['x'])), S.image('G_img', np_(d['G'])), S.histogram('z', np_(feed['z']))]
+        if sample_z is not None:
+            vals.append(S.histogram('z_sample', np_(sample_z)))
+        if g is not None:
+            vals += [S.scalar('G_loss_wass', -float(g['D_loss_fake'])), S.scalar('kl_loss', float(g['G_kl_loss'])),
+                     S.scalar('G_loss', float(g['G_loss']))]
+        for tag, key in (('D_loss_real', 'D_loss_real'), ('D_loss_fake', 'D_loss_fake'), ('real_gp', 'real_gp'), ('D_loss', 'D_loss'),
+                         ('reg_loss', 'reg_loss'), ('wdist', 'wdist'), ('wdist2', 'wdist2'), ('d_loss_mismatch', 'D_loss_mismatch'),
+                         ('real_gp2', 'real_gp2'), ('kt', 'kt'), ('balance_loss', 'balance_loss')):
+            vals.append(S.scalar(tag, float(d[key])))
+        self.writer.add_summary(vals, idx)
+        self.writer.flush()
+
     def train(self, max_steps=None, start_point=None, log=None, side_effects=False, graphs=False):
         """reference trainer.py:49-126.  With side_effects=True the periodic work around the hot path is on as in the
         reference: resume from the latest checkpoint in cfg.CHECKPOINT_DIR, captions of the fixed sample batch, a PNG grid
-        of `sampler` outputs every TRAIN.SAMPLE_PERIOD iterations, a checkpoint when idx % 500 == 2.  TF summaries are
-        replaced by the scalar log line (every SUMMARY_PERIOD iterations); the scalars are also returned per iteration.
+        of `sampler` outputs every TRAIN.SAMPLE_PERIOD iterations, a checkpoint when idx % 500 == 2, and a TensorBoard event file
+        in cfg.LOGS_DIR with the reference's images / histograms / scalars every SUMMARY_PERIOD iterations (write_summaries), next to
+        the scalar log line; the scalars are also returned per iteration.
         graphs=True: once a critic step and a generator step have run eagerly, the iteration is captured into hipGraphs and
         replayed (bit-identical to the eager launches, including the order of the conditioning-noise draws)."""
         from ...utils.saver import load, save
@@ -87,6 +115,8 @@ class WGanClsTrainer(object):
             _, sample_cond, _, captions = self.dataset.test.next_batch_test(m.sample_num, 0, 1)
             sample_cond = sample_cond[0]
             save_captions(self.cfg.SAMPLE_DIR, captions)
+            if getattr(self.cfg, 'LOGS_DIR', None):
+                self.define_summaries()
             could_load, counter = load(self.saver, None, self.cfg.CHECKPOINT_DIR)
             if start_point is None:
                 start_point = counter if could_load else 0
@@ -105,6 +135,8 @@ class WGanClsTrainer(object):
                 log('[%6d] D_loss %.4f G_loss %.4f wdist %.4f wdist2 %.4f gp %.4f gp2 %.4f kt %.4f (%.1fs)' % (
                     idx, float(d['D_loss']), float(g.get('G_loss', float('nan'))), float(d['wdist']), float(d['wdist2']),
                     float(d['real_gp']), float(d['real_gp2']), float(self.model.kt), time.time() - t0))
+            if side_effects and getattr(self, 'writer', None) is not None and idx % self.cfg.TRAIN.SUMMARY_PERIOD == 0:
+                self.write_summaries(idx, feed, out, sample_z)
             if side_effects:
                 epoch = idx // max(self.dataset.train.num_examples // m.batch_size, 1)
                 if idx % self.cfg.TRAIN.SAMPLE_PERIOD == 0:
