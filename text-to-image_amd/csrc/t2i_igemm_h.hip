@@ -602,8 +602,12 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   const int Csrc = (MODE == MODE_FWD) ? p.d.Cin : p.d.Cout;
   const int Wsrc = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
   const unsigned Hs = (MODE == MODE_FWD) ? p.d.H : p.d.Ho, Ws = (MODE == MODE_FWD) ? p.d.W : p.d.Wo;
-  int a_rowoff[A_LD], a_h0[A_LD], a_w0[A_LD];
-  bool a_ok[A_LD];
+  // Per-row loader state (round 4, second pass: the per-K-tile address arithmetic was 19 % of the loop — profiles/r04_bf16_loop_ablation.txt):
+  //   a_off2   byte offset of the row's pixel at tap (0, 0), this thread's 16-byte chunk included (may be "negative": padding)
+  //   a_hw     which taps are inside the image for this row: bit jh = row h0 +- jh is, bit 16 + jw = column w0 +- jw is; 0 = no such row
+  //   b_off2   byte offset of filter row n (poisoned beyond the buffer for n >= N: adding a tap offset < 2^30 keeps it there)
+  // A K-tile then costs one add, one and, one compare and one select per A row and one add per B row; tap decode is scalar.
+  unsigned a_off2[A_LD], a_hw[A_LD], b_off2[B_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = bm + r0 + RPP * i;
@@ -628,16 +632,20 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
       w0 = iwq + pi.ow_off;
       ok = ok && (ihq * p.d.SH + pi.ph < p.d.H) && (iwq * p.d.SW + pi.pw < p.d.W);
     }
-    a_ok[i] = ok; a_h0[i] = h0; a_w0[i] = w0;
-    a_rowoff[i] = (base + h0 * Wsrc + w0) * Csrc + kg * 8;
+    // taps j in [lo, hi) are inside: forward h0 + j in [0, Hs); input gradient h0 - j in [0, Hs)
+    const int nh = (MODE == MODE_FWD) ? p.d.KH : pi.nth, nw = (MODE == MODE_FWD) ? p.d.KW : pi.ntw;    // <= 15 each (host side)
+    auto taps_in = [](int x0, int size, int n) __attribute__((always_inline)) {
+      const int lo = (MODE == MODE_FWD) ? max(0, -x0) : max(0, x0 - size + 1);
+      const int hi = (MODE == MODE_FWD) ? min(n, size - x0) : min(n, x0 + 1);
+      return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    a_hw[i] = ok ? (taps_in(h0, (int)Hs, nh) | (taps_in(w0, (int)Ws, nw) << 16)) : 0u;
+    a_off2[i] = (unsigned)((base + h0 * Wsrc + w0) * Csrc + kg * 8) * 2u;
   }
-  int b_rowoff[B_LD];
-  bool b_ok[B_LD];
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
     const int n = bn + r0 + RPP * i;
-    b_ok[i] = n < p.N;
-    b_rowoff[i] = n * Csrc + kg * 8;
+    b_off2[i] = n < p.N ? (unsigned)(n * Csrc + kg * 8) * 2u : 0xC0000000u;
   }
   const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr_h)(As + wave_u * 8 * ROW);   // this wave's 8 rows of row group 0, buffer 0
   const unsigned lds_b0 = (unsigned)(size_t)(lds_ptr_h)(Bs + wave_u * 8 * ROW);
@@ -646,28 +654,35 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
     const int k0 = kbeg + t * HBK;
     const int tap = p.div_c.div(k0);                   // wave-uniform
     const int c0 = k0 - tap * Csrc;
-    const bool kok = (k0 + kg * 8) < kend;
-    int dh, dw, wtap;
+    const bool kok = (kg * 8) < (kend - k0);           // K tails and the look-ahead tiles past the end read zeros
+    int dh, dw, wtap, jh, jw;
     if (MODE == MODE_FWD) {
-      dh = p.div_kw.div(tap);
-      dw = tap - dh * p.d.KW;
+      jh = p.div_kw.div(tap);
+      jw = tap - jh * p.d.KW;
+      dh = jh; dw = jw;
       wtap = tap;
     } else {
-      const int jh = pi.div_ntw.div(tap);
-      const int jw = tap - jh * pi.ntw;
+      jh = pi.div_ntw.div(tap);
+      jw = tap - jh * pi.ntw;
       dh = -jh; dw = -jw;
       wtap = (pi.kh0 + jh * p.d.SH) * p.d.KW + (pi.kw0 + jw * p.d.SW);
     }
-    const int sa = (dh * Wsrc + dw) * Csrc + c0;
-    const int sb = wtap * p.N * Csrc + c0;
+    const unsigned sa2 = (unsigned)((dh * Wsrc + dw) * Csrc + c0) * 2u;
+    const unsigned sel = kok ? ((1u << (jh & 15)) | (0x10000u << (jw & 15))) : 0xFFFFFFFFu;      // all ones never matches (bit 15 is never set)
+    const unsigned sb2 = kok ? (unsigned)(wtap * p.N * Csrc + c0) * 2u : 0xC0000000u;
+#if defined(T2I_HEXP) && (T2I_HEXP & 4)      // timing only: no tap decode, no bounds checks — a plain strided GEMM's addressing
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const bool ok = a_ok[i] & kok & ((unsigned)(a_h0[i] + dh) < Hs) & ((unsigned)(a_w0[i] + dw) < Ws);
-      dma16_h(wa, ok ? (unsigned)(a_rowoff[i] + sa) * 2u : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
-    }
+    for (int i = 0; i < A_LD; ++i) dma16_h(wa, a_off2[i] + (t & 7) * 128, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) dma16_h(wb, b_off2[i] + (t & 7) * 128, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      dma16_h(wa, (a_hw[i] & sel) == sel ? a_off2[i] + sa2 : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
-      dma16_h(wb, (b_ok[i] & kok) ? (unsigned)(b_rowoff[i] + sb) * 2u : HOOB, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
+      dma16_h(wb, b_off2[i] + sb2, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
   };
 
   f32x16 acc[WMT][WNT];
@@ -797,10 +812,17 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
       cur = nxt;
     }
   } else {
+#if defined(T2I_HEXP) && (T2I_HEXP & 8)
+  bf16x8 fa[WMT][4], fb[WNT][4];
+#endif
   for (int t = 0; t < ntiles; ++t) {
     const unsigned* as = As + (t & 1) * S::A_DW;
     const unsigned* bs = Bs + (t & 1) * S::B_DW;
+#if defined(T2I_HEXP) && (T2I_HEXP & 8)      // timing only: the fragments are read once
+    if (t == 0)
+#else
     bf16x8 fa[WMT][4], fb[WNT][4];
+#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -814,8 +836,13 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
         fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[row * ROW + (((2 * s + lh) ^ ((row >> 1) & 7)) << 2)]));
       }
     }
+#if !(defined(T2I_HEXP) && (T2I_HEXP & 64))
     __syncthreads();                                   // every wave holds its fragments of tile t: buf[t & 1] is free
+#endif
+#if !(defined(T2I_HEXP) && (T2I_HEXP & 16))
     dma_tile(t + 2, t & 1);                            // past the end: zeros (k >= kend), never read
+#endif
+#if !(defined(T2I_HEXP) && (T2I_HEXP & 32))
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -823,6 +850,12 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 #pragma unroll
         for (int n = 0; n < WNT; ++n)
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
+#else
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int n = 0; n < WNT; ++n) acc[i][n][0] += (float)fa[i][t & 3][0] * (float)fb[n][t & 3][1];
+#endif
     // tile t+1 (issued an iteration ago) has landed when at most this iteration's pieces are outstanding
     if constexpr (A_LD + B_LD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -888,10 +921,13 @@ __global__ __launch_bounds__(256) void igemm_hd_kernel(IgemmParams p) {
   hd_body<MODE, WMT, WNT, PIPE>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 
-// 8 waves, tile 256 x 128 (see hd_body)
-template <int MODE, int PIPE>
+// 8 waves (4 x 2).  WMT = 2: tile 256 x 128 (see hd_body).  WMT = 1: the 128 x 128 tile with 32 x 64 wave tiles — two waves per SIMD on
+// the tile the planner already uses: a wave's K-tile is then 8 MFMAs, 12 fragment reads and 4 DMA pieces, and while one wave of
+// a SIMD pays for its address arithmetic, LDS reads and DMA issue, the other's MFMAs run (the 4-wave loop pays them one after the
+// other: profiles/r04_bf16_loop_ablation.txt).  Same k order per output element: bit-identical to the 4-wave kernel.
+template <int MODE, int WMT, int PIPE>
 __global__ __launch_bounds__(512) void igemm_hd8_kernel(IgemmParams p) {
-  hd_body<MODE, 2, 2, PIPE, 8>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+  hd_body<MODE, WMT, 2, PIPE, 8>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1388,17 +1424,19 @@ hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, 
   return hipErrorInvalidValue;
 }
 
-template <int MODE, int PIPE>
+template <int MODE, int PIPE, int WMT = 2>
 static hipError_t launch_hd8(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = SmemD<4, 2, (PIPE == 8 ? 3 : (PIPE > 2 ? PIPE : 2))>;
-  auto k = igemm_hd8_kernel<MODE, PIPE>;
+  using S = SmemD<2 * WMT, 2, (PIPE == 8 ? 3 : (PIPE > 2 ? PIPE : 2))>;
+  constexpr int EPI = 8 * 32 * (32 * 2 + 4) * 4;       // store_tile_h: one 32 x 68 float patch per wave
+  constexpr int bytes = S::BYTES > EPI ? S::BYTES : EPI;
+  auto k = igemm_hd8_kernel<MODE, WMT, PIPE>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(512), S::BYTES, stream, p);
+  hipLaunchKernelGGL(k, grid, dim3(512), bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -1415,6 +1453,10 @@ hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipS
     if (mode == MODE_FWD) return pipe ? launch_hd8<MODE_FWD, 2>(p, grid, stream) : launch_hd8<MODE_FWD, 0>(p, grid, stream);
     if (mode == MODE_BWD_DATA) return pipe ? launch_hd8<MODE_BWD_DATA, 2>(p, grid, stream) : launch_hd8<MODE_BWD_DATA, 0>(p, grid, stream);
     return hipErrorInvalidValue;
+  }
+  if (wmt == 2 && wnt == 2 && tuning().bf16_dma == 1 && tuning().bf16_waves == 8) {       // the 128 x 128 tile on 8 waves
+    if (mode == MODE_FWD) return launch_hd8<MODE_FWD, 0, 1>(p, grid, stream);
+    if (mode == MODE_BWD_DATA) return launch_hd8<MODE_BWD_DATA, 0, 1>(p, grid, stream);
   }
 #define T2I_H(M_, a, b) if (mode == M_ && wmt == a && wnt == b) return launch_h<M_, a, b>(p, grid, stream);
   T2I_H(MODE_FWD, 2, 2) T2I_H(MODE_FWD, 2, 1) T2I_H(MODE_FWD, 1, 2) T2I_H(MODE_FWD, 1, 1)

@@ -1,0 +1,117 @@
+// dma_ingest.hip — how many bytes per second does ONE compute unit take in through `buffer_load_dwordx4 ... lds` (and through
+// registers) when the data sits in L2, as a function of the access pattern?  The bf16 GEMM's K loop (t2i_igemm_h.hip) stages 32 KB
+// per 128x128x64 K-tile and runs at 0.53-0.67 us per K-tile whatever the loop structure; this isolates the staging.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/probe/libs/dma_ingest tools/probe/dma_ingest.hip && tools/probe/libs/dma_ingest
+// pattern 0: every DMA instruction reads 1 KB contiguous (a pre-tiled operand image)
+// pattern 1: every DMA instruction reads 8 rows x 128 B, rows `stride` bytes apart (an activation tensor with stride/2 channels)
+// mode 0: LDS-DMA   1: global_load_dwordx4 -> ds_write_b128   2: LDS-DMA with 16 MFMAs per wave and K-tile next to it
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+template <int PATTERN, int MODE, int PIECES>
+__global__ __launch_bounds__(256) void ingest(const char* src, unsigned region_bytes, int share, int iters, unsigned stride, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const char* base = src + (size_t)(blockIdx.x / share) * region_bytes;
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  i32x4 rsrc = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)region_bytes, 0x00020000};
+  __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), (short)0, (int)region_bytes, 0x00020000);
+  constexpr int TILE = PIECES * 4 * 1024;          // bytes per K-tile and workgroup
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;   // LDS byte address of the dynamic segment (0 for the only segment)
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  bf16x8 fa, fb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { fa[e] = (__bf16)(float)(lane + e); fb[e] = (__bf16)(float)(lane - e); }
+  const unsigned ncol = PATTERN == 1 ? stride / 128 : 1;
+  for (int t = 0; t < iters; ++t) {
+    const unsigned buf = (t & 1) * TILE;
+    u32x4 regs[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const unsigned piece = wave * PIECES + i;
+      unsigned voff;
+      if (PATTERN == 0) voff = ((t * TILE) % region_bytes) + piece * 1024 + lane * 16;
+      else voff = (piece * 8 + (lane >> 3)) * stride + (t % ncol) * 128 + (lane & 7) * 16;
+      if (MODE == 1) regs[i] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
+      else dma16(rsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + buf + piece * 1024)));
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds) + buf + (wave * PIECES + i) * 1024 + lane * 16) = regs[i];
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i & 3], 0, 0, 0);
+    }
+    if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES) : "memory");     // the previous K-tile has landed
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += acc[i][0];
+  if (lds[tid] == 0x12345678u || s == 1.2345f) sink[blockIdx.x] = s + lds[tid];
+}
+
+template <int PATTERN, int MODE, int PIECES>
+static double run(const char* src, unsigned region, int share, int grid, int iters, unsigned stride, float* sink) {
+  constexpr int TILE = PIECES * 4 * 1024;
+  auto k = ingest<PATTERN, MODE, PIECES>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), 2 * TILE, 0, src, region, share, iters, stride, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k, dim3(grid), dim3(256), 2 * TILE, 0, src, region, share, iters, stride, sink);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(1); }
+  return ms / 5 * 1e3;      // us per launch
+}
+
+int main() {
+  const size_t total = 64u << 20;
+  char* src; float* sink;
+  hipMalloc(&src, total); hipMemset(src, 1, total); hipMalloc(&sink, 1 << 20);
+  const int iters = 512;
+  const char* mode_name[3] = {"LDS-DMA", "regs+ds_write", "LDS-DMA + 16 MFMA/wave"};
+  printf("%-26s %-34s %6s %9s %12s %10s\n", "mode", "pattern", "WGs", "us", "GB/s per CU", "us/K-tile");
+  for (int grid : {256, 512, 32}) {
+    const int cus = grid < 256 ? grid : 256;
+#define ROW(P, M, PC, region, share, stride, label)                                                                   \
+    { double us = run<P, M, PC>(src, region, share, grid, iters, stride, sink);                                        \
+      double bytes = (double)grid * iters * PC * 4096.0;                                                               \
+      printf("%-26s %-34s %6d %9.1f %12.1f %10.3f\n", mode_name[M], label, grid, us, bytes / us / 1e3 / cus, us / iters); }
+    ROW(0, 0, 8, 65536u, 1, 0u, "1 KB contiguous, 64 KB per WG")
+    ROW(0, 1, 8, 65536u, 1, 0u, "1 KB contiguous, 64 KB per WG")
+    ROW(0, 2, 8, 65536u, 1, 0u, "1 KB contiguous, 64 KB per WG")
+    ROW(1, 0, 8, 262144u, 8, 1024u, "8 x 128 B rows, stride 1 KB")
+    ROW(1, 1, 8, 262144u, 8, 1024u, "8 x 128 B rows, stride 1 KB")
+    ROW(1, 2, 8, 262144u, 8, 1024u, "8 x 128 B rows, stride 1 KB")
+    ROW(1, 0, 8, 65536u, 8, 256u, "8 x 128 B rows, stride 256 B")
+    ROW(1, 0, 8, 524288u, 8, 2048u, "8 x 128 B rows, stride 2 KB")
+    ROW(0, 0, 4, 65536u, 1, 0u, "1 KB contiguous, 16 KB K-tiles")
+    ROW(0, 2, 4, 65536u, 1, 0u, "1 KB contiguous, 16 KB K-tiles")
+  }
+  return 0;
+}
