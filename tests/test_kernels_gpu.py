@@ -385,6 +385,37 @@ def test_bf16_gemm_loop_and_tile_variants(K, dma, tile):
         K.set_math('f32')
 
 
+@pytest.mark.parametrize('waves,paired', [(4, 0), (4, 4096), (8, 4096)])
+def test_bf16_gemm_wave_count_and_paired_k_tiles(K, waves, paired):
+    """Round 4, second pass: the 128x128 bf16 tile on 8 waves of 32x64 (the default, T2I_BF16_WAVES) against 4 waves of 64x64, and the
+    loop that takes two K-tiles per barrier pair (bf16_pair_tiles; odd and even numbers of K-tiles, split and unsplit): same k order
+    per output element, so the same bits — forward with bias + lrelu, input gradient of a stride-2 layer (four phases), ragged M and N."""
+    rng = np.random.default_rng(17)
+    cases = [(5, 16, 16, 128, 200, 3, 1), (3, 16, 16, 64, 136, 4, 2), (9, 8, 8, 192, 256, 3, 1), (4, 8, 8, 64, 128, 1, 1)]   # 18 / 16 / 27 / 1 K-tiles
+    K.set_math('bf16')
+    try:
+        for B, H, W, Ci, Co, k, s in cases:
+            x = dev(rng.standard_normal((B, H, W, Ci)).astype(np.float32))
+            w = dev((rng.standard_normal((k, k, Ci, Co)) / np.sqrt(k * k * Ci)).astype(np.float32))
+            b = dev(rng.standard_normal(Co).astype(np.float32))
+            d, _ = K.conv_desc(B, H, W, Ci, Co, k, k, s, s, 'SAME')
+            dy = dev(rng.standard_normal((B, d.Ho, d.Wo, Co)).astype(np.float32))
+            ws = 256 << 20
+            outs = {}
+            K.tuning_set('force_tile', 22)
+            for name, (v_w, v_p) in (('default', (8, 0)), ('variant', (waves, paired))):
+                K.tuning_set('bf16_waves', v_w); K.tuning_set('bf16_pair_tiles', v_p)
+                for sk in (1, 2, 3):
+                    K.tuning_set('force_splitk', sk)
+                    outs[name, sk] = (K.conv_fwd(x, w, b, d, ws, K.ACT_LRELU, 0.2), K.conv_bwd_data(dy, w, None, d, ws))
+            for sk in (1, 2, 3):
+                assert torch.equal(outs['variant', sk][0], outs['default', sk][0]), (B, H, Ci, Co, sk, 'fwd')
+                assert torch.equal(outs['variant', sk][1], outs['default', sk][1]), (B, H, Ci, Co, sk, 'bwd_data')
+    finally:
+        K.tuning_set('bf16_waves', 8); K.tuning_set('bf16_pair_tiles', 0); K.tuning_set('force_tile', 0); K.tuning_set('force_splitk', 0)
+        K.set_math('f32')
+
+
 def test_conv_epilogue_batch_norm_statistics(K):
     """conv_fwd_stats: the GEMM epilogue's per-tile column sums, finished by take_stats, == column sums of the output (1e-5 of
     their scale) for every tile shape; when the planner splits K the fused path declines and nothing is cached."""

@@ -135,6 +135,7 @@ static Tuning& tuning_mut() {
     v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
     v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
     v.bf16_waves = env_int("T2I_BF16_WAVES", 8);           // 8: the 128x128 bf16 tile runs on 8 waves of 32x64 (two per SIMD) instead of 4 of 64x64
+    v.bf16_pair_tiles = env_int("T2I_BF16_PAIR_TILES", 0); // > 0: 128x128 bf16 launches of at most this many workgroups run the paired-K-tile loop (two K-tiles per barrier pair)
     v.pair_reduce = env_int("T2I_PAIR_REDUCE", 1);         // the split-K reductions of a pair launch's two GEMMs in one launch (splitk_reduce2_kernel)
     v.h_stats = env_int("T2I_H_STATS", 0);                 // bf16-operand forward GEMM: batch-norm statistics from the epilogue (0, default: the batch norm reduces the tensor itself; measured round 4: 10 871 vs 10 827 img/s, the reduce is cheaper than the longer epilogue)
     v.pair_cus = env_int("T2I_PAIR_CUS", 128);             // ... each of the two GEMMs is planned for this many CUs (they share the chip)
@@ -1393,7 +1394,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -550,7 +550,8 @@ struct SmemD {
 template <int MODE, int WMT, int WNT, int PIPE, int NW = 4>      // PIPE: 0 = two-phase K loop; 2, 3, 4 = software-pipelined loop with that many LDS buffers
 __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, const int nbx, const int by, const int bz) {
   constexpr bool PINGPONG = (PIPE == 8);                // 8 waves only: the two waves of a SIMD alternate between a load phase and a multiply phase
-  constexpr int NBUF = PINGPONG ? 3 : (PIPE > 2 ? PIPE : 2);
+  constexpr bool PAIRED = (PIPE == 6);                  // two K-tiles per barrier pair, four one-tile LDS buffers (two stages)
+  constexpr int NBUF = PINGPONG ? 3 : (PAIRED ? 4 : (PIPE > 2 ? PIPE : 2));
   using S = SmemD<WMT * (NW / 4), WNT, NBUF>;
   constexpr int RPP = NW * 8;                           // rows staged per pass: 8 threads per 128-byte row
   constexpr int BM = S::BM, BN = S::BN, ROW = S::ROW;
@@ -650,7 +651,8 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   const unsigned lds_a0 = (unsigned)(size_t)(lds_ptr_h)(As + wave_u * 8 * ROW);   // this wave's 8 rows of row group 0, buffer 0
   const unsigned lds_b0 = (unsigned)(size_t)(lds_ptr_h)(Bs + wave_u * 8 * ROW);
 
-  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+  struct TileAddr { unsigned sa2, sel, sb2; };
+  auto tile_addr = [&](int t) __attribute__((always_inline)) {
     const int k0 = kbeg + t * HBK;
     const int tap = p.div_c.div(k0);                   // wave-uniform
     const int c0 = k0 - tap * Csrc;
@@ -670,19 +672,20 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
     const unsigned sa2 = (unsigned)((dh * Wsrc + dw) * Csrc + c0) * 2u;
     const unsigned sel = kok ? ((1u << (jh & 15)) | (0x10000u << (jw & 15))) : 0xFFFFFFFFu;      // all ones never matches (bit 15 is never set)
     const unsigned sb2 = kok ? (unsigned)(wtap * p.N * Csrc + c0) * 2u : 0xC0000000u;
-#if defined(T2I_HEXP) && (T2I_HEXP & 4)      // timing only: no tap decode, no bounds checks — a plain strided GEMM's addressing
+    TileAddr ta = {sa2, sel, sb2};
+    return ta;
+  };
+  // piece q of a K-tile: q < A_LD an A row group, else a B row group
+  auto dma_piece = [&](const TileAddr& ta, int q, int buf) __attribute__((always_inline)) {
+    if (q < A_LD)
+      dma16_h(wa, (a_hw[q] & ta.sel) == ta.sel ? a_off2[q] + ta.sa2 : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + RPP * q * ROW) * 4u);
+    else
+      dma16_h(wb, b_off2[q - A_LD] + ta.sb2, lds_b0 + (unsigned)(buf * S::B_DW + RPP * (q - A_LD) * ROW) * 4u);
+  };
+  auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+    const TileAddr ta = tile_addr(t);
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) dma16_h(wa, a_off2[i] + (t & 7) * 128, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) dma16_h(wb, b_off2[i] + (t & 7) * 128, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i)
-      dma16_h(wa, (a_hw[i] & sel) == sel ? a_off2[i] + sa2 : HOOB, lds_a0 + (unsigned)(buf * S::A_DW + RPP * i * ROW) * 4u);
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i)
-      dma16_h(wb, b_off2[i] + sb2, lds_b0 + (unsigned)(buf * S::B_DW + RPP * i * ROW) * 4u);
+    for (int q = 0; q < A_LD + B_LD; ++q) dma_piece(ta, q, buf);
   };
 
   f32x16 acc[WMT][WNT];
@@ -696,8 +699,69 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
   constexpr int PIECES = A_LD + B_LD;
 #pragma unroll
   for (int b = 0; b < NBUF; ++b) dma_tile(b, b);
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES * (NBUF - 1)) : "memory");
-  __syncthreads();                                     // tile 0 is in LDS
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PIECES * (PAIRED ? 2 : NBUF - 1)) : "memory");
+  __syncthreads();                                     // tile 0 is in LDS (paired loop: tiles 0 and 1)
+  if constexpr (PAIRED) {
+    // Two K-tiles per barrier pair (round 4, second pass; single-round launches: one workgroup per CU).  The per-K-tile chain
+    // (barrier -> DMA issue -> MFMAs -> wait for the next tile -> barrier -> fragment-read latency, profiles/r04_bf16_loop_ablation.txt)
+    // is paid once per TWO tiles: stage st = i & 1 holds tiles 2i and 2i+1 in buffers 2 st, 2 st + 1.  Iteration i: the fragments
+    // of both tiles are requested back to back, tile 2i multiplies while tile 2i+1's fragments arrive, barrier (the stage is free),
+    // then the 2 x PIECES DMA pieces of tiles 2i+4, 2i+5 are issued ONE IN FRONT OF EACH MFMA of tile 2i+1 (the matrix pipe never
+    // waits for a burst of DMA issue), wait for this wave's pieces of the other stage (issued an iteration ago), barrier.
+    // Same k order per output element as every other loop: bit-identical.
+    auto read_tile = [&](const unsigned* as, const unsigned* bs, bf16x8 (&fa)[WMT][4], bf16x8 (&fb)[WNT][4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+          const int row = wm * 32 * WMT + i * 32 + l31;
+          fa[i][s4] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&as[row * ROW + (((2 * s4 + lh) ^ ((row >> 1) & 7)) << 2)]));
+        }
+#pragma unroll
+        for (int i = 0; i < WNT; ++i) {
+          const int row = wn * 32 * WNT + i * 32 + l31;
+          fb[i][s4] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&bs[row * ROW + (((2 * s4 + lh) ^ ((row >> 1) & 7)) << 2)]));
+        }
+      }
+    };
+    const int npairs = (ntiles + 1) >> 1;
+    for (int i = 0; i < npairs; ++i) {
+      const int st = i & 1;
+      bf16x8 fa0[WMT][4], fb0[WNT][4], fa1[WMT][4], fb1[WNT][4];
+      read_tile(As + (2 * st) * S::A_DW, Bs + (2 * st) * S::B_DW, fa0, fb0);
+      read_tile(As + (2 * st + 1) * S::A_DW, Bs + (2 * st + 1) * S::B_DW, fa1, fb1);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int m = 0; m < WMT; ++m)
+#pragma unroll
+          for (int n = 0; n < WNT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[m][s4], fb0[n][s4], acc[m][n], 0, 0, 0);
+      __syncthreads();                                   // every wave holds the fragments of both tiles: stage st is free
+      const TileAddr t0 = tile_addr(2 * i + 4), t1 = tile_addr(2 * i + 5);     // past the end: zeros, never read
+      constexpr int NMMA = 4 * WMT * WNT;
+      if ((2 * i + 1) < ntiles) {
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {                 // the 2 PIECES pieces spread over the NMMA multiply instructions
+#pragma unroll
+          for (int d = q * 2 * PIECES / NMMA; d < (q + 1) * 2 * PIECES / NMMA; ++d) {
+            if (d < PIECES) dma_piece(t0, d, 2 * st);
+            else dma_piece(t1, d - PIECES, 2 * st + 1);
+          }
+          const int s4 = q / (WMT * WNT), m = (q / WNT) % WMT, n = q % WNT;
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[m][s4], fb1[n][s4], acc[m][n], 0, 0, 0);
+        }
+      } else {                                           // odd number of K-tiles: the last pair's second tile does not exist
+#pragma unroll
+        for (int d = 0; d < 2 * PIECES; ++d) {
+          if (d < PIECES) dma_piece(t0, d, 2 * st);
+          else dma_piece(t1, d - PIECES, 2 * st + 1);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PIECES) : "memory");     // this wave's pieces of tiles 2i+2, 2i+3 have landed
+      __syncthreads();
+    }
+  } else
   if constexpr (PINGPONG) {
     // Ping-pong K loop (round 4, 8 waves).  Waves w and w + 4 share a SIMD.  Every K-tile is two phases separated by workgroup
     // barriers; in each phase one half of the waves (a "group") reads its fragments of a tile from LDS and issues its DMA pieces
@@ -1354,7 +1418,7 @@ hipError_t igemm_h_filter_launch(const IgemmParams& p, int wmt, int wnt, hipStre
 
 template <int MODE, int WMT, int WNT, int PIPE>
 static hipError_t launch_hd1(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = SmemD<WMT, WNT, (PIPE > 2 ? PIPE : 2)>;
+  using S = SmemD<WMT, WNT, (PIPE == 6 ? 4 : (PIPE > 2 ? PIPE : 2))>;
   auto k = igemm_hd_kernel<MODE, WMT, WNT, PIPE>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
@@ -1369,6 +1433,8 @@ template <int MODE, int WMT, int WNT>
 static hipError_t launch_hd(const IgemmParams& p, dim3 grid, hipStream_t stream) {
   const int v = tuning().bf16_dma;
   if constexpr (WMT == 2 && WNT == 2) {       // deeper LDS rings (experiment): 96 / 128 KB, one workgroup per CU
+    if (v == 1 && tuning().bf16_pair_tiles && grid.x * grid.y * grid.z <= (unsigned)tuning().bf16_pair_tiles)
+      return launch_hd1<MODE, WMT, WNT, 6>(p, grid, stream);       // single-round launch: two K-tiles per barrier pair (128 KB of LDS)
     if (v == 3) return launch_hd1<MODE, WMT, WNT, 3>(p, grid, stream);
     if (v == 4) return launch_hd1<MODE, WMT, WNT, 4>(p, grid, stream);
   }
@@ -1426,7 +1492,7 @@ hipError_t igemm_pair_launch(int mode, const IgemmParams& pa, int wmt, int wnt, 
 
 template <int MODE, int PIPE, int WMT = 2>
 static hipError_t launch_hd8(const IgemmParams& p, dim3 grid, hipStream_t stream) {
-  using S = SmemD<2 * WMT, 2, (PIPE == 8 ? 3 : (PIPE > 2 ? PIPE : 2))>;
+  using S = SmemD<2 * WMT, 2, (PIPE == 8 ? 3 : (PIPE == 6 ? 4 : (PIPE > 2 ? PIPE : 2)))>;
   constexpr int EPI = 8 * 32 * (32 * 2 + 4) * 4;       // store_tile_h: one 32 x 68 float patch per wave
   constexpr int bytes = S::BYTES > EPI ? S::BYTES : EPI;
   auto k = igemm_hd8_kernel<MODE, WMT, PIPE>;
@@ -1455,6 +1521,10 @@ hipError_t igemm_h_launch(int mode, const IgemmParams& p, int wmt, int wnt, hipS
     return hipErrorInvalidValue;
   }
   if (wmt == 2 && wnt == 2 && tuning().bf16_dma == 1 && tuning().bf16_waves == 8) {       // the 128 x 128 tile on 8 waves
+    if (tuning().bf16_pair_tiles && grid.x * grid.y * grid.z <= (unsigned)tuning().bf16_pair_tiles) {     // single-round launch: paired K-tiles
+      if (mode == MODE_FWD) return launch_hd8<MODE_FWD, 6, 1>(p, grid, stream);
+      if (mode == MODE_BWD_DATA) return launch_hd8<MODE_BWD_DATA, 6, 1>(p, grid, stream);
+    }
     if (mode == MODE_FWD) return launch_hd8<MODE_FWD, 0, 1>(p, grid, stream);
     if (mode == MODE_BWD_DATA) return launch_hd8<MODE_BWD_DATA, 0, 1>(p, grid, stream);
   }

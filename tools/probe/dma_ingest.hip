@@ -23,7 +23,7 @@ template <int PATTERN, int MODE, int PIECES>
 __global__ __launch_bounds__(256) void ingest(const char* src, unsigned region_bytes, int share, int iters, unsigned stride, float* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const char* base = src + (size_t)(blockIdx.x / share) * region_bytes;
+  const char* base = src + (size_t)(share < 0 ? (blockIdx.x & 7) : blockIdx.x / share) * region_bytes;   // share < 0: one region per XCD, read by all its workgroups
   const uint64_t a = reinterpret_cast<uint64_t>(base);
   i32x4 rsrc = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)region_bytes, 0x00020000};
   __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), (short)0, (int)region_bytes, 0x00020000);
@@ -110,6 +110,13 @@ int main() {
     ROW(1, 2, 8, 262144u, 8, 1024u, "8 x 128 B rows, stride 1 KB")
     ROW(1, 0, 8, 65536u, 8, 256u, "8 x 128 B rows, stride 256 B")
     ROW(1, 0, 8, 524288u, 8, 2048u, "8 x 128 B rows, stride 2 KB")
+    ROW(1, 0, 8, 65536u, -1, 256u, "rows, stride 256 B, region per XCD")
+    ROW(1, 0, 8, 131072u, -1, 512u, "rows, stride 512 B, region per XCD")
+    ROW(1, 0, 8, 262144u, -1, 1024u, "rows, stride 1 KB, region per XCD")
+    ROW(1, 0, 8, 524288u, -1, 2048u, "rows, stride 2 KB, region per XCD")
+    ROW(1, 0, 8, 2097152u, -1, 8192u, "rows, stride 8 KB, region per XCD")
+    ROW(1, 2, 8, 262144u, -1, 1024u, "rows, stride 1 KB, region per XCD")
+    ROW(1, 2, 8, 2097152u, -1, 8192u, "rows, stride 8 KB, region per XCD")
     ROW(0, 0, 4, 65536u, 1, 0u, "1 KB contiguous, 16 KB K-tiles")
     ROW(0, 2, 4, 65536u, 1, 0u, "1 KB contiguous, 16 KB K-tiles")
   }
