@@ -427,6 +427,7 @@ static int conv_h(int mode, const t2i_conv_desc* d, const float* in, const void*
   char* base = reinterpret_cast<char*>(ws);
   int rc = T2I_OK;
   if (!in_h || !aligned16(in_h)) {                  // no caller-held image of the gathered tensor: stage one
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_bf16 operand (conv_h): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     rc = check(cast_bf16_launch(in, n_in, base, stream), what);
     if (rc != T2I_OK) return rc;
     in_h = base;
@@ -511,11 +512,13 @@ static int conv_h_filter(const t2i_conv_desc* d, const float* x, const float* dy
   char* base = reinterpret_cast<char*>(ws);
   int rc = T2I_OK;
   if (!x_h || !aligned16(x_h)) {
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_bf16 x (filter gradient): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     rc = check(cast_bf16_launch(x, nx, base, stream), what);
     if (rc != T2I_OK) return rc;
     x_h = base;
   }
   if (!dy_h || !aligned16(dy_h)) {
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_bf16 dy (filter gradient): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     rc = check(cast_bf16_launch(dy, ny, base + off_y, stream), what);
     if (rc != T2I_OK) return rc;
     dy_h = base + off_y;
@@ -752,6 +755,7 @@ static int conv2d_fwd_storage(const t2i_conv_desc* d, const void* xv, const floa
   if (xh) {
     float* t = st.take(nx);
     if (!t) { set_error("t2i_conv2d_fwd: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_f32 t2i_conv2d_fwd(stage): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     if ((rc = check(cast_f32_launch(xv, nx, t, (hipStream_t)stream), "t2i_conv2d_fwd(stage)"))) return rc;
     x32 = t;
   }
@@ -860,6 +864,7 @@ int t2i_conv2d_bwd_data(const t2i_conv_desc* d, const void* dyv, const float* w,
   if (gh) {
     float* t = st.take(ny);
     if (!t) { set_error("t2i_conv2d_bwd_data: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_f32 t2i_conv2d_bwd_data(stage): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     if ((rc = check(cast_f32_launch(dyv, ny, t, (hipStream_t)stream), "t2i_conv2d_bwd_data(stage)"))) return rc;
     dy32 = t;
   }
@@ -937,12 +942,14 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* xv, const void* dy
   if (xh) {
     float* t = st.take(nx);
     if (!t) { set_error("t2i_conv2d_bwd_filter: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_f32 t2i_conv2d_bwd_filter(stage): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     if ((rc = check(cast_f32_launch(xv, nx, t, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stage)"))) return rc;
     x32 = t;
   }
   if (gh) {
     float* t = st.take(ny);
     if (!t) { set_error("t2i_conv2d_bwd_filter: workspace too small for the fp32 staging copy"); return T2I_ERR_WORKSPACE; }
+    if (tuning().debug_plan) fprintf(stderr, "[t2i stage] cast_f32 t2i_conv2d_bwd_filter(stage): B=%d %dx%dx%d->%d k%d s%d\n", d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->SH);
     if ((rc = check(cast_f32_launch(dyv, ny, t, (hipStream_t)stream), "t2i_conv2d_bwd_filter(stage)"))) return rc;
     dy32 = t;
   }
