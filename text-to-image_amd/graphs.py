@@ -11,6 +11,21 @@ import torch
 from . import kernels as K
 
 
+def capture_mode(requested='global'):
+    """The capture_error_mode a capture in this process should use.  As soon as a process group exists, its watchdog thread
+    polls events on the HIP runtime at any time; in 'global' mode such a call from another thread while a capture is open is an
+    error that tears the process down (seen once in the full GPU suite: a single-GPU capture after a data-parallel test in the same
+    process).  'thread_local' confines the checks to the capturing thread, which is all these captures need."""
+    if requested == 'global':
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return 'thread_local'
+        except Exception:          # noqa: BLE001 — a build without torch.distributed has no watchdog either
+            pass
+    return requested
+
+
 class StepGraphs(object):
     def __init__(self, example_feed, keys, filters=()):
         """example_feed: name -> device tensor (shapes/dtypes of every later feed); keys: the entries the bodies read;
@@ -35,7 +50,7 @@ class StepGraphs(object):
         dev = next(iter(self.static.values())).device
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool, capture_error_mode=capture_error_mode):
+        with torch.cuda.graph(g, pool=self._pool, capture_error_mode=capture_mode(capture_error_mode)):
             if refresh:
                 for t in self.filters:               # one batched launch per arena; the convs of this graph then find every
                     K.filter_cache_refresh(t)        # known image of these filters filled

@@ -462,19 +462,21 @@ class WGanCls(object):
         torch.cuda.synchronize(self.device)
         gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.dp is None:
+            from ...graphs import capture_mode
+            _plain_mode = capture_mode('global')     # 'thread_local' once any process group (and its watchdog thread) exists in this process
             # every graph starts with ONE batched regeneration of the cached filter images (a graph contains every transform
             # it depends on; filled lazily they are ~60 small launches)
-            with torch.cuda.graph(gd):
+            with torch.cuda.graph(gd, capture_error_mode=_plain_mode):
                 self._refresh_filters()
                 d_out = self._d_body(static)
-            with torch.cuda.graph(gg, pool=gd.pool()):
+            with torch.cuda.graph(gg, pool=gd.pool(), capture_error_mode=_plain_mode):
                 self._refresh_filters()
                 g_out = self._g_body(static)
             gref = torch.cuda.CUDAGraph()                # the critic's filter images alone (dg_step: after an outside write); captured,
-            with torch.cuda.graph(gref, pool=gd.pool()): # because a capture regenerates every image the cache holds of the range
+            with torch.cuda.graph(gref, pool=gd.pool(), capture_error_mode=_plain_mode):   # because a capture regenerates every image the cache holds of the range
                 K.filter_cache_refresh(self.d_arena.flat)
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
-            with torch.cuda.graph(gdg, pool=gd.pool()):  # dg_step returns this capture's own output tensors
+            with torch.cuda.graph(gdg, pool=gd.pool(), capture_error_mode=_plain_mode):  # dg_step returns this capture's own output tensors
                 if _TRUST_IMAGES:
                     # the critic's images were regenerated behind its Adam step by the previous replay (_d_update: refresh=True) —
                     # by whichever step function ran last, in fact: all of them leave the critic's images current — so only the
