@@ -906,7 +906,6 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 #if !(defined(T2I_HEXP) && (T2I_HEXP & 16))
     dma_tile(t + 2, t & 1);                            // past the end: zeros (k >= kend), never read
 #endif
-#if !(defined(T2I_HEXP) && (T2I_HEXP & 32))
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -914,12 +913,6 @@ __device__ __forceinline__ void hd_body(const IgemmParams& p, const int bx, cons
 #pragma unroll
         for (int n = 0; n < WNT; ++n)
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[n][s], acc[i][n], 0, 0, 0);
-#else
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-      for (int n = 0; n < WNT; ++n) acc[i][n][0] += (float)fa[i][t & 3][0] * (float)fb[n][t & 3][1];
-#endif
     // tile t+1 (issued an iteration ago) has landed when at most this iteration's pieces are outstanding
     if constexpr (A_LD + B_LD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (A_LD + B_LD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");

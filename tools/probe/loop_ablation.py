@@ -1,6 +1,10 @@
 #!/usr/bin/env python
-"""us per 128x128x64 K-tile of igemm_hd_kernel for the timing-only builds in tools/probe/libs/x<bits> (T2I_HEXP bits: 4 cheap
-addressing, 8 fragments read once, 16 no DMA in the loop, 32 no MFMA, 64 no first barrier).  One subprocess per library."""
+"""us per 128x128x64 K-tile of igemm_hd_kernel (4-wave, two-phase loop: run with T2I_BF16_WAVES=4) for timing-only builds:
+    for v in 8 16 24 64; do HIPCC="/opt/rocm/bin/hipcc -DT2I_HEXP=$v" bash text-to-image_amd/csrc/build.sh $PWD/tools/probe/libs/x$v; done
+T2I_HEXP bits: 8 fragments read once, 16 no DMA in the loop, 64 no first barrier (1 / 2: no epilogue stores / no K loop).  The "cheap
+addressing" build of profiles/r04_bf16_loop_ablation.txt (bit 4) went away with the loader rewrite it motivated.  The libraries
+compute wrong results and are never shipped (tools/probe/libs/ is git-ignored).  One subprocess per library; the environment
+(T2I_BF16_WAVES, T2I_BF16_DMA, T2I_BF16_PAIR_TILES) is passed through."""
 import os
 import subprocess
 import sys
@@ -31,7 +35,7 @@ a, b = run(16384, 256, 128, 3), run(16384, 256, 512, 3)
 out.append('3x3 M=16384: Cin128 %%6.1f Cin512 %%6.1f -> %%.3f us/K-tile' %% (a, b, (b - a) / 54))
 print(' | '.join(out))
 ''' % ROOT
-libs = sys.argv[1:] or ['default', 'x4', 'x8', 'x16', 'x32', 'x64', 'x12', 'x28', 'x44', 'x60', 'x76']
+libs = sys.argv[1:] or ['default', 'x8', 'x16', 'x24', 'x64']
 for name in libs:
     env = dict(os.environ)
     if name != 'default':
