@@ -224,3 +224,26 @@ def test_bf16_image_cache_is_keyed_on_base_version_and_capture(monkeypatch):
     shim.cap = 8                                                      # ... nor is one made in an earlier capture
     assert K.bf16_image(y) is not img3 and len(made) == 5
     assert K.bf16_image(torch.randn(3, 5)) is None                    # 15 elements: no 8-element groups
+
+
+def test_capture_mode_follows_the_process_group(t2i, tmp_path):
+    """graphs.capture_mode: 'global' (torch's default) in a process without a process group; 'thread_local' as soon as one exists —
+    its watchdog thread may touch the runtime while a capture is open (seen once as an abort of the full GPU suite).  An
+    explicit 'thread_local' is never downgraded.  (One-rank gloo group over a file store: no network needed.)"""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import t2i_amd
+from t2i_amd.graphs import capture_mode
+assert capture_mode() == 'global' and capture_mode('thread_local') == 'thread_local'
+dist.init_process_group('gloo', init_method='file://%s', rank=0, world_size=1)
+assert capture_mode() == 'thread_local' and capture_mode('global') == 'thread_local'
+dist.destroy_process_group()
+assert capture_mode() == 'global'
+print('ok')
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'store'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
