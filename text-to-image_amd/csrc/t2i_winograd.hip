@@ -115,6 +115,17 @@ static inline int wino_blocks(size_t n) {
   return b < 1 ? 1 : (int)b;
 }
 
+// Store of one float4 of a transformed operand (V, Z: written once, streamed once by the batched GEMM).  -DT2I_NT_PLANES: nontemporal
+// (experiment, profiles/r04_winograd_transform_bw.txt).
+__device__ __forceinline__ void wst(float4* p, float4 v) {
+#if defined(T2I_NT_PLANES)
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(__builtin_bit_cast(f4v, v), reinterpret_cast<f4v*>(p));
+#else
+  *p = v;
+#endif
+}
+
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
@@ -201,10 +212,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const size_t plane = T * C4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[(size_t)wino_slot(r, 0, flip) * plane] = f4sub(tt[r][0], tt[r][2]);
-      o[(size_t)wino_slot(r, 1, flip) * plane] = f4add(tt[r][1], tt[r][2]);
-      o[(size_t)wino_slot(r, 2, flip) * plane] = f4sub(tt[r][2], tt[r][1]);
-      o[(size_t)wino_slot(r, 3, flip) * plane] = f4sub(tt[r][1], tt[r][3]);
+      wst(&o[(size_t)wino_slot(r, 0, flip) * plane], f4sub(tt[r][0], tt[r][2]));
+      wst(&o[(size_t)wino_slot(r, 1, flip) * plane], f4add(tt[r][1], tt[r][2]));
+      wst(&o[(size_t)wino_slot(r, 2, flip) * plane], f4sub(tt[r][2], tt[r][1]));
+      wst(&o[(size_t)wino_slot(r, 3, flip) * plane], f4sub(tt[r][1], tt[r][3]));
     }
   }
 }
@@ -338,10 +349,10 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     float4* o = reinterpret_cast<float4*>(Z) + t * N4 + n4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[(size_t)(r * 4 + 0) * plane] = s[r][0];
-      o[(size_t)(r * 4 + 1) * plane] = f4add(s[r][0], s[r][1]);
-      o[(size_t)(r * 4 + 2) * plane] = f4sub(s[r][0], s[r][1]);
-      o[(size_t)(r * 4 + 3) * plane] = f4sub(zero, s[r][1]);
+      wst(&o[(size_t)(r * 4 + 0) * plane], s[r][0]);
+      wst(&o[(size_t)(r * 4 + 1) * plane], f4add(s[r][0], s[r][1]));
+      wst(&o[(size_t)(r * 4 + 2) * plane], f4sub(s[r][0], s[r][1]));
+      wst(&o[(size_t)(r * 4 + 3) * plane], f4sub(zero, s[r][1]));
     }
   }
 }
@@ -372,9 +383,9 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
       if (accumulate) {
         w0 = f4add(w0, o[(size_t)(r * 3 + 0) * plane]); w1 = f4add(w1, o[(size_t)(r * 3 + 1) * plane]); w2 = f4add(w2, o[(size_t)(r * 3 + 2) * plane]);
       }
-      o[(size_t)(r * 3 + 0) * plane] = w0;
-      o[(size_t)(r * 3 + 1) * plane] = w1;
-      o[(size_t)(r * 3 + 2) * plane] = w2;
+      wst(&o[(size_t)(r * 3 + 0) * plane], w0);
+      wst(&o[(size_t)(r * 3 + 1) * plane], w1);
+      wst(&o[(size_t)(r * 3 + 2) * plane], w2);
     }
   }
 }
@@ -440,9 +451,9 @@ __device__ __forceinline__ void wino2_filter_body(const float* __restrict__ w, i
     float4* o = reinterpret_cast<float4*>(U) + ((size_t)ph * Cin + ci) * N4 + n4;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
-      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
-      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
+      wst(&o[(size_t)(r * 3 + 0) * plane], s[r][0]);
+      wst(&o[(size_t)(r * 3 + 1) * plane], f4add(s[r][0], s[r][1]));
+      wst(&o[(size_t)(r * 3 + 2) * plane], s[r][1]);
     }
   }
 }
@@ -486,9 +497,9 @@ __global__ __launch_bounds__(256) void wino2_input_kernel(const float* __restric
     float4* o = reinterpret_cast<float4*>(V) + (t * 4 + ph) * C4 + c4;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[(size_t)(r * 3 + 0) * plane] = f4sub(tt[r][0], tt[r][1]);
-      o[(size_t)(r * 3 + 1) * plane] = tt[r][1];
-      o[(size_t)(r * 3 + 2) * plane] = f4sub(tt[r][2], tt[r][1]);
+      wst(&o[(size_t)(r * 3 + 0) * plane], f4sub(tt[r][0], tt[r][1]));
+      wst(&o[(size_t)(r * 3 + 1) * plane], tt[r][1]);
+      wst(&o[(size_t)(r * 3 + 2) * plane], f4sub(tt[r][2], tt[r][1]));
     }
   }
 }
@@ -621,9 +632,9 @@ __global__ __launch_bounds__(256) void wino2b_input_kernel(const float* __restri
     float4* o = reinterpret_cast<float4*>(V) + t * C4 + c4;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[(size_t)wino2b_slot(r, 0, phs) * plane] = f4sub(tt[r][0], tt[r][1]);
-      o[(size_t)wino2b_slot(r, 1, phs) * plane] = tt[r][1];
-      o[(size_t)wino2b_slot(r, 2, phs) * plane] = f4sub(tt[r][2], tt[r][1]);
+      wst(&o[(size_t)wino2b_slot(r, 0, phs) * plane], f4sub(tt[r][0], tt[r][1]));
+      wst(&o[(size_t)wino2b_slot(r, 1, phs) * plane], tt[r][1]);
+      wst(&o[(size_t)wino2b_slot(r, 2, phs) * plane], f4sub(tt[r][2], tt[r][1]));
     }
   }
 }
@@ -724,9 +735,9 @@ __global__ __launch_bounds__(256) void wino2_dy_kernel(const float* __restrict__
     float4* o = reinterpret_cast<float4*>(Z) + t * N4 + n4;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[(size_t)(r * 3 + 0) * plane] = s[r][0];
-      o[(size_t)(r * 3 + 1) * plane] = f4add(s[r][0], s[r][1]);
-      o[(size_t)(r * 3 + 2) * plane] = s[r][1];
+      wst(&o[(size_t)(r * 3 + 0) * plane], s[r][0]);
+      wst(&o[(size_t)(r * 3 + 1) * plane], f4add(s[r][0], s[r][1]));
+      wst(&o[(size_t)(r * 3 + 2) * plane], s[r][1]);
     }
   }
 }
