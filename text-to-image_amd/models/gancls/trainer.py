@@ -34,9 +34,9 @@ class GanClsTrainer(object):
         with update_ops():      # D_optim is built under control_dependencies(UPDATE_OPS): every BN moving average moves
             with torch.no_grad():
                 G = m.generator(z, phi, reuse=True)
-            _, l_fake = m.discriminator(G, phi, reuse=True)
-            _, l_match = m.discriminator(x, phi, reuse=True)
-            _, l_mis = m.discriminator(xw, phi, reuse=True)
+            p_fake, l_fake = m.discriminator(G, phi, reuse=True)
+            p_match, l_match = m.discriminator(x, phi, reuse=True)
+            p_mis, l_mis = m.discriminator(xw, phi, reuse=True)
         D_synthetic_loss = sigmoid_cross_entropy_with_logits(l_fake, 0.0).mean()
         D_real_match_loss = sigmoid_cross_entropy_with_logits(l_match, 0.9).mean()       # one-sided label smoothing
         D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
@@ -47,7 +47,8 @@ class GanClsTrainer(object):
         D_loss.backward(inputs=list(m.d_vars.values()))
         A.side_join()
         return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
-                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G)
+                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G,
+                    D_synthetic=p_fake.detach(), D_real_match=p_match.detach(), D_real_mismatch=p_mis.detach())
 
     def g_losses(self, feed):
         m = self.model
@@ -133,13 +134,38 @@ class GanClsTrainer(object):
         return {'inputs': images, 'wrong_inputs': wrong_images, 'phi_inputs': embed,
                 'z': torch.randn((m.batch_size, m.z_dim), generator=self.gen, device=m.device)}
 
-    def train(self, max_updates=None, log=None):
+    def define_summaries(self):
+        """reference trainer.py:53-75: the FileWriter on cfg.LOGS_DIR (utils/summary.py: TensorBoard event files without TensorFlow)."""
+        from ...utils.summary import FileWriter
+        self.writer = FileWriter(self.cfg.LOGS_DIR)
+
+    def write_summaries(self, counter, feed, out):
+        """The two merged summaries the reference adds per update (trainer.py:66-72,115-134) — D: histograms of the three critic
+        outputs and of the three loss terms, scalar d_loss; G: image g_sum, scalar g_loss — plus histogram z, from the values the
+        iteration computed (the reference fetches them in the same sess.run as the optimizer steps)."""
+        from ...utils import summary as S
+        np_ = lambda t: t.detach().float().cpu().numpy()
+        d, g = out['d'], out['g']
+        self.writer.add_summary([S.histogram('d_real_mismatch_sum', np_(d['D_real_mismatch'])), S.histogram('d_real_match_sum', np_(d['D_real_match'])),
+                                 S.histogram('d_synthetic_sum', np_(d['D_synthetic'])), S.histogram('d_synthetic_sum_loss', np_(d['D_synthetic_loss'])),
+                                 S.histogram('d_real_mismatch_sum_loss', np_(d['D_real_mismatch_loss'])),
+                                 S.histogram('d_real_match_sum_loss', np_(d['D_real_match_loss'])), S.scalar('d_loss', float(d['D_loss']))], counter)
+        self.writer.add_summary([S.image('g_sum', np_(g['G'])), S.scalar('g_loss', float(g['G_loss'])), S.histogram('z', np_(feed['z']))], counter)
+        self.writer.flush()
+
+    def train(self, max_updates=None, log=None, summaries=False):
+        """summaries=True: an event file in cfg.LOGS_DIR with the reference's per-update summaries (write_summaries)."""
         log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
+        if summaries and getattr(self.cfg, 'LOGS_DIR', None):
+            self.define_summaries()
         t0, counter = time.time(), 1
         for epoch in range(self.cfg.TRAIN.EPOCH):
             updates_per_epoch = self.dataset.train.num_examples // self.model.batch_size
             for idx in range(updates_per_epoch):
-                out = self.iteration(self.make_feed())
+                feed = self.make_feed()
+                out = self.iteration(feed)
+                if getattr(self, 'writer', None) is not None:
+                    self.write_summaries(counter, feed, out)
                 if counter % 10 == 0:
                     log('Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f' % (
                         epoch, idx, updates_per_epoch, time.time() - t0, float(out['d']['D_loss']), float(out['g']['G_loss'])))
