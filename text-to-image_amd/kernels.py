@@ -982,6 +982,7 @@ def conv_algo(d, which):
 
 
 _FC_ARENA = [None]
+_FC_ON = [False]
 
 
 def filter_cache(on, device=None):
@@ -996,7 +997,13 @@ def filter_cache(on, device=None):
         buf = torch.empty(int(os.environ.get('T2I_FILTER_CACHE_MB', '1024')) << 20, dtype=torch.uint8, device=dev)
         check(lib.t2i_filter_cache_attach(_ptr(buf), buf.numel()), 't2i_filter_cache_attach')
         _FC_ARENA[0] = buf           # kept for the life of the process: captured graphs point into it
+    _FC_ON[0] = bool(on) and _FC_ARENA[0] is not None
     return bool(lib.t2i_filter_cache_enable(1 if on else 0))
+
+
+def filter_cache_enabled():
+    """True while the transformed-filter cache is on through filter_cache() (and has its arena)."""
+    return _FC_ON[0]
 
 
 def filter_cache_reset():

@@ -472,12 +472,15 @@ class WGanCls(object):
             with torch.cuda.graph(gg, pool=gd.pool(), capture_error_mode=_plain_mode):
                 self._refresh_filters()
                 g_out = self._g_body(static)
-            gref = torch.cuda.CUDAGraph()                # the critic's filter images alone (dg_step: after an outside write); captured,
-            with torch.cuda.graph(gref, pool=gd.pool(), capture_error_mode=_plain_mode):   # because a capture regenerates every image the cache holds of the range
-                K.filter_cache_refresh(self.d_arena.flat)
+            trust = _TRUST_IMAGES and K.filter_cache_enabled()        # nothing to trust (and nothing to capture below) without the cache
+            gref = None
+            if trust:
+                gref = torch.cuda.CUDAGraph()            # the critic's filter images alone (dg_step: after an outside write); captured,
+                with torch.cuda.graph(gref, pool=gd.pool(), capture_error_mode=_plain_mode):   # because a capture regenerates every image the cache holds of the range
+                    K.filter_cache_refresh(self.d_arena.flat)
             gdg = torch.cuda.CUDAGraph()                 # both halves in one launch, same outputs' addresses not needed:
             with torch.cuda.graph(gdg, pool=gd.pool(), capture_error_mode=_plain_mode):  # dg_step returns this capture's own output tensors
-                if _TRUST_IMAGES:
+                if trust:
                     # the critic's images were regenerated behind its Adam step by the previous replay (_d_update: refresh=True) —
                     # by whichever step function ran last, in fact: all of them leave the critic's images current — so only the
                     # generator's are due here; dg_step vouches for the critic's (t2i_filter_cache_assume)
@@ -489,7 +492,7 @@ class WGanCls(object):
                 d_out2 = self._d_body(static)
                 g_out2 = self._g_body(static, ahead)
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
-                            'static': static, 'loaded': False, 'trust': _TRUST_IMAGES, 'epoch': None, 'dref': gref}
+                            'static': static, 'loaded': False, 'trust': trust, 'epoch': None, 'dref': gref}
             return
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
         gdu, ggu = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
