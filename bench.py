@@ -144,7 +144,7 @@ def _signature(model):
     return [model.d_arena.flat.clone(), model.g_arena.flat.clone(), model.D_optim.v.clone(), model.G_optim.v.clone(), model.kt.clone()]
 
 
-def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtype='f32'):
+def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtype='f32', net_math=None):
     """Self-check of the N-rank exchange before anything is timed (first contact with a multi-GPU node must diagnose itself):
     every rank runs 4 iterations on IDENTICAL data, once as a single replica (no communicator) and once through the
     data-parallel schedule that will be timed (2 eager iterations that learn the bucket counts, then the captured segments).
@@ -164,6 +164,7 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
     sigs, losses = [], []
     for dp in ((LocalRounding() if grad_dtype == 'bf16' else None), make_dp()):
         model = WGanCls(cfg, device=device, seed=0, dp=dp)
+        model.net_math = dict(net_math or {})
         real = dp is not None and not isinstance(dp, LocalRounding)
         if real:
             dp.broadcast_variables(model.store)
@@ -201,8 +202,11 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
     return report
 
 
-def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, headline=True):
-    """Builds the model in arithmetic `math` ('f32' = BASELINE config 2, the metric; 'bf16' = config 3), warms it up, times it and
+def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, headline=True, g_mode='config3'):
+    """g_mode (math 'bf16' only): 'config3' = the arithmetic whose parity test holds every tensor to 2e-2 (kernels.CONFIG3_NET_MATH: critic
+    and the generator's backward GEMMs in bf16 math, the generator's forward GEMMs in fp32 math); 'all_bf16' = every GEMM in bf16 math
+    (a labelled side row: outside the stated tolerance).
+    Builds the model in arithmetic `math` ('f32' = BASELINE config 2, the metric; 'bf16' = config 3), warms it up, times it and
     (rank 0) attaches the roofline block.  Everything it creates is released before it returns, so that a second configuration
     can run in the same process (cached filter images of the first are dropped: their graphs are gone)."""
     import gc
@@ -217,15 +221,17 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     if math == 'bf16' and args.storage == 'bf16':
         K.set_storage('bf16')           # config 3 end to end: activations and their gradients are bf16 tensors between the kernels
         storage = 'bf16'
+    net_math = dict(K.CONFIG3_NET_MATH) if (math == 'bf16' and g_mode == 'config3') else {}
     cfg = make_cfg(args.batch)
     dp, grad_dtype = make_dp(math)
     use_graphs = not args.no_graphs and args.instrument != 'inline' and not (use_dp and os.environ.get('T2I_DP_GRAPHS') == '0')
     preflight = None
     if world > 1 and os.environ.get('T2I_PREFLIGHT', '1') != '0':
-        preflight = dp_preflight(cfg, device, lambda: make_dp(math)[0], use_graphs, rank, world, args.batch, grad_dtype=grad_dtype)
+        preflight = dp_preflight(cfg, device, lambda: make_dp(math)[0], use_graphs, rank, world, args.batch, grad_dtype=grad_dtype, net_math=net_math)
         if rank == 0:
             sys.stderr.write('[bench] data-parallel preflight (%s) passed: %r\n' % (math, preflight))
     model = WGanCls(cfg, device=device, seed=0, dp=dp)
+    model.net_math = net_math
     if dp is not None:
         dp.broadcast_variables(model.store)
     trainer = WGanClsTrainer(None, model, None, cfg)
@@ -295,6 +301,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     while len(regions) < want:
         regions.append(timed_region())
     dt = sorted(regions)[len(regions) // 2]     # median region
+    exchange = None
     inst_steps = args.steps
     if args.instrument == 'after':          # same workload, immediately after the timed region, with per-launch events
         inst_steps = min(args.steps, 3)
@@ -336,6 +343,20 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
             raise SystemExit('replicas diverged: %s vs %s; variables that differ: %s' % (lo.tolist(), hi.tolist(), bad[:40]))
         if rank == 0:
             sys.stderr.write('[bench] replica sync check passed: %s\n' % sig.tolist())
+    # the exchange itself, measured on 3 more iterations of the same schedule (events on the communication stream around every
+    # collective, on the compute stream around every wait for them): bytes, ms in collectives, ms stalled, overlap fraction
+    if use_dp and dp is not None:
+        barrier()
+        dp.begin_stats()
+        for i in range(3):
+            trainer.iteration(it, feed)
+            it += 1
+        barrier()
+        exchange = dp.end_stats(3)
+        ones = torch.ones(1, device=device)
+        torch.distributed.all_reduce(ones)
+        exchange['ranks_counted_by_all_reduce'] = int(ones.item())
+        exchange['backend'] = str(torch.distributed.get_backend())
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
     schedule = getattr(model, 'dp_schedule', None)
@@ -356,6 +377,18 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
                       'gpu_busy_s': sum(regions), 'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
     if preflight is not None:
         out['dp_preflight'] = preflight
+    if exchange is not None:
+        # rccl_ranks: how many ranks an all-reduce of ones over the communicator counted (== n_gpus or the line is not an N-GPU line)
+        out['rccl_ranks'] = exchange['ranks_counted_by_all_reduce']
+        out['gradient_exchange'] = exchange
+    if math == 'bf16':
+        out['arithmetic'] = ({'mode': 'config3', 'critic': 'bf16 MFMA on bf16 tensors (17 of the iteration\'s 21 network passes)',
+                              'generator_backward': 'bf16 MFMA (input- and filter-gradient GEMMs), fp32 tensors with bf16 operand images',
+                              'generator_forward': 'fp32 MFMA on fp32 tensors (2 passes per iteration)',
+                              'why': 'DESIGN 4.16: every tensor of the step within BASELINE.md\'s 2e-2 (tests/test_step_b64_gpu.py[config3])'}
+                             if g_mode == 'config3' else
+                             {'mode': 'all_bf16', 'note': 'every GEMM of both networks in bf16 math: outside the 2e-2 tolerance (generator-step gradients '
+                                                          'up to 1.07e-1), NOT a config-3 claim'})
     if rank == 0 and args.instrument != 'off':
         s = timer.summary()
         info = K.device_info(local_rank)
@@ -439,6 +472,29 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks of ONE node, exactly the way the driver
+    does it (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...).
+    Rank 0's JSON line is the child's stdout, passed through untouched.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get('T2I_SAME_DEVICE') != '1':
+        sys.stderr.write('[bench] --gpus %d but %d GPU(s) visible here (T2I_SAME_DEVICE=1 T2I_DIST_BACKEND=gloo runs the N-rank path '
+                         'on one device as a pre-flight)\n' % (n, have))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:       # a free port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('[bench] launching %d ranks: %s\n' % (n, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -470,11 +526,14 @@ def main():
         cpu_baseline_child(args.cpu_baseline_only)
         return
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))            # `python bench.py --gpus N` on its own: one rank per GPU through torch.distributed.run
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or unset WORLD_SIZE and let bench.py launch itself)'
+                         % (args.gpus, world, args.gpus))
     # Pre-flight hooks for boxes with ONE GPU: T2I_SAME_DEVICE=1 puts every rank on device 0 and T2I_DIST_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device), so the whole multi-process path — rendezvous, bucket order,
     # overlap hooks, barriers, max-over-ranks timing — runs for real, minus the xGMI transport.  Never set by the driver.
@@ -520,24 +579,35 @@ def main():
         import copy
         a3 = copy.copy(args)
         a3.repeats = max(1, min(args.repeats, 3))
-        c3 = run_config(a3, 'bf16', device, rank, local_rank, world, use_dp, make_dp, headline=False)
+        c3 = run_config(a3, 'bf16', device, rank, local_rank, world, use_dp, make_dp, headline=False, g_mode='config3')
+        side = None
+        if os.environ.get('T2I_BENCH_ALL_BF16_ROW', '1') != '0':
+            a3b = copy.copy(a3)
+            a3b.repeats, a3b.min_busy_s, a3b.instrument = 1, 0.0, 'off'
+            side = run_config(a3b, 'bf16', device, rank, local_rank, world, use_dp, make_dp, headline=False, g_mode='all_bf16')
         if rank == 0:
-            keep = ('value', 'unit', 'ms_per_step', 'dtype', 'n_gpus', 'steps', 'warmup', 'config', 'timing', 'roofline', 'dp_preflight')
+            keep = ('value', 'unit', 'ms_per_step', 'dtype', 'n_gpus', 'steps', 'warmup', 'config', 'arithmetic', 'timing', 'roofline', 'dp_preflight',
+                    'rccl_ranks', 'gradient_exchange')
             blk = {k: c3[k] for k in keep if k in c3}
             blk['vs_fp32_line'] = c3['value'] / out['value'] if out.get('value') else None
+            if side is not None:
+                blk['all_bf16_side_row'] = {'value': side['value'], 'unit': side['unit'], 'ms_per_step': side['ms_per_step'],
+                                            'vs_fp32_line': side['value'] / out['value'] if out.get('value') else None,
+                                            'arithmetic': side.get('arithmetic'),
+                                            'parity': 'NOT within BASELINE.md\'s 2e-2 (tests/test_step_b64_gpu.py[all_bf16] states its measured envelope: G 2.15e-2, '
+                                                      'D(x_hat) 3.8e-2, generator-step gradients <= 1.07e-1): reported for the kernels\' sake, not as config 3'}
             blk['parity'] = {
-                'test': 'tests/test_step_b64_gpu.py::test_b64_bf16_steps_mask_pinned[B64-bf16] (B=64, full width, mask-pinned vs the float64 oracle)',
+                'test': 'tests/test_step_b64_gpu.py::test_b64_bf16_steps_mask_pinned[B64-config3] (B=64, full width, mask-pinned vs the float64 oracle)',
                 'stated_in_BASELINE_md': 'bf16-MFMA configuration: rel <= 2e-2 vs the fp32 oracle',
-                'bounds_relative_l2': {'G': 2.5e-2, 'D(x_hat)': 5e-2, 'loss_scalars': 2e-2, 'critic_step_gradients': 2e-2,
-                                       'generator_step_gradients': 1.2e-1},
-                # measured on MI355X, round 4 (profiles/r04_bf16_layer_errors.txt, tools/bf16_error_table.py): what exceeds 2e-2 is listed with its value
-                'measured_relative_l2': {'G': 2.15e-2, 'D(x) activations, every layer': '<= 6.5e-3', 'D(x_hat) logit': 3.8e-2,
-                                         'D(x_hat) first-layer activation (inherits G through x_hat)': 1.8e-2, 'grad_x_hat': 6.5e-3,
-                                         'critic_step_gradients worst': 1.5e-2, 'loss_scalars worst': 7.0e-3,
-                                         'generator_step_gradients worst / median': [1.07e-1, 5.7e-2]},
-                'above_2e-2': 'G by 7 %, D(x_hat) (3.8e-2) and the generator-step gradients (median 5.7e-2): the error grows 1e-3..2e-3 per bf16 GEMM layer '
-                              'over 12 (critic) / 24 (generator step) layers in series and no stored tensor dominates — fp32 arithmetic on the last 3-5 generator '
-                              'layers lowers it by < 15 % (same table); with fp32 activation tensors (bf16 operand rounding only): G 1.8e-2, gradients worst 8.4e-2',
+                'bounds_relative_l2': {'G': 2e-2, 'D(x_hat)': 2e-2, 'grad_x_hat': 2e-2, 'loss_scalars': 2e-2, 'critic_step_gradients': 2e-2,
+                                       'generator_step_gradients': 2e-2},
+                # measured on MI355X, round 5 (profiles/r05_config3_error_table.txt, tools/bf16_error_table.py --variants g_fwd_f32)
+                'measured_relative_l2': {'G': 3.5e-6, 'D(x) activations, every layer': '<= 6.5e-3', 'D(x_hat) logit': 1.24e-2, 'grad_x_hat': 6.6e-3,
+                                         'critic_step_gradients worst': 1.49e-2, 'loss_scalars worst': 7.0e-3,
+                                         'generator_step_gradients worst / median': [1.04e-2, 8.4e-3]},
+                'above_2e-2': None,
+                'forward_error_yardstick': 'config 3: relative L2 per tensor.  The fp32 headline\'s G is held to max|G - ref| <= 1e-5 x max|pre-tanh logits| '
+                                           '(logits reach |59|; against max|G| = 1 the same run measures <= 2.3e-5, tests/test_step_b64_gpu.py prints both)',
                 'kernel_arithmetic': 'tests/test_kernels_gpu.py::test_bf16_operand_gemm_matches_rounded_oracle: 1e-5 / 1e-4 vs float64 on bf16-rounded operands'}
             out['config3_bf16'] = blk
     # SURVEY 8(d)'s strong-scaling share (global 64 = 8 per GPU = the yml's BATCH_SIZE) and the next rows (gancls, StackGAN, PGGAN):

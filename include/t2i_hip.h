@@ -158,8 +158,13 @@ int t2i_conv2d_bwd_filter(const t2i_conv_desc* d, const void* x, const void* dy,
  * (models/wgancls/model.py:94-106) every conv2d (utils/ops.py:58-63) contributes an input gradient conv^T(g, w) AND a filter
  * gradient x (*) g, every conv2d_transpose (utils/ops.py:66-71) contributes conv(g, w) AND a filter gradient g (*) saved dy: two
  * independent GEMMs on the same incoming gradient.  first = T2I_PAIR_BWD_DATA: out1 = conv^T(g, w);  T2I_PAIR_FWD: out1 = conv(g, w)
- * (no bias, no activation);  then dw = fx (*) fdy (accumulate != 0: dw += ...).  The results are bit for bit those of
- * t2i_conv2d_bwd_data / t2i_conv2d_fwd followed by t2i_conv2d_bwd_filter with the same opts; where both GEMMs run on the
+ * (no bias, no activation);  then dw = fx (*) fdy (accumulate != 0: dw += ...).  The results are the SAME SUMS as those of
+ * t2i_conv2d_bwd_data / t2i_conv2d_fwd followed by t2i_conv2d_bwd_filter with the same opts (same operand rounding, same fp32
+ * accumulation inside a K range) but not necessarily the same bits: a shared launch plans each GEMM for its share of the chip
+ * (tuning pair_cus, default half), which may choose another split-K grouping, i.e. another order of the fp32 partial sums
+ * (tests/test_storage_gpu.py bounds the difference at the fp32 GEMM tolerance).  Hence bf16-storage results depend on whether the
+ * pair path is taken (kernels.pair_calls, and autograd takes it only on one stream): runs are bit-reproducible for a FIXED
+ * setting, the side-stream / pair toggles are not bit-neutral in bf16.  Where both GEMMs run on the
  * bf16-operand kernels they share one launch (a B = 64 layer leaves each of them one workgroup per CU; two streams of a captured
  * graph do not overlap on this stack).  opts1 (in_dtype bit 0: g, out_dtype: out1) and opts2 (bit 0: fx, bit 1: fdy) are
  * required; ws1 / ws2 (each t2i_conv2d_workspace_bytes(d)) are in use at the same time and must not overlap. */

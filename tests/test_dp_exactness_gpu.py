@@ -56,3 +56,32 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
     # bit for bit, a single replica whose gradient arena is rounded to bf16 once (dp.LocalRounding) and aborts otherwise
     _two_ranks(29814, ['--math', 'bf16', '--warmup', '1', '--steps', '1'], {})
     # (both two-rank runs also went through bench.py's own data-parallel preflight, which aborts the run on a mismatch)
+
+
+def test_bench_gpus_2_launches_itself_and_describes_the_exchange():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the driver's SCALE invocation form): bench.py re-runs itself as two
+    ranks through torch.distributed.run (two gloo ranks on GPU 0 here: T2I_SAME_DEVICE / T2I_DIST_BACKEND), and rank 0's ONE JSON line
+    says how many ranks the communicator counted and what the gradient exchange moved and cost."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(T2I_SAME_DEVICE='1', T2I_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--repeats', '1', '--min-busy-s', '0',
+                        '--no-cpu-baseline', '--no-config3', '--instrument', 'off'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['steps'] == 2
+    assert out['config']['global_batch'] == 128 and out['scaling'] == 'weak'
+    ex = out['gradient_exchange']
+    assert ex['ranks'] == 2 and ex['dtype_on_wire'] == 'f32' and ex['backend'] == 'gloo'
+    # both arenas cross the wire once per iteration: 28 995 329 + 22 643 287 fp32 parameters (+ per-variable padding to 16 bytes)
+    assert 4 * (28995329 + 22643287) <= ex['payload_bytes_per_step'] <= 4 * (28995329 + 22643287) + 4096
+    assert ex['ms_in_collectives_per_step'] > 0 and ex['ms_compute_stream_stalled_per_step'] >= 0
+    assert out['dp_preflight']['ok'] and out['dp_preflight']['exact']

@@ -125,6 +125,8 @@ def test_b64_critic_step_mask_pinned(setup):
     # applies to the conv output, and |dG| <= |dlogits| because tanh' <= 1 — so G's error is measured against max|logits|.
     # (Yardstick: torch-CPU fp32 on the same step sits 5.8e-5 from float64 on G, i.e. 3.3e-6 of max|logits|.)
     chk('G (vs max|logits| %.1f)' % ref['G_logits_absmax'], relerr(d['G'], ref['G'], scale=ref['G_logits_absmax']), 1e-5)
+    # the same difference against max|G| (= 1): printed — bench.py's parity block quotes both yardsticks
+    print('  G against max|G| instead: %.2e (the yardstick above is max|logits|)' % relerr(d['G'], ref['G']))
     chk('D(x_hat)', relerr(d['Dx_hat_logit'], ref['Dx_hat']), 1e-5)      # SURVEY 8(c)'s forward bound (12 layers in series; measured 0.7e-5)
     # ---- losses: 1e-5 relative
     for k in ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'reg_loss'):
@@ -211,22 +213,30 @@ def test_b64_generator_step_mask_pinned(setup):
             _check_grad_kinks(m.g_arena.grad_of(n), free['grads'][n].numpy(), n, 0.0)
 
 
-@pytest.mark.parametrize('storage', ['f32', 'bf16'])
-def test_b64_bf16_steps_mask_pinned(setup, storage):
+CONFIG3 = 'config3'          # BASELINE configs[2] as benchmarked: the compliant per-network arithmetic (kernels.CONFIG3_NET_MATH)
+
+
+@pytest.mark.parametrize('mode', [CONFIG3, 'all_bf16_f32_tensors', 'all_bf16'])
+def test_b64_bf16_steps_mask_pinned(setup, mode):
     """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate, master weights in fp32) at the metric's own size,
-    mask-pinned like the fp32 tests above; storage = 'f32': fp32 activation tensors with bf16 operand images (round 2),
-    'bf16': bf16 activation tensors end to end (ABI v6 — every activation and activation gradient with a multiple of 64 channels is
-    rounded once more, where its producer stores it; measured values for both in brackets below).  At bf16 the forward differs from float64 by ~1e-2, which flips ~0.4 % of
-    the lrelu branches per layer; un-pinned, those flips dominate every gradient comparison (tests/test_step_gpu.py can only
-    ask for a cosine there).  With the oracle replaying the HIP run's branches both sides differentiate the same
-    piecewise-linear function, and what is left is the operand rounding itself: every product carries 2^-8 relative error with
-    random sign.  Stated tolerances, relative L2 per tensor (measured in brackets):
-      * forward: G <= 2e-2 [1.8e-2]; D(x_hat) <= 5e-2 [3.6e-2] (x_hat already carries G's error into 12 more layers);
-      * loss scalars <= 2e-2 of max(|ref|, 1) [<= 6.4e-3];
-      * critic-step gradients (12-layer chain, no normalisation) <= 2e-2 per tensor [3.6e-3 .. 7.8e-3];
-      * generator-step gradients <= 1.2e-1 per tensor [0.7e-2 .. 8.9e-2]: the chain is twice as long, runs through nine
-        batch norms (1/sigma of perturbed statistics) and starts at tanh'(logits) = 1 - G^2 with |logits| up to 59, whose
-        relative error is ~2 |logit| d(logit) for the nearly saturated pixels that carry most of the gradient.
+    mask-pinned like the fp32 tests above.
+
+    mode 'config3' — THE parity claim of config 3 (BASELINE.md section 3 / SURVEY 8(c): relative error <= 2e-2 against the fp32
+    oracle).  Every bound below is 2e-2, none widened: G, D(x_hat), grad_x_hat, every loss scalar, every critic-step gradient and
+    every generator-step gradient.  The arithmetic that meets it (profiles/r05_config3_error_table.txt): the critic — 17 of the iteration's
+    21 network passes — in bf16 math on bf16 tensors; the generator's input- and filter-gradient GEMMs in bf16 math; the generator's
+    FORWARD GEMMs in fp32 math on fp32 tensors.  Why the forward: the backward is linear in the upstream gradient, so its operand
+    roundings add up once (1e-3..2e-3 per layer), while a forward error of 2e-2 in G re-enters through every nonlinear term of the
+    backward (tanh' = 1 - G^2 at |logits| up to 59, the batch norms' 1/sigma and x_hat, the filter gradients' x operand) and
+    through x_hat into the second critic pass — with all 24 layers of the generator step in bf16 the gradients were 5.7e-2 (median)
+    and D(x_hat) 3.8e-2 off.  Measured in this mode: G 3.5e-6, D(x_hat) 1.24e-2, grad_x_hat 6.6e-3, critic-step gradients <= 1.49e-2,
+    generator-step gradients <= 1.04e-2 (median 8.4e-3), loss scalars <= 7e-3.
+
+    modes 'all_bf16_f32_tensors' / 'all_bf16' — NOT config 3's parity claim: every GEMM of both networks in bf16 math (fp32 activation
+    tensors with bf16 operand images / bf16 activation tensors end to end).  Kept as kernel coverage of the generator's bf16 forward
+    path at full width and reported as a labelled side row by bench.py; their bounds are the measured envelope of that arithmetic and
+    exceed 2e-2 where stated: G <= 2e-2 / 2.5e-2 [1.8e-2 / 2.15e-2]; D(x_hat) <= 5e-2 [3.6e-2 / 4.1e-2]; loss scalars, grad_x_hat and
+    critic-step gradients <= 2e-2 [<= 1.5e-2]; generator-step gradients <= 1.2e-1 [<= 1.07e-1, median 5.7e-2].
     For comparison the un-pinned bf16 check (tests/test_step_gpu.py) can only ask for a cosine >= 0.95."""
     T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
     if B != 64:
@@ -244,11 +254,13 @@ def test_b64_bf16_steps_mask_pinned(setup, storage):
         if not err <= tol:
             bad.append((name, err, tol))
     K.set_math('bf16')
-    K.set_storage(storage)
-    # bf16 storage rounds every activation once more where its producer stores it: measured G 2.15e-2 (fp32 tensors: 1.8e-2),
-    # D(x_hat) 4.1e-2 (3.6e-2), critic-step gradients <= 7.8e-3 (7.8e-3), generator-step gradients <= 9.9e-2 (8.9e-2), loss scalars
-    # <= 7.0e-3 (6.4e-3) — the forward bound on G is the only one that needs room
-    g_tol = 2e-2 if storage == 'f32' else 2.5e-2
+    K.set_storage('f32' if mode == 'all_bf16_f32_tensors' else 'bf16')
+    compliant = mode == CONFIG3
+    saved_net_math = m.net_math
+    m.net_math = dict(K.CONFIG3_NET_MATH) if compliant else {}
+    g_tol = 2e-2 if mode != 'all_bf16' else 2.5e-2
+    dxh_tol = 2e-2 if compliant else 5e-2
+    ggrad_tol = 2e-2 if compliant else 1.2e-1
     try:
         rec = []
         with record_branches(rec):
@@ -256,10 +268,11 @@ def test_b64_bf16_steps_mask_pinned(setup, storage):
             torch.cuda.synchronize()
         masks = _split_d_masks(rec, B)
         ref = T.d_step(P, ocfg, feed, 0.7, masks=masks)
-        e = rel_l2(d['G'], ref['G'])
-        assert e > 1e-4, 'reduced precision is not in use'
-        chk('G', e, g_tol)
-        chk('D(x_hat)', rel_l2(d['Dx_hat_logit'], ref['Dx_hat']), 5e-2)
+        assert rel_l2(d['grad_x_hat'], ref['grad_x_hat']) > 1e-4, 'reduced precision is not in use'
+        if compliant:
+            assert d['G'].dtype == torch.float32 and rel_l2(d['G'], ref['G']) < 1e-4, 'the generator forward is meant to be exact here'
+        chk('G', rel_l2(d['G'], ref['G']), g_tol)
+        chk('D(x_hat)', rel_l2(d['Dx_hat_logit'], ref['Dx_hat']), dxh_tol)
         for k, tol in (('D_loss_real', 2e-2), ('D_loss_fake', 2e-2), ('D_loss_mismatch', 2e-2), ('wdist', 2e-2), ('wdist2', 2e-2),
                        ('real_gp', 2e-2), ('real_gp2', 2e-2), ('D_loss', 2e-2)):
             chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), tol)
@@ -285,8 +298,9 @@ def test_b64_bf16_steps_mask_pinned(setup, storage):
             r = gref['grads'][n]
             if float(r.abs().max()) < 1e-9:
                 continue
-            chk('grad ' + n, rel_l2(m.g_arena.grad_of(n), r), 1.2e-1)
+            chk('grad ' + n, rel_l2(m.g_arena.grad_of(n), r), ggrad_tol)
     finally:
+        m.net_math = saved_net_math
         K.set_storage('f32')
         K.set_math('f32')
     assert not bad, bad

@@ -602,3 +602,35 @@ def test_trainer_train_with_graphs_matches_eager(gpu):
     assert states[0][1] == states[1][1]
     for n in states[0][0]:
         assert torch.equal(states[0][0][n], states[1][0][n]), n
+
+
+def test_adam_first_moment_survives_a_stray_zero_grad(gpu):
+    """beta1 == 0: the optimizer neither reads nor writes its first moment; `m` is formed from the gradient arena on demand
+    (optim.AdamTF).  A zero_grad / backward between the step and the checkpoint must not change what the checkpoint holds
+    (ADVICE round 4): an eager Arena.zero_grad forms the stale moment before it clears its source; assigning `m` sticks."""
+    from t2i_amd.models.wgancls.model import WGanCls
+    from t2i_amd.models.wgancls.trainer import WGanClsTrainer
+    B = 4
+    cfg = _cfg(8, 32, 16, 8, 8, B)
+    g = torch.Generator(device=gpu).manual_seed(5)
+    feed = {'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1, 'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+            'cond': torch.randn(B, 32, generator=g, device=gpu), 'z': torch.randn(B, 8, generator=g, device=gpu),
+            'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4}
+    m = WGanCls(cfg, device=gpu, seed=3)
+    assert m.D_optim.skip_m and m.G_optim.skip_m
+    tr = WGanClsTrainer(None, m, None, cfg)
+    tr.iteration(1, feed)
+    tr.iteration(2, feed)
+    want_d, want_g = m.d_arena.grad.clone(), m.g_arena.grad.clone()          # m_t = g_t (beta1 = 0, grad_scale = 1)
+    assert float(want_d.abs().max()) > 0 and float(want_g.abs().max()) > 0
+    m.d_arena.zero_grad()                                                    # stray: nobody has asked for m yet
+    m.g_losses(feed)                                                         # a backward that refills the generator arena with other gradients
+    assert not torch.equal(m.g_arena.grad, want_g)
+    state = tr.make_saver().state()
+    name = 'd_net/Conv_3/weights'
+    o, k = m.d_arena.offsets[name]
+    assert np.array_equal(state['D_optim/%s/Adam' % name].reshape(-1), want_d[o:o + k].cpu().numpy())
+    assert torch.equal(m.D_optim.m, want_d) and torch.equal(m.G_optim.m, want_g)
+    m.D_optim.m = torch.full_like(want_d, 0.25)                              # assignment sticks (no moments_loaded() needed)
+    m.d_arena.zero_grad()
+    assert float(m.D_optim.m.min()) == 0.25 == float(m.D_optim.m.max())

@@ -183,7 +183,8 @@ class Conv2dFn(Function):
         ctx.set_materialize_grads(False)   # an undefined upstream gradient must not become a zero-filled conv launch
         # want_stats: a batch norm consumes this output next; the GEMM epilogue leaves it the per-tile column sums
         # the filter gradient of this layer transforms the same x (fp32 Winograd): keep the transform if a gradient will be asked for
-        keep = bool(ctx.needs_input_grad[1]) and not _INPUTS_ONLY[0]
+        ctx.geom_b = K.bwd_geom(geom)       # the backward GEMMs' descriptor (kernels.math_scope(bwd_math=...)); usually geom itself
+        keep = bool(ctx.needs_input_grad[1]) and not _INPUTS_ONLY[0] and ctx.geom_b is geom
         y = (K.conv_fwd_stats(x, w, b, d, ws, act, alpha, keep_xform=keep, out_dtype=out_dtype) if want_stats
              else K.conv_fwd(x, w, b, d, ws, act, alpha, keep_xform=keep, out_dtype=out_dtype))
         ctx.xform = K.LAST_XFORM[0] if keep else None
@@ -217,12 +218,12 @@ class Conv2dFn(Function):
                 gb = ColSumFn.apply(gpre)
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, x, w):
             # final backward on bf16 tensors: the input gradient and the (sunk) filter gradient in one launch
-            gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), ctx.geom[0], ctx.geom[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
+            gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), ctx.geom_b[0], ctx.geom_b[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
             _notify(w)
             ctx.xform = None
             return gx, None, gb, None, None, None, None, None
-        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
-        gw = _filter_grad(x, gpre, ctx.geom, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
+        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom_b, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
+        gw = _filter_grad(x, gpre, ctx.geom_b, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
         ctx.xform = None
         return gx, gw, gb, None, None, None, None, None
 
@@ -239,6 +240,7 @@ class ConvBwdDataFn(Function):
         out = K.conv_bwd_data(dy, w, b, d, ws, act, alpha, out_dtype=out_dtype)
         ctx.save_for_backward(dy, w, out if act != K.ACT_NONE else None)
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, b is not None
+        ctx.geom_b = K.bwd_geom(geom)
         ctx.bias_ref = b
         return out
 
@@ -250,12 +252,12 @@ class ConvBwdDataFn(Function):
         gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
         params = not _INPUTS_ONLY[0]
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, dy, w):
-            g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), ctx.geom[0], ctx.geom[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
+            g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), ctx.geom_b[0], ctx.geom_b[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
             _notify(w)
             g_w = None
         else:
-            g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
-            g_w = _filter_grad(gpre, dy, ctx.geom, w) if (ctx.needs_input_grad[1] and params) else None
+            g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom_b, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
+            g_w = _filter_grad(gpre, dy, ctx.geom_b, w) if (ctx.needs_input_grad[1] and params) else None
         g_b = None
         if ctx.has_bias and ctx.needs_input_grad[2] and params:
             bsink = _sink_of(ctx.bias_ref)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds libt2i_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  Usage: build.sh [outdir]
+# Builds libt2i_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  Usage: [T2I_BUILD_FORCE=1] build.sh [outdir]
+# Objects newer than their sources (and the two headers) are reused unless T2I_BUILD_FORCE=1; the last line says how many were compiled.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/../lib}"
@@ -7,13 +8,17 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 pids=()
+compiled=0
+total=0
 for f in t2i_igemm t2i_igemm_h t2i_bgemm t2i_aux t2i_thin t2i_winograd t2i_capi; do
-  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/t2i_internal.h" -nt "$OUT/$f.o" ] \
+  total=$((total + 1))
+  if [ "${T2I_BUILD_FORCE:-0}" = "1" ] || [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/t2i_internal.h" -nt "$OUT/$f.o" ] \
      || [ "$HERE/../../include/t2i_hip.h" -nt "$OUT/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" &
     pids+=($!)
+    compiled=$((compiled + 1))
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done     # (set -e: a failed compile fails the build here)
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libt2i_hip.so" "$OUT/t2i_igemm.o" "$OUT/t2i_igemm_h.o" "$OUT/t2i_bgemm.o" "$OUT/t2i_aux.o" "$OUT/t2i_thin.o" "$OUT/t2i_winograd.o" "$OUT/t2i_capi.o"
-echo "built $OUT/libt2i_hip.so"
+echo "built $OUT/libt2i_hip.so: compiled $compiled of $total objects (the others were up to date), linked 1 shared library"

@@ -295,11 +295,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = bm + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-#if defined(T2I_BEXP) && (T2I_BEXP & 1)
-          if (m < p.M && n < p.N && acc[i][j][e] == 1.2345e38f) out[(size_t)m * p.N + n] = acc[i][j][e];
-#else
           if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[i][j][e];
-#endif
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;

@@ -741,7 +741,7 @@ static int conv2d_fwd_storage(const t2i_conv_desc* d, const void* xv, const floa
   if ((rc = storage_check(d, opts, "t2i_conv2d_fwd"))) return rc;
   if (!xv || !w || !yv) { set_error("t2i_conv2d_fwd: null tensor"); return T2I_ERR_INVALID; }
   opts->out_image_written = 0; opts->xform_kept = 0;
-  if (!tuning().no_thin && stem_fwd_eligible(*d) && aligned16(w) && !xh && yh)           // fp32 image in, bf16 activation out
+  if (!tuning().no_thin && stem_fwd_eligible(*d) && aligned16(w) && aligned16(yv) && (!bias || aligned16(bias)) && !xh && yh)   // fp32 image in, bf16 activation out (vector epilogue: 16-byte stores, float4 bias loads)
     return check(stem_fwd_launch(*d, reinterpret_cast<const float*>(xv), w, bias, nullptr, act, alpha, (hipStream_t)stream, yv), "t2i_conv2d_fwd(stem)");
   const bool head = !tuning().no_thin && head_conv_eligible(*d);
   if (!head && h_eligible(*d, false) && (d->Cout % 4) == 0 && aligned16(xv) && aligned16(w) && aligned16(yv))
@@ -805,7 +805,7 @@ static int conv2d_fwd_impl(const t2i_conv_desc* d, const float* x, const float* 
       return check(head_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(head)");
     if (tiny_conv_eligible(*d, false))
       return check(tiny_conv_launch(*d, false, x, w, bias, y, act, alpha, (hipStream_t)stream), "t2i_conv2d_fwd(tiny)");
-    if (stem_fwd_eligible(*d) && aligned16(w)) {
+    if (stem_fwd_eligible(*d) && aligned16(w) && aligned16(y) && (!y_h || aligned16(y_h)) && (!bias || aligned16(bias))) {   // (the LDS epilogue stores 16 bytes per lane)
       if (y_h) *y_h_written = 1;
       return check(stem_fwd_launch(*d, x, w, bias, y, act, alpha, (hipStream_t)stream, y_h), "t2i_conv2d_fwd(stem)");
     }
@@ -1003,11 +1003,20 @@ int t2i_conv2d_bwd_pair(const t2i_conv_desc* d, int first, const void* g, const 
     }
     rc = conv_h(mode, d, nullptr, g, w, nullptr, nullptr, out1, nullptr, T2I_ACT_NONE, 0.f, ws1, ws1_bytes, (hipStream_t)stream, what, &ga, one ? cus : 256);
     if (rc != T2I_OK) return rc;
+    if (one && !(ga.wmt <= 2 && ga.wnt <= 2)) {
+      // the shared launch dispatches the {1,2} x {1,2} wave tiles only; the planner may hand the first GEMM the 8-wave (4,2) tile
+      // (T2I_TILE8_EFF / force_tile): then two launches, each planned for the whole chip
+      one = false;
+      rc = conv_h_filter(d, nullptr, nullptr, fx, fdy, dw, accumulate ? 1 : 0, ws2, ws2_bytes, (hipStream_t)stream, &gb, 256);
+      if (rc != T2I_OK) return rc;
+      rc = conv_h(mode, d, nullptr, g, w, nullptr, nullptr, out1, nullptr, T2I_ACT_NONE, 0.f, ws1, ws1_bytes, (hipStream_t)stream, what, &ga, 256);
+      if (rc != T2I_OK) return rc;
+    }
     if (one) {
       if (tuning().debug_plan) fprintf(stderr, "[t2i plan] pair: one launch, %d + %d workgroups\n",
                                        ga.p.tiles_m * ga.p.tiles_n * ga.p.splitk * (mode == MODE_BWD_DATA ? ga.p.nphase : 1), gb.p.tiles_m * gb.p.tiles_n * gb.p.splitk);
       rc = check(igemm_pair_launch(mode, ga.p, ga.wmt, ga.wnt, gb.p, (hipStream_t)stream), what);
-      ++g_stat_pair_fused;
+      if (rc == T2I_OK) ++g_stat_pair_fused;
     } else {
       rc = check(igemm_h_launch(mode, ga.p, ga.wmt, ga.wnt, (hipStream_t)stream), what);
       if (rc == T2I_OK) rc = check(igemm_h_filter_launch(gb.p, gb.wmt, gb.wnt, (hipStream_t)stream), what);

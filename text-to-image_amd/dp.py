@@ -54,6 +54,35 @@ class DataParallel(object):
         self._a2a = {}
         # early bucket launches during the backward; T2I_DP_NO_OVERLAP=1 (or overlap = False) exchanges after it instead
         self.overlap = os.environ.get('T2I_DP_NO_OVERLAP') != '1'
+        self._stats = None                    # begin_stats(): per-exchange HIP events + byte counts (bench.py's gradient_exchange block)
+
+    # ---- measurement of the exchange itself ------------------------------------------------------------------------------
+    def begin_stats(self):
+        """From now on every collective is bracketed by events on the communication stream and every finish_allreduce by events on
+        the calling stream (the time that stream stalls = the exposed part of the exchange).  Costs a host wait per collective in
+        fp32 mode (the async work is waited for on the communication stream so that the closing event sees its end): use on a few
+        extra iterations, not inside a timed region."""
+        self._stats = {'payload_bytes': 0, 'collectives': 0, 'comm': [], 'stall': [], 'exchanges': 0}
+
+    def end_stats(self, steps=1):
+        """-> dict (per step): payload bytes, collectives, ms inside collectives (communication stream), ms the compute stream stalled
+        in finish_allreduce, overlap fraction = 1 - stalled / in-collectives."""
+        st, self._stats = self._stats, None
+        if st is None:
+            return None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        comm = sum(a.elapsed_time(b) for a, b in st['comm'])
+        stall = sum(a.elapsed_time(b) for a, b in st['stall'])
+        n = max(1, steps)
+        ring = 2.0 * (self.world - 1) / max(self.world, 1)
+        return {'dtype_on_wire': self.grad_dtype, 'ranks': self.world, 'payload_bytes_per_step': st['payload_bytes'] / n,
+                'bytes_sent_per_rank_per_step': st['payload_bytes'] * ring / n, 'collectives_per_step': st['collectives'] / float(n),
+                'exchanges_per_step': st['exchanges'] / float(n), 'ms_in_collectives_per_step': comm / n,
+                'ms_compute_stream_stalled_per_step': stall / n,
+                'overlap_fraction': (1.0 - stall / comm) if comm > 0 else None,
+                'algorithm_bandwidth_GBps': (st['payload_bytes'] / 1e9) / (comm * 1e-3) if comm > 0 else None,
+                'steps_measured': n}
 
     # ---- bucket plan ---------------------------------------------------------------------------------------------------
     def _plan(self, arena):
@@ -227,6 +256,15 @@ class DataParallel(object):
         return got
 
     def _launch_range(self, st, start, end):
+        from .utils import roctx
+        with roctx.range('dp.exchange %s[%d:%d] %s' % (self._arena_tag(st), start, end, self.grad_dtype)):
+            self._launch_range_impl(st, start, end)
+
+    def _arena_tag(self, st):
+        names = st['arena'].names
+        return (names[0].split('/')[0] if names else 'arena')
+
+    def _launch_range_impl(self, st, start, end):
         buf = st['arena'].grad[start:end]
         bf16 = self.grad_dtype == 'bf16'
         if buf.is_cuda:
@@ -237,10 +275,23 @@ class DataParallel(object):
             if A.SIDE.stream is not None:                                   # ... including the filter-gradient stream's
                 self._side.wait_stream(A.SIDE.stream)
             with torch.cuda.stream(self._side):
+                stats = self._stats
+                if stats is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 if not bf16:
-                    st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if stats is not None:
+                        w.wait()         # the communication stream waits for the collective: the closing event sees its end
+                    else:
+                        st['works'].append(w)
                 else:                # everything ordered on the communication stream
                     self._exchange_bf16(st, buf)
+                if stats is not None:
+                    e1.record()
+                    stats['comm'].append((e0, e1))
+                    stats['payload_bytes'] += buf.numel() * (2 if bf16 else 4)
+                    stats['collectives'] += 1 if not bf16 else 2
         elif not bf16:
             st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -308,11 +359,22 @@ class DataParallel(object):
 
     def finish_allreduce(self, arena):
         """Make the calling stream wait for the exchange started by start_allreduce; returns 1/world."""
+        from .utils import roctx
         st = self.attach(arena)
+        roctx.push('dp.finish_allreduce %s (compute stream waits for the exchange)' % self._arena_tag(st))
+        stats = self._stats if arena.grad.is_cuda else None
+        if stats is not None:
+            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            m0.record()
         for w in st['works']:
             w.wait()
         if self._side is not None and arena.grad.is_cuda:
             torch.cuda.current_stream(arena.grad.device).wait_stream(self._side)
+        if stats is not None:
+            m1.record()
+            stats['stall'].append((m0, m1))
+            stats['exchanges'] += 1
+        roctx.pop()
         st['armed'] = False
         st['works'] = []
         st['partial'] = False

@@ -131,9 +131,12 @@ MATH_F32, MATH_BF16 = 0, 1
 _MATH = [MATH_F32]
 
 
+_MATH_CODES = {'f32': MATH_F32, 'fp32': MATH_F32, 'bf16': MATH_BF16}
+
+
 def set_math(mode):
     """Select the arithmetic of every conv/deconv/dense descriptor created from now on: 'f32' or 'bf16'."""
-    _MATH[0] = {'f32': MATH_F32, 'fp32': MATH_F32, 'bf16': MATH_BF16}[str(mode).lower()]
+    _MATH[0] = _MATH_CODES[str(mode).lower()]
 
 
 def get_math():
@@ -168,6 +171,57 @@ def f32_outputs():
         yield
     finally:
         _FORCE_F32[0] -= 1
+
+
+# Per-network arithmetic (config 3's compliant mode): a scope in which descriptors are created with another math mode and
+# activations are allocated with another storage dtype than the process-wide setting.  The backward of a layer follows its forward
+# (descriptors travel in the autograd context, gradients take the dtype of the tensor they are the gradient of), so entering the
+# scope around a network's FORWARD is enough.  _MIXED: a scope has been used — with bf16 storage outside the scope every tensor
+# that wants a bf16 image is one already, so float32 outputs (the scoped network's) get no bf16 twin.
+_MIXED = [False]
+_BWD_MATH = [None]          # arithmetic of the BACKWARD GEMMs of layers created in the current scope (None: the forward's)
+
+
+@contextlib.contextmanager
+def math_scope(math=None, storage=None, bwd_math=None):
+    """with math_scope('f32', 'f32'): ...  — conv descriptors and activation tensors created inside use this arithmetic / storage.
+    bwd_math: the input- and filter-gradient GEMMs of those layers run in this arithmetic instead (the backward is linear in the
+    upstream gradient, so its rounding errors add up once; the forward's are amplified by every nonlinear term behind them)."""
+    if math is None and storage is None and bwd_math is None:
+        yield
+        return
+    pm, ps, pb = _MATH[0], _STORE[0], _BWD_MATH[0]
+    _MIXED[0] = 'bwd_bf16' if (bwd_math is not None and _MATH_CODES[str(bwd_math).lower()] == MATH_BF16) or _MIXED[0] == 'bwd_bf16' else 'fwd'
+    try:
+        if math is not None:
+            _MATH[0] = _MATH_CODES[str(math).lower()]
+        if storage is not None:
+            _STORE[0] = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}[str(storage).lower()]
+        _BWD_MATH[0] = _MATH_CODES[str(bwd_math).lower()] if bwd_math is not None else None
+        yield
+    finally:
+        _MATH[0], _STORE[0], _BWD_MATH[0] = pm, ps, pb
+
+
+# BASELINE configs[2] ("bf16 MFMA") as benchmarked and as its parity test asserts (<= 2e-2 on every tensor, tests/test_step_b64_gpu.py):
+# per-network arithmetic (math, storage, backward math) handed to math_scope by the models.  Networks not named run in the
+# process-wide setting (set_math('bf16') + set_storage('bf16')): the critic.  DESIGN.md 4.16.
+CONFIG3_NET_MATH = {'g_net': ('f32', 'f32', 'bf16')}
+
+
+def bwd_geom(geom):
+    """(descriptor, workspace bytes) for the backward GEMMs of a layer whose forward uses `geom`: the same geometry in the scope's
+    backward arithmetic (math_scope(bwd_math=...)), or `geom` itself."""
+    bm = _BWD_MATH[0]
+    d = geom[0]
+    if bm is None or bm == d.math:
+        return geom
+    key = ('bwd', id(d), bm)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        d2 = ConvDesc(d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.SH, d.SW, d.pad_t, d.pad_l, bm)
+        hit = _DESC_CACHE[key] = (d2, int(lib.t2i_conv2d_workspace_bytes(ctypes.byref(d2))), d)      # (keeps d alive: id(d) is the key)
+    return hit[0], hit[1]
 
 
 def _act_dtype(shape, want=None):
@@ -347,7 +401,13 @@ def bf16_twins(on):
 def _twin_for(out, *inputs):
     """A buffer for the bf16 twin of `out` (bf16 math, a multiple of 64 channels: a conv reads it next), or None.  The producers
     write it on their vectorised path only, so every tensor of the call must be 16-byte aligned (the entry points refuse otherwise)."""
-    if out.dtype != torch.float32 or _MATH[0] != MATH_BF16 or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
+    want = _MATH[0] == MATH_BF16
+    if _MIXED[0]:
+        if _BWD_MATH[0] == MATH_BF16:            # inside a scope whose backward GEMMs read bf16 images: the saved activations get theirs here
+            want = torch.is_grad_enabled()
+        elif _STORE[0] is torch.bfloat16:        # outside the scope, bf16 storage: a float32 tensor here belongs to the scoped network's backward
+            want = _MIXED[0] == 'bwd_bf16'
+    if out.dtype != torch.float32 or not want or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:
         return None
     if any(t is not None and t.data_ptr() % 16 for t in (out,) + inputs):
         return None

@@ -141,8 +141,9 @@ class GanClsTrainer(object):
 
     def write_summaries(self, counter, feed, out):
         """The two merged summaries the reference adds per update (trainer.py:66-72,115-134) — D: histograms of the three critic
-        outputs and of the three loss terms, scalar d_loss; G: image g_sum, scalar g_loss — plus histogram z, from the values the
-        iteration computed (the reference fetches them in the same sess.run as the optimizer steps)."""
+        outputs and of the three loss terms, scalar d_loss; G: image g_sum, scalar g_loss (the reference defines a histogram z_sum but
+        merges it into neither, so the event file has no 'z' tag) — from the values the iteration computed (the reference fetches
+        them in the same sess.run as the optimizer steps)."""
         from ...utils import summary as S
         np_ = lambda t: t.detach().float().cpu().numpy()
         d, g = out['d'], out['g']
@@ -150,7 +151,7 @@ class GanClsTrainer(object):
                                  S.histogram('d_synthetic_sum', np_(d['D_synthetic'])), S.histogram('d_synthetic_sum_loss', np_(d['D_synthetic_loss'])),
                                  S.histogram('d_real_mismatch_sum_loss', np_(d['D_real_mismatch_loss'])),
                                  S.histogram('d_real_match_sum_loss', np_(d['D_real_match_loss'])), S.scalar('d_loss', float(d['D_loss']))], counter)
-        self.writer.add_summary([S.image('g_sum', np_(g['G'])), S.scalar('g_loss', float(g['G_loss'])), S.histogram('z', np_(feed['z']))], counter)
+        self.writer.add_summary([S.image('g_sum', np_(g['G'])), S.scalar('g_loss', float(g['G_loss']))], counter)
         self.writer.flush()
 
     def train(self, max_updates=None, log=None, summaries=False):

@@ -19,6 +19,7 @@ from ... import autograd as A
 from ... import kernels as K
 from ... import optim
 from ... import scope as S
+from ...utils import roctx
 from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
                           reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
 
@@ -61,6 +62,11 @@ class WGanCls(object):
         self._capturing = False
         self._consts = {}
         self._kl = None
+        # per-network arithmetic: {'g_net': (math, storage)} — layers of that network are created under kernels.math_scope
+        self.net_math = {}
+        if os.environ.get('T2I_G_MATH'):
+            gm = os.environ['T2I_G_MATH'].split(',')     # "f32" or "f32,bf16" (forward arithmetic[, backward arithmetic])
+            self.net_math['g_net'] = (gm[0], 'f32') + tuple(gm[1:2])
 
         if build_model:
             self.build_model()
@@ -237,6 +243,10 @@ class WGanCls(object):
         return out
 
     def d_step(self, feed):
+        with roctx.range('wgancls.d_step'):
+            return self._d_step(feed)
+
+    def _d_step(self, feed):
         self.D_optim.prepare(float(feed['learning_rate_d']))
         if self._graphs is not None:
             self._load_static(feed, noise=('ca_noise_d',))
@@ -337,6 +347,10 @@ class WGanCls(object):
         return out
 
     def g_step(self, feed):
+        with roctx.range('wgancls.g_step'):
+            return self._g_step(feed)
+
+    def _g_step(self, feed):
         self.G_optim.prepare(float(feed['learning_rate_g']))
         if self._graphs is not None:
             if not self._graphs['loaded']:
@@ -371,23 +385,29 @@ class WGanCls(object):
                 # whenever someone outside the training step wrote filters since the last one, they are regenerated here
                 g['dref'].replay()
                 g['epoch'] = K.filter_epoch()
-            g['dg'].replay()
+            with roctx.range('wgancls.iteration: d_step + g_step (one hipGraph replay)'):
+                g['dg'].replay()
         else:
             # five graph launches, four collectives; each backward is cut once so that the bulk of its gradients is on the wire
             # while the rest of the backward (and, for the critic, the generator's forward) still runs — see enable_graphs
             dA, dB = self._cut_ranges(self.d_arena, self._CUT_D)
             gA, gB = self._cut_ranges(self.g_arena, self._CUT_G)
-            g['d_a'].replay()                      # critic losses + backward down to the input of Conv_3
+            with roctx.range('d_step segment A: critic losses + backward to Conv_3'):
+                g['d_a'].replay()                  # critic losses + backward down to the input of Conv_3
             self.dp.start_allreduce(self.d_arena, extra=g['dg_out'][0]['wd_sums'], ranges=dA)
-            g['gf_d_b'].replay()                   # generator forward (needs no critic variable) + the rest of the critic backward
+            with roctx.range('segment B: generator forward + rest of critic backward'):
+                g['gf_d_b'].replay()               # generator forward (needs no critic variable) + the rest of the critic backward
             self.dp.start_allreduce(self.d_arena, ranges=dB)
             self.dp.finish_allreduce(self.d_arena)
-            g['dupd_g_a'].replay()                 # critic Adam + kt; critic on G; backward down to the generator's 4x4 -> 8x8 boundary
+            with roctx.range('g_step segment A: critic Adam + kt, D(G), backward to the 8x8 boundary'):
+                g['dupd_g_a'].replay()             # critic Adam + kt; critic on G; backward down to the generator's 4x4 -> 8x8 boundary
             self.dp.start_allreduce(self.g_arena, ranges=gA)
-            g['g_b'].replay()                      # the rest of the generator backward
+            with roctx.range('g_step segment B: rest of generator backward'):
+                g['g_b'].replay()                  # the rest of the generator backward
             self.dp.start_allreduce(self.g_arena, ranges=gB)
             self.dp.finish_allreduce(self.g_arena)
-            g['g_upd'].replay()
+            with roctx.range('generator Adam'):
+                g['g_upd'].replay()
         K.filter_cache_invalidate(external=False)
         self.global_step += 1
         return g['dg_out']
@@ -599,6 +619,11 @@ class WGanCls(object):
         return batch_norm(u, train=train, act=act, df=fmt)
 
     def generator(self, z, embed, reuse=False, is_training=True, df=NCHW, cond_noise=True):
+        # config 3's compliant mode: the generator's layers in their own arithmetic / storage (self.net_math['g_net'])
+        with K.math_scope(*self.net_math.get('g_net', (None, None))):
+            return self._generator(z, embed, reuse, is_training, df, cond_noise)
+
+    def _generator(self, z, embed, reuse, is_training, df, cond_noise):
         nf, grid = self.gf_dim, self.output_size // 16
         with S.variable_scope('g_net', reuse=reuse):
             mean, log_sigma = self.generate_conditionals(embed)

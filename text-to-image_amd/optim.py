@@ -36,7 +36,15 @@ class Arena(object):
         K.filter_cache_invalidate()                  # the variables moved (possibly onto recycled addresses)
 
     def zero_grad(self):
+        # an optimizer that derives its first moment from this arena on demand (AdamTF with beta1 == 0) is about to lose its source:
+        # let it form the moment first.  (Not inside a capture: a replayed iteration leaves the last step's gradients behind, so the
+        # on-demand path stays valid between replays, and the host does not run here on replay anyway.)
+        if self.before_zero and not (self.grad.is_cuda and torch.cuda.is_current_stream_capturing()):
+            for cb in self.before_zero:
+                cb()
         self.grad.zero_()
+
+    before_zero = ()
 
     def enable_sinks(self):
         """Let the filter-gradient GEMMs accumulate directly into this arena (autograd.SINKS)."""
@@ -61,26 +69,43 @@ class AdamTF(object):
         # writes it (4 bytes per parameter less of the 24 the update streams); `m` is formed from the gradient arena when somebody
         # asks for it — a checkpoint between two iterations — which is valid until the arena is zeroed for the next backward
         self.skip_m = beta1 == 0.0 and os.environ.get('T2I_ADAM_SKIP_M', '1') != '0'
-        self._m_valid_t, self._last_scale = 0, 1.0      # the step count `_m` was last brought up to date at
+        self._m_stale, self._last_scale = False, 1.0    # `_m` lags the last step (it is re-formed from the gradient arena on demand)
         self.t = 0
         self.lr_t_dev = torch.zeros(4, dtype=torch.float32, device=arena.flat.device)   # [0] = this step's lr_t
+        if self.skip_m:
+            arena.before_zero = tuple(arena.before_zero) + (self._materialize_m,)
 
     @property
     def m(self):
-        """First moment.  With the beta1 == 0 fast path it is (re)built from the gradient arena on access (see __init__)."""
-        if self.skip_m and self.t != self._m_valid_t:       # (t advances in prepare(), the host half of every step, replayed or not)
+        """First moment.  With the beta1 == 0 fast path it is (re)built from the gradient arena on access (see __init__): the arena
+        holds the last step's gradients until the next zero_grad, and an EAGER Arena.zero_grad forms a stale `m` before it clears
+        them (_materialize_m), so a checkpoint taken after a stray zero_grad / backward still holds the last step's moment."""
+        if self.skip_m and self._m_stale:
             with torch.no_grad():
                 torch.mul(self.arena.grad, self._last_scale, out=self._m)
-            self._m_valid_t = self.t
+            self._m_stale = False
         return self._m
+
+    @m.setter
+    def m(self, value):
+        """Assigning the first moment (a checkpoint restore, a test) keeps the assigned values until the next step."""
+        with torch.no_grad():
+            self._m.copy_(value)
+        self._m_stale = False
+
+    def _materialize_m(self):
+        """Arena.zero_grad (eager) is about to clear the gradients the on-demand first moment is formed from."""
+        if self.skip_m and self._m_stale:
+            self.m
 
     def moments_loaded(self):
         """The caller has just written m (and t) from a checkpoint: keep those values until the next step."""
-        self._m_valid_t = self.t
+        self._m_stale = False
 
     def prepare(self, lr):
         """Host half of a step: advance t and publish lr_t to the device scalar (outside any captured graph)."""
         self.t += 1
+        self._m_stale = self.skip_m          # every step (eager or replayed: this is its host half) leaves `_m` behind
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
         self.lr_t_dev.fill_(lr_t)
         return lr_t
@@ -95,6 +120,7 @@ class AdamTF(object):
                   lr_t_dev=self.lr_t_dev)
         if self.skip_m:
             self._last_scale = float(grad_scale)
+            self._m_stale = True             # (an eager zero_grad between prepare() and here has formed the PREVIOUS step's moment)
         if refresh is None:
             refresh = self.arena.flat.is_cuda and not torch.cuda.is_current_stream_capturing()
         if refresh and self.arena.flat.is_cuda:

@@ -8,6 +8,8 @@ Variants (which conv descriptors are forced to fp32 math while the rest of the s
   base_f32store   none, fp32 activation tensors (bf16 operand rounding only)
   hw32_f32    every conv / deconv whose larger map side is >= 32 (the generator's last three GEMM layers, the critic's first two)
   hw16_f32    ... >= 16
+  g_f32       the generator's layers in fp32 math on fp32 tensors, the critic in bf16 math on bf16 tensors
+  g_fwd_f32   ... only the generator's FORWARD GEMMs in fp32 math; its input- and filter-gradient GEMMs in bf16 math (fp32 tensors)
   f32         all (the fp32 path: the floor of the comparison)"""
 import argparse
 import os
@@ -66,7 +68,8 @@ def main():
 
     for var in a.variants:
         K.set_math('f32' if var == 'f32' else 'bf16')
-        K.set_storage('bf16' if var == 'base' else 'f32')      # mixed-math variants keep fp32 tensors (a fp32 conv cannot read a bf16 tensor)
+        K.set_storage('bf16' if var in ('base', 'g_f32', 'g_fwd_f32') else 'f32')
+        m.net_math = {'g_net': ('f32', 'f32')} if var == 'g_f32' else {'g_net': ('f32', 'f32', 'bf16')} if var == 'g_fwd_f32' else {}      # mixed-math variants keep fp32 tensors (a fp32 conv cannot read a bf16 tensor)
         if var == 'hw32_f32':
             force(lambda s: s >= 32)
         elif var == 'hw16_f32':
