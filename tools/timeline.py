@@ -33,6 +33,10 @@ def main():
         b[0] += 1; b[1] += e - s; b[2] += gap
         idle_total += gap; busy_total += e - s
         recs.append((e - s, gap, name, grid, s - t0))
+    if os.environ.get('T2I_TIMELINE_SEQUENCE'):       # every dispatch in issue order: start us, duration us, gap us, grid, kernel
+        with open(os.environ['T2I_TIMELINE_SEQUENCE'], 'w') as fh:
+            for dur, gap, name, grid, at in recs:
+                fh.write('%9.1f %7.1f %5.1f %6d  %s\n' % (at / 1e3, dur / 1e3, gap / 1e3, grid, name[:90]))
     print('last iteration: %d dispatches, span %.3f ms, kernels %.3f ms, idle gaps %.3f ms (avg %.2f us)' % (
         len(it), span / 1e6, busy_total / 1e6, idle_total / 1e6, idle_total / 1e3 / len(it)))
     short = [r for r in recs if r[0] < 8000]
