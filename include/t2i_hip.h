@@ -72,7 +72,7 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 7 (v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 8 (v8: t2i_sigmoid_ce_head added, the BN entry points below take `groups`; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
@@ -277,6 +277,14 @@ int t2i_row_scale_div(const void* g, const float* num, const float* den, int32_t
 int t2i_wgan_d_head(const float* logits, const float* slopes1, const float* slopes2, const float* kt_dev, int32_t B,
                     float gp_coeff, float* seed_logits, float* seed_slopes1, float* seed_slopes2, float* scalars,
                     t2i_stream_t stream);
+/* Sigmoid cross-entropy heads: reference models/gancls/trainer.py:20-34 (tf.nn.sigmoid_cross_entropy_with_logits on the critic's fake /
+ * match / mismatch logits with constant labels 0 / 0.9 / 0, weighted 1-alpha / 1 / alpha; G_loss with label 1) and
+ * models/stackgan/stageI/trainer.py:53-77.  For each head k < 3 with logits l_k[B] (l1, l2 may be NULL):
+ *   losses[1+k] = mean_i [max(l,0) - l y_k + log1p(exp(-|l|))],  losses[0] = sum_k w_k losses[1+k],
+ *   seed_k[i] = w_k (sigmoid(l) - y_k) / B  (= d losses[0] / d l_k[i]),  prob_k[i] = sigmoid(l)   (seed_k / prob_k may be NULL).
+ * One workgroup; replaces ~25 elementwise / reduction launches per set of heads. */
+int t2i_sigmoid_ce_head(const float* l0, const float* l1, const float* l2, float y0, float y1, float y2, float w0, float w1, float w2, int32_t B,
+                        float* seed0, float* seed1, float* seed2, float* prob0, float* prob1, float* prob2, float* losses, t2i_stream_t stream);
 /* code = mean + exp(log_sigma)*eps (eps: the truncated-normal draw) and kl[0] = mean(-ls + .5(-1 + exp(2 ls) + mean^2))
  * over the n = B*D elements; bwd: dmean = dcode + dkl/n * mean, dlog_sigma = dcode*eps*exp(ls) + dkl/n * (exp(2 ls) - 1)
  * (dcode and/or dkl may be NULL = zero). */

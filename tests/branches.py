@@ -27,7 +27,7 @@ def record_branches(out):
 
     try:
         wrap('conv_fwd', 5); wrap('conv_fwd_stats', 5); wrap('conv_bwd_data', 5)
-        wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
+        wrap('bn_apply_groups', 3); wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
         yield out
     finally:
         for n, fn in saved.items():

@@ -205,7 +205,12 @@ def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, ch
     """Critic step then generator step of a sigmoid-CE conditional GAN (gancls, StackGAN Stage-I) against its float64 oracle,
     mask-pinned; d_oracle / g_oracle: callables that run the oracle step under whatever tape is installed."""
     moving0 = {n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n}
-    plan = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
+    # the HIP passes in launch order (tests/branches.split_sections): gancls stacks the critic passes of one sess.run along the batch axis
+    # (GanClsTrainer.batched: fake | match | mismatch in the critic step; fake, then match | mismatch, in the generator step)
+    if getattr(tr, 'batched', False):
+        plan, plan_g = [('G',), ('Dfake', 'Dmatch', 'Dmis')], [('G',), ('Dfake',), ('Dmatch', 'Dmis')]
+    else:
+        plan = plan_g = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
     rec = []
     with record_branches(rec):
         d = tr.d_losses(hf)
@@ -234,7 +239,7 @@ def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, ch
     own = T.SectionTape()
     with T.use_tape(own):
         g_oracle()
-    masks = split_sections(rec, own.record, plan)
+    masks = split_sections(rec, own.record, plan_g)
     fl, units = flips(own.record, masks)
     print('%s generator step: %d of %d branches differ (%.2e)' % (tag, fl, units, fl / units))
     assert fl <= 1e-4 * units

@@ -843,3 +843,32 @@ def test_filter_cache_refresh_regenerates_only_the_named_range(K):
             assert relerr(g, 2.0 * r.double().cpu().numpy()) <= 2e-6
     finally:
         K.filter_cache(prev)
+
+
+def test_sigmoid_ce_head_matches_float64(K):
+    """t2i_sigmoid_ce_head against the float64 restatement of tf.nn.sigmoid_cross_entropy_with_logits (oracle/torch_gancls.py:145,
+    reference models/gancls/trainer.py:20-36): per-head means, the weighted total, d total / d logits and the probabilities — for one
+    and three heads, a ragged B, and logits large enough to saturate either branch of the stable form."""
+    gpu = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for B, n in ((64, 3), (7, 3), (300, 1), (64, 2)):
+        ls = [torch.randn(B, generator=g) * s for s in (1.0, 30.0, 0.01)][:n]
+        ls[0][0] = 80.0
+        ls[-1][-1] = -80.0
+        labels, weights = [0.0, 0.9, 0.0][:n], [0.5, 1.0, 0.5][:n]
+        losses, seeds, probs = K.sigmoid_ce_head([t.to(gpu) for t in ls], labels, weights)
+        torch.cuda.synchronize()
+        total = 0.0
+        for k in range(n):
+            l = ls[k].double().numpy()
+            ce = np.maximum(l, 0) - l * labels[k] + np.log1p(np.exp(-np.abs(l)))
+            p = 1.0 / (1.0 + np.exp(-l))
+            total += weights[k] * ce.mean()
+            assert abs(float(losses[1 + k]) - ce.mean()) <= 1e-6 * max(abs(ce.mean()), 1.0), (B, n, k)
+            assert np.abs(probs[k].cpu().numpy() - p).max() <= 1e-6
+            assert np.abs(seeds[k].cpu().numpy() - weights[k] * (p - labels[k]) / B).max() <= 1e-7
+        for k in range(n, 3):
+            assert float(losses[1 + k]) == 0.0
+        assert abs(float(losses[0]) - total) <= 1e-6 * max(abs(total), 1.0)
+    only = K.sigmoid_ce_head([ls[0].to(gpu)], [1.0], [1.0], want_prob=False)
+    assert only[2] is None

@@ -68,6 +68,7 @@ SIGNATURES = {
     't2i_row_scale_div': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _i32, _p]),
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
+    't2i_sigmoid_ce_head': (ctypes.c_int, [_p, _p, _p, _f, _f, _f, _f, _f, _f, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     't2i_ca_kl_bwd': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     't2i_lerp_dev': (ctypes.c_int, [_p, _p, _p, _i32, _i64, _p, _p]),
@@ -103,7 +104,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError('libt2i_hip.so not found at %s — build it with text-to-image_amd/csrc/build.sh '
                       '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback' % LIB_PATH)
 
-ABI_VERSION = 7          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
+ABI_VERSION = 8          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
 
 lib = ctypes.CDLL(LIB_PATH)
 try:

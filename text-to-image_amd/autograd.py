@@ -424,6 +424,62 @@ class BatchNormTrainFn(Function):
         return dx, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None, None
 
 
+class BatchNormTrainGroupedFn(Function):
+    """Training-mode batch norm of a BATCHED pass whose `groups` equal slices along the batch axis are separate passes of the
+    reference graph (models/gancls/model.py:48-51: the critic on fake / match / mismatch images, each with its own batch statistics):
+    statistics, normalisation and backward per slice — the slices are contiguous, so each is handed to the ordinary kernels as a view —
+    while every convolution around it runs once on the whole batch.  Moving averages move once per slice, in slice order (what three
+    sequential passes did); dgamma / dbeta are summed over the slices.  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, decay, act, alpha, groups):
+        x = _c(x)
+        Bt = x.shape[0]
+        assert Bt % groups == 0, (Bt, groups)
+        b = Bt // groups
+        stats, scales, shifts = [], [], []
+        for g in range(groups):
+            mean, rstd, scale, shift = K.bn_train_stats(x[g * b:(g + 1) * b], gamma, beta, eps, decay, moving_mean, moving_var)
+            stats += [mean, rstd]
+            scales.append(scale); shifts.append(shift)
+        y = K.bn_apply_groups(x, scales, shifts, act, alpha)
+        ctx.save_for_backward(x, gamma, y if act != K.ACT_NONE else None, *stats)
+        ctx.act, ctx.alpha, ctx.groups = act, alpha, groups
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 10
+        x, gamma, y = ctx.saved_tensors[:3]
+        stats = ctx.saved_tensors[3:]
+        gy = _c(gy)
+        groups = ctx.groups
+        b = x.shape[0] // groups
+        if not (gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x)) and (x[:b].numel() * x.element_size()) % 16 == 0):
+            raise NotImplementedError('grouped batch norm needs C % 4 == 0 and 16-byte aligned slices')
+        want_g, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gsink = _sink_of(ctx.gamma_ref) if want_g else None
+        bsink = _sink_of(ctx.beta_ref) if want_b else None
+        sunk = gsink is not None and bsink is not None
+        dx = torch.empty_like(x)
+        dgamma = dbeta = None
+        for g in range(groups):
+            sl = slice(g * b, (g + 1) * b)
+            _, dg, db = K.bn_bwd_fused(gy[sl], y[sl] if ctx.act != K.ACT_NONE else None, x[sl], stats[2 * g], stats[2 * g + 1], gamma, ctx.act,
+                                       ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None, out=dx[sl])
+            if not sunk:
+                dgamma = dg if dgamma is None else dgamma + dg
+                dbeta = db if dbeta is None else dbeta + db
+        if sunk:
+            _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
+            return (dx,) + (None,) * 9
+        return (dx, dgamma if want_g else None, dbeta if want_b else None) + (None,) * 7
+
+
 class GpSlopesFn(Function):
     """slopes[b] = ||g[b]||_2 (reference models/wgancls/model.py:64,69).  Its backward feeds the double backward of the
     critic; it is itself only differentiated once."""

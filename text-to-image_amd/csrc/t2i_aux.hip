@@ -1404,6 +1404,43 @@ hipError_t wgan_d_head_launch(const float* logits, const float* s1, const float*
   return hipGetLastError();
 }
 
+// Sigmoid cross-entropy heads (reference models/gancls/trainer.py:20-34, models/stackgan/stageI/trainer.py:53-77): for each of up to three
+// logit vectors of B samples  loss_k = mean_i [max(l,0) - l y_k + log1p(exp(-|l|))]  (tf.nn.sigmoid_cross_entropy_with_logits with a constant
+// label y_k), total = sum_k w_k loss_k, the backward seeds d total / d l = w_k (sigmoid(l) - y_k) / B and the probabilities sigmoid(l) the
+// reference's discriminator returns beside its logits.  One workgroup, one launch — the tensor-library version was ~25 launches per head set.
+struct CeHeads { const float* l[3]; float y[3], w[3]; float* seed[3]; float* prob[3]; };
+
+__global__ __launch_bounds__(256) void sigmoid_ce_head_kernel(CeHeads h, int B, float* __restrict__ losses) {
+  __shared__ float red[4];
+  const float invB = 1.0f / (float)B;
+  float total = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!h.l[k]) { if (threadIdx.x == 0) losses[1 + k] = 0.f; continue; }      // (workgroup-uniform)
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+      const float l = h.l[k][i];
+      const float e = expf(-fabsf(l));                      // in (0, 1]
+      acc += fmaxf(l, 0.f) - l * h.y[k] + log1pf(e);
+      const float p = l >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      if (h.seed[k]) h.seed[k][i] = h.w[k] * (p - h.y[k]) * invB;
+      if (h.prob[k]) h.prob[k][i] = p;
+    }
+    const float lk = block_sum256(acc, red) * invB;
+    if (threadIdx.x == 0) losses[1 + k] = lk;
+    total += h.w[k] * lk;
+  }
+  if (threadIdx.x == 0) losses[0] = total;
+}
+
+hipError_t sigmoid_ce_head_launch(const float* const* l, const float* y, const float* w, float* const* seed, float* const* prob, int B,
+                                  float* losses, hipStream_t stream) {
+  CeHeads h;
+  for (int k = 0; k < 3; ++k) { h.l[k] = l[k]; h.y[k] = y[k]; h.w[k] = w[k]; h.seed[k] = seed[k]; h.prob[k] = prob[k]; }
+  hipLaunchKernelGGL(sigmoid_ce_head_kernel, dim3(1), dim3(256), 0, stream, h, B, losses);
+  return hipGetLastError();
+}
+
 // One workgroup of 1024 threads (the KL term is one scalar over all B*128 elements): a thread's elements are fetched with all
 // loads in flight before the first expf (the 256-thread version walked 32 dependent load -> expf rounds: 27 us for 8192
 // elements), summed in index order per thread, then lanes by shuffle and the 16 waves in fixed order.

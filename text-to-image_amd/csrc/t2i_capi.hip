@@ -50,6 +50,7 @@ hipError_t row_moments_launch(const float*, const float*, int, int64_t, float*, 
 size_t row_moments_ws(int B);
 hipError_t row_fma2_launch(const float*, const float*, const float*, const float*, const float*, int, int64_t, float*, hipStream_t);
 hipError_t wgan_d_head_launch(const float*, const float*, const float*, const float*, int, float, float*, float*, float*, float*, hipStream_t);
+hipError_t sigmoid_ce_head_launch(const float* const*, const float*, const float*, float* const*, float* const*, int, float*, hipStream_t);
 hipError_t ca_kl_fwd_launch(const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t ca_kl_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 hipError_t lerp_dev_launch(const float*, const float*, const float*, int, size_t, float*, hipStream_t);
@@ -641,7 +642,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 7; }
+int t2i_version(void) { return 8; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -1365,6 +1366,19 @@ int t2i_wgan_d_head(const float* logits, const float* slopes1, const float* slop
   }
   return check(wgan_d_head_launch(logits, slopes1, slopes2, kt_dev, B, gp_coeff, seed_logits, seed_slopes1, seed_slopes2, scalars,
                                   (hipStream_t)stream), "t2i_wgan_d_head");
+}
+
+int t2i_sigmoid_ce_head(const float* l0, const float* l1, const float* l2, float y0, float y1, float y2, float w0, float w1, float w2, int32_t B,
+                        float* seed0, float* seed1, float* seed2, float* prob0, float* prob1, float* prob2, float* losses, t2i_stream_t stream) {
+  if (!l0 || !losses || B <= 0 || (!l1 && (seed1 || prob1)) || (!l2 && (seed2 || prob2))) {
+    set_error("t2i_sigmoid_ce_head: bad argument (l0 and losses are required; outputs only for heads that have logits)");
+    return T2I_ERR_INVALID;
+  }
+  const float* l[3] = {l0, l1, l2};
+  const float y[3] = {y0, y1, y2}, w[3] = {w0, w1, w2};
+  float* seed[3] = {seed0, seed1, seed2};
+  float* prob[3] = {prob0, prob1, prob2};
+  return check(sigmoid_ce_head_launch(l, y, w, seed, prob, B, losses, (hipStream_t)stream), "t2i_sigmoid_ce_head");
 }
 
 int t2i_ca_kl_fwd(const float* mean, const float* log_sigma, const float* eps, int64_t n, float* code, float* kl, t2i_stream_t stream) {

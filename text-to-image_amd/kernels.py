@@ -529,13 +529,17 @@ def bn_train_stats(x, gamma, beta, eps, decay, moving_mean=None, moving_var=None
     return mean, rstd, scale, shift
 
 
-def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, dbeta_out=None):
+def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, dbeta_out=None, out=None):
     """Training-mode batch-norm backward in three launches (C % 4 == 0).  y: the activation output behind the batch norm or
-    None.  -> (dx, dgamma, dbeta); dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into."""
+    None.  -> (dx, dgamma, dbeta); dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into; out: where dx goes (a group's
+    slice of a batched pass; no bf16 twin then)."""
     _chk(dy, 'dy'); _chk(x, 'x')
     C = x.shape[-1]
     rows = x.numel() // C
-    dx = torch.empty_like(x)
+    if out is not None:
+        assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous()
+        _drop_image(out)
+    dx = out if out is not None else torch.empty_like(x)
     gmask = torch.empty_like(x) if y is not None else None
     acc = dgamma_out is not None
     assert acc == (dbeta_out is not None)
@@ -543,7 +547,7 @@ def bn_bwd_fused(dy, y, x, mean, rstd, gamma, act, alpha=0.2, dgamma_out=None, d
     dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, int(lib.t2i_bn_bwd_fused_workspace_bytes(rows, C)))
-        twin = _twin_for(dx)                    # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
+        twin = _twin_for(dx) if out is None else None     # dx is the gradient of the conv in front of the batch norm: its bwd_data / bwd_filter operand
         check(lib.t2i_bn_bwd_fused(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
                                    rows, C, act, alpha, _ptr(gmask), _ptr(dx), _ptr(twin), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0, wsp, wsn,
                                    _same_dt(dy, y, x), _stream()), 't2i_bn_bwd_fused')
@@ -711,16 +715,34 @@ def bn_finalize(s, ss, n, gamma, beta, eps, decay, moving_mean=None, moving_var=
     return mean, rstd, scale, shift
 
 
-def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2):
+def bn_apply(x, scale, shift, act=ACT_NONE, alpha=0.2, out=None):
+    """out: a contiguous tensor (view) of x's shape and dtype to write into — one group's slice of a batched pass (no bf16 twin then)."""
     _chk(x, 'x')
     C = x.shape[-1]
-    y = torch.empty_like(x)
+    if out is not None:
+        assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous()
+        _drop_image(out)
+    y = out if out is not None else torch.empty_like(x)
     if _live(x):
-        twin = _twin_for(y, x, scale, shift)
+        twin = _twin_for(y, x, scale, shift) if out is None else None
         check(lib.t2i_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), x.numel() // C, C, act, alpha, _ptr(y), _ptr(twin), _dt(x), _stream()),
               't2i_bn_apply')
         _twin_keep(y, twin)
     return y
+
+
+def bn_apply_groups(x, scales, shifts, act=ACT_NONE, alpha=0.2):
+    """bn_apply on a batched pass: slice g of x along the batch axis is normalised with (scales[g], shifts[g]); one output tensor.
+    (A wrapper of its own so that instrumentation sees one call per batch-norm layer, like every other layer of a batched pass.)"""
+    groups = len(scales)
+    b = x.shape[0] // groups
+    y = torch.empty_like(x)
+    for g in range(groups):
+        _bn_apply_one(x[g * b:(g + 1) * b], scales[g], shifts[g], act, alpha, out=y[g * b:(g + 1) * b])
+    return y
+
+
+_bn_apply_one = bn_apply          # (instrumentation replaces the public name; the per-slice calls above are not layers of their own)
 
 
 def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_x, dgamma_out=None, dbeta_out=None):
@@ -1009,6 +1031,36 @@ def wgan_d_head(logits, slopes1, slopes2, kt, gp_coeff):
         check(lib.t2i_wgan_d_head(_ptr(logits), _ptr(slopes1), _ptr(slopes2), _ptr(kt), B, gp_coeff, _ptr(sl), _ptr(s1), _ptr(s2),
                                   _ptr(scal), _stream()), 't2i_wgan_d_head')
     return scal, sl, s1, s2
+
+
+def sigmoid_ce_head(logits, labels, weights, want_prob=True, seeds_into=None):
+    """logits: 1-3 tensors of B logits each; labels / weights: one float per head.  -> (losses [4]: total, per head; seeds: list of
+    d total / d logits_k; probs: list of sigmoid(logits_k) or None)  — t2i_sigmoid_ce_head, one launch.
+    seeds_into: a flat float32 tensor of n*B elements whose slices receive the seeds (the heads of ONE batched pass)."""
+    n = len(logits)
+    assert 1 <= n <= 3 and len(labels) == n and len(weights) == n
+    for t in logits:
+        _chk(t, 'logits', f32=True)
+    B = logits[0].numel()
+    assert all(t.numel() == B and t.is_contiguous() for t in logits)
+    losses = torch.empty(4, dtype=torch.float32, device=logits[0].device)
+    if seeds_into is not None:
+        _chk(seeds_into, 'seeds_into', f32=True)
+        assert seeds_into.numel() == n * B
+        flat = seeds_into.view(-1)
+        seeds = [flat[k * B:(k + 1) * B] for k in range(n)]
+    else:
+        seeds = [torch.empty_like(t) for t in logits]
+    probs = [torch.empty_like(t) for t in logits] if want_prob else None
+    if _live(logits[0]):
+        pad = lambda xs, fill: list(xs) + [fill] * (3 - n)
+        lp = pad([_ptr(t) for t in logits], None)
+        sp = pad([_ptr(t) for t in seeds], None)
+        pp = pad([_ptr(t) for t in probs], None) if want_prob else [None] * 3
+        y, w = pad([float(v) for v in labels], 0.0), pad([float(v) for v in weights], 0.0)
+        check(lib.t2i_sigmoid_ce_head(lp[0], lp[1], lp[2], y[0], y[1], y[2], w[0], w[1], w[2], B, sp[0], sp[1], sp[2], pp[0], pp[1], pp[2],
+                                      _ptr(losses), _stream()), 't2i_sigmoid_ce_head')
+    return losses, seeds, probs
 
 
 def ca_kl_fwd(mean, log_sigma, eps):

@@ -53,28 +53,33 @@ class GanCls(object):
         with torch.no_grad():
             return self.generator(z_sample, phi_sample, is_training=False, reuse=True)
 
-    def discriminator(self, inputs, embed, is_training=True, reuse=False):
-        """-> (sigmoid(logits), logits), logits [B,1,1,1]  (reference model.py:54-109)"""
+    def discriminator(self, inputs, embed, is_training=True, reuse=False, _prob=True, groups=1):
+        """-> (sigmoid(logits), logits), logits [B,1,1,1]  (reference model.py:54-109).  _prob=False (the trainer): the first element is
+        None — the loss head kernel (kernels.sigmoid_ce_head) returns the probabilities with the losses, one launch for all passes.
+        groups > 1 (the trainer): `inputs` / `embed` hold that many passes of the reference graph stacked along the batch axis (fake | match |
+        mismatch, model.py:48-51).  Convolutions, activations and the text projection are per-sample, so they run once on the stacked batch;
+        every batch norm keeps SEPARATE statistics per pass (ops.batch_norm(groups=...)), moving averages move once per pass in stacking
+        order — the same values as `groups` sequential calls, in a third of the launches."""
         nf, act, bn_init, s16 = self.df_dim, lrelu_act(0.2), self.batch_norm_init, self.output_size / 16
         with S.variable_scope('d_net', reuse=reuse):
             h = conv2d(inputs, nf, (4, 4), (2, 2), 'same', activation=act, kernel_initializer=self.w_init)
             for mult, a in ((2, act), (4, act), (8, None)):        # conv2d_1..3 + BatchNorm..BatchNorm_2
                 h = conv2d(h, nf * mult, (4, 4), (2, 2), 'same', kernel_initializer=self.w_init)
-                h = batch_norm(h, train=is_training, init=bn_init, act=a)
+                h = batch_norm(h, train=is_training, init=bn_init, act=a, groups=groups)
             trunk = h
             r = conv2d(trunk, nf * 2, (1, 1), (1, 1), 'valid', kernel_initializer=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 2, (3, 3), (1, 1), 'same', kernel_initializer=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 8, (3, 3), (1, 1), 'same', kernel_initializer=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=None)
+            r = batch_norm(r, train=is_training, init=bn_init, act=None, groups=groups)
             joined = add(trunk, r, act=act)
             text = dense(embed, self.compressed_embed_dim, activation=act)            # glorot-uniform (tf.layers default)
             h = concat_tile(joined, text)
             h = conv2d(h, nf * 8, (1, 1), (1, 1), 'valid', kernel_initializer=self.w_init)
-            h = batch_norm(h, train=is_training, init=bn_init, act=act)
+            h = batch_norm(h, train=is_training, init=bn_init, act=act, groups=groups)
             logits = conv2d(h, 1, (s16, s16), (s16, s16), 'valid', kernel_initializer=self.w_init)
-            return torch.sigmoid(logits), logits
+            return (torch.sigmoid(logits) if _prob else None), logits
 
     def _bottleneck(self, x, mid, out, train):
         bn_init = self.batch_norm_init

@@ -1,24 +1,22 @@
 """GanClsTrainer — reference models/gancls/trainer.py:12-164: losses, the two Adam optimizers (both under UPDATE_OPS) and
 the D-then-G update order of every iteration."""
+import os
 import sys
 import time
 
 import torch
 
 from ... import autograd as A
+from ... import kernels as K
 from ... import optim
 from ...utils.ops import update_ops
-
-
-def sigmoid_cross_entropy_with_logits(logits, label):
-    """tf.nn.sigmoid_cross_entropy_with_logits on the [B] logit vector: max(l,0) - l*y + log(1+exp(-|l|))."""
-    return torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))
 
 
 class GanClsTrainer(object):
     def __init__(self, sess, model, dataset, cfg):
         self.sess, self.model, self.dataset, self.cfg = sess, model, dataset, cfg     # sess unused (no TF session)
         self.gen = torch.Generator(device=model.device).manual_seed(1234)
+        self.batched = os.environ.get('T2I_GANCLS_BATCHED', '1') != '0'      # the critic's passes of one sess.run as one stacked batch
         self.define_losses()
 
     def define_losses(self):
@@ -34,21 +32,31 @@ class GanClsTrainer(object):
         with update_ops():      # D_optim is built under control_dependencies(UPDATE_OPS): every BN moving average moves
             with torch.no_grad():
                 G = m.generator(z, phi, reuse=True)
-            p_fake, l_fake = m.discriminator(G, phi, reuse=True)
-            p_match, l_match = m.discriminator(x, phi, reuse=True)
-            p_mis, l_mis = m.discriminator(xw, phi, reuse=True)
-        D_synthetic_loss = sigmoid_cross_entropy_with_logits(l_fake, 0.0).mean()
-        D_real_match_loss = sigmoid_cross_entropy_with_logits(l_match, 0.9).mean()       # one-sided label smoothing
-        D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
-        D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
+            # the critic's three passes (fake / match / mismatch, model.py:48-51) as ONE stacked batch: per-sample layers run once on 3B
+            # samples, every batch norm keeps its statistics per pass (discriminator(groups=3)); T2I_GANCLS_BATCHED=0: three calls
+            if self.batched:
+                _, logits = m.discriminator(torch.cat([G, x, xw], 0), torch.cat([phi, phi, phi], 0), reuse=True, _prob=False, groups=3)
+                B = x.shape[0]
+                lv = logits.detach().reshape(3, B)
+                heads, outs = [lv[0], lv[1], lv[2]], [logits]
+                seed = torch.empty(3 * B, dtype=torch.float32, device=logits.device)
+            else:
+                _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
+                _, l_match = m.discriminator(x, phi, reuse=True, _prob=False)
+                _, l_mis = m.discriminator(xw, phi, reuse=True, _prob=False)
+                heads, outs, seed = [l_fake.detach().reshape(-1), l_match.detach().reshape(-1), l_mis.detach().reshape(-1)], [l_fake, l_match, l_mis], None
+        # the three heads of trainer.py:20-34 in ONE launch (labels 0 / 0.9 one-sided smoothing / 0; D_loss = match + alpha mismatch +
+        # (1 - alpha) fake): the loss scalars, d D_loss / d logits as the seeds of the backward pass, and the sigmoid outputs
+        losses, seeds, probs = K.sigmoid_ce_head(heads, [0.0, 0.9, 0.0], [1.0 - self.alpha, 1.0, self.alpha], seeds_into=seed)
         m.d_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.d_arena)
-        D_loss.backward(inputs=list(m.d_vars.values()))
+        grads = [seed.view_as(outs[0])] if seed is not None else [s_.view_as(l_) for s_, l_ in zip(seeds, outs)]
+        torch.autograd.backward(outs, grads, inputs=list(m.d_vars.values()))
         A.side_join()
-        return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
-                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G,
-                    D_synthetic=p_fake.detach(), D_real_match=p_match.detach(), D_real_mismatch=p_mis.detach())
+        shape = (x.shape[0], 1, 1, 1)
+        return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G,
+                    D_synthetic=probs[0].view(shape), D_real_match=probs[1].view(shape), D_real_mismatch=probs[2].view(shape))
 
     def g_losses(self, feed):
         m = self.model
@@ -56,19 +64,22 @@ class GanClsTrainer(object):
         with update_ops():
             G = m.generator(z, phi, reuse=True)
             with m.store.frozen('d_net'):
-                _, l_fake = m.discriminator(G, phi, reuse=True)
+                _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
             # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
             # sess.run too, only to move their batch-norm moving averages (trainer.py:46-51)
             with torch.no_grad():
-                m.discriminator(x, phi, reuse=True)
-                m.discriminator(xw, phi, reuse=True)
-        G_loss = sigmoid_cross_entropy_with_logits(l_fake, 1.0).mean()
+                if self.batched:
+                    m.discriminator(torch.cat([x, xw], 0), torch.cat([phi, phi], 0), reuse=True, _prob=False, groups=2)
+                else:
+                    m.discriminator(x, phi, reuse=True, _prob=False)
+                    m.discriminator(xw, phi, reuse=True, _prob=False)
+        losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1)], [1.0], [1.0], want_prob=False)      # G_loss: label 1 (trainer.py:36)
         m.g_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.g_arena)
-        G_loss.backward(inputs=list(m.g_vars.values()))
+        torch.autograd.backward([l_fake], [seeds[0].view_as(l_fake)], inputs=list(m.g_vars.values()))
         A.side_join()
-        return dict(G_loss=G_loss.detach(), G=G.detach())
+        return dict(G_loss=losses[0], G=G.detach())
 
     # ---- device-only halves of an iteration (graph-capturable) ------------------------------------------------------------
     def _d_body(self, feed):

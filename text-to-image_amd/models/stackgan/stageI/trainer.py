@@ -7,13 +7,9 @@ import time
 import torch
 
 from .... import autograd as A
+from .... import kernels as K
 from .... import optim
 from ....utils.ops import update_ops
-
-
-def sigmoid_cross_entropy_with_logits(logits, label):
-    """tf.nn.sigmoid_cross_entropy_with_logits: max(l,0) - l*y + log(1+exp(-|l|))."""
-    return torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))
 
 
 class ConditionalGanTrainer(object):
@@ -50,17 +46,16 @@ class ConditionalGanTrainer(object):
             _, l_fake = m.discriminator(G, phi, reuse=True)
             _, l_match = m.discriminator(x, phi, reuse=True)
             _, l_mis = m.discriminator(xw, phi, reuse=True)
-        D_synthetic_loss = sigmoid_cross_entropy_with_logits(l_fake, 0.0).mean()
-        D_real_match_loss = sigmoid_cross_entropy_with_logits(l_match, self.REAL_LABEL).mean()
-        D_real_mismatch_loss = sigmoid_cross_entropy_with_logits(l_mis, 0.0).mean()
-        D_loss = D_real_match_loss + self.alpha * D_real_mismatch_loss + (1.0 - self.alpha) * D_synthetic_loss
+        # the three heads (trainer.py:24-33) in one launch: loss scalars + d D_loss / d logits as the seeds of the backward pass
+        losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1), l_match.detach().reshape(-1), l_mis.detach().reshape(-1)],
+                                             [0.0, self.REAL_LABEL, 0.0], [1.0 - self.alpha, 1.0, self.alpha], want_prob=False)
         m.d_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.d_arena)
-        D_loss.backward(inputs=list(m.d_vars.values()))
+        torch.autograd.backward([l_fake, l_match, l_mis], [s_.view_as(l_) for s_, l_ in zip(seeds, (l_fake, l_match, l_mis))],
+                                inputs=list(m.d_vars.values()))
         A.side_join()
-        return dict(D_loss=D_loss.detach(), D_real_match_loss=D_real_match_loss.detach(),
-                    D_real_mismatch_loss=D_real_mismatch_loss.detach(), D_synthetic_loss=D_synthetic_loss.detach(), G=G)
+        return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G)
 
     def g_losses(self, feed):
         m = self.model
@@ -74,15 +69,19 @@ class ConditionalGanTrainer(object):
             with torch.no_grad():
                 m.discriminator(x, phi, reuse=True)
                 m.discriminator(xw, phi, reuse=True)
-        G_gan_loss = sigmoid_cross_entropy_with_logits(l_fake, 1.0).mean()
+        # G_loss = CE(fake, 1) + kl_coeff * KL (trainer.py:35-41): the CE head gives its value and d/d logits; the KL term stays a
+        # differentiable tensor expression, so the two are seeded together
+        losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1)], [1.0], [1.0], want_prob=False)
+        G_gan_loss = losses[1]
         G_kl_loss = self.kl_loss(mean, log_sigma)
-        G_loss = G_gan_loss + self.kl_coeff * G_kl_loss
         m.g_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.g_arena)
-        G_loss.backward(inputs=list(m.g_vars.values()))
+        torch.autograd.backward([l_fake, G_kl_loss], [seeds[0].view_as(l_fake), torch.full_like(G_kl_loss, self.kl_coeff)],
+                                inputs=list(m.g_vars.values()))
         A.side_join()
-        return dict(G_loss=G_loss.detach(), G_gan_loss=G_gan_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
+        G_loss = G_gan_loss + self.kl_coeff * G_kl_loss.detach()
+        return dict(G_loss=G_loss, G_gan_loss=G_gan_loss, G_kl_loss=G_kl_loss.detach(), G=G.detach())
 
     # ---- device-only halves of an iteration (graph-capturable: Adam reads its step size from device memory) -----------------
     def _d_body(self, feed):

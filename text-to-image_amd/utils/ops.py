@@ -142,9 +142,11 @@ class update_ops(object):
         _UPDATE_OPS[0] = self.prev
 
 
-def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df=NHWC):
+def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df=NHWC, groups=1):
     """reference utils/ops.py:7-29 (tf.contrib.layers.batch_norm, fused, scale=True).  Rank-4 (per channel) or rank-2
-    (per feature).  Variables: <scope>/BatchNorm[_k]/{beta, gamma, moving_mean, moving_variance}."""
+    (per feature).  Variables: <scope>/BatchNorm[_k]/{beta, gamma, moving_mean, moving_variance}.
+    groups > 1 (not in the reference; training mode): x is a batched pass whose `groups` equal slices along the batch axis are separate
+    passes of the reference graph — each slice is normalised with its own batch statistics (autograd.BatchNormTrainGroupedFn)."""
     st = S.default_store()
     _check_df(df)
     if x.dim() == 4:
@@ -161,7 +163,10 @@ def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df
         gamma = st.get_variable('gamma', (C,), init.get('gamma', S.constant_init(1.0)))
         mm = st.get_variable('moving_mean', (C,), S.constant_init(0.0), trainable=False)
         mv = st.get_variable('moving_variance', (C,), S.constant_init(1.0), trainable=False)
-    if train:
+    if train and groups > 1:
+        upd = _UPDATE_OPS[0]
+        y = A.BatchNormTrainGroupedFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, int(groups))
+    elif train:
         upd = _UPDATE_OPS[0]
         y, _, _ = A.BatchNormTrainFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha)
     else:
