@@ -72,28 +72,29 @@ class ConditionalGan(object):
         return mean
 
     # ---- networks ------------------------------------------------------------------------------------------------------
-    def discriminator(self, inputs, embed, is_training=True, reuse=False):
+    def discriminator(self, inputs, embed, is_training=True, reuse=False, _prob=True, groups=1):
         """-> (sigmoid(logits), logits), logits [B,1,1,1]  (model.py:77-121)"""
         nf, act, bn_init, s16 = self.df_dim, lrelu_act(0.2), self.batch_norm_init, self.output_size // 16
         with S.variable_scope('d_net', reuse=reuse):
             h = conv2d(inputs, nf, ks=(4, 4), s=(2, 2), act=act, init=self.w_init)
             for mult, a in ((2, act), (4, act), (8, None)):
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), init=self.w_init)
-                h = batch_norm(h, train=is_training, init=bn_init, act=a)
+                h = batch_norm(h, train=is_training, init=bn_init, act=a, groups=groups)
             trunk = h
             r = conv2d(trunk, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 2, ks=(3, 3), s=(1, 1), init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 8, ks=(3, 3), s=(1, 1), init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init)
+            r = batch_norm(r, train=is_training, init=bn_init, groups=groups)
             joined = add(trunk, r, act=act)
             text = dense(embed, self.compressed_embed_dim, activation=act)          # tf.layers default: glorot-uniform
             h = concat_tile(joined, text)
             h = conv2d(h, nf * 8, ks=(1, 1), s=(1, 1), padding='valid', init=self.w_init)
-            h = batch_norm(h, train=is_training, init=bn_init, act=act)
+            h = batch_norm(h, train=is_training, init=bn_init, act=act, groups=groups)
             logits = conv2d(h, 1, ks=(s16, s16), s=(s16, s16), padding='valid', init=self.w_init)
-            return torch.sigmoid(logits), logits
+            # _prob=False / groups: see models/gancls/model.py (the trainer stacks the critic passes of one sess.run along the batch axis)
+            return (torch.sigmoid(logits) if _prob else None), logits
 
     def _bottleneck(self, x, mid, out, train):
         bn_init = self.batch_norm_init

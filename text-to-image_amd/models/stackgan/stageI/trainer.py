@@ -1,6 +1,7 @@
 """ConditionalGanTrainer (Stage-I) — reference models/stackgan/stageI/trainer.py:11-165: sigmoid cross-entropy losses
 (real label 0.9), KL term of the conditioning augmentation, two Adam optimizers on ONE learning-rate placeholder
 (D_LR * 0.5 ** (epoch // 100)), both under tf.GraphKeys.UPDATE_OPS, D update then G update every iteration."""
+import os
 import sys
 import time
 
@@ -19,6 +20,7 @@ class ConditionalGanTrainer(object):
         self.sess, self.model, self.dataset, self.cfg = sess, model, dataset, cfg     # sess unused (no TF session)
         self.lr = float(cfg.TRAIN.D_LR)
         self.gen = torch.Generator(device=model.device).manual_seed(1234)
+        self.batched = os.environ.get('T2I_GANCLS_BATCHED', '1') != '0'      # the critic's passes of one sess.run as one stacked batch (models/gancls)
         self.define_losses()
 
     def define_losses(self):
@@ -43,17 +45,24 @@ class ConditionalGanTrainer(object):
         with update_ops():      # D_optim sits under control_dependencies(UPDATE_OPS): every BN moving average moves
             with torch.no_grad():
                 G, _, _ = self._generate(feed, 'd')
-            _, l_fake = m.discriminator(G, phi, reuse=True)
-            _, l_match = m.discriminator(x, phi, reuse=True)
-            _, l_mis = m.discriminator(xw, phi, reuse=True)
+            if self.batched:          # fake | match | mismatch stacked along the batch axis, batch-norm statistics per pass
+                _, logits = m.discriminator(torch.cat([G, x, xw], 0), torch.cat([phi, phi, phi], 0), reuse=True, _prob=False, groups=3)
+                B = x.shape[0]
+                lv = logits.detach().reshape(3, B)
+                heads, outs = [lv[0], lv[1], lv[2]], [logits]
+                seed = torch.empty(3 * B, dtype=torch.float32, device=logits.device)
+            else:
+                _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
+                _, l_match = m.discriminator(x, phi, reuse=True, _prob=False)
+                _, l_mis = m.discriminator(xw, phi, reuse=True, _prob=False)
+                heads, outs, seed = [l_fake.detach().reshape(-1), l_match.detach().reshape(-1), l_mis.detach().reshape(-1)], [l_fake, l_match, l_mis], None
         # the three heads (trainer.py:24-33) in one launch: loss scalars + d D_loss / d logits as the seeds of the backward pass
-        losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1), l_match.detach().reshape(-1), l_mis.detach().reshape(-1)],
-                                             [0.0, self.REAL_LABEL, 0.0], [1.0 - self.alpha, 1.0, self.alpha], want_prob=False)
+        losses, seeds, _ = K.sigmoid_ce_head(heads, [0.0, self.REAL_LABEL, 0.0], [1.0 - self.alpha, 1.0, self.alpha], want_prob=False, seeds_into=seed)
         m.d_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):
             m.dp.arm(m.d_arena)
-        torch.autograd.backward([l_fake, l_match, l_mis], [s_.view_as(l_) for s_, l_ in zip(seeds, (l_fake, l_match, l_mis))],
-                                inputs=list(m.d_vars.values()))
+        grads = [seed.view_as(outs[0])] if seed is not None else [s_.view_as(l_) for s_, l_ in zip(seeds, outs)]
+        torch.autograd.backward(outs, grads, inputs=list(m.d_vars.values()))
         A.side_join()
         return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G)
 
@@ -63,12 +72,15 @@ class ConditionalGanTrainer(object):
         with update_ops():
             G, mean, log_sigma = self._generate(feed, 'g')
             with m.store.frozen(m.d_scope):
-                _, l_fake = m.discriminator(G, phi, reuse=True)
+                _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
             # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
             # sess.run too, only to move their batch-norm moving averages (trainer.py:50-55)
             with torch.no_grad():
-                m.discriminator(x, phi, reuse=True)
-                m.discriminator(xw, phi, reuse=True)
+                if self.batched:
+                    m.discriminator(torch.cat([x, xw], 0), torch.cat([phi, phi], 0), reuse=True, _prob=False, groups=2)
+                else:
+                    m.discriminator(x, phi, reuse=True, _prob=False)
+                    m.discriminator(xw, phi, reuse=True, _prob=False)
         # G_loss = CE(fake, 1) + kl_coeff * KL (trainer.py:35-41): the CE head gives its value and d/d logits; the KL term stays a
         # differentiable tensor expression, so the two are seeded together
         losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1)], [1.0], [1.0], want_prob=False)

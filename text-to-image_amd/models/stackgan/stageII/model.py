@@ -80,30 +80,31 @@ class ConditionalGan(object):
         return mean
 
     # ---- discriminator (stageII/model.py:78-133) --------------------------------------------------------------------------
-    def discriminator(self, inputs, embed, is_training=True, reuse=False):
+    def discriminator(self, inputs, embed, is_training=True, reuse=False, _prob=True, groups=1):
         nf, act, bn_init, s16 = self.df_dim, lrelu_act(0.2), self.batch_norm_init, self.output_size // 64
         with S.variable_scope('stageII_d_net', reuse=reuse):
             h = conv2d(inputs, nf, ks=(4, 4), s=(2, 2), act=act, init=self.w_init)
             for mult in (2, 4, 8, 16, 32):
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), init=self.w_init)
-                h = batch_norm(h, train=is_training, init=bn_init, act=act)
+                h = batch_norm(h, train=is_training, init=bn_init, act=act, groups=groups)
             h = conv2d(h, nf * 16, ks=(4, 4), s=(1, 1), init=self.w_init)
-            h = batch_norm(h, train=is_training, init=bn_init, act=act)
+            h = batch_norm(h, train=is_training, init=bn_init, act=act, groups=groups)
             h = conv2d(h, nf * 8, ks=(4, 4), s=(1, 1), init=self.w_init)
-            h7 = batch_norm(h, train=is_training, init=bn_init)
+            h7 = batch_norm(h, train=is_training, init=bn_init, groups=groups)
             r = conv2d(h7, nf * 2, ks=(1, 1), s=(1, 1), init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 2, ks=(3, 3), s=(1, 1), init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init, act=act)
+            r = batch_norm(r, train=is_training, init=bn_init, act=act, groups=groups)
             r = conv2d(r, nf * 8, ks=(3, 3), s=(1, 1), init=self.w_init)
-            r = batch_norm(r, train=is_training, init=bn_init)
+            r = batch_norm(r, train=is_training, init=bn_init, groups=groups)
             h8 = add(r, r, act=act)                                   # tf.add(net, net), not tf.add(net_h7, net)
             text = dense(embed, self.compressed_embed_dim, activation=act)
             h = concat_tile(h8, text)
             h = conv2d(h, nf * 8, ks=(1, 1), s=(1, 1), init=self.w_init)
-            h = batch_norm(h, train=is_training, init=bn_init, act=act)
+            h = batch_norm(h, train=is_training, init=bn_init, act=act, groups=groups)
             logits = conv2d(h, 1, ks=(s16, s16), s=(s16, s16), init=self.w_init)
-            return torch.sigmoid(logits), logits
+            # _prob=False / groups: see models/gancls/model.py (the trainer stacks the critic passes of one sess.run along the batch axis)
+            return (torch.sigmoid(logits) if _prob else None), logits
 
     # ---- generator (stageII/model.py:135-201) -----------------------------------------------------------------------------
     def generator_encode_image(self, image, is_training=True):
