@@ -72,7 +72,7 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 8 (v8: t2i_sigmoid_ce_head added, the BN entry points below take `groups`; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 8 (v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
@@ -228,6 +228,22 @@ size_t t2i_bn_bwd_fused_workspace_bytes(int64_t rows, int32_t C);
 int t2i_bn_bwd_fused(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows,
                      int32_t C, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate, void* ws,
                      size_t ws_bytes, int32_t dtype /* of dy, y, x, gmask, dx */, t2i_stream_t stream);
+
+/* Batch norm of a STACKED batch (v8).  The reference evaluates its batch-normalised critic three times per sess.run with shared variables
+ * (models/gancls/model.py:48-51: fake / match / mismatch images; models/stackgan/stageI/model.py:44-48): convolutions, activations and the text
+ * projection are per-sample, so the three passes can run as ONE batch of groups * B samples — except batch norm, which must keep each pass's own
+ * statistics.  x is [groups * rows_per_group, C], group g = rows [g * rows_per_group, (g + 1) * rows_per_group) (contiguous: the batch axis is the
+ * slowest).  Forward: statistics per group (mean / rstd / scale / shift are [groups][C]), moving averages updated once per group in group order
+ * (what `groups` sequential passes do), y = act(x * scale_g + shift_g) — three launches for all groups.  Backward: dx with the group's own
+ * statistics, dgamma / dbeta summed over the groups (accumulate != 0: += into the arena slots) — three launches.  groups = 1 is the ordinary
+ * training-mode batch norm.  C % 4 == 0, 16-byte aligned tensors; ws >= t2i_bn_grouped_workspace_bytes(...) for either call. */
+size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t groups);
+int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
+                             float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
+                             float alpha, void* y, void* y_h, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream);
+int t2i_bn_bwd_grouped(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows_per_group,
+                       int32_t C, int32_t groups, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate,
+                       void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------------- */
 /* y = act(x) */

@@ -13,21 +13,23 @@ def record_branches(out):
     from t2i_amd import kernels as K
     saved = {}
 
-    def wrap(name, act_pos):
+    def wrap(name, act_pos, first=False):
         fn = getattr(K, name)
         saved[name] = fn
 
         def tapped(*a, **kw):
             y = fn(*a, **kw)
+            if first:                      # (the activation output is the first element of a tuple)
+                res, y = y, y[0]
             act = a[act_pos] if len(a) > act_pos else kw.get('act', K.ACT_NONE)
             if act in (K.ACT_LRELU, K.ACT_RELU):
                 out.append((y > 0).cpu())
-            return y
+            return res if first else y
         setattr(K, name, tapped)
 
     try:
         wrap('conv_fwd', 5); wrap('conv_fwd_stats', 5); wrap('conv_bwd_data', 5)
-        wrap('bn_apply_groups', 3); wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
+        wrap('bn_train_fwd_grouped', 6, first=True); wrap('bn_apply_groups', 3); wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
         yield out
     finally:
         for n, fn in saved.items():

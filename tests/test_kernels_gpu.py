@@ -872,3 +872,52 @@ def test_sigmoid_ce_head_matches_float64(K):
         assert abs(float(losses[0]) - total) <= 1e-6 * max(abs(total), 1.0)
     only = K.sigmoid_ce_head([ls[0].to(gpu)], [1.0], [1.0], want_prob=False)
     assert only[2] is None
+
+
+@pytest.mark.parametrize('shape,groups,act', [((3 * 8, 4, 4, 64), 3, 'lrelu'), ((2 * 16, 8, 8, 128), 2, 'none'), ((3 * 64, 16, 16, 128), 3, 'relu'),
+                                               ((3 * 5, 4, 4, 36), 3, 'lrelu'), ((1 * 7, 2, 2, 8), 1, 'relu')])
+def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
+    """t2i_bn_train_fwd_grouped / t2i_bn_bwd_grouped (a stacked batch: per-group statistics, three launches for all groups) against the
+    ordinary training-mode batch norm applied to each group's slice in turn — what `groups` sequential critic passes of the reference do
+    (models/gancls/model.py:48-51): outputs, per-group mean / rstd, the moving averages after `groups` updates in order, dx, and
+    dgamma / dbeta summed over the groups (plain and accumulated into an existing slot).  Same arithmetic per element; the chunking of
+    the column reductions differs, hence 1e-6 relative instead of bit equality."""
+    g = torch.Generator(device='cpu').manual_seed(17)
+    C = shape[-1]
+    kind = {'none': K.ACT_NONE, 'relu': K.ACT_RELU, 'lrelu': K.ACT_LRELU}[act]
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.4).cuda().contiguous()
+    for grp in range(groups):                  # the groups must really differ in their statistics
+        x[grp * (shape[0] // groups):(grp + 1) * (shape[0] // groups)] += 0.8 * grp
+    gy = torch.randn(shape, generator=g).cuda().contiguous()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    b = shape[0] // groups
+
+    def close(a, r, tol=2e-6):
+        a, r = a.double().cpu(), r.double().cpu()
+        return float((a - r).abs().max()) <= tol * max(float(r.abs().max()), 1e-3)
+    mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    y, mean, rstd = K.bn_train_fwd_grouped(x, gamma, beta, 1e-5, 0.9, groups, kind, 0.2, mm, mv)
+    mm2, mv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    ys, stats = [], []
+    for grp in range(groups):
+        xg = x[grp * b:(grp + 1) * b]
+        m1, r1, sc, sh = K.bn_train_stats(xg, gamma, beta, 1e-5, 0.9, mm2, mv2)
+        ys.append(K.bn_apply(xg, sc, sh, kind, 0.2))
+        stats.append((m1, r1))
+        assert close(mean[grp], m1) and close(rstd[grp], r1), grp
+    assert close(y, torch.cat(ys, 0)) and close(mm, mm2) and close(mv, mv2)
+    acc_g, acc_b = torch.full((C,), 0.5, device='cuda'), torch.full((C,), -0.25, device='cuda')
+    yy = y if kind != K.ACT_NONE else None
+    dx, dg, db = K.bn_bwd_grouped(gy, yy, x, mean, rstd, gamma, groups, kind, 0.2)
+    dxa, _, _ = K.bn_bwd_grouped(gy, yy, x, mean, rstd, gamma, groups, kind, 0.2, dgamma_out=acc_g, dbeta_out=acc_b)
+    ref_dx, ref_dg, ref_db = [], torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    for grp in range(groups):
+        sl = slice(grp * b, (grp + 1) * b)
+        if C % 4 == 0:
+            d1, g1, b1 = K.bn_bwd_fused(gy[sl], ys[grp] if kind != K.ACT_NONE else None, x[sl], stats[grp][0], stats[grp][1], gamma, kind, 0.2)
+        else:
+            pytest.skip('C % 4 != 0 is refused by the grouped entry (the Function falls back to per-slice calls)')
+        ref_dx.append(d1); ref_dg += g1; ref_db += b1
+    assert close(dx, torch.cat(ref_dx, 0), 5e-6) and torch.equal(dx, dxa)
+    assert close(dg, ref_dg, 5e-6) and close(db, ref_db, 5e-6)
+    assert close(acc_g, ref_dg + 0.5, 5e-6) and close(acc_b, ref_db - 0.25, 5e-6)

@@ -427,9 +427,15 @@ class BatchNormTrainFn(Function):
 class BatchNormTrainGroupedFn(Function):
     """Training-mode batch norm of a BATCHED pass whose `groups` equal slices along the batch axis are separate passes of the
     reference graph (models/gancls/model.py:48-51: the critic on fake / match / mismatch images, each with its own batch statistics):
-    statistics, normalisation and backward per slice — the slices are contiguous, so each is handed to the ordinary kernels as a view —
-    while every convolution around it runs once on the whole batch.  Moving averages move once per slice, in slice order (what three
-    sequential passes did); dgamma / dbeta are summed over the slices.  First order only."""
+    statistics, normalisation and backward per slice, while every convolution around it runs once on the whole batch.  Moving averages
+    move once per slice, in slice order (what three sequential passes did); dgamma / dbeta are summed over the slices.  Three launches
+    forward, three backward for all slices (t2i_bn_train_fwd_grouped / t2i_bn_bwd_grouped; C % 4 == 0 and 16-byte alignment — otherwise
+    the slices go through the ordinary kernels one by one).  First order only."""
+
+    @staticmethod
+    def _fast(x, groups):
+        b = x.shape[0] // groups
+        return x.shape[-1] % 4 == 0 and x.data_ptr() % 16 == 0 and (x[:b].numel() * x.element_size()) % 16 == 0
 
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, decay, act, alpha, groups):
@@ -437,12 +443,17 @@ class BatchNormTrainGroupedFn(Function):
         Bt = x.shape[0]
         assert Bt % groups == 0, (Bt, groups)
         b = Bt // groups
-        stats, scales, shifts = [], [], []
-        for g in range(groups):
-            mean, rstd, scale, shift = K.bn_train_stats(x[g * b:(g + 1) * b], gamma, beta, eps, decay, moving_mean, moving_var)
-            stats += [mean, rstd]
-            scales.append(scale); shifts.append(shift)
-        y = K.bn_apply_groups(x, scales, shifts, act, alpha)
+        ctx.fast = BatchNormTrainGroupedFn._fast(x, groups)
+        if ctx.fast:
+            y, mean, rstd = K.bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act, alpha, moving_mean, moving_var)
+            stats = [mean, rstd]
+        else:
+            stats, scales, shifts = [], [], []
+            for g in range(groups):
+                mean, rstd, scale, shift = K.bn_train_stats(x[g * b:(g + 1) * b], gamma, beta, eps, decay, moving_mean, moving_var)
+                stats += [mean, rstd]
+                scales.append(scale); shifts.append(shift)
+            y = K.bn_apply_groups(x, scales, shifts, act, alpha)
         ctx.save_for_backward(x, gamma, y if act != K.ACT_NONE else None, *stats)
         ctx.act, ctx.alpha, ctx.groups = act, alpha, groups
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
@@ -459,21 +470,27 @@ class BatchNormTrainGroupedFn(Function):
         gy = _c(gy)
         groups = ctx.groups
         b = x.shape[0] // groups
-        if not (gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x)) and (x[:b].numel() * x.element_size()) % 16 == 0):
-            raise NotImplementedError('grouped batch norm needs C % 4 == 0 and 16-byte aligned slices')
         want_g, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gsink = _sink_of(ctx.gamma_ref) if want_g else None
         bsink = _sink_of(ctx.beta_ref) if want_b else None
         sunk = gsink is not None and bsink is not None
-        dx = torch.empty_like(x)
-        dgamma = dbeta = None
-        for g in range(groups):
-            sl = slice(g * b, (g + 1) * b)
-            _, dg, db = K.bn_bwd_fused(gy[sl], y[sl] if ctx.act != K.ACT_NONE else None, x[sl], stats[2 * g], stats[2 * g + 1], gamma, ctx.act,
-                                       ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None, out=dx[sl])
-            if not sunk:
-                dgamma = dg if dgamma is None else dgamma + dg
-                dbeta = db if dbeta is None else dbeta + db
+        if ctx.fast and gy.data_ptr() % 16 == 0:
+            dx, dgamma, dbeta = K.bn_bwd_grouped(gy, y if ctx.act != K.ACT_NONE else None, x, stats[0], stats[1], gamma, groups, ctx.act, ctx.alpha,
+                                                 dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
+        else:
+            if ctx.fast:                 # per-group views of the [groups, C] statistics
+                stats = [t[g] for g in range(groups) for t in (stats[0], stats[1])]
+            if not (gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x)) and (x[:b].numel() * x.element_size()) % 16 == 0):
+                raise NotImplementedError('grouped batch norm needs C % 4 == 0 and 16-byte aligned slices')
+            dx = torch.empty_like(x)
+            dgamma = dbeta = None
+            for g in range(groups):
+                sl = slice(g * b, (g + 1) * b)
+                _, dg, db = K.bn_bwd_fused(gy[sl], y[sl] if ctx.act != K.ACT_NONE else None, x[sl], stats[2 * g], stats[2 * g + 1], gamma, ctx.act,
+                                           ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None, out=dx[sl])
+                if not sunk:
+                    dgamma = dg if dgamma is None else dgamma + dg
+                    dbeta = db if dbeta is None else dbeta + db
         if sunk:
             _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
             return (dx,) + (None,) * 9

@@ -168,13 +168,21 @@ template <bool WANT1, bool HAS_B, bool H = false>
 __global__ __launch_bounds__(256) void col_reduce_stage1_v4(const void* __restrict__ a, const void* __restrict__ b,
                                                             int64_t rows, int C, int64_t rows_per_chunk,
                                                             float* __restrict__ part0, float* __restrict__ part1, int shift,
-                                                            const float* __restrict__ center) {
+                                                            const float* __restrict__ center, int64_t rows_g = 0, int ncg = 0) {
   __shared__ float4 red[16][16];
   __shared__ float4 red1[WANT1 ? 16 : 1][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
-  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
-  int64_t rend = rbeg + rows_per_chunk;
+  // rows_g != 0: the rows are `rows / rows_g` groups of rows_g (the passes of a stacked batch), ncg chunks each; a chunk never
+  // straddles groups and `center` is per group ([groups][C])
+  int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk, rend = rbeg + rows_per_chunk;
+  if (rows_g) {
+    const int g = blockIdx.y / ncg, j = blockIdx.y - g * ncg;
+    rbeg = (int64_t)g * rows_g + (int64_t)j * rows_per_chunk;
+    rend = rbeg + rows_per_chunk;
+    if (rend > (int64_t)(g + 1) * rows_g) rend = (int64_t)(g + 1) * rows_g;
+    if (center) center += (size_t)g * C;
+  }
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
@@ -341,14 +349,16 @@ struct BnFin {
   float* mean; float* rstd; float* scale; float* shift; float* mmean; float* mvar;
 };
 
-__device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float mu, float m2) {
+__device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float mu, float m2, size_t goff = 0) {
+  // goff = group * C: the per-group outputs of a stacked batch; gamma / beta / moving averages are the layer's own (the moving averages
+  // move once per group, in group order: the caller walks the groups sequentially in one thread)
   const float var = fmaxf(m2, 0.f) / n;                      // biased batch variance
   const float rs = rsqrtf(var + f.eps);
-  f.mean[c] = mu;
-  f.rstd[c] = rs;
+  f.mean[goff + c] = mu;
+  f.rstd[goff + c] = rs;
   const float sc = f.gamma[c] * rs;
-  f.scale[c] = sc;
-  f.shift[c] = f.beta[c] - mu * sc;
+  f.scale[goff + c] = sc;
+  f.shift[goff + c] = f.beta[c] - mu * sc;
   if (f.mmean) {                                             // TF fused BN: the moving variance takes the UNBIASED estimate
     const float unb = var * (n / fmaxf(n - 1.f, 1.f));
     f.mmean[c] = f.decay * f.mmean[c] + (1.f - f.decay) * mu;
@@ -432,60 +442,67 @@ template <bool TILES, bool H = false>
 __global__ __launch_bounds__(256) void bn_stats_stage2_v4(const float* __restrict__ part0, const float* __restrict__ part1,
                                                           const void* __restrict__ x, int nchunks, int64_t rows,
                                                           int64_t rows_per_chunk, int C, float* __restrict__ sum, float* __restrict__ m2,
-                                                          BnFin fin) {
+                                                          BnFin fin, int groups = 1) {
+  // groups > 1: `rows` rows and `nchunks` chunks PER GROUP (chunk index g * nchunks + k, rows g * rows ...): the groups are walked one
+  // after the other by the same threads, so the moving averages move once per group in group order; outputs are [groups][C]
   __shared__ float sn[64][4];
   __shared__ float4 sm[64][4], sq[64][4];
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
   const int c = blockIdx.x * 16 + tx * 4;
-  Agg4 a;
-  a.n = 0.f; a.mean = make_float4(0.f, 0.f, 0.f, 0.f); a.m2 = a.mean;
-  if (c < C) {
-    for (int k = ty; k < nchunks; k += 64) {
-      const int64_t rbeg = (int64_t)k * rows_per_chunk;
-      int64_t rend = rbeg + rows_per_chunk;
-      if (rend > rows) rend = rows;
-      Agg4 b;
-      b.n = (float)(rend - rbeg);
-      const float4 p0 = *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c);
-      const float4 p1 = *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c);
-      const float inv = 1.f / b.n;
-      if (TILES) {
-        b.mean = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
-        b.m2 = p1;
-      } else {
-        const float4 s = ld4<H>(x, (size_t)(rbeg * C + c) >> 2);
-        const float4 d = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
-        b.mean = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
-        b.m2 = make_float4(fmaxf(p1.x - p0.x * d.x, 0.f), fmaxf(p1.y - p0.y * d.y, 0.f), fmaxf(p1.z - p0.z * d.z, 0.f),
-                           fmaxf(p1.w - p0.w * d.w, 0.f));
-      }
-      a = agg4_merge(a, b);
-    }
-  }
-  // 64 -> 16 -> 4 -> 1 lanes; lane ty of a level merges entries 4 ty .. 4 ty + 3 of the level below, in that order
-#pragma unroll
-  for (int width = 64; width > 1; width >>= 2) {
-    __syncthreads();
-    if (ty < width) { sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2; }
-    __syncthreads();
-    if (ty < (width >> 2)) {
-      a.n = sn[4 * ty][tx]; a.mean = sm[4 * ty][tx]; a.m2 = sq[4 * ty][tx];
-#pragma unroll
-      for (int j = 1; j < 4; ++j) {
+  for (int g = 0; g < groups; ++g) {
+    Agg4 a;
+    a.n = 0.f; a.mean = make_float4(0.f, 0.f, 0.f, 0.f); a.m2 = a.mean;
+    const int64_t row0 = (int64_t)g * rows;
+    if (c < C) {
+      for (int k = ty; k < nchunks; k += 64) {
+        const int64_t rbeg = (int64_t)k * rows_per_chunk;
+        int64_t rend = rbeg + rows_per_chunk;
+        if (rend > rows) rend = rows;
         Agg4 b;
-        b.n = sn[4 * ty + j][tx]; b.mean = sm[4 * ty + j][tx]; b.m2 = sq[4 * ty + j][tx];
+        b.n = (float)(rend - rbeg);
+        const size_t kk = (size_t)g * nchunks + k;
+        const float4 p0 = *reinterpret_cast<const float4*>(part0 + kk * C + c);
+        const float4 p1 = *reinterpret_cast<const float4*>(part1 + kk * C + c);
+        const float inv = 1.f / b.n;
+        if (TILES) {
+          b.mean = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
+          b.m2 = p1;
+        } else {
+          const float4 s = ld4<H>(x, (size_t)((row0 + rbeg) * C + c) >> 2);
+          const float4 d = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
+          b.mean = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
+          b.m2 = make_float4(fmaxf(p1.x - p0.x * d.x, 0.f), fmaxf(p1.y - p0.y * d.y, 0.f), fmaxf(p1.z - p0.z * d.z, 0.f),
+                             fmaxf(p1.w - p0.w * d.w, 0.f));
+        }
         a = agg4_merge(a, b);
       }
     }
-  }
-  if (ty == 0 && c < C) {
-    const Agg4 r = a;
-    const float mu[4] = {r.mean.x, r.mean.y, r.mean.z, r.mean.w};
-    const float mo[4] = {r.m2.x, r.m2.y, r.m2.z, r.m2.w};
+    // 64 -> 16 -> 4 -> 1 lanes; lane ty of a level merges entries 4 ty .. 4 ty + 3 of the level below, in that order
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (sum) { sum[c + e] = mu[e] * r.n; m2[c + e] = mo[e]; }
-      if (fin.gamma) bn_fin_col(fin, c + e, r.n, mu[e], mo[e]);
+    for (int width = 64; width > 1; width >>= 2) {
+      __syncthreads();
+      if (ty < width) { sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2; }
+      __syncthreads();
+      if (ty < (width >> 2)) {
+        a.n = sn[4 * ty][tx]; a.mean = sm[4 * ty][tx]; a.m2 = sq[4 * ty][tx];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          Agg4 b;
+          b.n = sn[4 * ty + j][tx]; b.mean = sm[4 * ty + j][tx]; b.m2 = sq[4 * ty + j][tx];
+          a = agg4_merge(a, b);
+        }
+      }
+    }
+    if (ty == 0 && c < C) {
+      const Agg4 r = a;
+      const float mu[4] = {r.mean.x, r.mean.y, r.mean.z, r.mean.w};
+      const float mo[4] = {r.m2.x, r.m2.y, r.m2.z, r.m2.w};
+      const size_t goff = (size_t)g * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (sum) { sum[goff + c + e] = mu[e] * r.n; m2[goff + c + e] = mo[e]; }
+        if (fin.gamma) bn_fin_col(fin, c + e, r.n, mu[e], mo[e], goff);
+      }
     }
   }
 }
@@ -573,12 +590,13 @@ __device__ __forceinline__ void st4(float* y, void* yh, size_t i4, const float4 
 template <bool VEC, bool H = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ xv, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, size_t n, int C, int act,
-                                                       float alpha, float* __restrict__ y, uint2* __restrict__ yh) {
+                                                       float alpha, float* __restrict__ y, uint2* __restrict__ yh, size_t per_group4 = 0) {
   const float* x = reinterpret_cast<const float*>(xv);
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-      const int c = (int)((i * 4) % (size_t)C);
+      // per_group4 != 0: element quads per group of a stacked batch; scale / shift are [groups][C]
+      const int c = (int)((i * 4) % (size_t)C) + (per_group4 ? (int)(i / per_group4) * C : 0);
       float4 v = ld4<H>(xv, i);
       const float4 sc = *reinterpret_cast<const float4*>(scale + c);
       const float4 sh = *reinterpret_cast<const float4*>(shift + c);
@@ -620,42 +638,58 @@ __global__ __launch_bounds__(256) void bn_bwd_stage2_coef_v4(const float* __rest
                                                              int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, float n, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ k_dy, float* __restrict__ k_x,
-                                                             float* __restrict__ k_0, int accumulate) {
+                                                             float* __restrict__ k_0, int accumulate, int groups = 1) {
+  // groups > 1 (a stacked batch): nchunks partials, n rows, mean / rstd [C] and one coefficient triple [3][C] PER GROUP (chunk g * nchunks + k,
+  // mean + g C, k_* + g 3 C); dgamma / dbeta are the sums over the groups, formed in group order by the column's own thread
   __shared__ float4 red[16][16], red1[16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < C) {
-    for (int k = ty; k < nchunks; k += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(part0 + (size_t)k * C + c);
-      const float4 w = *reinterpret_cast<const float4*>(part1 + (size_t)k * C + c);
-      a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
-      a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+  float tg[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < groups; ++g) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      for (int k = ty; k < nchunks; k += 16) {
+        const size_t kk = (size_t)g * nchunks + k;
+        const float4 v = *reinterpret_cast<const float4*>(part0 + kk * C + c);
+        const float4 w = *reinterpret_cast<const float4*>(part1 + kk * C + c);
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+        a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+      }
+    }
+    if (g) __syncthreads();
+    red[ty][tx] = a0;
+    red1[ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+      float4 s0 = red[0][tx], s1 = red1[0][tx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = red[k][tx], w = red1[k][tx];
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+      }
+      const float sd[4] = {s0.x, s0.y, s0.z, s0.w}, sx[4] = {s1.x, s1.y, s1.z, s1.w};
+      const size_t goff = (size_t)g * C, koff = (size_t)g * 3 * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = c + e;
+        const float mu = mean[goff + cc], rs = rstd[goff + cc], gm = gamma[cc], sdy = sd[e];
+        const float sdyxh = rs * sx[e];
+        tg[e] = g ? tg[e] + sdyxh : sdyxh;
+        tb[e] = g ? tb[e] + sdy : sdy;
+        const float grs = gm * rs;
+        k_dy[koff + cc] = grs;
+        k_x[koff + cc] = -grs * rs * sdyxh / n;
+        k_0[koff + cc] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
+      }
     }
   }
-  red[ty][tx] = a0;
-  red1[ty][tx] = a1;
-  __syncthreads();
   if (ty == 0 && c < C) {
-    float4 s0 = red[0][tx], s1 = red1[0][tx];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const float4 v = red[k][tx], w = red1[k][tx];
-      s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-      s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
-    }
-    const float sd[4] = {s0.x, s0.y, s0.z, s0.w}, sx[4] = {s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int cc = c + e;
-      const float mu = mean[cc], rs = rstd[cc], g = gamma[cc], sdy = sd[e];
-      const float sdyxh = rs * sx[e];
-      dgamma[cc] = accumulate ? dgamma[cc] + sdyxh : sdyxh;
-      dbeta[cc] = accumulate ? dbeta[cc] + sdy : sdy;
-      const float grs = g * rs;
-      k_dy[cc] = grs;
-      k_x[cc] = -grs * rs * sdyxh / n;
-      k_0[cc] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
+      dgamma[cc] = accumulate ? dgamma[cc] + tg[e] : tg[e];
+      dbeta[cc] = accumulate ? dbeta[cc] + tb[e] : tb[e];
     }
   }
 }
@@ -665,13 +699,14 @@ template <bool VEC, bool HD = false, bool HX = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dyv, const void* __restrict__ xv,
                                                            const float* __restrict__ k_dy, const float* __restrict__ k_x,
                                                            const float* __restrict__ k_0, size_t n, int C,
-                                                           float* __restrict__ dx, uint2* __restrict__ dxh) {
+                                                           float* __restrict__ dx, uint2* __restrict__ dxh, size_t per_group4 = 0) {
   const float* dy = reinterpret_cast<const float*>(dyv);
   const float* x = reinterpret_cast<const float*>(xv);
   if (VEC) {
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-      const int c = (int)((i * 4) % (size_t)C);
+      // per_group4 != 0: element quads per group of a stacked batch; one coefficient triple [3][C] per group
+      const int c = (int)((i * 4) % (size_t)C) + (per_group4 ? (int)(i / per_group4) * 3 * C : 0);
       const float4 d = ld4<HD>(dyv, i);
       const float4 v = ld4<HX>(xv, i);
       const float4 a = *reinterpret_cast<const float4*>(k_dy + c);
@@ -795,13 +830,20 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_stage1(const void* __restr
                                                              const void* __restrict__ x2, const float* __restrict__ center,
                                                              int64_t rows, int C, int64_t rows_per_chunk, int act, float alpha,
                                                              float* __restrict__ dx, float* __restrict__ part,
-                                                             float* __restrict__ part1, unsigned short* __restrict__ dxh) {
+                                                             float* __restrict__ part1, unsigned short* __restrict__ dxh,
+                                                             int64_t rows_g = 0, int ncg = 0) {
   __shared__ float4 red[16][16];
   __shared__ float4 red1[SECOND ? 16 : 1][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
-  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk;
-  int64_t rend = rbeg + rows_per_chunk;
+  int64_t rbeg = (int64_t)blockIdx.y * rows_per_chunk, rend = rbeg + rows_per_chunk;
+  if (rows_g) {                          // grouped rows (see col_reduce_stage1_v4): chunks per group, `center` per group
+    const int g = blockIdx.y / ncg, j = blockIdx.y - g * ncg;
+    rbeg = (int64_t)g * rows_g + (int64_t)j * rows_per_chunk;
+    rend = rbeg + rows_per_chunk;
+    if (rend > (int64_t)(g + 1) * rows_g) rend = (int64_t)(g + 1) * rows_g;
+    if (center) center += (size_t)g * C;
+  }
   if (rend > rows) rend = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
@@ -902,6 +944,96 @@ hipError_t bn_bwd_fused_launch(const void* dy, const void* y, const void* x, con
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
                        reinterpret_cast<uint2*>(dx_h));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batch norm of a STACKED batch: `groups` passes of the reference graph (the critic on fake / match / mismatch images,
+// reference models/gancls/model.py:48-51) run as one batch of groups * B samples; convolutions are per-sample, batch norm is not —
+// every pass keeps its own statistics.  The passes are contiguous row ranges, so the same three launches serve all of them:
+// stage 1 with chunks that never straddle a group, stage 2 walking the groups (moving averages move once per group, in order),
+// normalisation with per-group scale / shift; the backward likewise.  C % 4 == 0, 16-byte aligned tensors.
+// ---------------------------------------------------------------------------------------------------------------
+static void bn_group_plan(int64_t rows_g, int C, int groups, int* ct, int* ncg, int64_t* rpc) {
+  col_reduce_plan(rows_g, C, ct, ncg, rpc);
+  const int cap = tuning().colred_cap / groups > 0 ? tuning().colred_cap / groups : 1;     // the same total number of partial rows as one pass
+  if (*ncg > cap) {
+    *rpc = (rows_g + cap - 1) / cap;
+    *ncg = (int)((rows_g + *rpc - 1) / *rpc);
+  }
+}
+
+size_t bn_grouped_ws(int64_t rows_g, int C, int groups) {
+  int ct, ncg; int64_t rpc;
+  bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
+  return ((size_t)groups * ncg * C * 2 + (size_t)groups * 3 * C) * sizeof(float);
+}
+
+hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int groups, const float* gamma, const float* beta, float eps, float decay,
+                                 float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, int act, float alpha, float* y,
+                                 void* y_h, void* ws, hipStream_t stream, bool x_bf16) {
+  int ct, ncg; int64_t rpc;
+  bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
+  float* part0 = reinterpret_cast<float*>(ws);
+  float* part1 = part0 + (size_t)groups * ncg * C;
+  const int64_t rows = rows_g * groups;
+  if (x_bf16)
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, true>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
+                       part0, part1, 1, (const float*)nullptr, rows_g, ncg);
+  else
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
+                       part0, part1, 1, (const float*)nullptr, rows_g, ncg);
+  const BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv);
+  if (x_bf16)
+    hipLaunchKernelGGL((bn_stats_stage2_v4<false, true>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C,
+                       (float*)nullptr, (float*)nullptr, fin, groups);
+  else
+    hipLaunchKernelGGL((bn_stats_stage2_v4<false, false>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C,
+                       (float*)nullptr, (float*)nullptr, fin, groups);
+  const size_t n = (size_t)rows * C, pg4 = ((size_t)rows_g * C) >> 2;
+  if (x_bf16)
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y,
+                       reinterpret_cast<uint2*>(y_h), pg4);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y,
+                       reinterpret_cast<uint2*>(y_h), pg4);
+  return hipGetLastError();
+}
+
+hipError_t bn_bwd_grouped_launch(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                 int64_t rows_g, int C, int groups, int act, float alpha, void* gmask, float* dx, float* dgamma, float* dbeta,
+                                 int accumulate, void* ws, hipStream_t stream, void* dx_h, bool in_bf16) {
+  int ct, ncg; int64_t rpc;
+  bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
+  const int64_t rows = rows_g * groups;
+  float* part = reinterpret_cast<float*>(ws);
+  float* part1 = part + (size_t)groups * ncg * C;
+  float* coef = part1 + (size_t)groups * ncg * C;            // [groups][3][C] behind the partials
+  const void* g = dy;
+  const dim3 grid(ct, groups * ncg);
+  if (y) {
+    if (in_bf16)
+      hipLaunchKernelGGL((act_bwd_colsum_stage1<true, true>), grid, dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha,
+                         (float*)nullptr, part, part1, reinterpret_cast<unsigned short*>(gmask), rows_g, ncg);
+    else
+      hipLaunchKernelGGL((act_bwd_colsum_stage1<true, false>), grid, dim3(256), 0, stream, dy, y, x, mean, rows, C, rpc, act, alpha,
+                         reinterpret_cast<float*>(gmask), part, part1, (unsigned short*)nullptr, rows_g, ncg);
+    g = gmask;
+  } else if (in_bf16) {
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, true>), grid, dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean, rows_g, ncg);
+  } else {
+    hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, false>), grid, dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean, rows_g, ncg);
+  }
+  float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
+  hipLaunchKernelGGL(bn_bwd_stage2_coef_v4, dim3(ct), dim3(256), 0, stream, part, part1, ncg, C, mean, rstd, gamma, (float)rows_g, dgamma, dbeta,
+                     k_dy, k_x, k_0, accumulate, groups);
+  const size_t n = (size_t)rows * C, pg4 = ((size_t)rows_g * C) >> 2;
+  if (in_bf16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
+                       reinterpret_cast<uint2*>(dx_h), pg4);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, g, x, k_dy, k_x, k_0, n, C, dx,
+                       reinterpret_cast<uint2*>(dx_h), pg4);
   return hipGetLastError();
 }
 

@@ -34,6 +34,11 @@ hipError_t bn_bwd_fused_launch(const void*, const void*, const void*, const floa
 hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const float*, const float*, float, float, float*,
                               float*, float*, float*, float*, float*, hipStream_t);
 hipError_t bn_apply_launch(const void*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h, bool x_bf16);
+size_t bn_grouped_ws(int64_t rows_g, int C, int groups);
+hipError_t bn_fwd_grouped_launch(const void*, int64_t, int, int, const float*, const float*, float, float, float*, float*, float*, float*, float*, float*,
+                                 int, float, float*, void*, void*, hipStream_t, bool);
+hipError_t bn_bwd_grouped_launch(const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, int, int, float, void*,
+                                 float*, float*, float*, int, void*, hipStream_t, void*, bool);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                          int64_t, int, float*, float*, float*, float*, int, hipStream_t);
 hipError_t ew_launch(int, const void*, const void*, size_t, int, float, float, float*, hipStream_t, void* y_h, bool in_bf16);
@@ -1208,6 +1213,48 @@ int t2i_bn_apply(const void* x, const float* scale, const float* shift, int64_t 
   const bool h = dtype == T2I_DT_BF16;
   return check(bn_apply_launch(x, scale, shift, rows, al ? C : -C, act, alpha, h ? nullptr : reinterpret_cast<float*>(y), (hipStream_t)stream,
                                h ? y : y_h, h), "t2i_bn_apply");
+}
+
+size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t groups) {
+  if (rows_per_group <= 0 || C <= 0 || groups <= 0) return 0;
+  return bn_grouped_ws(rows_per_group, C, groups);
+}
+
+int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
+                             float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
+                             float alpha, void* y, void* y_h, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+  if (!x || !gamma || !beta || !mean || !rstd || !scale || !shift || !y || rows_per_group <= 0 || C <= 0 || (C & 3) || groups <= 0 ||
+      ((moving_mean == nullptr) != (moving_var == nullptr))) {
+    set_error("t2i_bn_train_fwd_grouped: bad argument (C %% 4 == 0 required)");
+    return T2I_ERR_INVALID;
+  }
+  if (!(aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(y_h))) {
+    set_error("t2i_bn_train_fwd_grouped: tensors must be 16-byte aligned");
+    return T2I_ERR_INVALID;
+  }
+  if (!ws || ws_bytes < bn_grouped_ws(rows_per_group, C, groups) || !aligned16(ws)) { set_error("t2i_bn_train_fwd_grouped: workspace too small"); return T2I_ERR_WORKSPACE; }
+  if (int rc = h_contract(dtype, true, C, y_h, "t2i_bn_train_fwd_grouped")) return rc;
+  const bool h = dtype == T2I_DT_BF16;
+  return check(bn_fwd_grouped_launch(x, rows_per_group, C, groups, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, act, alpha,
+                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h), "t2i_bn_train_fwd_grouped");
+}
+
+int t2i_bn_bwd_grouped(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows_per_group,
+                       int32_t C, int32_t groups, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate,
+                       void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows_per_group <= 0 || C <= 0 || (C & 3) || groups <= 0 || (y && !gmask)) {
+    set_error("t2i_bn_bwd_grouped: bad argument (C %% 4 == 0 required; gmask needed with an activation)");
+    return T2I_ERR_INVALID;
+  }
+  if (!(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(mean) && aligned16(dx_h) && (!y || (aligned16(y) && aligned16(gmask))))) {
+    set_error("t2i_bn_bwd_grouped: tensors must be 16-byte aligned");
+    return T2I_ERR_INVALID;
+  }
+  if (!ws || ws_bytes < bn_grouped_ws(rows_per_group, C, groups) || !aligned16(ws)) { set_error("t2i_bn_bwd_grouped: workspace too small"); return T2I_ERR_WORKSPACE; }
+  if (int rc = h_contract(dtype, true, C, dx_h, "t2i_bn_bwd_grouped")) return rc;
+  const bool h = dtype == T2I_DT_BF16;
+  return check(bn_bwd_grouped_launch(dy, y, x, mean, rstd, gamma, rows_per_group, C, groups, act, alpha, gmask, h ? nullptr : reinterpret_cast<float*>(dx),
+                                     dgamma, dbeta, accumulate ? 1 : 0, ws, (hipStream_t)stream, h ? dx : dx_h, h), "t2i_bn_bwd_grouped");
 }
 
 int t2i_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

@@ -742,6 +742,46 @@ def bn_apply_groups(x, scales, shifts, act=ACT_NONE, alpha=0.2):
     return y
 
 
+def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None):
+    """Training-mode batch norm of a stacked batch in three launches (t2i_bn_train_fwd_grouped): x [groups * b, ..., C] with per-group
+    statistics.  -> (y, mean [groups, C], rstd [groups, C]); moving averages updated in place once per group, in group order."""
+    _chk(x, 'x')
+    C = x.shape[-1]
+    rows_g = x.numel() // C // groups
+    stat = torch.empty((4, groups, C), dtype=torch.float32, device=x.device)       # mean, rstd, scale, shift
+    y = torch.empty_like(x)
+    if _live(x):
+        wsp, wsn = _ws_args(x, int(lib.t2i_bn_grouped_workspace_bytes(rows_g, C, groups)))
+        twin = _twin_for(y, x)
+        check(lib.t2i_bn_train_fwd_grouped(_ptr(x), rows_g, C, groups, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(stat[0]), _ptr(stat[1]),
+                                           _ptr(stat[2]), _ptr(stat[3]), _ptr(moving_mean), _ptr(moving_var), act, alpha, _ptr(y), _ptr(twin), wsp, wsn,
+                                           _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
+        _twin_keep(y, twin)
+    return y, stat[0], stat[1]
+
+
+def bn_bwd_grouped(dy, y, x, mean, rstd, gamma, groups, act, alpha=0.2, dgamma_out=None, dbeta_out=None):
+    """Backward of bn_train_fwd_grouped in three launches.  mean / rstd: [groups, C].  -> (dx, dgamma, dbeta) with dgamma / dbeta summed
+    over the groups; dgamma_out / dbeta_out: gradient-arena slots to ACCUMULATE into."""
+    _chk(dy, 'dy'); _chk(x, 'x')
+    C = x.shape[-1]
+    rows_g = x.numel() // C // groups
+    dx = torch.empty_like(x)
+    gmask = torch.empty_like(x) if y is not None else None
+    acc = dgamma_out is not None
+    assert acc == (dbeta_out is not None)
+    dgamma = dgamma_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = dbeta_out if acc else torch.empty(C, dtype=torch.float32, device=x.device)
+    if _live(x):
+        wsp, wsn = _ws_args(x, int(lib.t2i_bn_grouped_workspace_bytes(rows_g, C, groups)))
+        twin = _twin_for(dx)
+        check(lib.t2i_bn_bwd_grouped(_ptr(dy), _ptr(_chk(y, 'y') if y is not None else None), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(_chk(gamma)),
+                                     rows_g, C, groups, act, alpha, _ptr(gmask), _ptr(dx), _ptr(twin), _ptr(dgamma), _ptr(dbeta), 1 if acc else 0,
+                                     wsp, wsn, _same_dt(dy, y, x), _stream()), 't2i_bn_bwd_grouped')
+        _twin_keep(dx, twin)
+    return dx, dgamma, dbeta
+
+
 _bn_apply_one = bn_apply          # (instrumentation replaces the public name; the per-slice calls above are not layers of their own)
 
 
