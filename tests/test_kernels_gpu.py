@@ -921,3 +921,13 @@ def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
     assert close(dx, torch.cat(ref_dx, 0), 5e-6) and torch.equal(dx, dxa)
     assert close(dg, ref_dg, 5e-6) and close(db, ref_db, 5e-6)
     assert close(acc_g, ref_dg + 0.5, 5e-6) and close(acc_b, ref_db - 0.25, 5e-6)
+    # the second stage folded into the normalisation / dx kernel (default where the partials are few) against three separate launches
+    K.tuning_set('bn_fuse', 0)
+    try:
+        mm3, mv3 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        y3, mean3, rstd3 = K.bn_train_fwd_grouped(x, gamma, beta, 1e-5, 0.9, groups, kind, 0.2, mm3, mv3)
+        dx3, dg3, db3 = K.bn_bwd_grouped(gy, y3 if kind != K.ACT_NONE else None, x, mean3, rstd3, gamma, groups, kind, 0.2)
+    finally:
+        K.tuning_set('bn_fuse', 1)
+    assert close(y, y3) and close(mean, mean3) and close(rstd, rstd3) and close(mm, mm3) and close(mv, mv3)
+    assert close(dx, dx3, 5e-6) and close(dg, dg3, 5e-6) and close(db, db3, 5e-6)

@@ -373,6 +373,9 @@ class ActFn(Function):
         return ActBwdFn.apply(gy, y, ctx.act, ctx.alpha), None, None
 
 
+_BN_ONE_ENTRY = [os.environ.get('T2I_BN_ONE_ENTRY', '1') != '0']     # 0: the separate statistics / normalise calls of rounds 1-4
+
+
 class BatchNormTrainFn(Function):
     """Training-mode fused batch norm + activation: reference utils/ops.py:7-29.  Normalises with the biased batch
     variance; if moving_mean/var are given they are updated in place with the unbiased one (TF UPDATE_OPS semantics are
@@ -385,8 +388,14 @@ class BatchNormTrainFn(Function):
         n = x.numel() // C
         # statistics (the producing conv's epilogue partials when ops.conv2d(..., stats=True) left any, else a pass over x;
         # numerically stable either way) and the finalize step in one chain of launches
-        mean, rstd, scale, shift = K.bn_train_stats(x, gamma, beta, eps, decay, moving_mean, moving_var)
-        y = K.bn_apply(x, scale, shift, act, alpha)
+        # round 5: one entry point — [first stage unless the conv left tile partials] -> [second stage + finalize] -> [normalise], the
+        # middle launch folded into the last one's prologue for the small tensors (t2i_bn_train_fwd_grouped with groups = 1)
+        if _BN_ONE_ENTRY[0] and C % 4 == 0 and x.data_ptr() % 16 == 0 and gamma.data_ptr() % 4 == 0:
+            y, mean, rstd = K.bn_train_fwd_grouped(x, gamma, beta, eps, decay, 1, act, alpha, moving_mean, moving_var)
+            mean, rstd = mean[0], rstd[0]
+        else:
+            mean, rstd, scale, shift = K.bn_train_stats(x, gamma, beta, eps, decay, moving_mean, moving_var)
+            y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
         ctx.act, ctx.alpha = act, alpha
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
@@ -412,7 +421,10 @@ class BatchNormTrainFn(Function):
         gsink = _sink_of(ctx.gamma_ref) if want_g else None
         bsink = _sink_of(ctx.beta_ref) if want_b else None
         sunk = gsink is not None and bsink is not None
-        if fused:            # [act backward + both reductions] -> [second stage + coefficients] -> [dx]: three launches
+        if fused and _BN_ONE_ENTRY[0]:      # [act backward + both reductions] -> [second stage + coefficients + dx]: two launches when the partials are few
+            dx, dgamma, dbeta = K.bn_bwd_grouped(gy, y if ctx.act != K.ACT_NONE else None, x, mean, rstd, gamma, 1, ctx.act, ctx.alpha,
+                                                 dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
+        elif fused:          # [act backward + both reductions] -> [second stage + coefficients] -> [dx]: three launches
             dx, dgamma, dbeta = K.bn_bwd_fused(gy, y if ctx.act != K.ACT_NONE else None, x, mean, rstd, gamma, ctx.act, ctx.alpha,
                                                dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
         else:

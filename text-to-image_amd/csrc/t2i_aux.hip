@@ -954,6 +954,208 @@ hipError_t bn_bwd_fused_launch(const void* dy, const void* y, const void* x, con
 // stage 1 with chunks that never straddle a group, stage 2 walking the groups (moving averages move once per group, in order),
 // normalisation with per-group scale / shift; the backward likewise.  C % 4 == 0, 16-byte aligned tensors.
 // ---------------------------------------------------------------------------------------------------------------
+// ---- second stage folded into the consumer (round 5) ------------------------------------------------------------------------------------
+// With few partial rows per column (<= BN_FUSE_MAX_CHUNKS per group: the small, launch-bound tensors) the second stage of the statistics is not a
+// launch of its own: every workgroup of the NORMALISATION owns 64 columns x a run of rows of one group, and its prologue merges the partials of
+// exactly those 64 columns (16 chunk lanes x 16 column quads, then 16 -> 4 -> 1 through LDS, Chan's update in a fixed order) into scale / shift in
+// LDS.  The workgroup at (group 0, first run of rows) also walks ALL groups in order to write mean / rstd / scale / shift and to move the moving
+// averages once per group — the one place where groups meet.  One launch less per batch norm, forward and backward.
+constexpr int BN_FUSE_MAX_CHUNKS = 64;
+
+template <bool TILES, bool H>
+__device__ __forceinline__ Agg4 bn_merge_group(const float* __restrict__ part0, const float* __restrict__ part1, const void* __restrict__ x,
+                                               int g, int nchunks, int64_t rows_g, int64_t rpc, int C, int c, int tx, int ty, bool col_ok,
+                                               float (*sn)[16], float4 (*sm)[16], float4 (*sq)[16]) {
+  Agg4 a;
+  a.n = 0.f; a.mean = make_float4(0.f, 0.f, 0.f, 0.f); a.m2 = a.mean;
+  if (col_ok) {
+    for (int k = ty; k < nchunks; k += 16) {
+      const int64_t rbeg = (int64_t)k * rpc;
+      int64_t rend = rbeg + rpc;
+      if (rend > rows_g) rend = rows_g;
+      Agg4 b;
+      b.n = (float)(rend - rbeg);
+      const size_t kk = (size_t)g * nchunks + k;
+      const float4 p0 = *reinterpret_cast<const float4*>(part0 + kk * C + c);
+      const float4 p1 = *reinterpret_cast<const float4*>(part1 + kk * C + c);
+      const float inv = 1.f / b.n;
+      if (TILES) {
+        b.mean = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
+        b.m2 = p1;
+      } else {
+        const float4 s = ld4<H>(x, (size_t)(((int64_t)g * rows_g + rbeg) * C + c) >> 2);
+        const float4 d = make_float4(p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv);
+        b.mean = make_float4(s.x + d.x, s.y + d.y, s.z + d.z, s.w + d.w);
+        b.m2 = make_float4(fmaxf(p1.x - p0.x * d.x, 0.f), fmaxf(p1.y - p0.y * d.y, 0.f), fmaxf(p1.z - p0.z * d.z, 0.f),
+                           fmaxf(p1.w - p0.w * d.w, 0.f));
+      }
+      a = agg4_merge(a, b);
+    }
+  }
+#pragma unroll
+  for (int width = 16; width > 1; width >>= 2) {       // 16 -> 4 -> 1 chunk lanes
+    __syncthreads();
+    if (ty < width) { sn[ty][tx] = a.n; sm[ty][tx] = a.mean; sq[ty][tx] = a.m2; }
+    __syncthreads();
+    if (ty < (width >> 2)) {
+      a.n = sn[4 * ty][tx]; a.mean = sm[4 * ty][tx]; a.m2 = sq[4 * ty][tx];
+#pragma unroll
+      for (int j = 1; j < 4; ++j) {
+        Agg4 b;
+        b.n = sn[4 * ty + j][tx]; b.mean = sm[4 * ty + j][tx]; b.m2 = sq[4 * ty + j][tx];
+        a = agg4_merge(a, b);
+      }
+    }
+  }
+  return a;       // valid in the lanes ty == 0
+}
+
+// grid (ceil(C / 64), groups * nb_g): workgroup (bx, g * nb_g + j) normalises rows [g rows_g + j rpb, ...) of columns [64 bx, 64 bx + 64)
+template <bool TILES, bool H>
+__global__ __launch_bounds__(256) void bn_fwd_apply_fused(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                          const void* __restrict__ x, int nchunks, int64_t rows_g, int64_t rpc, int C, BnFin fin,
+                                                          int groups, int64_t rpb, int nb_g, int act, float alpha, float* __restrict__ y,
+                                                          uint2* __restrict__ yh) {
+  __shared__ float sn[16][16];
+  __shared__ float4 sm[16][16], sq[16][16];
+  __shared__ float4 s_scale[16], s_shift[16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  const bool col_ok = c < C;
+  const int g_own = blockIdx.y / nb_g, j = blockIdx.y - g_own * nb_g;
+  const bool scribe = blockIdx.y == 0;                 // writes the layer's outputs and moves the moving averages, group by group
+  for (int g = scribe ? 0 : g_own; g < (scribe ? groups : g_own + 1); ++g) {
+    const Agg4 r = bn_merge_group<TILES, H>(part0, part1, x, g, nchunks, rows_g, rpc, C, c, tx, ty, col_ok, sn, sm, sq);
+    if (ty == 0 && col_ok) {
+      const float mu[4] = {r.mean.x, r.mean.y, r.mean.z, r.mean.w};
+      const float mo[4] = {r.m2.x, r.m2.y, r.m2.z, r.m2.w};
+      float sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float var = fmaxf(mo[e], 0.f) / r.n;
+        const float rs = rsqrtf(var + fin.eps);
+        sc[e] = fin.gamma[c + e] * rs;
+        sh[e] = fin.beta[c + e] - mu[e] * sc[e];
+        if (scribe) bn_fin_col(fin, c + e, r.n, mu[e], mo[e], (size_t)g * C);     // (same expressions: the stored scale / shift are these bits)
+      }
+      if (g == g_own) { s_scale[tx] = make_float4(sc[0], sc[1], sc[2], sc[3]); s_shift[tx] = make_float4(sh[0], sh[1], sh[2], sh[3]); }
+    }
+  }
+  __syncthreads();
+  if (!col_ok) return;
+  const float4 sc = s_scale[tx], sh = s_shift[tx];
+  const int64_t rbeg = (int64_t)g_own * rows_g + (int64_t)j * rpb;
+  int64_t rend = rbeg + rpb;
+  if (rend > (int64_t)(g_own + 1) * rows_g) rend = (int64_t)(g_own + 1) * rows_g;
+#pragma unroll 4
+  for (int64_t r = rbeg + ty; r < rend; r += 16) {
+    const size_t e4 = (size_t)(r * C + c) >> 2;
+    float4 v = ld4<H>(x, e4);
+    v.x = apply_act(v.x * sc.x + sh.x, act, alpha);
+    v.y = apply_act(v.y * sc.y + sh.y, act, alpha);
+    v.z = apply_act(v.z * sc.z + sh.z, act, alpha);
+    v.w = apply_act(v.w * sc.w + sh.w, act, alpha);
+    st4(y, yh, e4, v);
+  }
+}
+
+// backward: prologue = sums of the group's partials (sum g, sum g (x - mean)) -> the three coefficients of dx for the workgroup's 64 columns;
+// the scribe workgroup also forms dgamma / dbeta over all groups.  dx = k_dy g + k_x x + k_0.
+template <bool HD, bool HX>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused(const float* __restrict__ part0, const float* __restrict__ part1, int nchunks,
+                                                          int64_t rows_g, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int accumulate, int groups, int64_t rpb, int nb_g, const void* __restrict__ gv,
+                                                          const void* __restrict__ xv, float* __restrict__ dx, uint2* __restrict__ dxh) {
+  __shared__ float4 red[16][16], red1[16][16];
+  __shared__ float4 s_a[16], s_b[16], s_e[16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  const bool col_ok = c < C;
+  const int g_own = blockIdx.y / nb_g, j = blockIdx.y - g_own * nb_g;
+  const bool scribe = blockIdx.y == 0;
+  const float n = (float)rows_g;
+  float tg[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = scribe ? 0 : g_own; g < (scribe ? groups : g_own + 1); ++g) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok) {
+      for (int k = ty; k < nchunks; k += 16) {
+        const size_t kk = (size_t)g * nchunks + k;
+        const float4 v = *reinterpret_cast<const float4*>(part0 + kk * C + c);
+        const float4 w = *reinterpret_cast<const float4*>(part1 + kk * C + c);
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+        a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+      }
+    }
+    __syncthreads();
+    red[ty][tx] = a0;
+    red1[ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && col_ok) {
+      float4 s0 = red[0][tx], s1 = red1[0][tx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = red[k][tx], w = red1[k][tx];
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+      }
+      const float sd[4] = {s0.x, s0.y, s0.z, s0.w}, sx[4] = {s1.x, s1.y, s1.z, s1.w};
+      float ka[4], kb[4], ke[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = c + e;
+        const float mu = mean[(size_t)g * C + cc], rs = rstd[(size_t)g * C + cc], gm = gamma[cc], sdy = sd[e];
+        const float sdyxh = rs * sx[e];
+        tg[e] = g ? tg[e] + sdyxh : sdyxh;
+        tb[e] = g ? tb[e] + sdy : sdy;
+        const float grs = gm * rs;
+        ka[e] = grs;
+        kb[e] = -grs * rs * sdyxh / n;
+        ke[e] = -grs * sdy / n + grs * rs * mu * sdyxh / n;
+      }
+      if (g == g_own) {
+        s_a[tx] = make_float4(ka[0], ka[1], ka[2], ka[3]); s_b[tx] = make_float4(kb[0], kb[1], kb[2], kb[3]);
+        s_e[tx] = make_float4(ke[0], ke[1], ke[2], ke[3]);
+      }
+    }
+  }
+  if (scribe && ty == 0 && col_ok) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dgamma[c + e] = accumulate ? dgamma[c + e] + tg[e] : tg[e];
+      dbeta[c + e] = accumulate ? dbeta[c + e] + tb[e] : tb[e];
+    }
+  }
+  __syncthreads();
+  if (!col_ok) return;
+  const float4 a = s_a[tx], b = s_b[tx], e = s_e[tx];
+  const int64_t rbeg = (int64_t)g_own * rows_g + (int64_t)j * rpb;
+  int64_t rend = rbeg + rpb;
+  if (rend > (int64_t)(g_own + 1) * rows_g) rend = (int64_t)(g_own + 1) * rows_g;
+#pragma unroll 4
+  for (int64_t r = rbeg + ty; r < rend; r += 16) {
+    const size_t e4 = (size_t)(r * C + c) >> 2;
+    const float4 d = ld4<HD>(gv, e4);
+    const float4 v = ld4<HX>(xv, e4);
+    float4 o;
+    o.x = a.x * d.x + b.x * v.x + e.x;
+    o.y = a.y * d.y + b.y * v.y + e.y;
+    o.z = a.z * d.z + b.z * v.z + e.z;
+    o.w = a.w * d.w + b.w * v.w + e.w;
+    st4(dx, dxh, e4, o);
+  }
+}
+
+// rows per workgroup of the fused normalisation: about 1024 workgroups in flight, runs of at least 16 rows
+static void bn_fuse_rows(int64_t rows_g, int ct, int groups, int64_t* rpb, int* nb_g) {
+  int64_t want = 1024 / ((int64_t)ct * groups);
+  if (want < 1) want = 1;
+  const int64_t maxb = (rows_g + 15) / 16;
+  if (want > maxb) want = maxb;
+  *rpb = (rows_g + want - 1) / want;
+  *nb_g = (int)((rows_g + *rpb - 1) / *rpb);
+}
+
 static void bn_group_plan(int64_t rows_g, int C, int groups, int* ct, int* ncg, int64_t* rpc) {
   col_reduce_plan(rows_g, C, ct, ncg, rpc);
   const int cap = tuning().colred_cap / groups > 0 ? tuning().colred_cap / groups : 1;     // the same total number of partial rows as one pass
@@ -971,32 +1173,50 @@ size_t bn_grouped_ws(int64_t rows_g, int C, int groups) {
 
 hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int groups, const float* gamma, const float* beta, float eps, float decay,
                                  float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, int act, float alpha, float* y,
-                                 void* y_h, void* ws, hipStream_t stream, bool x_bf16) {
+                                 void* y_h, void* ws, hipStream_t stream, bool x_bf16, const float* tile_sum, const float* tile_m2, int tile_chunks,
+                                 int tile_rows) {
+  // tile_sum != NULL: the producing conv's epilogue left per-tile partials (tile_chunks tiles of tile_rows rows per group): no first stage
   int ct, ncg; int64_t rpc;
   bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
-  float* part0 = reinterpret_cast<float*>(ws);
-  float* part1 = part0 + (size_t)groups * ncg * C;
+  const float* part0 = tile_sum;
+  const float* part1 = tile_m2;
+  const bool tiles = tile_sum != nullptr;
+  if (tiles) { ncg = tile_chunks; rpc = tile_rows; }
   const int64_t rows = rows_g * groups;
-  if (x_bf16)
-    hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, true>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
-                       part0, part1, 1, (const float*)nullptr, rows_g, ncg);
-  else
-    hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
-                       part0, part1, 1, (const float*)nullptr, rows_g, ncg);
+  if (!tiles) {
+    float* p0 = reinterpret_cast<float*>(ws);
+    float* p1 = p0 + (size_t)groups * ncg * C;
+    part0 = p0; part1 = p1;
+    if (x_bf16)
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, true>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
+                         p0, p1, 1, (const float*)nullptr, rows_g, ncg);
+    else
+      hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
+                         p0, p1, 1, (const float*)nullptr, rows_g, ncg);
+  }
   const BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv);
-  if (x_bf16)
-    hipLaunchKernelGGL((bn_stats_stage2_v4<false, true>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C,
-                       (float*)nullptr, (float*)nullptr, fin, groups);
-  else
-    hipLaunchKernelGGL((bn_stats_stage2_v4<false, false>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C,
-                       (float*)nullptr, (float*)nullptr, fin, groups);
+  uint2* yh = reinterpret_cast<uint2*>(y_h);
+  if (tuning().bn_fuse && ncg <= BN_FUSE_MAX_CHUNKS) {          // second stage in the normalisation's prologue: one launch less
+    int64_t rpb; int nb_g;
+    bn_fuse_rows(rows_g, ct, groups, &rpb, &nb_g);
+    const dim3 grid(ct, groups * nb_g);
+#define T2I_BNF(TL, HH) hipLaunchKernelGGL((bn_fwd_apply_fused<TL, HH>), grid, dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C, fin, groups, rpb, \
+                                           nb_g, act, alpha, y, yh)
+    if (tiles) { if (x_bf16) T2I_BNF(true, true); else T2I_BNF(true, false); }
+    else { if (x_bf16) T2I_BNF(false, true); else T2I_BNF(false, false); }
+#undef T2I_BNF
+    return hipGetLastError();
+  }
+#define T2I_BNS(TL, HH) hipLaunchKernelGGL((bn_stats_stage2_v4<TL, HH>), dim3((C + 15) / 16), dim3(256), 0, stream, part0, part1, x, ncg, rows_g, rpc, C, \
+                                           (float*)nullptr, (float*)nullptr, fin, groups)
+  if (tiles) { if (x_bf16) T2I_BNS(true, true); else T2I_BNS(true, false); }
+  else { if (x_bf16) T2I_BNS(false, true); else T2I_BNS(false, false); }
+#undef T2I_BNS
   const size_t n = (size_t)rows * C, pg4 = ((size_t)rows_g * C) >> 2;
   if (x_bf16)
-    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y,
-                       reinterpret_cast<uint2*>(y_h), pg4);
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y, yh, pg4);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y,
-                       reinterpret_cast<uint2*>(y_h), pg4);
+    hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(ew_blocks(n >> 2)), dim3(256), 0, stream, x, scale, shift, n, C, act, alpha, y, yh, pg4);
   return hipGetLastError();
 }
 
@@ -1023,6 +1243,18 @@ hipError_t bn_bwd_grouped_launch(const void* dy, const void* y, const void* x, c
     hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, true>), grid, dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean, rows_g, ncg);
   } else {
     hipLaunchKernelGGL((col_reduce_stage1_v4<true, true, false>), grid, dim3(256), 0, stream, dy, x, rows, C, rpc, part, part1, 0, mean, rows_g, ncg);
+  }
+  if (tuning().bn_fuse && ncg <= BN_FUSE_MAX_CHUNKS) {          // second stage + coefficients in the prologue of the dx kernel
+    int64_t rpb; int nb_g;
+    bn_fuse_rows(rows_g, ct, groups, &rpb, &nb_g);
+    const dim3 grid2(ct, groups * nb_g);
+    if (in_bf16)
+      hipLaunchKernelGGL((bn_bwd_apply_fused<true, true>), grid2, dim3(256), 0, stream, part, part1, ncg, rows_g, C, mean, rstd, gamma, dgamma, dbeta,
+                         accumulate, groups, rpb, nb_g, g, x, dx, reinterpret_cast<uint2*>(dx_h));
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_fused<false, false>), grid2, dim3(256), 0, stream, part, part1, ncg, rows_g, C, mean, rstd, gamma, dgamma, dbeta,
+                         accumulate, groups, rpb, nb_g, g, x, dx, reinterpret_cast<uint2*>(dx_h));
+    return hipGetLastError();
   }
   float* k_dy = coef; float* k_x = coef + C; float* k_0 = coef + 2 * (size_t)C;
   hipLaunchKernelGGL(bn_bwd_stage2_coef_v4, dim3(ct), dim3(256), 0, stream, part, part1, ncg, C, mean, rstd, gamma, (float)rows_g, dgamma, dbeta,

@@ -36,7 +36,7 @@ hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const fl
 hipError_t bn_apply_launch(const void*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h, bool x_bf16);
 size_t bn_grouped_ws(int64_t rows_g, int C, int groups);
 hipError_t bn_fwd_grouped_launch(const void*, int64_t, int, int, const float*, const float*, float, float, float*, float*, float*, float*, float*, float*,
-                                 int, float, float*, void*, void*, hipStream_t, bool);
+                                 int, float, float*, void*, void*, hipStream_t, bool, const float*, const float*, int, int);
 hipError_t bn_bwd_grouped_launch(const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, int, int, float, void*,
                                  float*, float*, float*, int, void*, hipStream_t, void*, bool);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
@@ -139,6 +139,7 @@ static Tuning& tuning_mut() {
     v.dma_split_us = env_int("T2I_DMA_SPLIT_US", 29);      // x0.1 us: fixed cost of its split-K reduction launch
     v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
     v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
+    v.bn_fuse = env_int("T2I_BN_FUSE", 1);                 // batch norm: second stage of the statistics in the normalisation's prologue when <= 64 partial rows (t2i_aux.hip)
     v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
     v.bf16_waves = env_int("T2I_BF16_WAVES", 8);           // 8: the 128x128 bf16 tile runs on 8 waves of 32x64 (two per SIMD) instead of 4 of 64x64
     v.bf16_pair_tiles = env_int("T2I_BF16_PAIR_TILES", 0); // > 0: 128x128 bf16 launches of at most this many workgroups run the paired-K-tile loop (two K-tiles per barrier pair)
@@ -1222,7 +1223,13 @@ size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t
 
 int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
                              float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
-                             float alpha, void* y, void* y_h, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+                             float alpha, void* y, void* y_h, const float* tile_sum, const float* tile_m2, int32_t tile_chunks, int32_t tile_rows,
+                             void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+  if (tile_sum && (!tile_m2 || tile_chunks <= 0 || tile_rows <= 0 || (int64_t)tile_chunks * tile_rows < rows_per_group ||
+                   (groups > 1 && rows_per_group % tile_rows != 0) || !aligned16(tile_sum) || !aligned16(tile_m2))) {
+    set_error("t2i_bn_train_fwd_grouped: bad tile partials (tile_chunks tiles of tile_rows rows per group; with groups > 1 a tile must not straddle groups)");
+    return T2I_ERR_INVALID;
+  }
   if (!x || !gamma || !beta || !mean || !rstd || !scale || !shift || !y || rows_per_group <= 0 || C <= 0 || (C & 3) || groups <= 0 ||
       ((moving_mean == nullptr) != (moving_var == nullptr))) {
     set_error("t2i_bn_train_fwd_grouped: bad argument (C %% 4 == 0 required)");
@@ -1236,7 +1243,8 @@ int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, i
   if (int rc = h_contract(dtype, true, C, y_h, "t2i_bn_train_fwd_grouped")) return rc;
   const bool h = dtype == T2I_DT_BF16;
   return check(bn_fwd_grouped_launch(x, rows_per_group, C, groups, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, act, alpha,
-                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h), "t2i_bn_train_fwd_grouped");
+                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h, tile_sum, tile_m2, tile_chunks, tile_rows),
+               "t2i_bn_train_fwd_grouped");
 }
 
 int t2i_bn_bwd_grouped(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows_per_group,
@@ -1471,7 +1479,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"bn_fuse", &t.bn_fuse}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -152,7 +152,7 @@ hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles, bn_fuse;
   double split_cost;
 };
 const Tuning& tuning();

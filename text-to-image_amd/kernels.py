@@ -743,19 +743,28 @@ def bn_apply_groups(x, scales, shifts, act=ACT_NONE, alpha=0.2):
 
 
 def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None):
-    """Training-mode batch norm of a stacked batch in three launches (t2i_bn_train_fwd_grouped): x [groups * b, ..., C] with per-group
-    statistics.  -> (y, mean [groups, C], rstd [groups, C]); moving averages updated in place once per group, in group order."""
+    """Training-mode batch norm in at most three launches (t2i_bn_train_fwd_grouped): x [groups * b, ..., C] with per-group statistics
+    (groups = 1: the ordinary batch norm).  Uses the producing conv's epilogue partials when it left any (conv_fwd_stats).
+    -> (y, mean [groups, C], rstd [groups, C]); moving averages updated in place once per group, in group order."""
     _chk(x, 'x')
     C = x.shape[-1]
     rows_g = x.numel() // C // groups
     stat = torch.empty((4, groups, C), dtype=torch.float32, device=x.device)       # mean, rstd, scale, shift
     y = torch.empty_like(x)
     if _live(x):
+        hit = _STATS.pop(x.data_ptr(), None)
+        if hit is not None and (tuple(x.shape) != hit[3] or (groups > 1 and rows_g % hit[2] != 0) or hit[0].data_ptr() % 16 or (hit[1] * C * 4) % 16):
+            hit = None
+        tsum = tm2 = None
+        tchunks = trows = 0
+        if hit is not None:
+            part, chunks, trows, _ = hit
+            tsum, tm2, tchunks = ctypes.c_void_p(part.data_ptr()), ctypes.c_void_p(part.data_ptr() + chunks * C * 4), chunks // groups
         wsp, wsn = _ws_args(x, int(lib.t2i_bn_grouped_workspace_bytes(rows_g, C, groups)))
         twin = _twin_for(y, x)
         check(lib.t2i_bn_train_fwd_grouped(_ptr(x), rows_g, C, groups, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(stat[0]), _ptr(stat[1]),
-                                           _ptr(stat[2]), _ptr(stat[3]), _ptr(moving_mean), _ptr(moving_var), act, alpha, _ptr(y), _ptr(twin), wsp, wsn,
-                                           _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
+                                           _ptr(stat[2]), _ptr(stat[3]), _ptr(moving_mean), _ptr(moving_var), act, alpha, _ptr(y), _ptr(twin),
+                                           tsum, tm2, tchunks, trows, wsp, wsn, _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
         _twin_keep(y, twin)
     return y, stat[0], stat[1]
 

@@ -82,20 +82,21 @@ def main():
             def record_values(out):          # the same taps as record_branches, keeping the activation outputs
                 saved = {}
 
-                def wrap(name, act_pos):
+                def wrap(name, act_pos, first=False):
                     fn = getattr(K, name)
                     saved[name] = fn
 
                     def tapped(*aa, **kw):
-                        y = fn(*aa, **kw)
+                        res = fn(*aa, **kw)
+                        y = res[0] if first else res
                         act = aa[act_pos] if len(aa) > act_pos else kw.get('act', K.ACT_NONE)
                         if act in (K.ACT_LRELU, K.ACT_RELU):
                             out.append(y.detach().float().cpu())
-                        return y
+                        return res
                     setattr(K, name, tapped)
                 try:
                     wrap('conv_fwd', 5); wrap('conv_fwd_stats', 5); wrap('conv_bwd_data', 5)
-                    wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
+                    wrap('bn_train_fwd_grouped', 6, first=True); wrap('bn_apply', 3); wrap('add_act', 2); wrap('act_fwd', 1)
                     yield out
                 finally:
                     for n, fn in saved.items():
