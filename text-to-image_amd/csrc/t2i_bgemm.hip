@@ -46,10 +46,12 @@ constexpr int BK = 32;
 constexpr int KSTRIDE = BK + 4;            // K-inner LDS row stride (36 dwords: conflict-free ds_read_b128)
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-template <int LAY, int WM, int WN>
+// NW waves as (NW / 2) x 2: 4 waves = the 64 WM x 64 WN tile of rounds 3-4; 8 waves (round 5) = 128 WM x 64 WN on 512 threads — per wave the
+// same accumulators, fragments and K loop, per workgroup 25 % fewer operand bytes per multiply-add (the A panel serves two more wave rows)
+template <int LAY, int WM, int WN, int NW = 4>
 struct BSmem {
   static constexpr bool A_KIN = LAY != 2, B_KIN = LAY == 1;
-  static constexpr int BM = 64 * WM, BN = 64 * WN;
+  static constexpr int BM = 32 * (NW / 2) * WM, BN = 64 * WN;
   static constexpr int A_ELEMS = A_KIN ? BM * KSTRIDE : BK * BM;
   static constexpr int B_ELEMS = B_KIN ? BN * KSTRIDE : BK * BN;
   static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
@@ -61,14 +63,15 @@ __device__ __forceinline__ float4 bl4(__amdgpu_buffer_rsrc_t r, int elem_off, bo
 }
 }  // namespace
 
-template <int LAY, int WM, int WN>
-__global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
-  using S = BSmem<LAY, WM, WN>;
+template <int LAY, int WM, int WN, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void bgemm_kernel(BgemmParams p) {
+  using S = BSmem<LAY, WM, WN, NW>;
   constexpr bool A_KIN = S::A_KIN, B_KIN = S::B_KIN;
   constexpr int BM = S::BM, BN = S::BN;
-  constexpr int A_LD = 2 * WM, B_LD = 2 * WN;              // 16-byte pieces per thread and K-tile
-  // M/N-inner image [32 k][64 W cols]: 16 W threads per k-row, 16 / W k-rows per pass, 2 W passes
-  constexpr int A_C4 = BM / 4, A_KR = 256 / A_C4, B_C4 = BN / 4, B_KR = 256 / B_C4;
+  constexpr int NT = 64 * NW, RPP = NT / 8;                // threads; rows of a K-inner image one pass of the loader covers
+  constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;    // 16-byte pieces per thread and K-tile
+  // M/N-inner image [32 k][cols]: cols / 4 threads per k-row, NT / (cols / 4) k-rows per pass
+  constexpr int A_C4 = BM / 4, A_KR = NT / A_C4, B_C4 = BN / 4, B_KR = NT / B_C4;
   extern __shared__ __attribute__((aligned(16))) float smem_b[];
   float* As = smem_b;
   float* Bs = smem_b + 2 * S::A_ELEMS;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       if (A_KIN) {
-        const int m = bm + r0 + 32 * i;
+        const int m = bm + r0 + RPP * i;
         a_ok[i] = m < p.M;
         a_off[i] = m * p.K + kq * 4;
       } else {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       if (B_KIN) {
-        const int n = bn + r0 + 32 * i;
+        const int n = bn + r0 + RPP * i;
         b_ok[i] = n < p.N;
         b_off[i] = n * p.K + kq * 4;
       } else {
@@ -168,12 +171,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
     float* bs = Bs + buf * S::B_ELEMS;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = ar[i];
+      if (A_KIN) *reinterpret_cast<float4*>(&as[(r0 + RPP * i) * KSTRIDE + kq * 4]) = ar[i];
       else *reinterpret_cast<float4*>(&as[(a_kr + A_KR * i) * BM + a_c4 * 4]) = ar[i];
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = br[i];
+      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + RPP * i) * KSTRIDE + kq * 4]) = br[i];
       else *reinterpret_cast<float4*>(&bs[(b_kr + B_KR * i) * BN + b_c4 * 4]) = br[i];
     }
   };
@@ -303,10 +306,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   }
 }
 
-template <int LAY, int WM, int WN>
+template <int LAY, int WM, int WN, int NW = 4>
 static hipError_t launch_b(const BgemmParams& p, hipStream_t stream) {
-  using S = BSmem<LAY, WM, WN>;
-  auto k = bgemm_kernel<LAY, WM, WN>;
+  using S = BSmem<LAY, WM, WN, NW>;
+  auto k = bgemm_kernel<LAY, WM, WN, NW>;
   static bool attr_done = false;   // benign race: idempotent
   if (!attr_done && S::BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
@@ -314,17 +317,23 @@ static hipError_t launch_b(const BgemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   // workgroups resident per CU: 4 of the 64x64 tile (its registers and LDS), 2 of the larger ones
-  const int per_cu = (WM * WN == 1) ? 4 : 2;
+  const int per_cu = (WM * WN == 1 && NW == 4) ? 4 : 2;
   const int per_xcd = (p.items + 7) / 8;
   int nslot = per_xcd < 32 * per_cu ? per_xcd : 32 * per_cu;   // fewer, evenly loaded workgroups (e.g. 72 x 2 items for 144) lose to the
   if (nslot < 1) nslot = 1;                                    // CU granularity: 72 workgroups on 32 CUs leave some CUs with 3, some with 2
-  hipLaunchKernelGGL(k, dim3(nslot * 8), dim3(256), S::BYTES, stream, p);
+  hipLaunchKernelGGL(k, dim3(nslot * 8), dim3(64 * NW), S::BYTES, stream, p);
   return hipGetLastError();
 }
 
 // lay: 0 forward, 1 input gradient, 2 filter gradient (see the header); wm, wn in {1, 2}: tile 64 wm x 64 wn.
 // p.items / p.ntiles / tiles_m / tiles_n are filled by the caller FOR THAT TILE.
 hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream_t stream) {
+  // wm == 4: the 128 x 64 tile on 8 waves (4 x 2 waves of one 32x32 accumulator each)
+  if (wm == 4 && wn == 1) {
+    if (lay == 0) return launch_b<0, 1, 1, 8>(p, stream);
+    if (lay == 1) return launch_b<1, 1, 1, 8>(p, stream);
+    if (lay == 2) return launch_b<2, 1, 1, 8>(p, stream);
+  }
 #define T2I_B(L, a, b) if (lay == L && wm == a && wn == b) return launch_b<L, a, b>(p, stream);
   T2I_B(0, 1, 1) T2I_B(0, 2, 1) T2I_B(0, 1, 2) T2I_B(0, 2, 2)
   T2I_B(1, 1, 1) T2I_B(1, 2, 1) T2I_B(1, 1, 2) T2I_B(1, 2, 2)

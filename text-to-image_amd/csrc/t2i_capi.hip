@@ -581,11 +581,13 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
         const int ft = tuning().bgemm_tile;
         const int64_t big = tuning().bgemm_big_items;
         if (ft == 22 || ft == 21 || ft == 12 || ft == 11) { wm = ft / 10; wn = ft % 10; }
+        else if (ft == 41 && M >= 128) { wm = 4; wn = 1; }          // 128 x 64 on EIGHT waves (round 5): wm = 4 names that kernel, its tile is 128 rows
         else if (M >= 128 && N >= 128 && items_of(2, 2) >= big) { wm = 2; wn = 2; }
         else if (M >= 128 && items_of(2, 1) >= big) { wm = 2; wn = 1; }
         else if (N >= 128 && items_of(1, 2) >= big) { wm = 1; wn = 2; }
       }
-      q.tiles_m = (M + 64 * wm - 1) / (64 * wm); q.tiles_n = (N + 64 * wn - 1) / (64 * wn);
+      const int bm_rows = wm == 4 ? 128 : 64 * wm;
+      q.tiles_m = (M + bm_rows - 1) / bm_rows; q.tiles_n = (N + 64 * wn - 1) / (64 * wn);
       { const int g = tuning().group_n; q.group_n = q.tiles_n < g ? q.tiles_n : g; if (q.group_n < 1) q.group_n = 1; }
       q.ntiles = ntiles;
       const int64_t items = (int64_t)nbatch * q.tiles_m * q.tiles_n;
@@ -594,7 +596,7 @@ int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float
         q.sa = sa; q.sb = sb; q.sc = sc;
         q.a_bytes = (uint32_t)(a_elems * 4); q.b_bytes = (uint32_t)(b_elems * 4);
         if (tuning().debug_plan)
-          fprintf(stderr, "[t2i plan] batched x%d M=%d N=%d K=%d mode %d -> persistent %dx%d, %lld items\n", nbatch, M, N, K, gmode, 64 * wm, 64 * wn, (long long)items);
+          fprintf(stderr, "[t2i plan] batched x%d M=%d N=%d K=%d mode %d -> persistent %dx%d, %lld items\n", nbatch, M, N, K, gmode, bm_rows, 64 * wn, (long long)items);
         return check(bgemm_launch(gmode == MODE_FWD ? 0 : (gmode == MODE_BWD_DATA ? 1 : 2), wm, wn, q, stream), what);
       }
     }

@@ -192,12 +192,19 @@ def measure_rows(names, math='f32', budget_s=1.0, device=None, storage='bf16'):
         if math == 'bf16' and storage == 'bf16':
             K.set_storage('bf16')
         t0 = time.time()
+        side = os.environ.get('T2I_SIDE_STREAM') == '1'        # diagnostics: sunk filter gradients on a second stream (autograd.enable_side_stream)
+        if side:
+            from t2i_amd import autograd as A
+            A.enable_side_stream(True)
         try:
             r = ROWS[name](K, dev, math, budget_s)
             r['storage'] = K.get_storage()
         except Exception as e:          # noqa: BLE001
             r = {'row': name, 'dtype': math, 'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         r['wall_s'] = time.time() - t0
+        if side:
+            A.enable_side_stream(False)
+            r['side_stream'] = True
         out.append(r)
         gc.collect()
         torch.cuda.synchronize()
