@@ -402,7 +402,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
         # the profile counts igemm_kernel dispatches; every conv entry-point call launches exactly one, except the small direct kernels
         igemm_per_step = launches_per_step - (s['by_algo'].get('direct_small', [0])[0] / float(inst_steps))
         suffix = '' if math == 'f32' else '_bf16'
-        for cand in ('r04_pmc_igemm%s.json' % suffix, 'r03_pmc_igemm%s.json' % suffix, 'r02_pmc_igemm%s.json' % suffix, 'r01_pmc_igemm.json'):
+        for cand in ('r05_pmc_igemm%s.json' % suffix, 'r04_pmc_igemm%s.json' % suffix, 'r03_pmc_igemm%s.json' % suffix, 'r02_pmc_igemm%s.json' % suffix, 'r01_pmc_igemm.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))
             except Exception:
