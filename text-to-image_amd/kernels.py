@@ -135,8 +135,10 @@ _MATH_CODES = {'f32': MATH_F32, 'fp32': MATH_F32, 'bf16': MATH_BF16}
 
 
 def set_math(mode):
-    """Select the arithmetic of every conv/deconv/dense descriptor created from now on: 'f32' or 'bf16'."""
+    """Select the arithmetic of every conv/deconv/dense descriptor created from now on: 'f32' or 'bf16'.  (Also forgets that a
+    math_scope has been used: a new configuration starts from the process-wide rules for bf16 twins.)"""
     _MATH[0] = _MATH_CODES[str(mode).lower()]
+    _MIXED[0] = False
 
 
 def get_math():
