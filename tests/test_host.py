@@ -247,3 +247,65 @@ print('ok')
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'store'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def test_config3_arithmetic_is_per_network_and_per_direction(t2i):
+    """kernels.math_scope / bwd_geom / CONFIG3_NET_MATH: inside the generator's scope descriptors are fp32-math and the
+    tensors fp32 while their BACKWARD descriptors are bf16-math with the same geometry; outside the scope the process-wide setting
+    (bf16 math, bf16 storage: the critic) holds again; a dry (launch-free) critic + generator step of the model routes every generator
+    forward conv to fp32 math, every generator backward GEMM and every critic conv to bf16 math."""
+    from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls.model import WGanCls
+    K.set_math('bf16')
+    K.set_storage('bf16')
+    try:
+        assert K._act_dtype((4, 4, 4, 64)) is torch.bfloat16
+        with K.math_scope(*K.CONFIG3_NET_MATH['g_net']):
+            g = K.conv_desc(4, 8, 8, 64, 128, 3, 3, 1, 1, 'SAME')
+            gb = K.bwd_geom(g)
+            assert g[0].math == K.MATH_F32 and gb[0].math == K.MATH_BF16 and gb is not g
+            assert [getattr(gb[0], f) for f, _ in g[0]._fields_[:-1]] == [getattr(g[0], f) for f, _ in g[0]._fields_[:-1]]
+            assert K.bwd_geom(g)[0] is gb[0]                                 # cached
+            assert K._act_dtype((4, 4, 4, 64)) is torch.float32
+        assert K.bwd_geom(g) is g and K._act_dtype((4, 4, 4, 64)) is torch.bfloat16      # outside: the layer's own arithmetic again
+        d = K.conv_desc(4, 8, 8, 64, 128, 3, 3, 1, 1, 'SAME')
+        assert d[0].math == K.MATH_BF16
+        # the model: record (entry point, descriptor math) of every conv call of a dry critic step + generator step
+        calls = []
+        saved = {n: getattr(K, n) for n in ('conv_fwd', 'conv_fwd_stats', 'conv_bwd_data', 'conv_bwd_filter', 'conv_bwd_pair')}
+
+        def tap(name, dpos):
+            fn = saved[name]
+
+            def f(*a, **kw):
+                calls.append((name, a[dpos].math, a[0].dtype))
+                return fn(*a, **kw)
+            setattr(K, name, f)
+        for n, pos in (('conv_fwd', 3), ('conv_fwd_stats', 3), ('conv_bwd_data', 3), ('conv_bwd_filter', 2), ('conv_bwd_pair', 5)):
+            tap(n, pos)
+        try:
+            m = WGanCls(_cfg(4), device='cpu')
+            m.net_math = dict(K.CONFIG3_NET_MATH)
+            B = 4
+            feed = {'x': torch.zeros(B, 64, 64, 3), 'x_mismatch': torch.zeros(B, 64, 64, 3), 'cond': torch.zeros(B, 1024), 'z': torch.zeros(B, 128),
+                    'epsilon': torch.zeros(B, 1, 1, 1), 'ca_noise_d': torch.zeros(B, 128), 'ca_noise_g': torch.zeros(B, 128)}
+            with K.dry_run():
+                calls.clear()
+                with torch.no_grad():
+                    m.generator(feed['z'], feed['cond'], reuse=True)
+                gen_fwd = list(calls)
+                calls.clear()
+                m.g_losses(feed)
+        finally:
+            for n, fn in saved.items():
+                setattr(K, n, fn)
+        assert gen_fwd and all(mth == K.MATH_F32 and dt == torch.float32 for _, mth, dt in gen_fwd), gen_fwd
+        n_fwd = len(gen_fwd)
+        step = calls
+        assert [c[1] for c in step[:n_fwd]] == [K.MATH_F32] * n_fwd                    # the generator step's own forward
+        rest = step[n_fwd:]                                                            # critic on G, then the whole backward
+        assert rest and all(mth == K.MATH_BF16 for _, mth, _ in rest), [c for c in rest if c[1] != K.MATH_BF16][:5]
+        assert any(n == 'conv_bwd_filter' and dt == torch.float32 for n, _, dt in rest)   # generator backward: bf16 math on fp32 tensors
+    finally:
+        K.set_storage('f32')
+        K.set_math('f32')
