@@ -931,3 +931,34 @@ def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
         K.tuning_set('bn_fuse', 1)
     assert close(y, y3) and close(mean, mean3) and close(rstd, rstd3) and close(mm, mm3) and close(mv, mv3)
     assert close(dx, dx3, 5e-6) and close(dg, dg3, 5e-6) and close(db, db3, 5e-6)
+
+
+@pytest.mark.parametrize('shape', [(6, 16, 16, 128, 256), (3, 8, 8, 256, 512), (2, 32, 32, 128, 128), (5, 12, 20, 160, 96)])
+def test_fused_winograd_k4s2_is_bit_identical(K, shape):
+    """bgemm9_kernel (tuning wino_fuse = 2): the nine position GEMMs of an F(2x2,2x2) tile and the output transform in one work item —
+    forward 4x4 stride-2 conv (with bias + lrelu) and its input gradient (= conv2d_transpose forward) — against the three-kernel path
+    (input transform, 9 / 36 batched GEMMs, output transform).  Every output element is the same fmaf chain over k per position and the
+    same adds in the same order afterwards, so the results must be equal bit for bit; ragged tile counts and channel tails included."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device='cpu').manual_seed(23)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(4, 4, Cin, Cout, generator=g) * 0.05).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    dy = torch.randn(B, H // 2, W // 2, Cout, generator=g).cuda()
+    d, ws = K.conv_desc(B, H, W, Cin, Cout, 4, 4, 2, 2, 'SAME')
+    if K.conv_algo(d, 'fwd') != 'winograd_f2x2_2x2' or K.conv_algo(d, 'bwd_data') != 'winograd_f2x2_2x2':
+        pytest.skip('this shape is not on the F(2x2,2x2) path')
+    K.tuning_set('wino_fuse', 0)
+    d, ws = K.conv_desc(B, H, W, Cin, Cout, 4, 4, 2, 2, 'SAME')
+    ref_y = K.conv_fwd(x, w, bias, d, ws, K.ACT_LRELU, 0.2)
+    ref_dx = K.conv_bwd_data(dy, w, None, d, ws)
+    K.tuning_set('wino_fuse', 2)
+    try:
+        d2, ws2 = K.conv_desc(B, H, W, Cin, Cout, 4, 4, 2, 2, 'SAME')
+        got_y = K.conv_fwd(x, w, bias, d2, ws2, K.ACT_LRELU, 0.2)
+        got_dx = K.conv_bwd_data(dy, w, None, d2, ws2)
+        torch.cuda.synchronize()
+    finally:
+        K.tuning_set('wino_fuse', 1)
+    assert torch.equal(got_y, ref_y), float((got_y - ref_y).abs().max())
+    assert torch.equal(got_dx, ref_dx), float((got_dx - ref_dx).abs().max())

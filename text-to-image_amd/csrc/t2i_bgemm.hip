@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "t2i_internal.h"
 
 namespace t2i {
@@ -304,6 +306,261 @@ __global__ __launch_bounds__(64 * NW) void bgemm_kernel(BgemmParams p) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// bgemm9_kernel (round 5): the nine position GEMMs of one F(2x2, 2x2) output tile in ONE work item, the output transform in the epilogue.
+// The 4x4 stride-2 layers (t2i_winograd.hip: forward = 9 GEMMs, input gradient = 4 phases x 9) write their 9 / 36 product planes M to the
+// workspace (2.25 x the output tensor) and read them back in a separate output-transform kernel.  Here a workgroup keeps the nine 64x64
+// products of its tile in registers (9 x 16 accumulator registers per lane: two workgroups per CU instead of four), walks the nine K loops
+// back to back without leaving the software pipeline (the loader switches operand planes the way bgemm_kernel switches items), and applies
+// A^T M A + bias + activation to its own accumulators: lane = output channel, register = tile, so the transform is register arithmetic in
+// exactly the order of wino2_output_kernel / wino2b_output_kernel — results are bit-identical to the unfused path.  M never exists.
+// Work items: phases x tiles_m x tiles_n (9 x coarser than bgemm_kernel's): the caller takes this path only where that still fills the chip.
+//   LAY 0  forward:        A = V[xi] [T][4 Cin] K-inner, B = U[xi] [4 Cin][Cout] N-inner, plane slot = xi
+//   LAY 1  input gradient: A = V[slot] [T][Cout] K-inner, B = U[slot] [Cin][Cout] K-inner, slot = ((2 - r) 3 + (2 - c)) 4 + (3 - phase)
+template <int LAY>
+__global__ __launch_bounds__(256, 2) void bgemm9_kernel(Bgemm9Params q) {
+  const BgemmParams& p = q.g;
+  using S = BSmem<LAY, 1, 1, 4>;
+  constexpr bool B_KIN = S::B_KIN;                          // A is K-inner in both layouts
+  constexpr int BM = 64, BN = 64, A_LD = 2, B_LD = 2;
+  constexpr int B_C4 = BN / 4, B_KR = 256 / B_C4;
+  extern __shared__ __attribute__((aligned(16))) float smem_b[];
+  float* As = smem_b;
+  float* Bs = smem_b + 2 * S::A_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int nslot = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int qq = p.items >> 3, rr_ = p.items & 7;
+  const int run0 = xcd * qq + min(xcd, rr_), runlen = qq + (xcd < rr_ ? 1 : 0);
+  if (slot >= runlen) return;
+  const int n_items = (runlen - slot + nslot - 1) / nslot;
+  const int tiles = p.tiles_m * p.tiles_n;
+
+  auto coords = [&](int w, int& phs, int& bm, int& bn) __attribute__((always_inline)) {
+    phs = w / tiles;
+    const int t = w - phs * tiles;
+    const int g = p.group_n, per_group = g * p.tiles_m;
+    const int grp = t / per_group, rr = t - grp * per_group, n0 = grp * g;
+    const int width = min(g, p.tiles_n - n0);
+    const int tm = rr / width;
+    bm = tm * BM;
+    bn = (n0 + rr - tm * width) * BN;
+  };
+  auto plane_slot = [&](int pos, int phs) __attribute__((always_inline)) {
+    if (LAY == 0) return pos;
+    const int r = pos / 3, c = pos - 3 * r;
+    return ((2 - r) * 3 + (2 - c)) * 4 + (3 - phs);
+  };
+
+  const int kq = tid & 7, r0 = tid >> 3;
+  const int b_c4 = tid % B_C4, b_kr = tid / B_C4;
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int a_off[A_LD], b_off[B_LD];
+  bool a_ok[A_LD], b_ok[B_LD];
+  int l_item = -1, l_pos = 8, l_t = 0, l_phs = 0, l_bm = 0, l_bn = 0;
+
+  auto next_sub = [&]() __attribute__((always_inline)) {          // the loader moves on to the next (item, position)
+    l_t = 0;
+    if (++l_pos == 9) {
+      l_pos = 0;
+      ++l_item;
+      if (l_item < n_items) coords(run0 + slot + l_item * nslot, l_phs, l_bm, l_bn);
+    }
+    if (l_item >= n_items) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) a_ok[i] = false;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) b_ok[i] = false;
+      return;
+    }
+    const int ps = plane_slot(l_pos, l_phs);
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (int64_t)ps * p.sa), (short)0, (int)p.a_bytes, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (int64_t)ps * p.sb), (short)0, (int)p.b_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = l_bm + r0 + 32 * i;
+      a_ok[i] = m < p.M;
+      a_off[i] = m * p.K + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if (B_KIN) {
+        const int n = l_bn + r0 + 32 * i;
+        b_ok[i] = n < p.N;
+        b_off[i] = n * p.K + kq * 4;
+      } else {
+        const int n = l_bn + b_c4 * 4;
+        b_ok[i] = n < p.N;
+        b_off[i] = (b_kr + B_KR * i) * p.N + n;
+      }
+    }
+  };
+
+  float4 areg[A_LD], breg[B_LD];
+  auto load_into = [&](float4* ar, float4* br) __attribute__((always_inline)) {
+    const int k0 = l_t * BK;
+    ++l_t;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) ar[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if (B_KIN) br[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
+      else br[i] = bl4(rb, b_off[i] + k0 * p.N, b_ok[i] & (k0 + b_kr + B_KR * i < p.K));
+    }
+  };
+  auto store_from = [&](int buf, const float4* ar, const float4* br) __attribute__((always_inline)) {
+    float* as = As + buf * S::A_ELEMS;
+    float* bs = Bs + buf * S::B_ELEMS;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4*>(&as[(r0 + 32 * i) * KSTRIDE + kq * 4]) = ar[i];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if (B_KIN) *reinterpret_cast<float4*>(&bs[(r0 + 32 * i) * KSTRIDE + kq * 4]) = br[i];
+      else *reinterpret_cast<float4*>(&bs[(b_kr + B_KR * i) * BN + b_c4 * 4]) = br[i];
+    }
+  };
+
+  struct Frag { float a[4]; float b[4]; };
+  auto read_frag = [&](Frag& f, const float* as, const float* bs, int c) __attribute__((always_inline)) {
+    {
+      const int row = wm * 32 + l31;
+      const float4 v = *reinterpret_cast<const float4*>(&as[row * KSTRIDE + c * 8 + lh * 4]);
+      f.a[0] = v.x; f.a[1] = v.y; f.a[2] = v.z; f.a[3] = v.w;
+    }
+    {
+      const int col = wn * 32 + l31;
+      if (B_KIN) {
+        const float4 v = *reinterpret_cast<const float4*>(&bs[col * KSTRIDE + c * 8 + lh * 4]);
+        f.b[0] = v.x; f.b[1] = v.y; f.b[2] = v.z; f.b[3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[j] = bs[(c * 8 + j + 4 * lh) * BN + col];
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // one K-tile on accumulator P (bgemm_kernel's schedule)
+  auto k_tile = [&](auto P_, int t, Frag& c0, Frag& c1, Frag& n0, Frag& n1) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value;
+    const float* as = As + (t & 1) * S::A_ELEMS;
+    const float* bs = Bs + (t & 1) * S::B_ELEMS;
+    const float* an = As + ((t + 1) & 1) * S::A_ELEMS;
+    const float* bn_ = Bs + ((t + 1) & 1) * S::B_ELEMS;
+    auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j], f.b[j], acc[P], 0, 0, 0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    mma(c0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c0, as, bs, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(c1);
+    store_from((t + 1) & 1, areg, breg);
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(c1, as, bs, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frag(n0, an, bn_, 0);
+    read_frag(n1, an, bn_, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_into(areg, breg);
+    mma(c0);
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(c1);
+  };
+
+  next_sub();
+  {
+    float4 a0[A_LD], b0[B_LD];
+    load_into(a0, b0);
+    load_into(areg, breg);
+    store_from(0, a0, b0);
+  }
+  __syncthreads();
+  Frag fa0, fa1, fb0, fb1;
+  read_frag(fa0, As, Bs, 0);
+  read_frag(fa1, As, Bs, 1);
+  auto run_pos = [&](auto P_) __attribute__((always_inline)) {
+    for (int t = 0; t < p.ntiles; t += 2) {
+      if (t + 2 == p.ntiles) next_sub();               // the loads run two K-tiles ahead: from here on the loader belongs to the next position
+      k_tile(P_, 0, fa0, fa1, fb0, fb1);
+      k_tile(P_, 1, fb0, fb1, fa0, fa1);
+    }
+  };
+  const int plane_px = q.Th * q.Tw;
+  for (int it = 0; it < n_items; ++it) {
+    run_pos(std::integral_constant<int, 0>{}); run_pos(std::integral_constant<int, 1>{}); run_pos(std::integral_constant<int, 2>{});
+    run_pos(std::integral_constant<int, 3>{}); run_pos(std::integral_constant<int, 4>{}); run_pos(std::integral_constant<int, 5>{});
+    run_pos(std::integral_constant<int, 6>{}); run_pos(std::integral_constant<int, 7>{}); run_pos(std::integral_constant<int, 8>{});
+    // ---- A^T M A + bias + activation on the accumulators (the arithmetic, and its order, of wino2_output_kernel / wino2b_output_kernel)
+    int phs, bm, bn;
+    coords(run0 + slot + it * nslot, phs, bm, bn);
+    const int ph = phs >> 1, pw = phs & 1;
+    const int n = bn + wn * 32 + l31;
+    const float bs_ = (q.bias && n < p.N) ? q.bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float z[2][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        z[0][c] = acc[0 * 3 + c][e] + acc[1 * 3 + c][e];
+        z[1][c] = acc[1 * 3 + c][e] + acc[2 * 3 + c][e];
+      }
+      if (m < p.M && n < p.N) {
+        const int b = m / plane_px, rem = m - b * plane_px;
+        const int ty = rem / q.Tw, tx = rem - ty * q.Tw;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float y0 = apply_act((z[r][0] + z[r][1]) + bs_, q.act, q.alpha);
+          const float y1 = apply_act((z[r][1] + z[r][2]) + bs_, q.act, q.alpha);
+          const size_t oh = (size_t)q.sr * (2 * ty + r) + ph, ow0 = (size_t)q.sr * (2 * tx) + pw;
+          float* o = q.out + (((size_t)b * q.OH + oh) * q.OW + ow0) * p.N + n;
+          o[0] = y0;
+          o[(size_t)q.sr * p.N] = y1;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  }
+}
+
+hipError_t bgemm9_launch(int lay, const Bgemm9Params& q, hipStream_t stream) {
+  if (lay != 0 && lay != 1) return hipErrorInvalidValue;
+  const int bytes = lay == 0 ? BSmem<0, 1, 1, 4>::BYTES : BSmem<1, 1, 1, 4>::BYTES;
+  const int per_xcd = (q.g.items + 7) / 8;
+  int nslot = per_xcd < 32 * 2 ? per_xcd : 32 * 2;             // two workgroups per CU (144 accumulator registers per lane)
+  if (nslot < 1) nslot = 1;
+  if (lay == 0) hipLaunchKernelGGL(bgemm9_kernel<0>, dim3(nslot * 8), dim3(256), bytes, stream, q);
+  else hipLaunchKernelGGL(bgemm9_kernel<1>, dim3(nslot * 8), dim3(256), bytes, stream, q);
+  return hipGetLastError();
 }
 
 template <int LAY, int WM, int WN, int NW = 4>

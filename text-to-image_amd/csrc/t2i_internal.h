@@ -148,11 +148,22 @@ struct BgemmParams {
   uint32_t a_bytes, b_bytes;  // extents of ONE member's operands (buffer-load range check)
 };
 hipError_t bgemm_launch(int lay, int wm, int wn, const BgemmParams& p, hipStream_t stream);   // tile 64 wm x 64 wn
+// the nine position GEMMs of an F(2x2,2x2) tile + the output transform in one work item (t2i_bgemm.hip: bgemm9_kernel)
+struct Bgemm9Params {
+  BgemmParams g;              // a = V planes, b = U planes (sa / sb = plane strides), M = tiles T, N, K, tiles_m/n, ntiles, items = phases * tiles_m * tiles_n; c unused
+  const float* bias;          // [N] or NULL
+  float* out;                 // the conv's output tensor [B, OH, OW, N]
+  int32_t OH, OW, Th, Tw;     // output map, tiles per image
+  int32_t sr;                 // 1: forward (pixel (2 ty + r, 2 tx + c));  2: input gradient (pixel (2 (2 ty + r) + ph, 2 (2 tx + c) + pw))
+  int32_t act;
+  float alpha;
+};
+hipError_t bgemm9_launch(int lay, const Bgemm9Params& q, hipStream_t stream);
 
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles, bn_fuse;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles, bn_fuse, wino_fuse, wino_fuse_items;
   double split_cost;
 };
 const Tuning& tuning();

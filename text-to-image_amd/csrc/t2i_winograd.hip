@@ -11,6 +11,8 @@
 // fp32 throughout (the GEMM follows the descriptor's math mode); transforms use only +, - and *0.5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -556,6 +558,37 @@ size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
   return al256(9 * K * d.Cout * 4) + al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4);
 }
 
+// The nine position GEMMs of an F(2x2,2x2) tile and its output transform as ONE work item (bgemm9_kernel, t2i_bgemm.hip): no M planes, no
+// output-transform launch.  Taken when tuning().wino_fuse says so (1: only where phases x tiles still give >= wino_fuse_items items; 2: wherever
+// the persistent kernel's operand conditions hold).  Returns T2I_OK after launching, or -1 if the caller should take the unfused path.
+static int wino2_fused_gemm(int lay, int phases, size_t T, int N, int K, const float* V, const float* U, int64_t sa, int64_t sb, const float* bias,
+                            float* out, int OH, int OW, int Th, int Tw, int sr, int act, float alpha, hipStream_t stream, const char* what) {
+  const int mode = tuning().wino_fuse;
+  if (!mode || !tuning().bgemm) return -1;
+  const int ntiles = (K + 31) / 32;
+  const int64_t a_elems = (int64_t)T * K, b_elems = (int64_t)N * K;
+  if ((ntiles & 1) || (T & 3) || (N & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(V) & 15) || (reinterpret_cast<uintptr_t>(U) & 15) || (sa & 3) || (sb & 3) ||
+      a_elems >= (1LL << 30) || b_elems >= (1LL << 30) || T >= (1u << 30))
+    return -1;
+  Bgemm9Params q;
+  memset(&q, 0, sizeof(q));
+  q.g.a = V; q.g.b = U; q.g.c = nullptr;
+  q.g.M = (int32_t)T; q.g.N = N; q.g.K = K;
+  q.g.tiles_m = (int32_t)((T + 63) / 64); q.g.tiles_n = (N + 63) / 64;
+  { const int g = tuning().group_n; q.g.group_n = q.g.tiles_n < g ? q.g.tiles_n : g; if (q.g.group_n < 1) q.g.group_n = 1; }
+  q.g.ntiles = ntiles;
+  const int64_t items = (int64_t)phases * q.g.tiles_m * q.g.tiles_n;
+  if (items >= (1LL << 30) || (mode == 1 && items < (int64_t)tuning().wino_fuse_items * (lay == 0 ? 4 : 1))) return -1;
+  q.g.items = (int32_t)items;
+  q.g.sa = sa; q.g.sb = sb; q.g.sc = 0;
+  q.g.a_bytes = (uint32_t)(a_elems * 4); q.g.b_bytes = (uint32_t)(b_elems * 4);
+  q.bias = bias; q.out = out; q.OH = OH; q.OW = OW; q.Th = Th; q.Tw = Tw; q.sr = sr; q.act = act; q.alpha = alpha;
+  if (tuning().debug_plan) fprintf(stderr, "[t2i plan] %s: fused 9-position items, %d phases x %d x %d tiles, K=%d\n", what, phases, q.g.tiles_m, q.g.tiles_n, K);
+  const hipError_t e = bgemm9_launch(lay, q, stream);
+  if (e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
+  return T2I_OK;
+}
+
 int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
                       void* ws, size_t ws_bytes, hipStream_t stream, float* Vkeep) {
   const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
@@ -575,6 +608,11 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
   hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.Cin = (int32_t)K; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  {   // all nine positions + the output transform in one work item where that still fills the chip
+    const int fr = wino2_fused_gemm(0, 1, T, d.Cout, (int)K, V, U, (int64_t)T * K, (int64_t)K * d.Cout, bias, y, d.Ho, d.Wo, Th, Tw, 1, act, alpha, stream,
+                                    "winograd k4s2 fused gemm");
+    if (fr != -1) return fr;
+  }
   const int rc = run_batched_gemm(gd, MODE_FWD, 9, V, U, Mx, (int64_t)T * K, (int64_t)K * d.Cout, (int64_t)T * d.Cout, stream, "winograd k4s2 gemm");
   if (rc != T2I_OK) return rc;
   hipLaunchKernelGGL(wino2_output_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, Mx, bias, d.Ho, d.Wo, d.Cout, Th, Tw, T, act,
@@ -702,6 +740,11 @@ int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float*
   hipLaunchKernelGGL(wino2b_input_kernel, dim3(wino_blocks(T * d.Cout)), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
+  {
+    const int fr = wino2_fused_gemm(1, 4, T, d.Cin, d.Cout, V, U, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, bias, dx, d.H, d.W, Th, Tw, 2, act, alpha, stream,
+                                    "winograd k4s2 input-gradient fused gemm");
+    if (fr != -1) return fr;
+  }
   const int rc = run_batched_gemm(gd, MODE_BWD_DATA, 36, V, U, Mx, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, (int64_t)T * d.Cin, stream,
                                   "winograd k4s2 input-gradient gemm");
   if (rc != T2I_OK) return rc;
