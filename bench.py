@@ -433,7 +433,7 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
         compulsory = (4 * 286e6 + 15 * 161e6) * (args.batch / 64.0) * (0.5 if storage == 'bf16' else 1.0)
         igemm_launches = prof['profile_igemm_launches_per_step'] if (prof and prof.get('counts_agree')) else None      # per-launch figures x the PROFILE's launch count = its per-step totals
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel)'
+            'bound': 'mfma', 'kernel': 't2i::igemm_kernel<MODE,WMT,WNT,VEC> + t2i::bgemm_kernel<LAY> / bgemm9_kernel<LAY> (all conv/deconv/dense launches; the Winograd paths\' batched GEMMs run in bgemm_kernel, the fused nine-position form in bgemm9_kernel)'
                      if math == 'f32' else 't2i::igemm_hd_kernel<MODE,WMT,WNT> + t2i::igemm_hft_kernel (bf16 operands by LDS DMA) + the fp32 thin-layer kernels',
             'achieved': driver_tflops, 'peak': peak, 'unit': 'TFLOP/s',
             # round 4: `frac` is the driver-clock figure (algorithmic FLOPs of the launched convs / ms_per_step of the replayed

@@ -13,7 +13,7 @@ def agg(d):
     tot = collections.defaultdict(float)
     seen, dur = set(), 0
     for r in csv.DictReader(open(f)):
-        if not any(k in r['Kernel_Name'] for k in ('igemm_kernel', 'bgemm_kernel', 'igemm_h_kernel', 'igemm_hd_kernel', 'igemm_hft_kernel', 'igemm_h_filter_kernel', 'igemm_pair_kernel', 'igemm_hd8_kernel')):
+        if not any(k in r['Kernel_Name'] for k in ('igemm_kernel', 'bgemm_kernel', 'bgemm9_kernel', 'igemm_h_kernel', 'igemm_hd_kernel', 'igemm_hft_kernel', 'igemm_h_filter_kernel', 'igemm_pair_kernel', 'igemm_hd8_kernel')):
             continue
         tot[r['Counter_Name']] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
@@ -32,7 +32,7 @@ fetch_b = fetch['FETCH_SIZE'] * 1024 * 2
 write_b = write['WRITE_SIZE'] * 1024
 cycles = mfma['GRBM_GUI_ACTIVE'] / 8.0                    # summed over the 8 XCDs
 out = {
-    'kernel': 't2i::igemm_kernel<*> + bgemm_kernel<*> + igemm_h_kernel<*> + igemm_hd_kernel<*> + igemm_hft_kernel + igemm_h_filter_kernel<*> + igemm_pair_kernel<*>', 'math': (sys.argv[6] if len(sys.argv) > 6 else 'f32'), 'iterations_profiled': iters, 'launches_per_iteration': nm / iters,
+    'kernel': 't2i::igemm_kernel<*> + bgemm_kernel<*> + bgemm9_kernel<*> + igemm_h_kernel<*> + igemm_hd_kernel<*> + igemm_hft_kernel + igemm_h_filter_kernel<*> + igemm_pair_kernel<*>', 'math': (sys.argv[6] if len(sys.argv) > 6 else 'f32'), 'iterations_profiled': iters, 'launches_per_iteration': nm / iters,
     'hbm_side_read_bytes_per_launch': fetch_b / nf, 'hbm_side_write_bytes_per_launch': write_b / nw,
     'traffic_bytes_per_launch': fetch_b / nf + write_b / nw,
     'traffic_bytes_per_iteration': (fetch_b + write_b) / iters,
