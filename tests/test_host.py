@@ -187,6 +187,12 @@ def test_conv_algorithm_choice_on_the_benchmark_layers():
     for (H, W, Ci, Co, k, s, pad), algos in want.items():
         d, _ = K.conv_desc(64, H, W, Ci, Co, k, k, s, s, pad)
         assert tuple(K.conv_algo(d, m) for m in ('fwd', 'bwd_data', 'bwd_filter')) == algos, (H, W, Ci, Co, k, s)
+    # round 5: the stride-2 F(2x2,2x2) form only where its position GEMMs fill the chip (T * 4 Cin * Cout >= 1.6e8, >= 400 work items):
+    # at the yml's batch of 8 (and for the 8x8 layer up to B = 24) one direct split-K GEMM is faster (profiles/r05_b8_winograd_threshold.txt)
+    for B, H, Ci, Co, algo in ((8, 32, 128, 256, G), (8, 16, 256, 512, G), (8, 8, 512, 1024, G), (16, 16, 256, 512, G), (24, 32, 128, 256, W2),
+                               (24, 16, 256, 512, W2), (24, 8, 512, 1024, G), (192, 8, 512, 1024, W2)):
+        d, _ = K.conv_desc(B, H, H, Ci, Co, 4, 4, 2, 2, 'SAME')
+        assert tuple(K.conv_algo(d, m) for m in ('fwd', 'bwd_data', 'bwd_filter')) == (algo,) * 3, (B, H, Ci, Co)
     d, _ = K.conv_desc(64, 8, 8, 512, 512, 3, 3, 1, 1, 'SAME', math=K.MATH_BF16)
     # bf16 math mode: no Winograd; all three primitives stage bf16 operand copies where the channel counts allow
     assert all(K.conv_algo(d, m) == 'implicit_gemm_bf16_operands' for m in ('fwd', 'bwd_data', 'bwd_filter'))

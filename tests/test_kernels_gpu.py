@@ -23,6 +23,18 @@ def K():
     return kernels
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _winograd_paths_on_small_shapes(K):
+    """The kernel tests exercise the F(2x2,2x2) stride-2 kernels on small shapes; the library's default takes that path only where the
+    position GEMMs fill the chip (round 5: T * 4 Cin * Cout >= 1.6e8 and >= 400 work items).  The thresholds are lifted for this module so
+    that the kernels stay covered at test sizes; tests/test_host.py pins the default routing."""
+    K.tuning_set('winograd_k4s2_minwork', 0)
+    K.tuning_set('winograd_k4s2_minitems', 0)
+    yield
+    K.tuning_set('winograd_k4s2_minwork', 160000000)
+    K.tuning_set('winograd_k4s2_minitems', 400)
+
+
 def dev(a):
     return torch.tensor(np.asarray(a), dtype=torch.float32, device='cuda').contiguous()
 

@@ -162,6 +162,8 @@ static Tuning& tuning_mut() {
     v.winograd_k4s2_minc = env_int("T2I_WINOGRAD_K4S2_MINC", 128);
     v.winograd_k4s2_bwd_minc = env_int("T2I_WINOGRAD_K4S2_BWD_MINC", 128);
     v.winograd_k4s2_bwdf = env_int("T2I_WINOGRAD_K4S2_BWDF", 1);
+    v.winograd_k4s2_minwork = env_int("T2I_WINOGRAD_K4S2_MINWORK", 160000000);   // T * 4 Cin * Cout below which one direct (split-K) GEMM beats the 9 / 36 position GEMMs + transforms
+    v.winograd_k4s2_minitems = env_int("T2I_WINOGRAD_K4S2_MINITEMS", 400);       // ... and the least number of 64x64 work items of the forward form
     v.adam_blocks = env_int("T2I_ADAM_BLOCKS", 2048);
     v.cache_refresh = env_int("T2I_CACHE_REFRESH", 0);     // 1: t2i_adam_tf itself regenerates the cached filter images of its arena (else the caller: t2i_filter_cache_refresh)
     v.thin_parts = env_int("T2I_THIN_PARTS", 2);          // 128 -> 3 k4s2 transposed conv: passes over the channels (Co / parts staged at a time)
@@ -1480,7 +1482,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"force_tile", &t.force_tile}, {"force_splitk", &t.force_splitk}, {"debug_plan", &t.debug_plan}, {"group_n", &t.group_n},
       {"no_ut", &t.no_ut}, {"no_thin", &t.no_thin}, {"winograd", &t.winograd}, {"winograd_minc", &t.winograd_minc},
       {"winograd_maxhw", &t.winograd_maxhw}, {"winograd_k4s2", &t.winograd_k4s2}, {"winograd_k4s2_minc", &t.winograd_k4s2_minc},
-      {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf},
+      {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf}, {"winograd_k4s2_minwork", &t.winograd_k4s2_minwork}, {"winograd_k4s2_minitems", &t.winograd_k4s2_minitems},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
       {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"bn_fuse", &t.bn_fuse}, {"wino_fuse", &t.wino_fuse}, {"wino_fuse_items", &t.wino_fuse_items}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};

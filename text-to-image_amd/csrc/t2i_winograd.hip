@@ -550,7 +550,14 @@ bool winograd_k4s2_eligible(const t2i_conv_desc& d, bool bwd_data) {
   // batched GEMM (t2i_bgemm.hip) the 128-channel layers gain too (155 -> 143 us at B=64, 457 -> 422 us at B=192)
   const int minc_bwd = tuning().winograd_k4s2_bwd_minc;
   const int m = bwd_data ? minc_bwd : minc;
-  return d.Cin >= m && d.Cout >= m;
+  if (!(d.Cin >= m && d.Cout >= m)) return false;
+  // ... and only where the 9 (36) position GEMMs still fill the chip (round 5, profiles/r05_b8_winograd_threshold.txt): at 8 - 16 images per GPU
+  // a layer has T = 64 - 1024 tiles, the batched launch 100 - 600 work items of 16 - 64 K-tiles each, and ONE direct GEMM with split-K wins by
+  // 15 - 40 % (B = 8) or ties (B = 16); 8x8x512->1024 at B = 24 (T = 96: two M-tiles, the second half empty) loses 28 % while its siblings with
+  // T = 384 / 1536 win 19 %.  Work = T * 4 Cin * Cout multiply-adds per position; items = 9 * M-tiles * N-tiles of the forward form.
+  const int64_t T = (int64_t)d.B * (d.Ho / 2) * (d.Wo / 2);
+  const int64_t items = 9 * ((T + 63) / 64) * ((d.Cout + 63) / 64);
+  return T * 4 * d.Cin * d.Cout >= (int64_t)tuning().winograd_k4s2_minwork && items >= tuning().winograd_k4s2_minitems;
 }
 
 size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
