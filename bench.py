@@ -357,6 +357,9 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
         torch.distributed.all_reduce(ones)
         exchange['ranks_counted_by_all_reduce'] = int(ones.item())
         exchange['backend'] = str(torch.distributed.get_backend())
+        if exchange['backend'] != 'nccl':
+            exchange['note'] = ('test transport: gloo blocks the HOST inside each collective, so the compute stream is idle rather than stalled — '
+                                'ms_compute_stream_stalled / overlap_fraction are meaningful with RCCL only')
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
     schedule = getattr(model, 'dp_schedule', None)
