@@ -69,7 +69,7 @@ SIGNATURES = {
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
     't2i_bn_grouped_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    't2i_bn_train_fwd_grouped': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, ctypes.c_int, _f, _p, _p, _p, _p, _i32, _i32, _p, _sz, _i32, _p]),
+    't2i_bn_train_fwd_grouped': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, ctypes.c_int, _f, _p, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     't2i_bn_bwd_grouped': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, ctypes.c_int, _f, _p, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _i32, _p]),
     't2i_sigmoid_ce_head': (ctypes.c_int, [_p, _p, _p, _f, _f, _f, _f, _f, _f, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),

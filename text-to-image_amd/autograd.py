@@ -382,7 +382,7 @@ class BatchNormTrainFn(Function):
     decided by the caller).  Generator only => first order."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, decay, act, alpha):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, decay, act, alpha, moving_updates=1):
         x = _c(x)
         C = x.shape[-1]
         n = x.numel() // C
@@ -391,9 +391,11 @@ class BatchNormTrainFn(Function):
         # round 5: one entry point — [first stage unless the conv left tile partials] -> [second stage + finalize] -> [normalise], the
         # middle launch folded into the last one's prologue for the small tensors (t2i_bn_train_fwd_grouped with groups = 1)
         if _BN_ONE_ENTRY[0] and C % 4 == 0 and x.data_ptr() % 16 == 0 and gamma.data_ptr() % 4 == 0:
-            y, mean, rstd = K.bn_train_fwd_grouped(x, gamma, beta, eps, decay, 1, act, alpha, moving_mean, moving_var)
+            y, mean, rstd = K.bn_train_fwd_grouped(x, gamma, beta, eps, decay, 1, act, alpha, moving_mean, moving_var, moving_updates)
             mean, rstd = mean[0], rstd[0]
         else:
+            for _ in range(moving_updates - 1 if moving_mean is not None else 0):      # (rare path: the statistics pass again per extra update)
+                K.bn_train_stats(x, gamma, beta, eps, decay, moving_mean, moving_var)
             mean, rstd, scale, shift = K.bn_train_stats(x, gamma, beta, eps, decay, moving_mean, moving_var)
             y = K.bn_apply(x, scale, shift, act, alpha)
         ctx.save_for_backward(x, gamma, mean, rstd, y if act != K.ACT_NONE else None)
@@ -407,7 +409,7 @@ class BatchNormTrainFn(Function):
     @once_differentiable
     def backward(ctx, gy, _gm, _gr):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, gamma, mean, rstd, y = ctx.saved_tensors
         gy = _c(gy)
         fused = gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x, mean))
@@ -432,8 +434,8 @@ class BatchNormTrainFn(Function):
                                          dbeta_out=bsink if sunk else None)
         if sunk:
             _notify(ctx.gamma_ref); _notify(ctx.beta_ref)
-            return dx, None, None, None, None, None, None, None, None
-        return dx, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None
+        return dx, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None, None, None
 
 
 class BatchNormTrainGroupedFn(Function):

@@ -347,6 +347,7 @@ struct Agg { float n, mean, m2; };
 struct BnFin {
   const float* gamma; const float* beta; float eps, decay;
   float* mean; float* rstd; float* scale; float* shift; float* mmean; float* mvar;
+  int updates;       // how many times the moving averages take this batch's statistics (1; 2 when one evaluation stands for two identical runs)
 };
 
 __device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float mu, float m2, size_t goff = 0) {
@@ -361,8 +362,13 @@ __device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float
   f.shift[goff + c] = f.beta[c] - mu * sc;
   if (f.mmean) {                                             // TF fused BN: the moving variance takes the UNBIASED estimate
     const float unb = var * (n / fmaxf(n - 1.f, 1.f));
-    f.mmean[c] = f.decay * f.mmean[c] + (1.f - f.decay) * mu;
-    f.mvar[c] = f.decay * f.mvar[c] + (1.f - f.decay) * unb;
+    float mm = f.mmean[c], mv = f.mvar[c];
+    for (int u = 0; u < f.updates; ++u) {                    // sequential exponential-average steps, as that many runs of the update op would take
+      mm = f.decay * mm + (1.f - f.decay) * mu;
+      mv = f.decay * mv + (1.f - f.decay) * unb;
+    }
+    f.mmean[c] = mm;
+    f.mvar[c] = mv;
   }
 }
 
@@ -521,10 +527,11 @@ static void bn_stats_stage2_launch(const float* part0, const float* part1, const
 }
 
 static BnFin make_fin(const float* gamma, const float* beta, float eps, float decay, float* mean, float* rstd, float* scale, float* shift,
-                      float* mm, float* mv) {
+                      float* mm, float* mv, int updates = 1) {
   BnFin f;
   f.gamma = gamma; f.beta = beta; f.eps = eps; f.decay = decay;
   f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift; f.mmean = mm; f.mvar = mv;
+  f.updates = updates < 1 ? 1 : updates;
   return f;
 }
 
@@ -1174,7 +1181,7 @@ size_t bn_grouped_ws(int64_t rows_g, int C, int groups) {
 hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int groups, const float* gamma, const float* beta, float eps, float decay,
                                  float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, int act, float alpha, float* y,
                                  void* y_h, void* ws, hipStream_t stream, bool x_bf16, const float* tile_sum, const float* tile_m2, int tile_chunks,
-                                 int tile_rows) {
+                                 int tile_rows, int moving_updates) {
   // tile_sum != NULL: the producing conv's epilogue left per-tile partials (tile_chunks tiles of tile_rows rows per group): no first stage
   int ct, ncg; int64_t rpc;
   bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
@@ -1194,7 +1201,7 @@ hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int group
       hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
                          p0, p1, 1, (const float*)nullptr, rows_g, ncg);
   }
-  const BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv);
+  const BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv, moving_updates);
   uint2* yh = reinterpret_cast<uint2*>(y_h);
   if (tuning().bn_fuse && ncg <= BN_FUSE_MAX_CHUNKS) {          // second stage in the normalisation's prologue: one launch less
     int64_t rpb; int nb_g;

@@ -36,7 +36,7 @@ hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const fl
 hipError_t bn_apply_launch(const void*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h, bool x_bf16);
 size_t bn_grouped_ws(int64_t rows_g, int C, int groups);
 hipError_t bn_fwd_grouped_launch(const void*, int64_t, int, int, const float*, const float*, float, float, float*, float*, float*, float*, float*, float*,
-                                 int, float, float*, void*, void*, hipStream_t, bool, const float*, const float*, int, int);
+                                 int, float, float*, void*, void*, hipStream_t, bool, const float*, const float*, int, int, int);
 hipError_t bn_bwd_grouped_launch(const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, int, int, float, void*,
                                  float*, float*, float*, int, void*, hipStream_t, void*, bool);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
@@ -1230,7 +1230,7 @@ size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t
 int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
                              float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
                              float alpha, void* y, void* y_h, const float* tile_sum, const float* tile_m2, int32_t tile_chunks, int32_t tile_rows,
-                             void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+                             int32_t moving_updates, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
   if (tile_sum && (!tile_m2 || tile_chunks <= 0 || tile_rows <= 0 || (int64_t)tile_chunks * tile_rows < rows_per_group ||
                    (groups > 1 && rows_per_group % tile_rows != 0) || !aligned16(tile_sum) || !aligned16(tile_m2))) {
     set_error("t2i_bn_train_fwd_grouped: bad tile partials (tile_chunks tiles of tile_rows rows per group; with groups > 1 a tile must not straddle groups)");
@@ -1249,7 +1249,7 @@ int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, i
   if (int rc = h_contract(dtype, true, C, y_h, "t2i_bn_train_fwd_grouped")) return rc;
   const bool h = dtype == T2I_DT_BF16;
   return check(bn_fwd_grouped_launch(x, rows_per_group, C, groups, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, act, alpha,
-                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h, tile_sum, tile_m2, tile_chunks, tile_rows),
+                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h, tile_sum, tile_m2, tile_chunks, tile_rows, moving_updates),
                "t2i_bn_train_fwd_grouped");
 }
 

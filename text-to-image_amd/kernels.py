@@ -744,7 +744,7 @@ def bn_apply_groups(x, scales, shifts, act=ACT_NONE, alpha=0.2):
     return y
 
 
-def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None):
+def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None, moving_updates=1):
     """Training-mode batch norm in at most three launches (t2i_bn_train_fwd_grouped): x [groups * b, ..., C] with per-group statistics
     (groups = 1: the ordinary batch norm).  Uses the producing conv's epilogue partials when it left any (conv_fwd_stats).
     -> (y, mean [groups, C], rstd [groups, C]); moving averages updated in place once per group, in group order."""
@@ -766,7 +766,7 @@ def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha
         twin = _twin_for(y, x)
         check(lib.t2i_bn_train_fwd_grouped(_ptr(x), rows_g, C, groups, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(stat[0]), _ptr(stat[1]),
                                            _ptr(stat[2]), _ptr(stat[3]), _ptr(moving_mean), _ptr(moving_var), act, alpha, _ptr(y), _ptr(twin),
-                                           tsum, tm2, tchunks, trows, wsp, wsn, _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
+                                           tsum, tm2, tchunks, trows, int(moving_updates), wsp, wsn, _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
         _twin_keep(y, twin)
     return y, stat[0], stat[1]
 

@@ -17,6 +17,13 @@ class GanClsTrainer(object):
         self.sess, self.model, self.dataset, self.cfg = sess, model, dataset, cfg     # sess unused (no TF session)
         self.gen = torch.Generator(device=model.device).manual_seed(1234)
         self.batched = os.environ.get('T2I_GANCLS_BATCHED', '1') != '0'      # the critic's passes of one sess.run as one stacked batch
+        # The D run and the G run of one iteration evaluate the generator on the SAME feed (trainer.py:115-134: same z, same phi), the generator
+        # has no noise input (model.py:111-192) and D_optim does not touch its variables: the two evaluations are the same numbers.  iteration()
+        # therefore evaluates it ONCE (with the autograd graph the G run needs), hands the critic step a detached view, and lets the batch norms'
+        # moving averages take the batch statistics twice, as the two runs under UPDATE_OPS do (update_ops(times=2)).  Single process only: under
+        # data parallelism the two halves live in separately captured graph segments.  T2I_GANCLS_SHARE_G=0: evaluate twice.
+        self.share_g = os.environ.get('T2I_GANCLS_SHARE_G', '1') != '0'
+        self._shared_G = None
         self.define_losses()
 
     def define_losses(self):
@@ -25,13 +32,20 @@ class GanClsTrainer(object):
         self.D_optim = optim.AdamTF(self.model.d_arena, float(t.D_BETA_DECAY), 0.999)
         self.G_optim = optim.AdamTF(self.model.g_arena, float(t.G_BETA_DECAY), 0.999)
 
-    def d_losses(self, feed):
-        """What sess.run([D_optim, ...]) evaluates before the update (trainer.py:20-34,115-123).  Gradients -> d_arena."""
+    def d_losses(self, feed, keep_g=False):
+        """What sess.run([D_optim, ...]) evaluates before the update (trainer.py:20-34,115-123).  Gradients -> d_arena.
+        keep_g (iteration() only): the generator is evaluated with its autograd graph and its moving averages move twice; the result is kept
+        for g_losses(G=...) of the same iteration (see __init__)."""
         m = self.model
         x, xw, phi, z = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs'], feed['z']
+        if keep_g:
+            with update_ops(times=2):
+                self._shared_G = m.generator(z, phi, reuse=True)
+            G = self._shared_G.detach()
         with update_ops():      # D_optim is built under control_dependencies(UPDATE_OPS): every BN moving average moves
-            with torch.no_grad():
-                G = m.generator(z, phi, reuse=True)
+            if not keep_g:
+                with torch.no_grad():
+                    G = m.generator(z, phi, reuse=True)
             # the critic's three passes (fake / match / mismatch, model.py:48-51) as ONE stacked batch: per-sample layers run once on 3B
             # samples, every batch norm keeps its statistics per pass (discriminator(groups=3)); T2I_GANCLS_BATCHED=0: three calls
             if self.batched:
@@ -58,11 +72,13 @@ class GanClsTrainer(object):
         return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G,
                     D_synthetic=probs[0].view(shape), D_real_match=probs[1].view(shape), D_real_mismatch=probs[2].view(shape))
 
-    def g_losses(self, feed):
+    def g_losses(self, feed, G=None):
+        """G: the generator output d_losses(keep_g=True) evaluated for this iteration (with its autograd graph), or None: evaluate it here."""
         m = self.model
         x, xw, phi, z = feed['inputs'], feed['wrong_inputs'], feed['phi_inputs'], feed['z']
         with update_ops():
-            G = m.generator(z, phi, reuse=True)
+            if G is None:
+                G = m.generator(z, phi, reuse=True)
             with m.store.frozen('d_net'):
                 _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
             # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
@@ -82,30 +98,41 @@ class GanClsTrainer(object):
         return dict(G_loss=losses[0], G=G.detach())
 
     # ---- device-only halves of an iteration (graph-capturable) ------------------------------------------------------------
-    def _d_body(self, feed):
+    def _d_body(self, feed, keep_g=False, refresh=None):
         m = self.model
-        d = self.d_losses(feed)
+        d = self.d_losses(feed, keep_g=keep_g)
         scale = m.dp.allreduce_arena(m.d_arena) if m.dp is not None else 1.0
-        self.D_optim.apply(grad_scale=scale)
+        self.D_optim.apply(grad_scale=scale, refresh=refresh)
         return d
 
-    def _g_body(self, feed):
+    def _g_body(self, feed, G=None):
         m = self.model
-        g = self.g_losses(feed)
+        g = self.g_losses(feed, G=G)
         scale = m.dp.allreduce_arena(m.g_arena) if m.dp is not None else 1.0
         self.G_optim.apply(grad_scale=scale)
         return g
 
+    def _dg_body(self, feed):
+        """Both halves with ONE generator evaluation (see __init__); the critic's cached filter images are regenerated behind its Adam step,
+        because the generator half of the same capture reads the updated filters."""
+        d = self._d_body(feed, keep_g=True, refresh=True)
+        G, self._shared_G = self._shared_G, None
+        return d, self._g_body(feed, G=G)
+
     def enable_graphs(self, feed):
-        """Capture the two halves into hipGraphs and replay them from then on (call after one eager iteration).  With data
-        parallelism each half is cut at its exchange step — [losses + backward] | all-reduce of the gradient arena, issued
-        eagerly | [Adam] — as in models/wgancls and models/stackgan: no collective is ever captured."""
+        """Capture the iteration into hipGraphs and replay it from then on (call after one eager iteration): one graph for both halves when
+        the generator evaluation is shared (single process), else one per half.  With data parallelism each half is cut at its exchange step —
+        [losses + backward] | all-reduce of the gradient arena, issued eagerly | [Adam] — as in models/wgancls and models/stackgan: no
+        collective is ever captured."""
         from ...graphs import StepGraphs
         m = self.model
         self._graphs = StepGraphs(feed, ('inputs', 'wrong_inputs', 'phi_inputs', 'z'), filters=(m.d_arena.flat, m.g_arena.flat))
         if m.dp is None:
-            self._graphs.capture('d', self._d_body)
-            self._graphs.capture('g', self._g_body)
+            if self.share_g:
+                self._graphs.capture('dg', self._dg_body)
+            else:
+                self._graphs.capture('d', self._d_body)
+                self._graphs.capture('g', self._g_body)
             return
         scale = 1.0 / m.dp.world
         self._capturing = True
@@ -120,9 +147,14 @@ class GanClsTrainer(object):
     def iteration(self, feed):
         lr_d, lr_g = float(self.cfg.TRAIN.D_LR), float(self.cfg.TRAIN.G_LR)
         graphs = getattr(self, '_graphs', None)
+        dp = self.model.dp
         if graphs is not None:
             graphs.load(feed)
-            dp = self.model.dp
+            if 'dg' in graphs.graphs:
+                self.D_optim.prepare(lr_d)
+                self.G_optim.prepare(lr_g)
+                d, g = graphs.replay('dg')
+                return {'d': d, 'g': g}
             self.D_optim.prepare(lr_d)
             d = graphs.replay('d')
             if dp is not None:
@@ -133,6 +165,11 @@ class GanClsTrainer(object):
             if dp is not None:
                 dp.allreduce_arena(self.model.g_arena)
                 graphs.replay('g_upd')
+            return {'d': d, 'g': g}
+        if self.share_g and dp is None:
+            self.D_optim.prepare(lr_d)
+            self.G_optim.prepare(lr_g)
+            d, g = self._dg_body(feed)
             return {'d': d, 'g': g}
         self.D_optim.prepare(lr_d)
         d = self._d_body(feed)

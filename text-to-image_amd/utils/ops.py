@@ -130,13 +130,19 @@ def fc(x, units, act=None, init=None, bias=True, name=None):
 # TF collects the moving-average assignments of batch_norm in GraphKeys.UPDATE_OPS and runs them only under ops that
 # depend on them (reference models/wgancls/model.py:98,102: G_optim yes, D_optim no).  Eager equivalent: the moving
 # statistics are updated by the BN kernel itself iff the caller is inside `update_ops()`.
-_UPDATE_OPS = [False]
+_UPDATE_OPS = [False]          # False, or how many times the moving averages take each batch norm's statistics (True == 1)
 
 
 class update_ops(object):
+    """times = 2: one evaluation stands for two identical evaluations of the reference graph, each of which would run the update op
+    (models/gancls/trainer.py: the generator in the D run and in the G run of one iteration)."""
+
+    def __init__(self, times=1):
+        self.times = int(times)
+
     def __enter__(self):
         self.prev = _UPDATE_OPS[0]
-        _UPDATE_OPS[0] = True
+        _UPDATE_OPS[0] = self.times
 
     def __exit__(self, *a):
         _UPDATE_OPS[0] = self.prev
@@ -165,10 +171,12 @@ def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df
         mv = st.get_variable('moving_variance', (C,), S.constant_init(1.0), trainable=False)
     if train and groups > 1:
         upd = _UPDATE_OPS[0]
+        if int(upd) > 1:
+            raise NotImplementedError('update_ops(times > 1) with a stacked batch')
         y = A.BatchNormTrainGroupedFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, int(groups))
     elif train:
         upd = _UPDATE_OPS[0]
-        y, _, _ = A.BatchNormTrainFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha)
+        y, _, _ = A.BatchNormTrainFn.apply(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, max(int(upd), 1))
     else:
         # inference: y = act(x*scale + shift) with the moving statistics; [C]-sized host-side vector math
         with torch.no_grad():

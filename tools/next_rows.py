@@ -97,11 +97,21 @@ def _gancls(K, dev, math, batch, budget_s):
             'z': torch.randn((batch, cfg.MODEL.Z_DIM), generator=g, device=dev)}
     tr.iteration(feed)
     flop, calls = _count_eager(K, lambda: tr.iteration(feed))
+    # the reference graph evaluates the generator in BOTH runs of an iteration (identical numbers: same feed, no noise, weights unchanged);
+    # GanClsTrainer evaluates it once.  Both FLOP counts are reported: what is launched, and what the reference's two runs contain.
+    shared, tr.share_g = tr.share_g, False
+    ref_flop, ref_calls = _count_eager(K, lambda: tr.iteration(feed))
+    tr.share_g = shared
     tr.enable_graphs(feed)
     tr.iteration(feed)
     dt, n = _time_replays(lambda: tr.iteration(feed), budget_s)
     tr._graphs = None
-    return _row('gancls', 'gancls 64x64 (reference dims: z 100, GF 128, DF 64), D + G update, both under UPDATE_OPS', batch, math, dt, n, flop, calls)
+    extra = {'generator_evaluations_per_iteration': 1 if shared and m.dp is None else 2,
+             'reference_graph_gflop_per_image': ref_flop / batch / 1e9, 'reference_graph_conv_calls': ref_calls,
+             'frac_vs_reference_graph_flops': ref_flop / dt / 1e12 / PEAK[math],
+             'note': 'algorithmic_gflop_per_image / frac_vs_driver_ms count the LAUNCHED convolutions (one generator forward per iteration); '
+                     'reference_graph_* count the two identical generator forwards the reference\'s D run and G run evaluate'}
+    return _row('gancls', 'gancls 64x64 (reference dims: z 100, GF 128, DF 64), D + G update, both under UPDATE_OPS', batch, math, dt, n, flop, calls, extra)
 
 
 def _stackgan(K, dev, math, stage, batch, budget_s):
@@ -235,6 +245,9 @@ def main():
             print('%-16s %-4s B=%-3d %8.2f ms/iteration %9.1f img/s | %7.2f GFLOP/img algorithmic (%d conv calls) | %7.1f TFLOP/s = %.3f of the %s matrix peak '
                   '(frac_vs_driver_ms) | %s' % (r['row'], r['dtype'], r['batch'], r['ms_per_iteration'], r['images_per_sec'], r['algorithmic_gflop_per_image'],
                                                 r['conv_calls_per_iteration'], r['achieved_tflops'], r['frac_vs_driver_ms'], r['dtype'], r['workload']))
+            if 'frac_vs_reference_graph_flops' in r:
+                print('%-16s      (the reference graph\'s %.2f GFLOP/img incl. its second, identical generator forward: %.3f of the peak)' % (
+                    '', r['reference_graph_gflop_per_image'], r['frac_vs_reference_graph_flops']))
 
 
 if __name__ == '__main__':
