@@ -966,11 +966,14 @@ def test_fused_winograd_k4s2_is_bit_identical(K, shape):
     ref_dx = K.conv_bwd_data(dy, w, None, d, ws)
     K.tuning_set('wino_fuse', 2)
     try:
-        d2, ws2 = K.conv_desc(B, H, W, Cin, Cout, 4, 4, 2, 2, 'SAME')
-        got_y = K.conv_fwd(x, w, bias, d2, ws2, K.ACT_LRELU, 0.2)
-        got_dx = K.conv_bwd_data(dy, w, None, d2, ws2)
-        torch.cuda.synchronize()
+        for xf in (0, 1):          # 1: the input transform of dy in the fused kernel's A loader as well (no V planes either)
+            K.tuning_set('wino_fuse_xf', xf)
+            d2, ws2 = K.conv_desc(B, H, W, Cin, Cout, 4, 4, 2, 2, 'SAME')
+            got_y = K.conv_fwd(x, w, bias, d2, ws2, K.ACT_LRELU, 0.2)
+            got_dx = K.conv_bwd_data(dy, w, None, d2, ws2)
+            torch.cuda.synchronize()
+            assert torch.equal(got_y, ref_y), (xf, float((got_y - ref_y).abs().max()))
+            assert torch.equal(got_dx, ref_dx), (xf, float((got_dx - ref_dx).abs().max()))
     finally:
         K.tuning_set('wino_fuse', 1)
-    assert torch.equal(got_y, ref_y), float((got_y - ref_y).abs().max())
-    assert torch.equal(got_dx, ref_dx), float((got_dx - ref_dx).abs().max())
+        K.tuning_set('wino_fuse_xf', 1)

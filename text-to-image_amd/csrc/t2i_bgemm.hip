@@ -319,8 +319,14 @@ __global__ __launch_bounds__(64 * NW) void bgemm_kernel(BgemmParams p) {
 // Work items: phases x tiles_m x tiles_n (9 x coarser than bgemm_kernel's): the caller takes this path only where that still fills the chip.
 //   LAY 0  forward:        A = V[xi] [T][4 Cin] K-inner, B = U[xi] [4 Cin][Cout] N-inner, plane slot = xi
 //   LAY 1  input gradient: A = V[slot] [T][Cout] K-inner, B = U[slot] [Cin][Cout] K-inner, slot = ((2 - r) 3 + (2 - c)) 4 + (3 - phase)
-template <int LAY>
+// XF (LAY 1 only, round 5): the INPUT transform in the A loader too.  The unfused form writes V = B^T d B of the incoming gradient once per output
+// phase (9 x |dy| through the workspace, the largest single stream of this layer class) and reads it back here.  With XF the loader fetches the
+// (up to) four dy pixels a V element is made of — V(r,c) = (d[r][c] - d[1][c]) - (d[r][1] - d[1][1]), with the taps of row / column 1 absent for
+// r = 1 / c = 1 — straight from dy (which stays in L2 / MALL: 1/9 of V's size) and forms the element in registers, in wino2b_input_kernel's order:
+// x - 0 is exact, so the bits are the same.  Padding taps and rows beyond T read zero through the buffer range check, as everywhere here.
+template <int LAY, bool XF = false>
 __global__ __launch_bounds__(256, 2) void bgemm9_kernel(Bgemm9Params q) {
+  static_assert(!XF || LAY == 1, "the in-loader input transform exists for the input-gradient form");
   const BgemmParams& p = q.g;
   using S = BSmem<LAY, 1, 1, 4>;
   constexpr bool B_KIN = S::B_KIN;                          // A is K-inner in both layouts
@@ -364,30 +370,63 @@ __global__ __launch_bounds__(256, 2) void bgemm9_kernel(Bgemm9Params q) {
   __amdgpu_buffer_rsrc_t ra, rb;
   int a_off[A_LD], b_off[B_LD];
   bool a_ok[A_LD], b_ok[B_LD];
+  unsigned a_win[A_LD];           // XF: which of the 3 x 3 window pixels of the row's tile lie inside the dy map (bit r' * 3 + c')
+  int x_tap[4];                   // XF: element offsets of the position's four taps relative to the window origin; x_bit: their window bits, 0 = tap absent
+  unsigned x_bit[4];
   int l_item = -1, l_pos = 8, l_t = 0, l_phs = 0, l_bm = 0, l_bn = 0;
+  if (XF) ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.dy), (short)0, (int)p.a_bytes, 0x00020000);
 
   auto next_sub = [&]() __attribute__((always_inline)) {          // the loader moves on to the next (item, position)
     l_t = 0;
+    bool new_item = false;
     if (++l_pos == 9) {
       l_pos = 0;
       ++l_item;
+      new_item = true;
       if (l_item < n_items) coords(run0 + slot + l_item * nslot, l_phs, l_bm, l_bn);
     }
     if (l_item >= n_items) {
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i) a_ok[i] = false;
+      for (int i = 0; i < A_LD; ++i) { a_ok[i] = false; a_win[i] = 0u; }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) b_ok[i] = false;
       return;
     }
     const int ps = plane_slot(l_pos, l_phs);
-    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (int64_t)ps * p.sa), (short)0, (int)p.a_bytes, 0x00020000);
+    if (!XF) ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (int64_t)ps * p.sa), (short)0, (int)p.a_bytes, 0x00020000);
     rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (int64_t)ps * p.sb), (short)0, (int)p.b_bytes, 0x00020000);
+    if (XF) {
+      const int r = l_pos / 3, c = l_pos - 3 * r;
+      const int rowpx = q.dWo * p.K;                      // elements per dy row
+      x_tap[0] = r * rowpx + c * p.K;  x_bit[0] = 1u << (r * 3 + c);
+      x_tap[1] = 1 * rowpx + c * p.K;  x_bit[1] = r != 1 ? 1u << (3 + c) : 0u;
+      x_tap[2] = r * rowpx + 1 * p.K;  x_bit[2] = c != 1 ? 1u << (r * 3 + 1) : 0u;
+      x_tap[3] = 1 * rowpx + 1 * p.K;  x_bit[3] = (r != 1 && c != 1) ? 1u << 4 : 0u;
+      if (new_item) {
+        const int ph = l_phs >> 1, pw = l_phs & 1;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int m = l_bm + r0 + 32 * i;
-      a_ok[i] = m < p.M;
-      a_off[i] = m * p.K + kq * 4;
+        for (int i = 0; i < A_LD; ++i) {
+          const int m = l_bm + r0 + 32 * i;
+          const int b = m / (q.Th * q.Tw), rem = m - b * (q.Th * q.Tw);
+          const int ty = rem / q.Tw, tx = rem - ty * q.Tw;
+          const int oh0 = 2 * ty + ph - 1, ow0 = 2 * tx + pw - 1;
+          a_off[i] = ((b * q.dHo + oh0) * q.dWo + ow0) * p.K + kq * 4;       // may point before the row / the map: only used under its window bit
+          unsigned w = 0u;
+#pragma unroll
+          for (int rr2 = 0; rr2 < 3; ++rr2)
+#pragma unroll
+            for (int cc2 = 0; cc2 < 3; ++cc2)
+              if ((unsigned)(oh0 + rr2) < (unsigned)q.dHo && (unsigned)(ow0 + cc2) < (unsigned)q.dWo) w |= 1u << (rr2 * 3 + cc2);
+          a_win[i] = m < p.M ? w : 0u;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int m = l_bm + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        a_off[i] = m * p.K + kq * 4;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -407,8 +446,21 @@ __global__ __launch_bounds__(256, 2) void bgemm9_kernel(Bgemm9Params q) {
   auto load_into = [&](float4* ar, float4* br) __attribute__((always_inline)) {
     const int k0 = l_t * BK;
     ++l_t;
+    if (XF) {
+      const bool kin = k0 + kq * 4 < p.K;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) ar[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
+      for (int i = 0; i < A_LD; ++i) {
+        const float4 ta = bl4(ra, a_off[i] + x_tap[0] + k0, kin & ((a_win[i] & x_bit[0]) != 0u));
+        const float4 tb = bl4(ra, a_off[i] + x_tap[1] + k0, kin & ((a_win[i] & x_bit[1]) != 0u));
+        const float4 tc = bl4(ra, a_off[i] + x_tap[2] + k0, kin & ((a_win[i] & x_bit[2]) != 0u));
+        const float4 td = bl4(ra, a_off[i] + x_tap[3] + k0, kin & ((a_win[i] & x_bit[3]) != 0u));
+        // (d[r][c] - d[1][c]) - (d[r][1] - d[1][1]): wino2b_input_kernel's tt / V arithmetic; absent taps are zeros
+        ar[i] = make_float4((ta.x - tb.x) - (tc.x - td.x), (ta.y - tb.y) - (tc.y - td.y), (ta.z - tb.z) - (tc.z - td.z), (ta.w - tb.w) - (tc.w - td.w));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) ar[i] = bl4(ra, a_off[i] + k0, a_ok[i] & (k0 + kq * 4 < p.K));
+    }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       if (B_KIN) br[i] = bl4(rb, b_off[i] + k0, b_ok[i] & (k0 + kq * 4 < p.K));
@@ -558,8 +610,9 @@ hipError_t bgemm9_launch(int lay, const Bgemm9Params& q, hipStream_t stream) {
   const int per_xcd = (q.g.items + 7) / 8;
   int nslot = per_xcd < 32 * 2 ? per_xcd : 32 * 2;             // two workgroups per CU (144 accumulator registers per lane)
   if (nslot < 1) nslot = 1;
-  if (lay == 0) hipLaunchKernelGGL(bgemm9_kernel<0>, dim3(nslot * 8), dim3(256), bytes, stream, q);
-  else hipLaunchKernelGGL(bgemm9_kernel<1>, dim3(nslot * 8), dim3(256), bytes, stream, q);
+  if (lay == 0) hipLaunchKernelGGL((bgemm9_kernel<0, false>), dim3(nslot * 8), dim3(256), bytes, stream, q);
+  else if (q.dy) hipLaunchKernelGGL((bgemm9_kernel<1, true>), dim3(nslot * 8), dim3(256), bytes, stream, q);
+  else hipLaunchKernelGGL((bgemm9_kernel<1, false>), dim3(nslot * 8), dim3(256), bytes, stream, q);
   return hipGetLastError();
 }
 

@@ -141,6 +141,7 @@ static Tuning& tuning_mut() {
     v.colred_wgs = env_int("T2I_COLRED_WGS", 768);         // column reductions, stage 1: workgroups in flight
     v.wino_fuse = env_int("T2I_WINO_FUSE", 1);             // 4x4 stride-2 Winograd: the nine position GEMMs + output transform in one work item (bgemm9_kernel); 0: never, 1: where it still
     v.wino_fuse_items = env_int("T2I_WINO_FUSE_ITEMS", 512);   // has >= wino_fuse_items items (input gradient; forward: 4x that — measured, profiles/r05_winograd_fused.txt), 2: always
+    v.wino_fuse_xf = env_int("T2I_WINO_FUSE_XF", 1);       // ... and the input transform of dy in its A loader (input gradient only): no V planes either
     v.bn_fuse = env_int("T2I_BN_FUSE", 1);                 // batch norm: second stage of the statistics in the normalisation's prologue when <= 64 partial rows (t2i_aux.hip)
     v.colred_cap = env_int("T2I_COLRED_CAP", 192);         // ... and the most row chunks (= partials the second stage sums per column)
     v.bf16_waves = env_int("T2I_BF16_WAVES", 8);           // 8: the 128x128 bf16 tile runs on 8 waves of 32x64 (two per SIMD) instead of 4 of 64x64
@@ -1485,7 +1486,7 @@ int t2i_tuning_set(const char* key, double value) {
       {"winograd_k4s2_bwd_minc", &t.winograd_k4s2_bwd_minc}, {"winograd_k4s2_bwdf", &t.winograd_k4s2_bwdf}, {"winograd_k4s2_minwork", &t.winograd_k4s2_minwork}, {"winograd_k4s2_minitems", &t.winograd_k4s2_minitems},
       {"adam_blocks", &t.adam_blocks}, {"max_chain", &t.max_chain}, {"bf16_operands", &t.bf16_operands},
       {"cache_refresh", &t.cache_refresh}, {"thin_parts", &t.thin_parts}, {"batch_lin", &t.batch_lin}, {"bgemm", &t.bgemm}, {"winograd_minwork", &t.winograd_minwork}, {"bf16_dma", &t.bf16_dma}, {"hft_boost", &t.hft_boost}, {"hft_ovh", &t.hft_ovh},
-      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"bn_fuse", &t.bn_fuse}, {"wino_fuse", &t.wino_fuse}, {"wino_fuse_items", &t.wino_fuse_items}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
+      {"bgemm_tile", &t.bgemm_tile}, {"bgemm_big_items", &t.bgemm_big_items}, {"vec_epi", &t.vec_epi}, {"pair", &t.pair}, {"pair_cus", &t.pair_cus}, {"h_stats", &t.h_stats}, {"pair_reduce", &t.pair_reduce}, {"bf16_waves", &t.bf16_waves}, {"bf16_pair_tiles", &t.bf16_pair_tiles}, {"colred_wgs", &t.colred_wgs}, {"colred_cap", &t.colred_cap}, {"bn_fuse", &t.bn_fuse}, {"wino_fuse", &t.wino_fuse}, {"wino_fuse_items", &t.wino_fuse_items}, {"wino_fuse_xf", &t.wino_fuse_xf}, {"tile8_eff", &t.tile8_eff}, {"dma_ovh", &t.dma_ovh}, {"dma_split_us", &t.dma_split_us}, {"pair_max_px", &t.pair_max_px}};
   for (auto& e : ints)
     if (!strcmp(key, e.name)) { *e.field = (int)value; return T2I_OK; }
   if (!strcmp(key, "split_cost")) { t.split_cost = value; return T2I_OK; }

@@ -157,13 +157,15 @@ struct Bgemm9Params {
   int32_t sr;                 // 1: forward (pixel (2 ty + r, 2 tx + c));  2: input gradient (pixel (2 (2 ty + r) + ph, 2 (2 tx + c) + pw))
   int32_t act;
   float alpha;
+  const float* dy;            // LAY 1, optional: the raw incoming gradient [B, dHo, dWo, K] — the loader forms V itself (g.a unused, g.a_bytes = dy's extent)
+  int32_t dHo, dWo;
 };
 hipError_t bgemm9_launch(int lay, const Bgemm9Params& q, hipStream_t stream);
 
 struct Tuning {
   int force_tile, force_splitk, debug_plan, group_n, no_ut, no_thin;
   int winograd, winograd_minc, winograd_maxhw, winograd_k4s2, winograd_k4s2_minc, winograd_k4s2_bwd_minc, winograd_k4s2_bwdf;
-  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles, bn_fuse, wino_fuse, wino_fuse_items, winograd_k4s2_minwork, winograd_k4s2_minitems;
+  int adam_blocks, max_chain, bf16_operands, cache_refresh, thin_parts, batch_lin, bgemm, winograd_minwork, bf16_dma, hft_boost, hft_ovh, bgemm_tile, bgemm_big_items, vec_epi, pair, pair_cus, pair_max_px, dma_ovh, dma_split_us, tile8_eff, colred_wgs, colred_cap, h_stats, pair_reduce, bf16_waves, bf16_pair_tiles, bn_fuse, wino_fuse, wino_fuse_items, wino_fuse_xf, winograd_k4s2_minwork, winograd_k4s2_minitems;
   double split_cost;
 };
 const Tuning& tuning();

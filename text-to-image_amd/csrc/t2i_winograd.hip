@@ -569,11 +569,14 @@ size_t winograd_k4s2_ws(const t2i_conv_desc& d) {
 // output-transform launch.  Taken when tuning().wino_fuse says so (1: only where phases x tiles still give >= wino_fuse_items items; 2: wherever
 // the persistent kernel's operand conditions hold).  Returns T2I_OK after launching, or -1 if the caller should take the unfused path.
 static int wino2_fused_gemm(int lay, int phases, size_t T, int N, int K, const float* V, const float* U, int64_t sa, int64_t sb, const float* bias,
-                            float* out, int OH, int OW, int Th, int Tw, int sr, int act, float alpha, hipStream_t stream, const char* what) {
+                            float* out, int OH, int OW, int Th, int Tw, int sr, int act, float alpha, hipStream_t stream, const char* what,
+                            const float* dy_raw = nullptr, int dHo = 0, int dWo = 0, int64_t dy_elems = 0) {
+  // dy_raw != NULL (input gradient): the loader transforms dy itself; V is not read (and need not have been written)
   const int mode = tuning().wino_fuse;
   if (!mode || !tuning().bgemm) return -1;
   const int ntiles = (K + 31) / 32;
-  const int64_t a_elems = (int64_t)T * K, b_elems = (int64_t)N * K;
+  const int64_t a_elems = dy_raw ? dy_elems : (int64_t)T * K, b_elems = (int64_t)N * K;
+  if (dy_raw) V = dy_raw;       // (alignment / extent checks below apply to the operand actually read)
   if ((ntiles & 1) || (T & 3) || (N & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(V) & 15) || (reinterpret_cast<uintptr_t>(U) & 15) || (sa & 3) || (sb & 3) ||
       a_elems >= (1LL << 30) || b_elems >= (1LL << 30) || T >= (1u << 30))
     return -1;
@@ -585,11 +588,18 @@ static int wino2_fused_gemm(int lay, int phases, size_t T, int N, int K, const f
   { const int g = tuning().group_n; q.g.group_n = q.g.tiles_n < g ? q.g.tiles_n : g; if (q.g.group_n < 1) q.g.group_n = 1; }
   q.g.ntiles = ntiles;
   const int64_t items = (int64_t)phases * q.g.tiles_m * q.g.tiles_n;
-  if (items >= (1LL << 30) || (mode == 1 && items < (int64_t)tuning().wino_fuse_items * (lay == 0 ? 4 : 1))) return -1;
+  if (items >= (1LL << 30)) return -1;
+  if (mode == 1) {
+    // auto: enough items, AND they must fill whole rounds of the 512 resident workgroups (2 per CU): 1536 and 512 items win 16-19 % on the
+    // 128 -> 256 input gradient, 768 items (1.5 rounds) lose 10 % on 256 -> 512 even with the loader transform (profiles/r05_winograd_fused.txt)
+    const int64_t rounds = (items + 511) / 512;
+    if (items < (int64_t)tuning().wino_fuse_items * (lay == 0 ? 4 : 1) || items * 100 < rounds * 512 * 85) return -1;
+  }
   q.g.items = (int32_t)items;
   q.g.sa = sa; q.g.sb = sb; q.g.sc = 0;
   q.g.a_bytes = (uint32_t)(a_elems * 4); q.g.b_bytes = (uint32_t)(b_elems * 4);
   q.bias = bias; q.out = out; q.OH = OH; q.OW = OW; q.Th = Th; q.Tw = Tw; q.sr = sr; q.act = act; q.alpha = alpha;
+  q.dy = dy_raw; q.dHo = dHo; q.dWo = dWo;
   if (tuning().debug_plan) fprintf(stderr, "[t2i plan] %s: fused 9-position items, %d phases x %d x %d tiles, K=%d\n", what, phases, q.g.tiles_m, q.g.tiles_n, K);
   const hipError_t e = bgemm9_launch(lay, q, stream);
   if (e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e)); return T2I_ERR_LAUNCH; }
@@ -744,6 +754,11 @@ int winograd_k4s2_bwd_data(const t2i_conv_desc& d, const float* dy, const float*
   if (float* Uc = filter_cache_get(w, 2, d.Cin, d.Cout, (size_t)36 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;      // the forward image
   if (fill)
     hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
+  if (tuning().wino_fuse_xf) {   // everything in one launch: dy -> (transform in the loader) -> 4 x 9 GEMMs -> (transform in the epilogue) -> dx
+    const int fr = wino2_fused_gemm(1, 4, T, d.Cin, d.Cout, V, U, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, bias, dx, d.H, d.W, Th, Tw, 2, act, alpha, stream,
+                                    "winograd k4s2 input-gradient fused gemm (loader transform)", dy, d.Ho, d.Wo, (int64_t)d.B * d.Ho * d.Wo * d.Cout);
+    if (fr != -1) return fr;
+  }
   hipLaunchKernelGGL(wino2b_input_kernel, dim3(wino_blocks(T * d.Cout)), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, V);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
