@@ -47,6 +47,23 @@ def test_descriptor_validation_without_gpu(t2i):
     assert (d.H, d.W, d.Cin, d.Cout, d.Ho, d.Wo) == (8, 8, 512, 1024, 4, 4)
     with pytest.raises(ValueError):
         K.conv_desc(1, 4, 4, 4, 4, 3, 3, 1, 1, 'FULL')
+    # hostile extents: four 31-bit factors overflow a 64-bit element count (UBSan finding of tools/sanitize_host.sh) — refused,
+    # with the size message, by all three queries
+    big = 2 ** 31 - 1
+    for desc in (_lib.ConvDesc(big, big, big, 4, big, big, 4, 3, 3, 1, 1, 1, 1), _lib.ConvDesc(1, 4, 4, big, 4, 4, big, big, big, 1, 1, 1, 1),
+                 _lib.ConvDesc(1, 46341, 46341, 1024, 46341, 46341, 1024, 3, 3, 1, 1, 1, 1)):
+        assert _lib.lib.t2i_conv2d_workspace_bytes(ctypes.byref(desc)) == 0
+        assert _lib.lib.t2i_conv2d_algo(ctypes.byref(desc), 0) == -1
+        assert b'2^30' in _lib.lib.t2i_last_error() or b'inconsistent' in _lib.lib.t2i_last_error()
+
+
+@pytest.mark.skipif(os.environ.get('T2I_TEST_SANITIZE') != '1', reason='two minutes of hipcc: run with T2I_TEST_SANITIZE=1 (output of the last run: profiles/r05_sanitize_host.txt)')
+def test_host_side_under_asan_ubsan():
+    """tools/sanitize_host.sh: the C ABI's host code built with AddressSanitizer + UndefinedBehaviorSanitizer and swept by
+    tests/workers/san_host.c (queries over every layer geometry and hostile descriptors; invalid compute calls).  No GPU."""
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'sanitize_host.sh')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0 and 'no sanitizer report' in r.stdout, r.stdout[-3000:]
 
 
 def test_no_cpu_fallback(t2i):

@@ -215,3 +215,38 @@ def test_stackgan_graph_replay_matches_eager(stage):
     assert d0 == d1 and g0 == g1
     for n in s0:
         assert torch.equal(s0[n], s1[n]), n
+
+
+@pytest.mark.gpu
+def test_stackgan_train_writes_the_reference_summaries(tmp_path):
+    """ConditionalGanTrainer.train(summaries=True): per update the D merged summary (three critic-output histograms, the three loss
+    scalars, d_loss) and the G merged summary (image g_sum, g_loss, g_gan_loss, g_kl_loss) of reference
+    models/stackgan/stageI/trainer.py:58-87,134-141, in a TensorBoard event file under cfg.LOGS_DIR (utils/summary.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from t2i_amd.data import SyntheticTextDataset
+    from t2i_amd.models.stackgan.stageI.trainer import ConditionalGanTrainer as T1
+    from t2i_amd.utils import summary as S
+    dev = torch.device('cuda')
+    m = _models(1, dev)
+    cfg = m.cfg
+    cfg['LOGS_DIR'] = str(tmp_path / 'logs')
+    B = int(cfg.TRAIN.BATCH_SIZE)
+    tr = T1(None, m, SyntheticTextDataset(cfg, dev, seed=3, num_examples=2 * B), cfg)
+    tr.train(log=lambda s: None, summaries=True)
+    torch.cuda.synchronize()
+    files = os.listdir(cfg['LOGS_DIR'])
+    assert len(files) == 1 and files[0].startswith('events.out.tfevents.')
+    ev = S.read_events(os.path.join(cfg['LOGS_DIR'], files[0]))
+    assert ev[0]['file_version'] == 'brain.Event:2' and [e['step'] for e in ev[1:]] == [1, 1, 2, 2]      # D then G, per update
+    assert [v['tag'] for v in ev[1]['values']] == ['d_real_mismatch_sum', 'd_real_match_sum', 'd_synthetic_sum', 'd_synthetic_sum_loss',
+                                                   'd_real_mismatch_sum_loss', 'd_real_match_sum_loss', 'd_loss']
+    assert [v['tag'] for v in ev[2]['values']] == ['g_sum/image/0', 'g_sum/image/1', 'g_sum/image/2', 'g_loss', 'g_gan_loss', 'g_kl_loss']
+    d, g = ev[-2]['values'], ev[-1]['values']
+    assert d[0]['histo']['num'] == B and 0.0 <= d[0]['histo']['min'] <= d[0]['histo']['max'] <= 1.0          # sigmoid outputs of the batch
+    alpha = float(cfg.TRAIN.COEFF.ALPHA_MISMATCH_LOSS)
+    want = d[5]['simple_value'] + alpha * d[4]['simple_value'] + (1.0 - alpha) * d[3]['simple_value']          # trainer.py:38-39
+    assert abs(d[6]['simple_value'] - want) <= 1e-5 * max(1.0, abs(want))
+    want_g = g[4]['simple_value'] + float(cfg.TRAIN.COEFF.KL) * g[5]['simple_value']
+    assert abs(g[3]['simple_value'] - want_g) <= 1e-5 * max(1.0, abs(want_g))
+    assert S.decode_png(g[0]['image']['png']).shape == (64, 64, 3)

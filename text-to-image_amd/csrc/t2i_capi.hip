@@ -4,6 +4,7 @@
 // captured into a hipGraph.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <initializer_list>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -101,14 +102,26 @@ static int validate_desc(const t2i_conv_desc* d) {
   if (d->SH > 4 || d->SW > 4) { set_error("stride > 4 unsupported (16 phases max)"); return T2I_ERR_INVALID; }
   if (d->math != T2I_MATH_F32 && d->math != T2I_MATH_BF16) { set_error("unknown math mode %d in conv descriptor", d->math); return T2I_ERR_INVALID; }
   // the last output pixel must start inside the padded image (true for TF SAME / VALID geometries)
-  if ((d->Ho - 1) * d->SH - d->pad_t >= d->H || (d->Wo - 1) * d->SW - d->pad_l >= d->W) {
+  if ((int64_t)(d->Ho - 1) * d->SH - d->pad_t >= d->H || (int64_t)(d->Wo - 1) * d->SW - d->pad_l >= d->W) {
     set_error("output extent inconsistent with input/stride/pad");
     return T2I_ERR_INVALID;
   }
-  const int64_t lim = (1LL << 30) - 16;   // buffer loads address with 32-bit byte offsets
-  int64_t nx = (int64_t)d->B * d->H * d->W * d->Cin, ny = (int64_t)d->B * d->Ho * d->Wo * d->Cout,
-          nw = (int64_t)d->KH * d->KW * d->Cin * d->Cout;
-  if (nx > lim || ny > lim || nw > lim) { set_error("tensor exceeds 2^30-16 elements"); return T2I_ERR_INVALID; }
+  // buffer loads address with 32-bit byte offsets.  The element counts are formed factor by factor against the limit: four
+  // 31-bit extents overflow int64 (found by tools/sanitize_host.sh: UBSan on a hostile descriptor), and every size the planner
+  // derives later relies on these products being small.
+  const int64_t lim = (1LL << 30) - 16;
+  auto fits = [lim](int64_t a, int64_t b, int64_t c, int64_t e) {
+    int64_t n = a;
+    for (int64_t f : {b, c, e}) {
+      if (n > lim / f) return false;      // n * f > lim without forming the product
+      n *= f;
+    }
+    return n <= lim;
+  };
+  if (!fits(d->B, d->H, d->W, d->Cin) || !fits(d->B, d->Ho, d->Wo, d->Cout) || !fits(d->KH, d->KW, d->Cin, d->Cout)) {
+    set_error("tensor exceeds 2^30-16 elements");
+    return T2I_ERR_INVALID;
+  }
   return T2I_OK;
 }
 

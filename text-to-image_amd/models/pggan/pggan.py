@@ -126,7 +126,8 @@ class PGGAN(object):
         D_loss.backward(inputs=list(self.d_vars.values()))
         A.side_join()
         return dict(D_loss=D_loss.detach(), wdist=wdist.detach(), wdist2=wdist2.detach(), real_gp=real_gp.detach(),
-                    real_gp2=real_gp2.detach(), reg_loss=(Dxmi_logit.detach() ** 2).mean(), G=G, Dx_hat_logit=Dx_hat_logit.detach())
+                    real_gp2=real_gp2.detach(), reg_loss=(Dxmi_logit.detach() ** 2).mean(), G=G, Dx_hat_logit=Dx_hat_logit.detach(),
+                    D_loss_real=D_loss_real.detach(), D_loss_fake=D_loss_fake.detach(), D_loss_mismatch=D_loss_mismatch.detach())
 
     def g_losses(self, feed):
         cond, z = feed['cond'], feed['z']
@@ -141,7 +142,7 @@ class PGGAN(object):
             self.dp.arm(self.g_arena)
         G_loss.backward(inputs=list(self.g_vars.values()))
         A.side_join()
-        return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach())
+        return dict(G_loss=G_loss.detach(), G_kl_loss=G_kl_loss.detach(), G=G.detach(), D_loss_fake=Dg_logit.detach().mean())
 
     def set_alpha(self, value):
         self.alpha_tra = float(value)
@@ -336,7 +337,30 @@ class PGGAN(object):
         return {'x': images, 'x_mismatch': wrong_images, 'cond': embed,
                 'z': torch.randn((self.batch_size, self.z_dim), generator=gen, device=self.device)}
 
-    def train(self, max_steps=None, log=None, side_effects=False):
+    def define_summaries(self):
+        """reference pggan.py:132-156,165: the FileWriter on log_dir (utils/summary.py: TensorBoard event files without TensorFlow)."""
+        from ...utils.summary import FileWriter
+        self.writer = FileWriter(self.log_dir)
+
+    def write_summaries(self, idx, feed, out, sample_z=None):
+        """The merged summary of reference pggan.py:132-156 at step idx (written every 20 steps, pggan.py:220-222): images `x` and
+        `G_img`, histograms `z` / `z_sample`, and the twelve scalars under the reference's tags.  The reference evaluates them in a
+        third sess.run after the two updates; here they are the values the iteration itself computed, as in models/wgancls."""
+        from ...utils import summary as S
+        d, g = out['d'], out['g']
+        np_ = lambda t: t.detach().float().cpu().numpy()
+        vals = [S.image('x', np_(feed['x'])), S.image('G_img', np_(g['G'])), S.histogram('z', np_(feed['z']))]
+        if sample_z is not None:
+            vals.append(S.histogram('z_sample', np_(sample_z)))
+        vals += [S.scalar('G_loss_wass', -float(g['D_loss_fake'])), S.scalar('kl_loss', float(g['G_kl_loss'])), S.scalar('G_loss', float(g['G_loss']))]
+        for tag, key in (('D_loss_real', 'D_loss_real'), ('D_loss_fake', 'D_loss_fake'), ('real_gp', 'real_gp'), ('D_loss', 'D_loss'),
+                         ('reg_loss', 'reg_loss'), ('wdist', 'wdist'), ('wdist2', 'wdist2'), ('d_loss_mismatch', 'D_loss_mismatch'),
+                         ('real_gp2', 'real_gp2')):
+            vals.append(S.scalar(tag, float(d[key])))
+        self.writer.add_summary(vals, idx)
+        self.writer.flush()
+
+    def train(self, max_steps=None, log=None, side_effects=False, summaries=False):
         """Stage schedule semantics of pggan.py:147-247: a transition stage restores the previous stage's variables
         (`get_variables_up_to_stage(stage - 1)`) from check_dir_read, a stabilisation stage its own; new variables keep
         their fresh initialisation; checkpoints of `get_variables_up_to_stage(stage)` go to check_dir_write."""
@@ -358,8 +382,13 @@ class PGGAN(object):
         end = min(self.steps, max_steps) if max_steps is not None else self.steps
         t0 = time.time()
         out = None
+        if summaries and self.log_dir:
+            self.define_summaries()
         for idx in range(1, end):
-            out = self.iteration(idx, self.make_feed(gen))
+            feed = self.make_feed(gen)
+            out = self.iteration(idx, feed)
+            if idx % 20 == 0 and getattr(self, 'writer', None) is not None:
+                self.write_summaries(idx, feed, out, sample_z if side_effects else None)
             if idx % 20 == 0:
                 epoch = idx // max(self.dataset.train.num_examples // self.batch_size, 1)
                 log('Epoch: [%2d] [%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f' % (

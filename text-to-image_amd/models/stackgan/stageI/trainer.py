@@ -64,7 +64,9 @@ class ConditionalGanTrainer(object):
         grads = [seed.view_as(outs[0])] if seed is not None else [s_.view_as(l_) for s_, l_ in zip(seeds, outs)]
         torch.autograd.backward(outs, grads, inputs=list(m.d_vars.values()))
         A.side_join()
-        return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G)
+        # the three critic outputs (fake, match, mismatch logits) ride along for the D summary's histograms (trainer.py:59-61)
+        return dict(D_loss=losses[0], D_real_match_loss=losses[2], D_real_mismatch_loss=losses[3], D_synthetic_loss=losses[1], G=G,
+                    D_logits=heads)
 
     def g_losses(self, feed):
         m = self.model
@@ -179,13 +181,40 @@ class ConditionalGanTrainer(object):
         return {'inputs': images, 'wrong_inputs': wrong_images, 'phi_inputs': embed,
                 'z': torch.randn((m.batch_size, m.z_dim), generator=self.gen, device=m.device)}
 
-    def train(self, max_updates=None, log=None):
+    def define_summaries(self):
+        """reference trainer.py:58-87: the FileWriter on cfg.LOGS_DIR (utils/summary.py: TensorBoard event files without TensorFlow)."""
+        from ....utils.summary import FileWriter
+        self.writer = FileWriter(self.cfg.LOGS_DIR)
+
+    def write_summaries(self, counter, out):
+        """The two merged summaries the reference adds per update (trainer.py:72-85,134-141).  D: histograms of the three critic
+        outputs (the sigmoid of the logits: model.D_synthetic / D_real_match / D_real_mismatch), scalars of the three loss terms and
+        d_loss; G: image g_sum, scalars g_loss / g_gan_loss / g_kl_loss (z_sum is defined by the reference but merged into neither) —
+        from the values the iteration computed, as the reference fetches them in the same sess.run as the optimizer steps."""
+        from ....utils import summary as S
+        np_ = lambda t: t.detach().float().cpu().numpy()
+        d, g = out['d'], out['g']
+        prob = [np_(torch.sigmoid(l_)) for l_ in d['D_logits']]           # fake, match, mismatch
+        self.writer.add_summary([S.histogram('d_real_mismatch_sum', prob[2]), S.histogram('d_real_match_sum', prob[1]),
+                                 S.histogram('d_synthetic_sum', prob[0]), S.scalar('d_synthetic_sum_loss', float(d['D_synthetic_loss'])),
+                                 S.scalar('d_real_mismatch_sum_loss', float(d['D_real_mismatch_loss'])),
+                                 S.scalar('d_real_match_sum_loss', float(d['D_real_match_loss'])), S.scalar('d_loss', float(d['D_loss']))], counter)
+        self.writer.add_summary([S.image('g_sum', np_(g['G'])), S.scalar('g_loss', float(g['G_loss'])),
+                                 S.scalar('g_gan_loss', float(g['G_gan_loss'])), S.scalar('g_kl_loss', float(g['G_kl_loss']))], counter)
+        self.writer.flush()
+
+    def train(self, max_updates=None, log=None, summaries=False):
+        """summaries=True: an event file in cfg.LOGS_DIR with the reference's per-update summaries (write_summaries)."""
         log = log or (lambda s: (sys.stdout.write(s + '\n'), sys.stdout.flush()))
+        if summaries and getattr(self.cfg, 'LOGS_DIR', None):
+            self.define_summaries()
         t0, counter = time.time(), 1
         for epoch in range(self.cfg.TRAIN.EPOCH):
             updates_per_epoch = self.dataset.train.num_examples // self.model.batch_size
             for idx in range(updates_per_epoch):
                 out = self.iteration(self.make_feed(), epoch)
+                if getattr(self, 'writer', None) is not None:
+                    self.write_summaries(counter, out)
                 log('Epoch: [%2d] [%4d/%4d] time: %4.4f, d_loss: %.8f, g_loss: %.8f' % (
                     epoch, idx, updates_per_epoch, time.time() - t0, float(out['d']['D_loss']), float(out['g']['G_loss'])))
                 counter += 1
