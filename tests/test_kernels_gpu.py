@@ -713,50 +713,52 @@ def test_bn_stats_are_stable_against_a_large_mean(K, rows, C, offset):
     assert float(np.abs(sdyxc.double().cpu().numpy() - ref).max() / np.abs(ref).max()) <= 1e-4
 
 
+@pytest.mark.parametrize('Co', [128, 64])
 @pytest.mark.parametrize('B,H', [(2, 64), (3, 16), (64, 64)])
-def test_stem_conv_forward(K, B, H):
-    """The critic's first layer (3 -> 128 channels, k4 s2 SAME) on its dedicated kernel: image rows staged in LDS, no K loop,
-    8*3 MFMA steps per 32 output channels; vs the float64 oracle at the forward tolerance, with bias + lrelu fused."""
+def test_stem_conv_forward(K, B, H, Co):
+    """The critic's first layer (3 -> 128 channels in wgancls, 3 -> 64 in gancls / StackGAN; k4 s2 SAME) on its dedicated kernel: image
+    rows staged in LDS, no K loop, 8*3 MFMA steps per 32 output channels; vs the float64 oracle at the forward tolerance, with bias + lrelu fused."""
     from oracle import np_ops as O
     rng = np.random.default_rng(B + H)
     x = rng.uniform(-1, 1, (B, H, H, 3)).astype(np.float32)
-    w = (rng.standard_normal((4, 4, 3, 128)) / np.sqrt(48)).astype(np.float32)
-    b = rng.standard_normal(128).astype(np.float32)
-    d, ws = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+    w = (rng.standard_normal((4, 4, 3, Co)) / np.sqrt(48)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    d, ws = K.conv_desc(B, H, H, 3, Co, 4, 4, 2, 2, 'SAME')
     assert K.conv_algo(d, 'fwd') == 'direct_small'
     y = K.conv_fwd(dev(x), dev(w), dev(b), d, ws, K.ACT_LRELU, 0.2)
     if B <= 3:
         assert relerr(y, O.lrelu(O.conv2d(x, w, b, (2, 2), 'SAME'))) <= FWD_TOL
     K.tuning_set('no_thin', 1)               # the general implicit-GEMM path computes the same thing
     try:
-        d2, ws2 = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+        d2, ws2 = K.conv_desc(B, H, H, 3, Co, 4, 4, 2, 2, 'SAME')
         y2 = K.conv_fwd(dev(x), dev(w), dev(b), d2, max(ws2, 64 << 20), K.ACT_LRELU, 0.2)
     finally:
         K.tuning_set('no_thin', 0)
     assert relerr(y, y2.double().cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize('Co', [128, 64])
 @pytest.mark.parametrize('B,H', [(2, 64), (3, 16), (1, 6), (64, 64), (192, 64)])
-def test_stem_filter_gradient(K, B, H):
-    """Filter gradient of the 3 -> 128 k4 s2 stem on its own kernel (one wave owns the 64x128 accumulator, MFMA k = pixel,
+def test_stem_filter_gradient(K, B, H, Co):
+    """Filter gradient of the 3 -> 128 (3 -> 64) k4 s2 stem on its own kernel (one wave owns the 64 x Co accumulator, MFMA k = pixel,
     fixed-order joins): against float64 at the gradient tolerance, ragged pixel counts and padding rows / columns included,
     plain and accumulate-into-arena, twice (same bits: no atomics anywhere)."""
     rng = np.random.default_rng(10 * B + H)
     x = rng.uniform(-1, 1, (B, H, H, 3)).astype(np.float32)
     Ho = H // 2
-    dy = rng.standard_normal((B, Ho, Ho, 128)).astype(np.float32)
-    d, ws = K.conv_desc(B, H, H, 3, 128, 4, 4, 2, 2, 'SAME')
+    dy = rng.standard_normal((B, Ho, Ho, Co)).astype(np.float32)
+    d, ws = K.conv_desc(B, H, H, 3, Co, 4, 4, 2, 2, 'SAME')
     assert K.conv_algo(d, 'bwd_filter') == 'direct_small'
     dw = K.conv_bwd_filter(dev(x), dev(dy), d, ws)
     xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
     gt = torch.from_numpy(dy).double().permute(0, 3, 1, 2)
-    wt = torch.zeros(128, 3, 4, 4, dtype=torch.float64, requires_grad=True)
+    wt = torch.zeros(Co, 3, 4, 4, dtype=torch.float64, requires_grad=True)
     y = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (1, 1, 1, 1)), wt, stride=2)
     (ref,) = torch.autograd.grad(y, wt, gt)
     ref = ref.permute(2, 3, 1, 0).numpy()               # OIHW -> HWIO
     assert relerr(dw, ref) <= 1e-5
     assert torch.equal(dw, K.conv_bwd_filter(dev(x), dev(dy), d, ws))
-    base = rng.standard_normal((4, 4, 3, 128)).astype(np.float32)
+    base = rng.standard_normal((4, 4, 3, Co)).astype(np.float32)
     acc = dev(base)
     K.conv_bwd_filter(dev(x), dev(dy), d, ws, out=acc)
     assert relerr(acc, base + ref) <= 1e-5

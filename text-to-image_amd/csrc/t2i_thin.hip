@@ -429,12 +429,12 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
   // after the barrier; each wave passes its 32 pixels x 128 channels through a private patch, 64 channels at a time, and a lane
   // then owns 8 consecutive channels of a pixel: one 16-byte store for the bf16 tensor, two for the fp32 one.  Same arithmetic.
   const int oh = oh0 + wave;
-  if constexpr (NB == 4) {
+  if constexpr (NB % 2 == 0) {                  // 128 channels (wgancls) or 64 (gancls / StackGAN, round 5): 64 channels per pass
     constexpr int SROW = 68;                    // 64 channels + 4 floats of padding
     __syncthreads();                            // xs / ws are no longer read
     float* st = lds_stem + wave * (32 * SROW);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NB / 2; ++half) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -499,15 +499,15 @@ __global__ __launch_bounds__(256) void stem_k4s2_fwd_kernel(const float* __restr
 }
 
 bool stem_fwd_eligible(const t2i_conv_desc& d) {
-  return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin == 3 && d.Cout == 128 &&
+  return d.KH == 4 && d.KW == 4 && d.SH == 2 && d.SW == 2 && d.pad_t == 1 && d.pad_l == 1 && d.Cin == 3 && (d.Cout == 128 || d.Cout == 64) &&
          (d.H & 1) == 0 && (d.W & 1) == 0 && d.Ho * 2 == d.H && d.Wo * 2 == d.W;   // fp32 arithmetic in both math modes, like the other thin kernels
 }
 
 hipError_t stem_fwd_launch(const t2i_conv_desc& d, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
                            hipStream_t stream, void* y_h) {
-  size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * 128) * sizeof(float);
+  size_t lds = ((size_t)10 * 66 * 3 + (size_t)48 * d.Cout) * sizeof(float);
   if (lds < (size_t)4 * 32 * 68 * sizeof(float)) lds = (size_t)4 * 32 * 68 * sizeof(float);      // the epilogue's staging patches
-  auto k = stem_k4s2_fwd_kernel<3, 4>;
+  auto k = d.Cout == 128 ? stem_k4s2_fwd_kernel<3, 4> : stem_k4s2_fwd_kernel<3, 2>;              // (the 3 -> 64 first layer of gancls / StackGAN: round 5)
   dim3 grid((d.Wo + 31) / 32, (d.Ho + 3) / 4, d.B);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, x, w, bias, y, d.H, d.W, act, alpha, reinterpret_cast<__bf16*>(y_h));
   return hipGetLastError();
@@ -601,10 +601,11 @@ __global__ __launch_bounds__(256) void tiny_bwdw_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool DYH>           // DYH: dy is a bf16 tensor (bf16 storage): 2-byte buffer loads, widened exactly
+template <bool DYH, int NB = 4>   // DYH: dy is a bf16 tensor (bf16 storage): 2-byte buffer loads, widened exactly; NB = Cout / 32 (4: wgancls, 2: gancls / StackGAN)
 __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __restrict__ x, const void* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Ho, int Wo, int pix_per_wave, FastDiv div_wo, FastDiv div_ho) {
-  extern __shared__ __attribute__((aligned(16))) float red[];     // 2 x [64][128]
+  extern __shared__ __attribute__((aligned(16))) float red[];     // 2 x [64][CO]
+  constexpr int CO = 32 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int P = B * Ho * Wo;                          // < 2^31: 32-bit index arithmetic throughout (a 64-bit divide is ~200 instructions)
@@ -621,11 +622,11 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
     a_kh[blk] = tap >> 2; a_kw[blk] = tap & 3;
     a_off[blk] = (a_kh[blk] * W + a_kw[blk]) * 3 + ci;
   }
-  stem_f32x16 acc[2][4];
+  stem_f32x16 acc[2][NB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -633,9 +634,9 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
   // (the load returns 0), so nothing depends on a load's result until the MFMA that consumes it — a select on the loaded
   // value would put an s_waitcnt behind every load
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((size_t)B * H * W * 3 * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), (short)0, (int)((size_t)P * 128 * (DYH ? 2 : 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), (short)0, (int)((size_t)P * CO * (DYH ? 2 : 4)), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  auto load = [&](int p, float (&a)[2], float (&b)[4]) __attribute__((always_inline)) {
+  auto load = [&](int p, float (&a)[2], float (&b)[NB]) __attribute__((always_inline)) {
     const int pix = p + lh;                           // k = lh
     const bool ok = pix < p_end;
     const int pp = ok ? pix : p_begin;
@@ -651,9 +652,9 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
       a[blk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (unsigned)(xbase + a_off[blk]) * 4u : OOB, 0, 0));
     }
     constexpr unsigned ES = DYH ? 2u : 4u;             // bytes per element of dy
-    const unsigned ybase = ok ? ((unsigned)pp * 128u + (unsigned)l31) * ES : OOB;
+    const unsigned ybase = ok ? ((unsigned)pp * (unsigned)CO + (unsigned)l31) * ES : OOB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
       if (DYH) b[j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ry, ok ? ybase + j * 32u * ES : OOB, 0, 0) << 16);
       else b[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ok ? ybase + j * 32u * ES : OOB, 0, 0));
     }
@@ -661,18 +662,18 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
 
   // 8 pixels (4 MFMA k-steps) per macro step; the 24 loads of the next macro step are issued before this one's 32 MFMAs,
   // so a full memory latency hides behind 2048 MFMA cycles (one wave per SIMD: nobody else would hide it)
-  float a0[4][2], b0[4][4], a1[4][2], b1[4][4];
-  auto load8 = [&](int p, float (&a)[4][2], float (&b)[4][4]) __attribute__((always_inline)) {
+  float a0[4][2], b0[4][NB], a1[4][2], b1[4][NB];
+  auto load8 = [&](int p, float (&a)[4][2], float (&b)[4][NB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) load(p + 2 * s, a[s], b[s]);
   };
-  auto mma8 = [&](float (&a)[4][2], float (&b)[4][4]) __attribute__((always_inline)) {
+  auto mma8 = [&](float (&a)[4][2], float (&b)[4][NB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
   };
   load8(p_begin, a0, b0);                           // pixels beyond p_end load zeros (out-of-range offsets): no branch in the loop
   for (int p = p_begin; p < p_end; p += 16) {
@@ -687,20 +688,20 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 128 + j * 32 + l31] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CO + j * 32 + l31] = acc[i][j][e];
   };
   auto add = [&](const float* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 128 + j * 32 + l31];
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += buf[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CO + j * 32 + l31];
   };
   float* buf0 = red;
-  float* buf1 = red + 64 * 128;
+  float* buf1 = red + 64 * CO;
   if (wave == 2) put(buf0);
   if (wave == 3) put(buf1);
   __syncthreads();
@@ -711,15 +712,15 @@ __global__ __launch_bounds__(256) void stem_k4s2_bwdf_kernel(const float* __rest
   __syncthreads();
   if (wave == 0) {
     add(buf0);
-    float* o = part + (size_t)blockIdx.x * 48 * 128;
+    float* o = part + (size_t)blockIdx.x * 48 * CO;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m < 48) o[m * 128 + j * 32 + l31] = acc[i][j][e];
+          if (m < 48) o[m * CO + j * 32 + l31] = acc[i][j][e];
         }
   }
 }
@@ -737,15 +738,16 @@ static int stem_bwdf_groups(const t2i_conv_desc& d, int* pix_per_wave) {
 
 size_t stem_bwdf_ws(const t2i_conv_desc& d) {
   int ppw;
-  return (size_t)stem_bwdf_groups(d, &ppw) * 48 * 128 * sizeof(float);
+  return (size_t)stem_bwdf_groups(d, &ppw) * 48 * d.Cout * sizeof(float);
 }
 
 hipError_t stem_bwdf_launch(const t2i_conv_desc& d, const float* x, const void* dy, float* dw, int accumulate, void* ws, hipStream_t stream, bool dy_bf16) {
   int ppw;
   const int G = stem_bwdf_groups(d, &ppw);
   float* part = reinterpret_cast<float*>(ws);
-  const size_t lds = (size_t)2 * 64 * 128 * sizeof(float);
-  auto k = dy_bf16 ? stem_k4s2_bwdf_kernel<true> : stem_k4s2_bwdf_kernel<false>;
+  const size_t lds = (size_t)2 * 64 * d.Cout * sizeof(float);
+  auto k = d.Cout == 128 ? (dy_bf16 ? stem_k4s2_bwdf_kernel<true, 4> : stem_k4s2_bwdf_kernel<false, 4>)
+                         : (dy_bf16 ? stem_k4s2_bwdf_kernel<true, 2> : stem_k4s2_bwdf_kernel<false, 2>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   FastDiv dwo, dho;
@@ -753,7 +755,7 @@ hipError_t stem_bwdf_launch(const t2i_conv_desc& d, const float* x, const void* 
   hipLaunchKernelGGL(k, dim3(G), dim3(256), lds, stream, x, dy, part, d.B, d.H, d.W, d.Ho, d.Wo, ppw, dwo, dho);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return splitk_reduce_launch(part, G, (size_t)48 * 128, nullptr, 128, T2I_ACT_NONE, 0.f, dw, accumulate, stream);
+  return splitk_reduce_launch(part, G, (size_t)48 * d.Cout, nullptr, d.Cout, T2I_ACT_NONE, 0.f, dw, accumulate, stream);
 }
 
 bool tiny_bwdw_eligible(const t2i_conv_desc& d) { return d.Cin == 3 && d.Cout == 3 && d.KH <= 3 && d.KW <= 3; }
