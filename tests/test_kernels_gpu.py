@@ -889,7 +889,9 @@ def test_sigmoid_ce_head_matches_float64(K):
 
 
 @pytest.mark.parametrize('shape,groups,act', [((3 * 8, 4, 4, 64), 3, 'lrelu'), ((2 * 16, 8, 8, 128), 2, 'none'), ((3 * 64, 16, 16, 128), 3, 'relu'),
-                                               ((3 * 5, 4, 4, 36), 3, 'lrelu'), ((1 * 7, 2, 2, 8), 1, 'relu')])
+                                               ((3 * 5, 4, 4, 36), 3, 'lrelu'), ((1 * 7, 2, 2, 8), 1, 'relu'), ((64, 4, 4, 1024), 1, 'relu'),
+                                               ((64, 8, 8, 512), 1, 'none'), ((64, 16384), 1, 'relu'), ((3 * 64, 4, 4, 512), 3, 'lrelu'),
+                                               ((2 * 61, 8, 8, 20), 2, 'lrelu')])
 def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
     """t2i_bn_train_fwd_grouped / t2i_bn_bwd_grouped (a stacked batch: per-group statistics, three launches for all groups) against the
     ordinary training-mode batch norm applied to each group's slice in turn — what `groups` sequential critic passes of the reference do
@@ -945,6 +947,11 @@ def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
         K.tuning_set('bn_fuse', 1)
     assert close(y, y3) and close(mean, mean3) and close(rstd, rstd3) and close(mm, mm3) and close(mv, mv3)
     assert close(dx, dx3, 5e-6) and close(dg, dg3, 5e-6) and close(db, db3, 5e-6)
+    # float64 reference of the statistics and the output
+    xd = x.double().reshape(groups, -1, C)
+    mu = xd.mean(1)
+    var = xd.var(1, unbiased=False)
+    assert close(mean, mu.float(), 2e-6) and close(rstd, (1.0 / torch.sqrt(var + 1e-5)).float(), 5e-6)
 
 
 @pytest.mark.parametrize('shape', [(6, 16, 16, 128, 256), (3, 8, 8, 256, 512), (2, 32, 32, 128, 128), (5, 12, 20, 160, 96)])
