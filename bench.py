@@ -199,6 +199,8 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
     # never met a real ring; if it alone is exceeded the line carries ok = false and the numbers, and the timing goes ahead.
     finite = all(bool(torch.isfinite(torch.as_tensor(t)).all()) for t in many)
     fatal = (not finite) or (not report['exact'] if want_exact else worst > 4 * 2.0 * 1.001)
+    if os.environ.get('T2I_PREFLIGHT') == 'strict':          # every bound stops the run, the statistical one included
+        fatal = fatal or not ok
     report['fatal'] = bool(fatal)
     flag = torch.tensor([1 if fatal else 0, 0 if ok else 1], device=device)
     torch.distributed.all_reduce(flag)
@@ -389,6 +391,9 @@ def run_config(args, math, device, rank, local_rank, world, use_dp, make_dp, hea
                       'gpu_busy_s': sum(regions), 'ms_per_step_by_region': [r / args.steps * 1e3 for r in regions]}}
     if preflight is not None:
         out['dp_preflight'] = preflight
+        # top level, beside `value`: a reader of the line (or of its exit status, below) cannot miss a run that was timed although
+        # the statistical part of the N > 2 fp32 bound was exceeded (T2I_PREFLIGHT=strict makes that fatal instead)
+        out['dp_preflight_ok'] = bool(preflight.get('ok'))
     if exchange is not None:
         # rccl_ranks: how many ranks an all-reduce of ones over the communicator counted (== n_gpus or the line is not an N-GPU line)
         out['rccl_ranks'] = exchange['ranks_counted_by_all_reduce']

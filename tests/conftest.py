@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """tests/test_step_b64_gpu.py: the all-bf16 side-row arithmetic is reported (bench.py) at B = 64 only, so its parity case exists
+    at B = 64 only — the B = 16 / B = 8 instances of the module-wide `setup` parametrisation are taken out of the collection
+    (deselected, not skipped: a skip would read as a case that ought to run)."""
+    drop = [it for it in items if it.name.startswith('test_b64_all_bf16_side_rows_mask_pinned[') and 'B64' not in it.name]
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = [it for it in items if it not in drop]
+
+
 @pytest.fixture(scope='session')
 def golden_ops():
     import numpy as np

@@ -39,7 +39,10 @@ def _worker(rank, world, port, mode, q):
         params = OrderedDict(('p%d' % i, torch.randn(s).requires_grad_(True)) for i, s in enumerate(shapes))
         arena = optim.Arena(params)
         # 'bf16': buckets are exchanged as bf16 and written back into the fp32 arena (BASELINE config 3)
-        dp = DataParallel(bucket_bytes=400, grad_dtype='bf16' if mode == 'bf16' else 'f32')        # tiny buckets -> several of them, exercised in reverse order
+        # 'rs_ag': the fp32 arena through the explicit reduce-scatter + all-gather form instead of the library all-reduce
+        dp = DataParallel(bucket_bytes=400, grad_dtype='bf16' if mode == 'bf16' else 'f32',        # tiny buckets -> several of them, exercised in reverse order
+                          f32_exchange='rs_ag' if mode == 'rs_ag' else 'allreduce')
+        assert dp.f32_exchange == ('rs_ag' if mode == 'rs_ag' else 'allreduce')
         plan = dp._plan(arena)
         # buckets tile the arena exactly once, last-created parameters first
         covered = sorted((s, e) for s, e, _ in plan)
@@ -86,7 +89,7 @@ def _worker(rank, world, port, mode, q):
             q.put((rank, 'ok'))
             return
         arena.zero_grad()
-        if mode in ('hooks', 'unused', 'bf16'):
+        if mode in ('hooks', 'unused', 'bf16', 'rs_ag'):
             dp.arm(arena)                           # overlap path: hooks launch buckets as they complete
         loss_fn().backward(inputs=list(params.values()))
         extra = torch.tensor(float(rank + 1))
@@ -104,6 +107,8 @@ def _worker(rank, world, port, mode, q):
                 want = sum(g[n].bfloat16().float() for g in gathered).bfloat16().float()      # bit for bit, on every rank
                 assert torch.equal(arena.grad_of(n), want), (n, (arena.grad_of(n) - want).abs().max())
                 assert arena.grad_of(n).dtype == torch.float32
+            elif mode == 'rs_ag':  # two ranks: a + b in either order is the same float — bit for bit what the all-reduce leaves
+                assert torch.equal(arena.grad_of(n), gathered[0][n] + gathered[1][n]), n
             else:
                 assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n
             assert params[n].grad.data_ptr() == arena.grad_of(n).data_ptr()     # still views of the arena
@@ -225,7 +230,7 @@ def _sinks_mode(dp, arena, params, data, rank, world):
     A.SINKS.clear()
 
 
-@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd', 'kt', 'bf16'])
+@pytest.mark.parametrize('mode', ['hooks', 'plain', 'unused', 'sinks', 'sinks_autograd', 'kt', 'bf16', 'rs_ag'])
 def test_dp_allreduce_two_ranks(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -79,7 +79,20 @@ def gpu():
     return torch.device('cuda')
 
 
-def test_stackgan_stage2_full_size(gpu):
+def _rel_l2(got, ref):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().double().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+# Measured envelope of the ALL-bf16 arithmetic on Stage-II at full width, batch 2 (relative L2 per tensor against the mask-pinned float64
+# oracle; MI355X, round 6) — what bench.py's `next_rows[stackgan_stage2, bf16]` row runs.  NOT a 2e-2 claim: ~60 conv + batch-norm
+# layers in series with statistics over two samples amplify the 2^-8 operand rounding far beyond it; the bounds below are ~1.5x the
+# measured values (printed by the test) and exist so that the row's arithmetic cannot get worse silently.
+STAGE2_BF16_ENVELOPE = dict(loss=1.0, image=1.0, d_grad=2.0, g_grad=2.0, flips=0.5)
+
+
+def _stage2_full_size(gpu, bf16):
     from oracle import torch_stackgan as SG, torch_step as T
     from t2i_amd.models.stackgan.stageI.model import ConditionalGan as StageI
     from t2i_amd.models.stackgan.stageII.model import ConditionalGan as StageII
@@ -105,6 +118,19 @@ def test_stackgan_stage2_full_size(gpu):
     else:
         plan = plan_g = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
     chk = Checker()
+    env = STAGE2_BF16_ENVELOPE
+    flip_tol = env['flips'] if bf16 else 1e-4
+
+    def grads(arena, names, ref, tol):
+        if not bf16:
+            return chk.grads(arena, names, ref, tol)
+        worst = []
+        for n in names:                         # relative L2 per tensor (the yardstick of the config-3 test), exact-zero tensors skipped
+            if float(ref[n].abs().max()) >= 1e-9:
+                worst.append((_rel_l2(arena.grad_of(n), ref[n]), n))
+        worst.sort()
+        print('  bf16 gradients, relative L2: median %.3e, worst %.3e (%s)' % (worst[len(worst) // 2][0], worst[-1][0], worst[-1][1]))
+        chk('worst gradient (relative L2)', worst[-1][0], tol)
     # ---- critic step
     rec = []
     with record_branches(rec):
@@ -116,13 +142,17 @@ def test_stackgan_stage2_full_size(gpu):
     masks = split_sections(rec, own.record, plan)
     fl, units = flips(own.record, masks)
     print('Stage-II critic step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
-    assert fl <= 1e-4 * units
+    assert fl <= flip_tol * units
     with T.use_tape(T.SectionTape(masks)):
         ref = SG.d_step(P, o2, feed, 2, o1)
     for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
-        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), 1e-4)
-    chk('G (256x256 image, tanh output)', relerr(d['G'], ref['G'], scale=1.0), 2e-4)
-    chk.grads(m.d_arena, m.d_vars, ref['grads'], 2e-4)
+        chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), env['loss'] if bf16 else 1e-4)
+    if bf16:
+        assert _rel_l2(d['G'], ref['G']) > 1e-4, 'reduced precision is not in use'
+        chk('G (256x256 image, relative L2)', _rel_l2(d['G'], ref['G']), env['image'])
+    else:
+        chk('G (256x256 image, tanh output)', relerr(d['G'], ref['G'], scale=1.0), 2e-4)
+    grads(m.d_arena, m.d_vars, ref['grads'], env['d_grad'] if bf16 else 2e-4)
     with torch.no_grad():                      # undo the moving-average side effect of the probe pass
         for n, v in moving0.items():
             m.store.vars[n].copy_(v)
@@ -137,13 +167,31 @@ def test_stackgan_stage2_full_size(gpu):
     masks = split_sections(rec, own.record, plan_g)
     fl, units = flips(own.record, masks)
     print('Stage-II generator step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
-    assert fl <= 1e-4 * units
+    assert fl <= flip_tol * units
     with T.use_tape(T.SectionTape(masks)):
         gref = SG.g_step(P, o2, feed, 2, o1)
     for k in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
-        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 1e-4)
-    chk.grads(m.g_arena, m.g_vars, gref['grads'], 2e-4)
+        chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), env['loss'] if bf16 else 1e-4)
+    grads(m.g_arena, m.g_vars, gref['grads'], env['g_grad'] if bf16 else 2e-4)
     assert not chk.bad, chk.bad
+
+
+def test_stackgan_stage2_full_size(gpu):
+    _stage2_full_size(gpu, bf16=False)
+
+
+def test_stackgan_stage2_all_bf16_envelope(gpu):
+    """The arithmetic of bench.py's `next_rows[stackgan_stage2, bf16]` row — set_math('bf16') with float32 activation tensors (bf16 operand
+    images), every GEMM of all three networks — on the same full-width Stage-II step, mask-pinned.  NOT a 2e-2 claim (the row says so):
+    the measured envelope, asserted (STAGE2_BF16_ENVELOPE)."""
+    from t2i_amd import kernels as K
+    K.set_math('bf16')
+    try:
+        _stage2_full_size(gpu, bf16=True)
+    finally:
+        K.set_storage('f32')
+        K.set_math('f32')
+        K.filter_cache_reset()
 
 
 @pytest.mark.parametrize('stage,trans,B', [(1, False, 16), (2, True, 16), (2, False, 16), (3, True, 16), (3, False, 8), (4, True, 8), (4, False, 8),

@@ -57,6 +57,30 @@ def test_descriptor_validation_without_gpu(t2i):
         assert b'2^30' in _lib.lib.t2i_last_error() or b'inconsistent' in _lib.lib.t2i_last_error()
 
 
+def test_grouped_batch_norm_refuses_bad_tile_partials_and_counts(t2i):
+    """t2i_bn_train_fwd_grouped / t2i_bn_bwd_grouped argument checks: an over-long tile_chunks (its last tiles would start
+    beyond the group: n <= 0 in the merge, inf / NaN into the moving averages), a moving_updates outside [1, 8] (a device loop count)
+    and element counts beyond the kernels' 32-bit offsets are refused BEFORE any launch — so this runs without a GPU, on fake
+    (non-null, 16-byte aligned) addresses that are never dereferenced."""
+    import ctypes
+    from t2i_amd import _lib
+    L = _lib.lib
+    P = lambda k: ctypes.c_void_p(0x10000 + 64 * k)
+    ws_n = max(int(L.t2i_bn_grouped_workspace_bytes(256, 64, 2)), 1 << 16)
+
+    def fwd(rows=256, C=64, groups=2, tile_chunks=4, tile_rows=64, moving_updates=1, tiles=True):
+        return L.t2i_bn_train_fwd_grouped(P(1), rows, C, groups, P(2), P(3), 1e-5, 0.9, P(4), P(5), P(6), P(7), P(8), P(9), 0, 0.2, P(10), None,
+                                          P(11) if tiles else None, P(12) if tiles else None, tile_chunks, tile_rows, moving_updates, P(13), ws_n, 0, None)
+    assert fwd(tile_chunks=5) == -1 and b'tile partials' in L.t2i_last_error()       # 5 tiles of 64 rows for 256 rows
+    assert fwd(tile_chunks=3) == -1                                                  # too few
+    assert fwd(moving_updates=0) == -1 and b'moving_updates' in L.t2i_last_error()
+    assert fwd(moving_updates=9) == -1
+    assert fwd(rows=1 << 28, C=64, groups=1, tiles=False) == -1 and b'2^30' in L.t2i_last_error()
+    assert fwd(rows=1 << 20, C=64, groups=32, tiles=False) == -1 and b'2^30' in L.t2i_last_error()
+    rc = L.t2i_bn_bwd_grouped(P(1), None, P(2), P(3), P(4), P(5), 1 << 28, 64, 1, 0, 0.2, None, P(6), None, P(7), P(8), 0, P(9), ws_n, 0, None)
+    assert rc == -1 and b'2^30' in L.t2i_last_error()
+
+
 @pytest.mark.skipif(os.environ.get('T2I_TEST_SANITIZE') != '1', reason='two minutes of hipcc: run with T2I_TEST_SANITIZE=1 (output of the last run: profiles/r05_sanitize_host.txt)')
 def test_host_side_under_asan_ubsan():
     """tools/sanitize_host.sh: the C ABI's host code built with AddressSanitizer + UndefinedBehaviorSanitizer and swept by

@@ -216,37 +216,37 @@ def test_b64_generator_step_mask_pinned(setup):
 CONFIG3 = 'config3'          # BASELINE configs[2] as benchmarked: the compliant per-network arithmetic (kernels.CONFIG3_NET_MATH)
 
 
-@pytest.mark.parametrize('mode', [CONFIG3, 'all_bf16_f32_tensors', 'all_bf16'])
-def test_b64_bf16_steps_mask_pinned(setup, mode):
-    """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate, master weights in fp32) at the metric's own size,
-    mask-pinned like the fp32 tests above.
+def _rel_l2(got, ref):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().double().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
 
-    mode 'config3' — THE parity claim of config 3 (BASELINE.md section 3 / SURVEY 8(c): relative error <= 2e-2 against the fp32
-    oracle).  Every bound below is 2e-2, none widened: G, D(x_hat), grad_x_hat, every loss scalar, every critic-step gradient and
-    every generator-step gradient.  The arithmetic that meets it (profiles/r05_config3_error_table.txt): the critic — 17 of the iteration's
-    21 network passes — in bf16 math on bf16 tensors; the generator's input- and filter-gradient GEMMs in bf16 math; the generator's
-    FORWARD GEMMs in fp32 math on fp32 tensors.  Why the forward: the backward is linear in the upstream gradient, so its operand
-    roundings add up once (1e-3..2e-3 per layer), while a forward error of 2e-2 in G re-enters through every nonlinear term of the
-    backward (tanh' = 1 - G^2 at |logits| up to 59, the batch norms' 1/sigma and x_hat, the filter gradients' x operand) and
-    through x_hat into the second critic pass — with all 24 layers of the generator step in bf16 the gradients were 5.7e-2 (median)
-    and D(x_hat) 3.8e-2 off.  Measured in this mode: G 3.5e-6, D(x_hat) 1.24e-2, grad_x_hat 6.6e-3, critic-step gradients <= 1.49e-2,
-    generator-step gradients <= 1.04e-2 (median 8.4e-3), loss scalars <= 7e-3.
 
-    modes 'all_bf16_f32_tensors' / 'all_bf16' — NOT config 3's parity claim: every GEMM of both networks in bf16 math (fp32 activation
-    tensors with bf16 operand images / bf16 activation tensors end to end).  Kept as kernel coverage of the generator's bf16 forward
-    path at full width and reported as a labelled side row by bench.py; their bounds are the measured envelope of that arithmetic and
-    exceed 2e-2 where stated: G <= 2e-2 / 2.5e-2 [1.8e-2 / 2.15e-2]; D(x_hat) <= 5e-2 [3.6e-2 / 4.1e-2]; loss scalars, grad_x_hat and
-    critic-step gradients <= 2e-2 [<= 1.5e-2]; generator-step gradients <= 1.2e-1 [<= 1.07e-1, median 5.7e-2].
-    For comparison the un-pinned bf16 check (tests/test_step_gpu.py) can only ask for a cosine >= 0.95."""
+def _oracle_own_branches(T, ocfg, P, feed, which):
+    """The float64 oracle's OWN activation branches for the passes `which` names (an un-pinned run): what mask pinning replaces."""
+    own = {k: T.MaskTape() for k in which}
+    with torch.no_grad():
+        noise = feed['ca_noise_d'] if 'Dxh' in which else feed['ca_noise_g']
+        G, _, _ = T.generator(P, ocfg, feed['z'], feed['cond'], noise, train=True, tape=own['G'])
+        T.discriminator(P, ocfg, G, feed['cond'], own['Dg'])
+        if 'Dxh' in which:
+            T.discriminator(P, ocfg, feed['x'], feed['cond'], own['Dx'])
+            T.discriminator(P, ocfg, feed['x_mismatch'], feed['cond'], own['Dxmi'])
+            T.discriminator(P, ocfg, feed['eps'] * G + (1.0 - feed['eps']) * feed['x'], feed['cond'], own['Dxh'])
+    return {k: t.record for k, t in own.items()}
+
+
+# Units whose branch the pinning replaces, as a fraction of all units of the step (bf16 rounding of ~4e-3 per pre-activation moves the
+# units that lie that close to their kink).  Measured on MI355X in the compliant arithmetic: see the values printed by the test; the
+# bound is asserted so that the pinning cannot grow into hiding a wrong forward.
+CONFIG3_FLIP_BOUND = 1.0e-2
+
+
+def _bf16_steps(setup, mode):
+    """Shared body of the bf16 parity tests: returns nothing, asserts everything (see the two tests below)."""
     T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
-    if B != 64:
-        pytest.skip('config 3 is quoted at B = 64')
     from t2i_amd import kernels as K
-
-    def rel_l2(got, ref):
-        got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
-        ref = ref.detach().double().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
-        return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+    rel_l2 = _rel_l2
     bad = []
 
     def chk(name, err, tol):
@@ -271,6 +271,21 @@ def test_b64_bf16_steps_mask_pinned(setup, mode):
         assert rel_l2(d['grad_x_hat'], ref['grad_x_hat']) > 1e-4, 'reduced precision is not in use'
         if compliant:
             assert d['G'].dtype == torch.float32 and rel_l2(d['G'], ref['G']) < 1e-4, 'the generator forward is meant to be exact here'
+            # ---- what does the pinning touch?  (fraction of units whose branch differs from the float64 oracle's own)
+            own = _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh'))
+            flips, units = _flip_fraction(own, masks)
+            per_pass = {k: _flip_fraction({k: own[k]}, masks) for k in own}
+            print('config 3, critic step (B=%d): %d of %d activation branches differ between the bf16 HIP run and float64 (%.3e); per pass: %s' % (
+                B, flips, units, flips / units, {k: '%.2e' % (a / max(b, 1)) for k, (a, b) in per_pass.items()}))
+            assert flips <= CONFIG3_FLIP_BOUND * units, (flips, units)
+            assert per_pass['G'][0] <= 1e-4 * per_pass['G'][1], 'the generator forward is fp32: its branches must be the fp32 tests\' handful'
+            # ---- UN-pinned forward check: forward values and loss scalars are continuous across the kinks, so they are held to the
+            # same 2e-2 against the FREE float64 oracle (no branch replayed)
+            free = T.d_step(P, ocfg, feed, 0.7)
+            chk('un-pinned G', rel_l2(d['G'], free['G']), 2e-2)
+            chk('un-pinned D(x_hat)', rel_l2(d['Dx_hat_logit'], free['Dx_hat']), 2e-2)
+            for k in ('D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'D_loss'):
+                chk('un-pinned ' + k, abs(float(d[k]) - free[k]) / max(abs(free[k]), 1.0), 2e-2)
         chk('G', rel_l2(d['G'], ref['G']), g_tol)
         chk('D(x_hat)', rel_l2(d['Dx_hat_logit'], ref['Dx_hat']), dxh_tol)
         for k, tol in (('D_loss_real', 2e-2), ('D_loss_fake', 2e-2), ('D_loss_mismatch', 2e-2), ('wdist', 2e-2), ('wdist2', 2e-2),
@@ -290,7 +305,17 @@ def test_b64_bf16_steps_mask_pinned(setup, mode):
             g = m.g_losses(f)
             torch.cuda.synchronize()
         rec = [_to_oracle_layout(x) for x in rec]
-        gref = T.g_step(P, ocfg, feed, masks={'G': rec[:N_G], 'Dg': rec[N_G:]})
+        gmasks = {'G': rec[:N_G], 'Dg': rec[N_G:]}
+        gref = T.g_step(P, ocfg, feed, masks=gmasks)
+        if compliant:
+            own = _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg'))
+            flips, units = _flip_fraction(own, gmasks)
+            print('config 3, generator step (B=%d): %d of %d activation branches differ (%.3e)' % (B, flips, units, flips / units))
+            assert flips <= CONFIG3_FLIP_BOUND * units, (flips, units)
+            gfree = T.g_step(P, ocfg, feed)
+            chk('un-pinned G (generator step)', rel_l2(g['G'], gfree['G']), 2e-2)
+            for k in ('G_loss', 'G_kl_loss', 'D_loss_fake'):
+                chk('un-pinned ' + k, abs(float(g[k]) - gfree[k]) / max(abs(gfree[k]), 1.0), 2e-2)
         chk('G (generator step)', rel_l2(g['G'], gref['G']), g_tol)
         for k in ('G_loss', 'G_kl_loss', 'D_loss_fake'):
             chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), 2e-2)
@@ -304,3 +329,37 @@ def test_b64_bf16_steps_mask_pinned(setup, mode):
         K.set_storage('f32')
         K.set_math('f32')
     assert not bad, bad
+
+
+def test_config3_bf16_steps_mask_pinned(setup):
+    """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate, master weights in fp32), mask-pinned like the fp32 tests
+    above — THE parity claim of config 3 (BASELINE.md section 3 / SURVEY 8(c): relative error <= 2e-2 against the fp32 oracle), at
+    every batch size a reported bf16 number runs at: B = 64 (the config), B = 16, and B = 8 (bench.py's b8_per_gpu.bf16 row).
+    Every bound is 2e-2, none widened: G, D(x_hat), grad_x_hat, every loss scalar, every critic-step gradient and every
+    generator-step gradient.  The arithmetic that meets it (profiles/r05_config3_error_table.txt): the critic — 17 of
+    the iteration's 21 network passes — in bf16 math on bf16 tensors; the generator's input- and filter-gradient GEMMs in bf16 math;
+    the generator's FORWARD GEMMs in fp32 math on fp32 tensors.  Why the forward: the backward is linear in the upstream gradient, so
+    its operand roundings add up once (1e-3..2e-3 per layer), while a forward error of 2e-2 in G re-enters through every nonlinear
+    term of the backward (tanh' = 1 - G^2 at |logits| up to 59, the batch norms' 1/sigma and x_hat, the filter gradients' x operand)
+    and through x_hat into the second critic pass — with all 24 layers of the generator step in bf16 the gradients were 5.7e-2
+    (median) and D(x_hat) 3.8e-2 off.  Measured at B = 64: G 3.5e-6, D(x_hat) 1.24e-2, grad_x_hat 6.6e-3, critic-step gradients
+    <= 1.49e-2, generator-step gradients <= 1.04e-2 (median 8.4e-3), loss scalars <= 7e-3.
+
+    Round 6: the test also (i) counts the units whose branch the pinning replaces against the float64 oracle's
+    own branches and asserts a bound on their fraction (CONFIG3_FLIP_BOUND; the generator's forward, being fp32, must show the fp32
+    tests' handful), and (ii) holds every FORWARD quantity — G, D(x_hat), every loss scalar of both steps — to the same 2e-2 against
+    the UN-pinned oracle: forward values are continuous across the kinks, so they need no pinning."""
+    _bf16_steps(setup, CONFIG3)
+
+
+@pytest.mark.parametrize('mode', ['all_bf16_f32_tensors', 'all_bf16'])
+def test_b64_all_bf16_side_rows_mask_pinned(setup, mode):
+    """NOT config 3's parity claim: every GEMM of both networks in bf16 math (fp32 activation tensors with bf16 operand images / bf16
+    activation tensors end to end).  Kept as kernel coverage of the generator's bf16 forward path at full width and reported as a
+    labelled side row by bench.py (config3_bf16.all_bf16_side_row); the bounds are the measured envelope of that arithmetic and
+    exceed 2e-2 where stated: G <= 2e-2 / 2.5e-2 [1.8e-2 / 2.15e-2]; D(x_hat) <= 5e-2 [3.6e-2 / 4.1e-2]; loss scalars, grad_x_hat and
+    critic-step gradients <= 2e-2 [<= 1.5e-2]; generator-step gradients <= 1.2e-1 [<= 1.07e-1, median 5.7e-2].  Runs at B = 64 only
+    (the only batch size at which a number in this arithmetic is reported); the other batch sizes are not collected for it
+    (conftest.pytest_collection_modifyitems), so nothing is skipped."""
+    assert setup['B'] == 64
+    _bf16_steps(setup, mode)

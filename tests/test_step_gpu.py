@@ -323,14 +323,17 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step, n_critic):
             assert torch.equal(plain[0][n], other[0][n]), n
 
 
-def test_bf16_math_step_within_config3_tolerance(gpu, golden_step):
-    """BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulation, fp32 tensors and master weights) on the
-    tiny golden step against the float64 oracle.  Stated tolerances (measured values in brackets):
+def test_all_bf16_math_tiny_step_unpinned_envelope(gpu, golden_step):
+    """KERNEL COVERAGE, not config 3's parity claim.  The ALL-bf16 arithmetic (every GEMM of both networks with bf16 MFMA operands,
+    fp32 accumulation, fp32 tensors and master weights; no per-network scope) on the tiny golden step against the UN-pinned float64
+    oracle — config 3's own arithmetic (kernels.CONFIG3_NET_MATH) and its 2e-2 claim are tests/test_step_b64_gpu.py::
+    test_config3_bf16_steps_mask_pinned, at full width, B = 64 / 16 / 8.  Bounds here are the measured envelope of this arithmetic
+    on an 8-channel model (measured values in brackets), two of them above 2e-2 and stated as such:
       * forward tensors (G, D(x_hat)): relative L2 <= 2e-2 [1.2e-2, 9.7e-3] — 2^-8 per product, ~sqrt(12 layers);
       * Wasserstein scalars: <= 2e-2 of max(|ref|, 1) [<= 6.5e-3]; the penalty terms 100*(slope-1)^2 and hence D_loss
-        amplify the slope error: <= 5e-2 [3.1e-2];
+        amplify the slope error: <= 5e-2 [3.1e-2] (ABOVE config 3's 2e-2: an 8-channel critic averages nothing);
       * gradients: cosine to the oracle's >= 0.95 [0.984 critic, 0.971 generator].  A per-element bound is not
-        meaningful: a 1e-2 forward perturbation flips ~0.4% of the lrelu masks per layer and each flip changes that
+        meaningful un-pinned: a 1e-2 forward perturbation flips ~0.4% of the lrelu masks per layer and each flip changes that
         unit's gradient by 80%, i.e. ~17% relative L2 over 12 layers — the same model property that makes
         test_full_width_step_vs_cpu_oracle use kink-robust criteria at fp32.
     The arithmetic itself is pinned to 1e-5 by test_every_tile_and_split_config[bf16] (oracle on bf16-rounded operands)."""

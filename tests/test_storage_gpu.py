@@ -7,7 +7,7 @@ That holds for the bf16-operand GEMMs too (a bf16 tensor is its own operand imag
 those of the fp32-tensor call) and for the paths that run on fp32 staging copies (thin / head kernels).
 
 Step level — the wgancls B = 64 iteration with bf16 tensors end to end against the float64 oracle, mask-pinned like
-tests/test_step_b64_gpu.py::test_b64_bf16_steps_mask_pinned, with its own stated tolerances; and hipGraph replay == eager."""
+tests/test_step_b64_gpu.py::test_config3_bf16_steps_mask_pinned (and the all-bf16 side rows beside it), with their own stated tolerances; and hipGraph replay == eager."""
 import os
 
 import numpy as np

@@ -444,7 +444,8 @@ class BatchNormTrainGroupedFn(Function):
     statistics, normalisation and backward per slice, while every convolution around it runs once on the whole batch.  Moving averages
     move once per slice, in slice order (what three sequential passes did); dgamma / dbeta are summed over the slices.  Three launches
     forward, three backward for all slices (t2i_bn_train_fwd_grouped / t2i_bn_bwd_grouped; C % 4 == 0 and 16-byte alignment — otherwise
-    the slices go through the ordinary kernels one by one).  First order only."""
+    the slices go through the ordinary kernels one by one, forward AND backward: tests/test_kernels_gpu.py::
+    test_grouped_batch_norm_odd_channels).  First order only."""
 
     @staticmethod
     def _fast(x, groups):
@@ -494,14 +495,23 @@ class BatchNormTrainGroupedFn(Function):
         else:
             if ctx.fast:                 # per-group views of the [groups, C] statistics
                 stats = [t[g] for g in range(groups) for t in (stats[0], stats[1])]
-            if not (gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x)) and (x[:b].numel() * x.element_size()) % 16 == 0):
-                raise NotImplementedError('grouped batch norm needs C % 4 == 0 and 16-byte aligned slices')
+            vec = gy.shape[-1] % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, x)) and (x[:b].numel() * x.element_size()) % 16 == 0
             dx = torch.empty_like(x)
             dgamma = dbeta = None
             for g in range(groups):
                 sl = slice(g * b, (g + 1) * b)
-                _, dg, db = K.bn_bwd_fused(gy[sl], y[sl] if ctx.act != K.ACT_NONE else None, x[sl], stats[2 * g], stats[2 * g + 1], gamma, ctx.act,
-                                           ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None, out=dx[sl])
+                if vec:
+                    _, dg, db = K.bn_bwd_fused(gy[sl], y[sl] if ctx.act != K.ACT_NONE else None, x[sl], stats[2 * g], stats[2 * g + 1], gamma, ctx.act,
+                                               ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None, out=dx[sl])
+                else:
+                    # a channel count that is not a multiple of 4 (an odd DF_DIM), or unaligned slices: the scalar kernels, slice by slice
+                    # — activation backward, the two column reductions about the slice's mean, then the batch-norm backward itself
+                    gs = K.act_bwd(_c(gy[sl]), _c(y[sl]), ctx.act, ctx.alpha) if ctx.act != K.ACT_NONE else _c(gy[sl])
+                    xs = _c(x[sl])
+                    sum_dy, sum_dy_x = K.col_reduce(gs, xs, True, center=stats[2 * g])
+                    dxs, dg, db = K.bn_bwd(gs, xs, stats[2 * g], stats[2 * g + 1], gamma, sum_dy, sum_dy_x,
+                                           dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
+                    dx[sl].copy_(dxs)
                 if not sunk:
                     dgamma = dg if dgamma is None else dgamma + dg
                     dbeta = db if dbeta is None else dbeta + db

@@ -1245,10 +1245,24 @@ int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, i
                              float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
                              float alpha, void* y, void* y_h, const float* tile_sum, const float* tile_m2, int32_t tile_chunks, int32_t tile_rows,
                              int32_t moving_updates, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+  // the partials of a group are tile_chunks tiles of tile_rows rows, the last one possibly short: every tile must START inside the group
+  // (an over-long tile_chunks would give the merge a tile of <= 0 rows: 1/n = inf, NaN statistics written into the moving averages)
   if (tile_sum && (!tile_m2 || tile_chunks <= 0 || tile_rows <= 0 || (int64_t)tile_chunks * tile_rows < rows_per_group ||
+                   (int64_t)(tile_chunks - 1) * tile_rows >= rows_per_group ||
                    (groups > 1 && rows_per_group % tile_rows != 0) || !aligned16(tile_sum) || !aligned16(tile_m2))) {
-    set_error("t2i_bn_train_fwd_grouped: bad tile partials (tile_chunks tiles of tile_rows rows per group; with groups > 1 a tile must not straddle groups)");
+    set_error("t2i_bn_train_fwd_grouped: bad tile partials (exactly ceil(rows_per_group / tile_rows) tiles of tile_rows rows per group; with groups > 1 a tile must not straddle groups)");
     return T2I_ERR_INVALID;
+  }
+  if (moving_updates < 1 || moving_updates > 8) {       // a device-side loop count: bounded (the trainers use 1 or 2)
+    set_error("t2i_bn_train_fwd_grouped: moving_updates must be in [1, 8]");
+    return T2I_ERR_INVALID;
+  }
+  if (rows_per_group > 0 && C > 0 && groups > 0) {       // element count against the 2^30 limit the conv descriptors enforce (32-bit offsets in the kernels)
+    const int64_t lim = ((int64_t)1 << 30) - 16;
+    if (rows_per_group > lim / C || rows_per_group * C > lim / groups) {
+      set_error("t2i_bn_train_fwd_grouped: rows_per_group * groups * C exceeds 2^30 - 16 elements");
+      return T2I_ERR_INVALID;
+    }
   }
   if (!x || !gamma || !beta || !mean || !rstd || !scale || !shift || !y || rows_per_group <= 0 || C <= 0 || (C & 3) || groups <= 0 ||
       ((moving_mean == nullptr) != (moving_var == nullptr))) {
@@ -1273,6 +1287,13 @@ int t2i_bn_bwd_grouped(const void* dy, const void* y, const void* x, const float
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || rows_per_group <= 0 || C <= 0 || (C & 3) || groups <= 0 || (y && !gmask)) {
     set_error("t2i_bn_bwd_grouped: bad argument (C %% 4 == 0 required; gmask needed with an activation)");
     return T2I_ERR_INVALID;
+  }
+  {
+    const int64_t lim = ((int64_t)1 << 30) - 16;
+    if (rows_per_group > lim / C || rows_per_group * C > lim / groups) {
+      set_error("t2i_bn_bwd_grouped: rows_per_group * groups * C exceeds 2^30 - 16 elements");
+      return T2I_ERR_INVALID;
+    }
   }
   if (!(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(mean) && aligned16(dx_h) && (!y || (aligned16(y) && aligned16(gmask))))) {
     set_error("t2i_bn_bwd_grouped: tensors must be 16-byte aligned");

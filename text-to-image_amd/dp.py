@@ -25,10 +25,20 @@ import os
 import torch
 import torch.distributed as dist
 
+from .utils import roctx as _roctx
+
 
 class DataParallel(object):
-    def __init__(self, bucket_bytes=32 << 20, process_group=None, grad_dtype='f32'):
-        """grad_dtype: 'f32' (exchange the fp32 arena in place) or 'bf16' (BASELINE config 3: bf16 on the wire — half the bytes
+    def __init__(self, bucket_bytes=32 << 20, process_group=None, grad_dtype='f32', f32_exchange=None):
+        """f32_exchange (grad_dtype 'f32' only): 'allreduce' (default) = one library all-reduce per bucket, whatever algorithm RCCL
+        picks (a ring is per-link bound: SURVEY section 5 prices the 116 MB critic arena at ~1.33 ms on 8 GPUs); 'rs_ag' = the
+        explicit reduce-scatter + all-gather over the same bucket, in place (every rank reduces ONE chunk with all of its 7 links
+        busy, then the chunks are gathered: ~0.19 ms by the same arithmetic) — the fp32 mirror of _exchange_bf16.  Selected by the
+        argument or T2I_DP_F32_EXCHANGE=rs_ag, so that an 8-GPU run can measure one against the other (bench.py reports which
+        ran in `gradient_exchange.f32_exchange`).  Each chunk's sum is formed by ONE rank and gathered, so all ranks leave with the
+        same bits, as with the library all-reduce; the summation ORDER may differ from the library's, so for N > 2 the two
+        forms agree to rounding, not bit for bit (N = 2: a + b is commutative, bit-identical — tests/test_dp_gloo.py[rs_ag]).
+        grad_dtype: 'f32' (exchange the fp32 arena in place) or 'bf16' (BASELINE config 3: bf16 on the wire — half the bytes
         on every xGMI link — with the SUM taken in fp32: a bucket is rounded to bf16 once (RNE), the ranks exchange chunks
         (all-to-all: rank j receives everybody's j-th chunk), each sums the N chunks it received in fp32, rounds that sum to
         bf16 once and the sums are all-gathered; the fp32 arena receives the result.  A ring all-reduce in bf16 would round the
@@ -47,6 +57,10 @@ class DataParallel(object):
         if grad_dtype not in ('f32', 'bf16'):
             raise ValueError("grad_dtype must be 'f32' or 'bf16', got %r" % (grad_dtype,))
         self.grad_dtype = grad_dtype
+        f32_exchange = f32_exchange or os.environ.get('T2I_DP_F32_EXCHANGE', 'allreduce')
+        if f32_exchange not in ('allreduce', 'rs_ag'):
+            raise ValueError("f32_exchange must be 'allreduce' or 'rs_ag', got %r" % (f32_exchange,))
+        self.f32_exchange = f32_exchange
         self._stage = {}                      # id(arena) -> (send, recv, [offset]) bf16 staging buffers
         # bf16 buckets: all-to-all + all-gather (RCCL) or the all-gather-everything fallback (gloo, test transports).  Decided
         # ONCE per device type from the backend's name — never by catching an exception around a collective: an OOM or a transient
@@ -76,7 +90,7 @@ class DataParallel(object):
         stall = sum(a.elapsed_time(b) for a, b in st['stall'])
         n = max(1, steps)
         ring = 2.0 * (self.world - 1) / max(self.world, 1)
-        return {'dtype_on_wire': self.grad_dtype, 'ranks': self.world, 'payload_bytes_per_step': st['payload_bytes'] / n,
+        return {'dtype_on_wire': self.grad_dtype, 'f32_exchange': self.f32_exchange if self.grad_dtype == 'f32' else None, 'ranks': self.world, 'payload_bytes_per_step': st['payload_bytes'] / n,
                 'bytes_sent_per_rank_per_step': st['payload_bytes'] * ring / n, 'collectives_per_step': st['collectives'] / float(n),
                 'exchanges_per_step': st['exchanges'] / float(n), 'ms_in_collectives_per_step': comm / n,
                 'ms_compute_stream_stalled_per_step': stall / n,
@@ -237,6 +251,32 @@ class DataParallel(object):
         dist.all_gather(parts, send, group=self.group)
         buf.copy_(torch.stack(parts).float().sum(0).to(torch.bfloat16)[:n])
 
+    def _exchange_f32_rs_ag(self, st, buf):
+        """fp32 reduce-scatter + all-gather, in place on `buf` (see __init__).  Runs on the calling stream (the communication
+        stream).  The bucket's first N * c elements (c = n // N) go through the two collectives — rank r's output chunk is the
+        view buf[r*c:(r+1)*c] of the input itself, the in-place form RCCL supports — and the < N leftover elements through one
+        tiny all-reduce.  Test transports without reduce_scatter_tensor (gloo) gather every rank's bucket and sum the ranks in rank
+        order: the same bits on every rank there too."""
+        n, N = buf.numel(), self.world
+        if not self._has_all_to_all(buf):
+            if N == 1:
+                return
+            parts = [torch.empty_like(buf) for _ in range(N)]
+            dist.all_gather(parts, buf, group=self.group)
+            acc = parts[0].clone()
+            for p_ in parts[1:]:
+                acc.add_(p_)
+            buf.copy_(acc)
+            return
+        c = n // N
+        if c > 0:
+            main = buf[:N * c]
+            mine = main[self.rank * c:(self.rank + 1) * c]
+            dist.reduce_scatter_tensor(mine, main, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(main, mine, group=self.group)
+        if n > N * c:
+            dist.all_reduce(buf[N * c:], op=dist.ReduceOp.SUM, group=self.group)
+
     def _has_all_to_all(self, buf):
         """Does the process group's backend for this tensor's device have all_to_all_single / all_gather_into_tensor?  RCCL
         ('nccl') does; gloo does not (neither on device tensors — the 2-ranks-on-1-GPU pre-flight — nor, for all_to_all, on the
@@ -256,8 +296,9 @@ class DataParallel(object):
         return got
 
     def _launch_range(self, st, start, end):
-        from .utils import roctx
-        with roctx.range('dp.exchange %s[%d:%d] %s' % (self._arena_tag(st), start, end, self.grad_dtype)):
+        if not _roctx.available():                 # (no marker library / T2I_ROCTX=0: not even the range's name is formatted)
+            return self._launch_range_impl(st, start, end)
+        with _roctx.range('dp.exchange %s[%d:%d] %s' % (self._arena_tag(st), start, end, self.grad_dtype)):
             self._launch_range_impl(st, start, end)
 
     def _arena_tag(self, st):
@@ -267,6 +308,7 @@ class DataParallel(object):
     def _launch_range_impl(self, st, start, end):
         buf = st['arena'].grad[start:end]
         bf16 = self.grad_dtype == 'bf16'
+        rs_ag = not bf16 and self.f32_exchange == 'rs_ag'
         if buf.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=buf.device)
@@ -279,7 +321,9 @@ class DataParallel(object):
                 if stats is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                if not bf16:
+                if rs_ag:            # everything ordered on the communication stream, like the bf16 form
+                    self._exchange_f32_rs_ag(st, buf)
+                elif not bf16:
                     w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                     if stats is not None:
                         w.wait()         # the communication stream waits for the collective: the closing event sees its end
@@ -291,7 +335,9 @@ class DataParallel(object):
                     e1.record()
                     stats['comm'].append((e0, e1))
                     stats['payload_bytes'] += buf.numel() * (2 if bf16 else 4)
-                    stats['collectives'] += 1 if not bf16 else 2
+                    stats['collectives'] += 2 if (bf16 or rs_ag) else 1
+        elif rs_ag:
+            self._exchange_f32_rs_ag(st, buf)
         elif not bf16:
             st['works'].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -359,7 +405,7 @@ class DataParallel(object):
 
     def finish_allreduce(self, arena):
         """Make the calling stream wait for the exchange started by start_allreduce; returns 1/world."""
-        from .utils import roctx
+        roctx = _roctx
         st = self.attach(arena)
         roctx.push('dp.finish_allreduce %s (compute stream waits for the exchange)' % self._arena_tag(st))
         stats = self._stats if arena.grad.is_cuda else None

@@ -158,6 +158,7 @@ def set_storage(mode):
     if mode is torch.bfloat16 and _MATH[0] != MATH_BF16:
         raise ValueError("set_storage('bf16') needs set_math('bf16') first (bf16 tensors feed the bf16 matrix pipe)")
     _STORE[0] = mode
+    _MIXED[0] = False          # a new configuration: the twin policy of an earlier math_scope does not carry over (see _MIXED)
 
 
 def get_storage():
@@ -180,8 +181,18 @@ def f32_outputs():
 # (descriptors travel in the autograd context, gradients take the dtype of the tensor they are the gradient of), so entering the
 # scope around a network's FORWARD is enough.  _MIXED: a scope has been used — with bf16 storage outside the scope every tensor
 # that wants a bf16 image is one already, so float32 outputs (the scoped network's) get no bf16 twin.
+# _MIXED is process-wide and sticky BY DESIGN within one configuration (the scoped network's backward runs outside the scope, long
+# after it exited, and must still see the policy); it is cleared by set_math(), set_storage() and forget_scopes() — the models call
+# the latter when they are constructed outside any scope, so a later, unscoped model in the same process starts from the plain rules.
 _MIXED = [False]
-_BWD_MATH = [None]          # arithmetic of the BACKWARD GEMMs of layers created in the current scope (None: the forward's)
+_BWD_MATH = [None]
+
+
+def forget_scopes():
+    """Clear the sticky twin policy a finished math_scope left behind (no-op while a scope is open)."""
+    if _BWD_MATH[0] is None:
+        _MIXED[0] = False
+          # arithmetic of the BACKWARD GEMMs of layers created in the current scope (None: the forward's)
 
 
 @contextlib.contextmanager

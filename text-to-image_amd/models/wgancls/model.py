@@ -64,6 +64,7 @@ class WGanCls(object):
         self._kl = None
         # per-network arithmetic: {'g_net': (math, storage)} — layers of that network are created under kernels.math_scope
         self.net_math = {}
+        K.forget_scopes()          # a scoped model that lived in this process before leaves no twin policy behind for this one
         if os.environ.get('T2I_G_MATH'):
             gm = os.environ['T2I_G_MATH'].split(',')     # "f32" or "f32,bf16" (forward arithmetic[, backward arithmetic])
             self.net_math['g_net'] = (gm[0], 'f32') + tuple(gm[1:2])

@@ -40,8 +40,15 @@ class Arena(object):
         # let it form the moment first.  (Not inside a capture: a replayed iteration leaves the last step's gradients behind, so the
         # on-demand path stays valid between replays, and the host does not run here on replay anyway.)
         if self.before_zero and not (self.grad.is_cuda and torch.cuda.is_current_stream_capturing()):
-            for cb in self.before_zero:
-                cb()
+            dead = False
+            for ref in self.before_zero:           # weak references to the optimizers: a discarded optimizer is not kept alive by its arena
+                opt = ref()
+                if opt is None:
+                    dead = True
+                else:
+                    opt._materialize_m()
+            if dead:
+                self.before_zero = tuple(r for r in self.before_zero if r() is not None)
         self.grad.zero_()
 
     before_zero = ()
@@ -69,11 +76,17 @@ class AdamTF(object):
         # writes it (4 bytes per parameter less of the 24 the update streams); `m` is formed from the gradient arena when somebody
         # asks for it — a checkpoint between two iterations — which is valid until the arena is zeroed for the next backward
         self.skip_m = beta1 == 0.0 and os.environ.get('T2I_ADAM_SKIP_M', '1') != '0'
+        # An EAGER Arena.zero_grad after a step forms the lagging moment before it clears its source (one read + one write of the
+        # arena: 8 bytes per parameter, more than the 4 the fast path saves on that iteration; replayed graphs never run it).  A
+        # loop that checkpoints only right after a step — every trainer here — may switch it off: `m` stays valid until the next
+        # zero_grad either way.  T2I_ADAM_KEEP_M=0 sets the default.
+        self.keep_m_across_zero_grad = os.environ.get('T2I_ADAM_KEEP_M', '1') != '0'
         self._m_stale, self._last_scale = False, 1.0    # `_m` lags the last step (it is re-formed from the gradient arena on demand)
         self.t = 0
         self.lr_t_dev = torch.zeros(4, dtype=torch.float32, device=arena.flat.device)   # [0] = this step's lr_t
         if self.skip_m:
-            arena.before_zero = tuple(arena.before_zero) + (self._materialize_m,)
+            import weakref
+            arena.before_zero = tuple(arena.before_zero) + (weakref.ref(self),)
 
     @property
     def m(self):
@@ -95,7 +108,7 @@ class AdamTF(object):
 
     def _materialize_m(self):
         """Arena.zero_grad (eager) is about to clear the gradients the on-demand first moment is formed from."""
-        if self.skip_m and self._m_stale:
+        if self.skip_m and self._m_stale and self.keep_m_across_zero_grad:
             self.m
 
     def moments_loaded(self):

@@ -129,7 +129,14 @@ def _stackgan(K, dev, math, stage, batch, budget_s):
     dt, n = _time_replays(lambda: tr.iteration(feed), budget_s)
     tr._graphs = None
     what = ('StackGAN Stage-I 64x64' if stage == 1 else 'StackGAN Stage-II 256x256 (frozen Stage-I generator in training mode inside)')
-    return _row('stackgan_stage%d' % stage, what + ', D + G update', batch, math, dt, n, flop, calls)
+    extra = None
+    if math == 'bf16':
+        # every GEMM of every network in bf16 math: NOT a 2e-2 claim (no tolerance is stated for this row anywhere in BASELINE.md); the
+        # measured envelope of exactly this arithmetic is asserted by tests/test_fullsize_gpu.py::test_stackgan_stage2_all_bf16_envelope
+        extra = {'arithmetic': {'mode': 'all_bf16', 'note': 'every GEMM of the critic, the Stage-II generator and the frozen Stage-I generator in bf16 '
+                                'math (bf16 MFMA operands, fp32 accumulate), %s activation tensors: OUTSIDE 2e-2, kernel throughput only — '
+                                'envelope in tests/test_fullsize_gpu.py::test_stackgan_stage2_all_bf16_envelope' % K.get_storage()}}
+    return _row('stackgan_stage%d' % stage, what + ', D + G update', batch, math, dt, n, flop, calls, extra)
 
 
 def _pggan(K, dev, math, stage, trans, budget_s):
@@ -162,6 +169,13 @@ def _wgancls(K, dev, math, batch, budget_s):
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
     cfg = bench.make_cfg(batch)
     m = WGanCls(cfg, device=dev, seed=0)
+    arith = None
+    if math == 'bf16':
+        # BASELINE configs[2]'s COMPLIANT arithmetic (kernels.CONFIG3_NET_MATH: critic and the generator's backward GEMMs in bf16 math, the
+        # generator's forward GEMMs in fp32 math) — the one tests/test_step_b64_gpu.py::test_config3_bf16_steps_mask_pinned[B8] holds to 2e-2
+        m.net_math = dict(K.CONFIG3_NET_MATH)
+        arith = {'mode': 'config3', 'net_math': {k: list(v) for k, v in K.CONFIG3_NET_MATH.items()},
+                 'parity': 'tests/test_step_b64_gpu.py::test_config3_bf16_steps_mask_pinned[B%d]: <= 2e-2 on every tensor, mask-pinned, plus un-pinned forward values' % batch}
     tr = WGanClsTrainer(None, m, None, cfg)
     feed = bench.synthetic_feed(cfg, dev, seed=1, with_noise=False)
     tr.iteration(1, feed)
@@ -177,7 +191,8 @@ def _wgancls(K, dev, math, batch, budget_s):
     dt, n = _time_replays(step, budget_s)
     m._graphs = None
     return _row('wgancls_b%d' % batch, 'wgancls 64x64 at batch %d per GPU = the strong-scaling share of global batch 64 on %d GPUs%s' % (
-        batch, 64 // batch, ' (= the yml\'s BATCH_SIZE)' if batch == 8 else ''), batch, math, dt, n, flop, calls)
+        batch, 64 // batch, ' (= the yml\'s BATCH_SIZE)' if batch == 8 else ''), batch, math, dt, n, flop, calls,
+        {'arithmetic': arith} if arith else None)
 
 
 ROWS = {
