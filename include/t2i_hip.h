@@ -72,7 +72,7 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 8 (v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 9 (v9: t2i_conv_opts.reserved became xform_valid_rows — same layout, 0 keeps the v8 meaning; v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
@@ -106,7 +106,9 @@ size_t t2i_conv2d_workspace_bytes(const t2i_conv_desc* d); /* upper bound for fw
  *                       per tile, 4x resp. 2.25x the size of x).  T2I_XFORM_KEEP on t2i_conv2d_fwd / _fwd_stats leaves V in
  *                       `xform` (>= t2i_conv2d_input_transform_bytes(d) bytes; xform_kept tells whether the call took a path
  *                       that has one); T2I_XFORM_HAVE on t2i_conv2d_bwd_filter (same d, same unchanged x) reads V from there
- *                       instead of transforming x again.
+ *                       instead of transforming x again; xform_valid_rows (below) restricts what is trusted to the leading images of the
+ *                       batch — the stacked critic step (text-to-image_amd/stacked.py) replaces the x_hat rows of a layer's input by
+ *                       the gradient penalty's tangent before its ONE filter-gradient launch over all 4B rows.
  *   in_dtype, out_dtype bf16 STORAGE: the activation tensors of the call are bf16 in memory.  The bf16-operand GEMMs and the
  *                       3 -> 128 stem read and write them directly (no cast, no fp32 copy anywhere); the remaining paths (thin /
  *                       head kernels, the generic kernel for channel counts that are not multiples of 64) run on fp32 staging copies
@@ -124,7 +126,9 @@ typedef struct t2i_conv_opts {
   int32_t in_dtype;          /* bf16 storage (needs math = T2I_MATH_BF16): bit 0 / bit 1 set = the call's first / second ACTIVATION operand
                               * (the pointer argument itself) is a bf16 tensor; a_image / b_image are then not consulted for it */
   int32_t out_dtype;         /* T2I_DT_BF16: the output pointer (y / dx) is a bf16 tensor and is the only thing written */
-  int32_t reserved;
+  int32_t xform_valid_rows;  /* v9, T2I_XFORM_HAVE: `xform` is current for the first xform_valid_rows images of the batch only (the caller
+                              * changed the images behind them since the forward conv); t2i_conv2d_bwd_filter regenerates the transform of
+                              * the remaining images from x, in place in `xform`.  0 (or >= B): all of it is current.  (v8: `reserved`, 0) */
 } t2i_conv_opts;
 size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);   /* > 0: fwd and bwd_filter of `d` both take a Winograd path */
 

@@ -210,6 +210,24 @@ class use_tape(object):
         TAPE[0] = self.prev
 
 
+class forward_only(object):
+    """Run an oracle step for its FORWARD passes only: inside, torch.autograd.grad returns zeros (nothing is differentiated) and no
+    autograd graph is built.  For the branch-recording pass of a mask-pinned comparison (tests/branches.py): the recording tape needs
+    the activations' signs and shapes, not the gradients — the float64 backward (and, for the WGAN-GP steps, the double backward) is
+    two thirds of a step's CPU time.  Everything the step returns inside this context is meaningless except what the tape recorded."""
+
+    def __enter__(self):
+        self.real = torch.autograd.grad
+        torch.autograd.grad = lambda outputs, inputs, *a, **k: tuple(torch.zeros_like(t) for t in inputs)
+        self.ng = torch.no_grad()
+        self.ng.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ng.__exit__(*a)
+        torch.autograd.grad = self.real
+
+
 class tape_section(object):
     def __init__(self, name):
         self.name = name

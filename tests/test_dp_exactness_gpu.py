@@ -48,7 +48,9 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
     # part's gradients on the wire while the rest (and the generator forward) runs
     graphs = _two_ranks(29812, ['--warmup', '1', '--steps', '1'], {})
     # the same segment sequence launched eagerly (WGanCls._dg_cut_eager)
-    cut_eager = _two_ranks(29813, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_DP_CUT_EAGER': '1'})
+    # ... with the fp32 buckets through the reduce-scatter + all-gather form (T2I_DP_F32_EXCHANGE=rs_ag; on gloo: its gather-and-sum
+    # stand-in): two ranks, so bit for bit the all-reduce's result
+    cut_eager = _two_ranks(29813, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_DP_CUT_EAGER': '1', 'T2I_DP_F32_EXCHANGE': 'rs_ag'})
     assert eager == single, (eager, single)
     assert graphs == single, (graphs, single)
     assert cut_eager == single, (cut_eager, single)

@@ -88,8 +88,11 @@ def _rel_l2(got, ref):
 # Measured envelope of the ALL-bf16 arithmetic on Stage-II at full width, batch 2 (relative L2 per tensor against the mask-pinned float64
 # oracle; MI355X, round 6) — what bench.py's `next_rows[stackgan_stage2, bf16]` row runs.  NOT a 2e-2 claim: ~60 conv + batch-norm
 # layers in series with statistics over two samples amplify the 2^-8 operand rounding far beyond it; the bounds below are ~1.5x the
-# measured values (printed by the test) and exist so that the row's arithmetic cannot get worse silently.
-STAGE2_BF16_ENVELOPE = dict(loss=1.0, image=1.0, d_grad=2.0, g_grad=2.0, flips=0.5)
+# measured values and exist so that the row's arithmetic cannot get worse silently.  Measured (profiles/r06_bf16_side_row_parity.txt):
+# 2.3e-2 / 2.1e-2 of the branches differ from the float64 oracle's own (fp32: 2.6e-6); mask-pinned: loss scalars <= 9.4e-2 (critic
+# step) / 2.6e-1 (G_gan_loss), the 256x256 image 1.46e-1, critic gradients median 2.4e-1 / worst 3.8e-1, generator gradients median
+# 4.2e-1 / worst 4.8e-1 (relative L2 per tensor).
+STAGE2_BF16_ENVELOPE = dict(loss=0.4, image=0.25, d_grad=0.6, g_grad=0.75, flips=4e-2)
 
 
 def _stage2_full_size(gpu, bf16):
@@ -137,7 +140,7 @@ def _stage2_full_size(gpu, bf16):
         d = tr.d_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         SG.d_step(P, o2, feed, 2, o1)
     masks = split_sections(rec, own.record, plan)
     fl, units = flips(own.record, masks)
@@ -162,7 +165,7 @@ def _stage2_full_size(gpu, bf16):
         g = tr.g_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         SG.g_step(P, o2, feed, 2, o1)
     masks = split_sections(rec, own.record, plan_g)
     fl, units = flips(own.record, masks)
@@ -219,7 +222,7 @@ def test_pggan_stage_full_width(gpu, stage, trans, B):
         d = m.d_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         PG.d_step(P, cfg, feed, stage, trans, alpha)
     masks = split_sections(rec, own.record, [('G',), ('Dg', 'Dx', 'Dxmi'), ('Dxh',)])
     fl, units = flips(own.record, masks)
@@ -237,7 +240,7 @@ def test_pggan_stage_full_width(gpu, stage, trans, B):
         g = m.g_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         PG.g_step(P, cfg, feed, stage, trans, alpha)
     masks = split_sections(rec, own.record, [('G',), ('Dg',)])
     fl, units = flips(own.record, masks)
@@ -267,7 +270,7 @@ def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, ch
         d = tr.d_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         d_oracle()
     masks = split_sections(rec, own.record, plan)
     fl, units = flips(own.record, masks)
@@ -288,7 +291,7 @@ def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, ch
         g = tr.g_losses(hf)
         torch.cuda.synchronize()
     own = T.SectionTape()
-    with T.use_tape(own):
+    with T.use_tape(own), T.forward_only():        # the oracle's own branches: forward passes only
         g_oracle()
     masks = split_sections(rec, own.record, plan_g)
     fl, units = flips(own.record, masks)

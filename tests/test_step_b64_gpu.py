@@ -46,10 +46,18 @@ N_G, N_D = 10, 9        # activations with a kink per generator pass / per criti
 
 
 def _split_d_masks(rec, B):
-    """HIP critic step: generator (10), batched critic pass over [G | x | x_mis] (9, batch 3B), critic on x_hat (9)."""
-    assert len(rec) == N_G + 2 * N_D, len(rec)
+    """HIP critic step: generator (10 activations), then the critic.  Round 6 (stacked.py, the single-GPU default): ONE stacked pass
+    over [G | x | x_mis | x_hat] (9 activations, batch 4B).  Rounds 1-5 / T2I_STACK_XHAT=0 / data parallel: the batched pass over
+    [G | x | x_mis] (9, batch 3B) followed by the pass on x_hat (9, batch B)."""
     rec = [_to_oracle_layout(m) for m in rec]
-    g, d3, dh = rec[:N_G], rec[N_G:N_G + N_D], rec[N_G + N_D:]
+    g = rec[:N_G]
+    if len(rec) == N_G + N_D:
+        d4 = rec[N_G:]
+        assert all(m.shape[0] == 4 * B for m in d4), [tuple(m.shape) for m in d4]
+        d3, dh = [m[:3 * B] for m in d4], [m[3 * B:] for m in d4]
+    else:
+        assert len(rec) == N_G + 2 * N_D, len(rec)
+        d3, dh = rec[N_G:N_G + N_D], rec[N_G + N_D:]
     assert all(m.shape[0] == 3 * B for m in d3) and all(m.shape[0] == B for m in dh)
     return {'G': g, 'Dg': [m[:B] for m in d3], 'Dx': [m[B:2 * B] for m in d3], 'Dxmi': [m[2 * B:] for m in d3], 'Dxh': dh}
 
@@ -96,6 +104,16 @@ def setup(request):
     return dict(T=T, ocfg=ocfg, P=P, feed=feed, m=m, f=f, B=B)
 
 
+def _cached(setup, key, fn):
+    """Oracle results that do not depend on the HIP run (the un-pinned float64 steps, the un-cancelled gradient scales, the oracle's
+    own branches) are computed once per batch size and shared by the tests of this module: the float64 CPU step is what these tests
+    spend their time in."""
+    c = setup.setdefault('_cache', {})
+    if key not in c:
+        c[key] = fn()
+    return c[key]
+
+
 def test_b64_critic_step_mask_pinned(setup):
     T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
     rec = []
@@ -105,14 +123,9 @@ def test_b64_critic_step_mask_pinned(setup):
     masks = _split_d_masks(rec, B)
     ref = T.d_step(P, ocfg, feed, 0.7, masks=masks)
     # how many units does the pinning actually touch?  (the oracle's own branches, from an un-pinned run of the same step)
-    free = T.d_step(P, ocfg, feed, 0.7)
-    own = {k: T.MaskTape() for k in masks}
-    with torch.no_grad():
-        G, _, _ = T.generator(P, ocfg, feed['z'], feed['cond'], feed['ca_noise_d'], train=True, tape=own['G'])
-        T.discriminator(P, ocfg, G, feed['cond'], own['Dg']); T.discriminator(P, ocfg, feed['x'], feed['cond'], own['Dx'])
-        T.discriminator(P, ocfg, feed['x_mismatch'], feed['cond'], own['Dxmi'])
-        T.discriminator(P, ocfg, feed['eps'] * G + (1.0 - feed['eps']) * feed['x'], feed['cond'], own['Dxh'])
-    flips, units = _flip_fraction({k: t.record for k, t in own.items()}, masks)
+    free = _cached(setup, 'free_d', lambda: T.d_step(P, ocfg, feed, 0.7))
+    own = _cached(setup, 'own_d', lambda: _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh')))
+    flips, units = _flip_fraction(own, masks)
     print('critic step: %d of %d activation branches differ between HIP fp32 and float64 (%.2e)' % (flips, units, flips / units))
     assert flips <= 1e-4 * units
     bad = []
@@ -136,7 +149,7 @@ def test_b64_critic_step_mask_pinned(setup):
     # ---- gradients: 1e-4 per tensor
     chk('grad_x_hat', relerr(d['grad_x_hat'], ref['grad_x_hat']), 1e-4)
     chk('grad_cond', relerr(d['grad_cond'], ref['grad_cond']), 1e-4)
-    scales = T.d_step_term_scales(P, ocfg, feed, 0.7)
+    scales = _cached(setup, 'scales', lambda: T.d_step_term_scales(P, ocfg, feed, 0.7))
     cancelling, exact_zero = [], []
     for n in m.d_vars:
         r = ref['grads'][n]
@@ -181,12 +194,9 @@ def test_b64_generator_step_mask_pinned(setup):
     rec = [_to_oracle_layout(x) for x in rec]
     masks = {'G': rec[:N_G], 'Dg': rec[N_G:]}
     ref = T.g_step(P, ocfg, feed, masks=masks)
-    free = T.g_step(P, ocfg, feed)
-    own = {k: T.MaskTape() for k in masks}
-    with torch.no_grad():
-        G, _, _ = T.generator(P, ocfg, feed['z'], feed['cond'], feed['ca_noise_g'], train=True, tape=own['G'])
-        T.discriminator(P, ocfg, G, feed['cond'], own['Dg'])
-    flips, units = _flip_fraction({k: t.record for k, t in own.items()}, masks)
+    free = _cached(setup, 'free_g', lambda: T.g_step(P, ocfg, feed))
+    own = _cached(setup, 'own_g', lambda: _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg')))
+    flips, units = _flip_fraction(own, masks)
     print('generator step: %d of %d activation branches differ between HIP fp32 and float64 (%.2e)' % (flips, units, flips / units))
     assert flips <= 1e-4 * units
     bad = []
@@ -237,9 +247,11 @@ def _oracle_own_branches(T, ocfg, P, feed, which):
 
 
 # Units whose branch the pinning replaces, as a fraction of all units of the step (bf16 rounding of ~4e-3 per pre-activation moves the
-# units that lie that close to their kink).  Measured on MI355X in the compliant arithmetic: see the values printed by the test; the
-# bound is asserted so that the pinning cannot grow into hiding a wrong forward.
-CONFIG3_FLIP_BOUND = 1.0e-2
+# units that lie that close to their kink).  Measured on MI355X in the compliant arithmetic (profiles/r06_bf16_side_row_parity.txt):
+# critic step 5.44e-4 / 5.40e-4 / 5.36e-4 of all units at B = 64 / 16 / 8 (6.4e-4 .. 6.8e-4 in each of the four critic passes, the fp32
+# generator pass <= 7e-7), generator step 3.47e-4 / 3.38e-4 / 3.50e-4.  The bound (~2.5x) is asserted so that the pinning cannot grow
+# into hiding a wrong forward; the un-pinned forward check beside it needs no pinning at all.
+CONFIG3_FLIP_BOUND = 1.5e-3
 
 
 def _bf16_steps(setup, mode):
@@ -272,7 +284,7 @@ def _bf16_steps(setup, mode):
         if compliant:
             assert d['G'].dtype == torch.float32 and rel_l2(d['G'], ref['G']) < 1e-4, 'the generator forward is meant to be exact here'
             # ---- what does the pinning touch?  (fraction of units whose branch differs from the float64 oracle's own)
-            own = _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh'))
+            own = _cached(setup, 'own_d', lambda: _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg', 'Dx', 'Dxmi', 'Dxh')))
             flips, units = _flip_fraction(own, masks)
             per_pass = {k: _flip_fraction({k: own[k]}, masks) for k in own}
             print('config 3, critic step (B=%d): %d of %d activation branches differ between the bf16 HIP run and float64 (%.3e); per pass: %s' % (
@@ -281,7 +293,7 @@ def _bf16_steps(setup, mode):
             assert per_pass['G'][0] <= 1e-4 * per_pass['G'][1], 'the generator forward is fp32: its branches must be the fp32 tests\' handful'
             # ---- UN-pinned forward check: forward values and loss scalars are continuous across the kinks, so they are held to the
             # same 2e-2 against the FREE float64 oracle (no branch replayed)
-            free = T.d_step(P, ocfg, feed, 0.7)
+            free = _cached(setup, 'free_d', lambda: T.d_step(P, ocfg, feed, 0.7))
             chk('un-pinned G', rel_l2(d['G'], free['G']), 2e-2)
             chk('un-pinned D(x_hat)', rel_l2(d['Dx_hat_logit'], free['Dx_hat']), 2e-2)
             for k in ('D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'D_loss'):
@@ -292,7 +304,7 @@ def _bf16_steps(setup, mode):
                        ('real_gp', 2e-2), ('real_gp2', 2e-2), ('D_loss', 2e-2)):
             chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), tol)
         chk('grad_x_hat', rel_l2(d['grad_x_hat'], ref['grad_x_hat']), 2e-2)
-        scales = T.d_step_term_scales(P, ocfg, feed, 0.7)
+        scales = _cached(setup, 'scales', lambda: T.d_step_term_scales(P, ocfg, feed, 0.7))
         for n in m.d_vars:
             r = ref['grads'][n]
             if scales[n] > 4.0 * float(r.abs().max()):      # a small difference of large terms (see the module docstring): L2 against the uncancelled scale
@@ -308,11 +320,11 @@ def _bf16_steps(setup, mode):
         gmasks = {'G': rec[:N_G], 'Dg': rec[N_G:]}
         gref = T.g_step(P, ocfg, feed, masks=gmasks)
         if compliant:
-            own = _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg'))
+            own = _cached(setup, 'own_g', lambda: _oracle_own_branches(T, ocfg, P, feed, ('G', 'Dg')))
             flips, units = _flip_fraction(own, gmasks)
             print('config 3, generator step (B=%d): %d of %d activation branches differ (%.3e)' % (B, flips, units, flips / units))
             assert flips <= CONFIG3_FLIP_BOUND * units, (flips, units)
-            gfree = T.g_step(P, ocfg, feed)
+            gfree = _cached(setup, 'free_g', lambda: T.g_step(P, ocfg, feed))
             chk('un-pinned G (generator step)', rel_l2(g['G'], gfree['G']), 2e-2)
             for k in ('G_loss', 'G_kl_loss', 'D_loss_fake'):
                 chk('un-pinned ' + k, abs(float(g[k]) - gfree[k]) / max(abs(gfree[k]), 1.0), 2e-2)

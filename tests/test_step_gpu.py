@@ -315,9 +315,14 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step, n_critic):
         st = next(iter(dp._arenas.values()))
         assert st['expect'] and len(st['buckets']) > 1      # counts were learned; the overlap path was live on steps 2-3
         cut = run(False, DataParallel(bucket_bytes=4096), graphs=True)
+        # (e) the fp32 buckets through the explicit reduce-scatter + all-gather form (dp.DataParallel(f32_exchange='rs_ag')): over RCCL
+        # with one rank both collectives are identities, so this pins the in-place call form (output chunk = a view of the input) and
+        # the bucket plumbing — the sums themselves are covered by tests/test_dp_gloo.py[rs_ag] and the two-rank run of
+        # tests/test_dp_exactness_gpu.py
+        rsag = run(True, DataParallel(bucket_bytes=4096, f32_exchange='rs_ag'))
     finally:
         dist.destroy_process_group()
-    for other in (side, both, cut):
+    for other in (side, both, cut, rsag):
         assert plain[1:] == other[1:]
         for n in plain[0]:
             assert torch.equal(plain[0][n], other[0][n]), n
@@ -442,9 +447,9 @@ def test_shared_winograd_input_transform_bit_identical(gpu):
     used = []
     real = K.conv_bwd_filter
 
-    def spy(x, dy, d, ws_bytes, out=None, xform=None):
+    def spy(x, dy, d, ws_bytes, out=None, xform=None, **kw):
         used.append(xform is not None)
-        return real(x, dy, d, ws_bytes, out=out, xform=xform)
+        return real(x, dy, d, ws_bytes, out=out, xform=xform, **kw)
 
     def run(share, graphs):
         prev = K.share_xform(share)

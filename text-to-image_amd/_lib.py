@@ -23,7 +23,7 @@ class ConvOpts(ctypes.Structure):
     """t2i_conv_opts: optional side inputs / outputs of one conv call (include/t2i_hip.h)"""
     _fields_ = [('a_image', ctypes.c_void_p), ('b_image', ctypes.c_void_p), ('out_image', ctypes.c_void_p), ('xform', ctypes.c_void_p),
                 ('xform_bytes', ctypes.c_size_t), ('xform_mode', ctypes.c_int32), ('out_image_written', ctypes.c_int32),
-                ('xform_kept', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('xform_kept', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('xform_valid_rows', ctypes.c_int32)]
 
 
 XFORM_NONE, XFORM_KEEP, XFORM_HAVE = 0, 1, 2
@@ -107,7 +107,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError('libt2i_hip.so not found at %s — build it with text-to-image_amd/csrc/build.sh '
                       '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback' % LIB_PATH)
 
-ABI_VERSION = 8          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
+ABI_VERSION = 9          # include/t2i_hip.h T2I_ABI_VERSION: argument lists changed in v5, v6 and v7 — symbols alone do not tell
 
 lib = ctypes.CDLL(LIB_PATH)
 try:

@@ -85,6 +85,22 @@ def side_join():
         SIDE.keep.clear()
 
 
+def sunk_launch(launch, keep):
+    """Run `launch()` — a sunk filter gradient: it feeds nothing but the optimizer — on the filter-gradient stream if there is one
+    (see _Side), else on the current stream.  keep: the tensors it reads, held until side_join()."""
+    if SIDE.stream is not None:
+        SIDE.stream.wait_stream(torch.cuda.current_stream())      # its operands and the zeroed arena are ready
+        K.WS_LANE[0] = 1                                          # its own split-K workspace
+        try:
+            with torch.cuda.stream(SIDE.stream):
+                launch()
+        finally:
+            K.WS_LANE[0] = 0
+        SIDE.keep.append(keep)
+    else:
+        launch()
+
+
 def _filter_grad(x, gpre, geom, w, xform=None):
     """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function.
     xform: the Winograd input transform of `x` the forward conv left behind (kernels.LAST_XFORM), or None."""
@@ -199,33 +215,39 @@ class Conv2dFn(Function):
         if gy is None:
             return None, None, None, None, None, None, None, None
         x, w, y = ctx.saved_tensors
-        params = not _INPUTS_ONLY[0]
-        want_b = ctx.has_bias and ctx.needs_input_grad[2] and params
-        gb = None
-        bsink = _sink_of(ctx.bias_ref) if want_b else None
-        if (want_b and ctx.act != K.ACT_NONE and not torch.is_grad_enabled() and gy.shape[-1] % 4 == 0):
-            # final (first-order) backward: activation backward and bias gradient in ONE pass over the tensor
-            gpre, gb = K.act_bwd_colsum(_c(gy), y, ctx.act, ctx.alpha, out=bsink)
-            if bsink is not None:
-                gb = None                       # already summed into the optimizer's arena
-                _notify(ctx.bias_ref)
-        else:
-            gpre = _act_bwd(gy, y, ctx.act, ctx.alpha)
-            if want_b and bsink is not None:
-                K.col_reduce(_c(gpre), out=bsink)
-                _notify(ctx.bias_ref)
-            elif want_b:
-                gb = ColSumFn.apply(gpre)
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, x, w):
-            # final backward on bf16 tensors: the input gradient and the (sunk) filter gradient in one launch
-            gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), ctx.geom_b[0], ctx.geom_b[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
-            _notify(w)
-            ctx.xform = None
-            return gx, None, gb, None, None, None, None, None
-        gx = ConvBwdDataFn.apply(gpre, w, None, ctx.geom_b, K.ACT_NONE, 0.0, x.dtype) if ctx.needs_input_grad[0] else None
-        gw = _filter_grad(x, gpre, ctx.geom_b, w, ctx.xform) if (ctx.needs_input_grad[1] and params) else None
+        gx, gw, gb = conv2d_backward(x, w, y, gy, ctx.geom_b, ctx.act, ctx.alpha, ctx.has_bias, ctx.bias_ref, ctx.needs_input_grad[:3], ctx.xform)
         ctx.xform = None
         return gx, gw, gb, None, None, None, None, None
+
+
+def conv2d_backward(x, w, y, gy, geom_b, act, alpha, has_bias, bias_ref, need, xform=None):
+    """Backward of y = act(conv(x, w) + b) for upstream gradient gy -> (gx, gw, gb); need = (x, w, b) wanted.  Shared by Conv2dFn and
+    the per-part cases of stacked.SConv2dFn (a slice of a stacked pass is an ordinary pass of its own)."""
+    params = not _INPUTS_ONLY[0]
+    want_b = has_bias and need[2] and params
+    gb = None
+    bsink = _sink_of(bias_ref) if want_b else None
+    if (want_b and act != K.ACT_NONE and not torch.is_grad_enabled() and gy.shape[-1] % 4 == 0):
+        # final (first-order) backward: activation backward and bias gradient in ONE pass over the tensor
+        gpre, gb = K.act_bwd_colsum(_c(gy), y, act, alpha, out=bsink)
+        if bsink is not None:
+            gb = None                       # already summed into the optimizer's arena
+            _notify(bias_ref)
+    else:
+        gpre = _act_bwd(gy, y, act, alpha)
+        if want_b and bsink is not None:
+            K.col_reduce(_c(gpre), out=bsink)
+            _notify(bias_ref)
+        elif want_b:
+            gb = ColSumFn.apply(gpre)
+    if need[0] and need[1] and params and _pair_ok(gpre, x, w):
+        # final backward on bf16 tensors: the input gradient and the (sunk) filter gradient in one launch
+        gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
+        _notify(w)
+        return gx, None, gb
+    gx = ConvBwdDataFn.apply(gpre, w, None, geom_b, K.ACT_NONE, 0.0, x.dtype) if need[0] else None
+    gw = _filter_grad(x, gpre, geom_b, w, xform) if (need[1] and params) else None
+    return gx, gw, gb
 
 
 class ConvBwdDataFn(Function):
@@ -249,24 +271,31 @@ class ConvBwdDataFn(Function):
         if gg is None:
             return None, None, None, None, None, None, None
         dy, w, out = ctx.saved_tensors
-        gpre = _act_bwd(gg, out, ctx.act, ctx.alpha)
-        params = not _INPUTS_ONLY[0]
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and params and _pair_ok(gpre, dy, w):
-            g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), ctx.geom_b[0], ctx.geom_b[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
-            _notify(w)
-            g_w = None
-        else:
-            g_dy = Conv2dFn.apply(gpre, w, None, ctx.geom_b, K.ACT_NONE, 0.0, False, dy.dtype) if ctx.needs_input_grad[0] else None
-            g_w = _filter_grad(gpre, dy, ctx.geom_b, w) if (ctx.needs_input_grad[1] and params) else None
-        g_b = None
-        if ctx.has_bias and ctx.needs_input_grad[2] and params:
-            bsink = _sink_of(ctx.bias_ref)
-            if bsink is not None:
-                K.col_reduce(_c(gpre), out=bsink)
-                _notify(ctx.bias_ref)
-            else:
-                g_b = ColSumFn.apply(gpre)
+        g_dy, g_w, g_b = bwd_data_backward(dy, w, out, gg, ctx.geom_b, ctx.act, ctx.alpha, ctx.has_bias, ctx.bias_ref, ctx.needs_input_grad[:3])
         return g_dy, g_w, g_b, None, None, None, None
+
+
+def bwd_data_backward(dy, w, out, gg, geom_b, act, alpha, has_bias, bias_ref, need):
+    """Backward of out = act(conv^T(dy, w) + b) for upstream gradient gg -> (g_dy, g_w, g_b).  Shared by ConvBwdDataFn and
+    stacked.SBwdDataFn (whose double backward runs on the x_hat rows only)."""
+    gpre = _act_bwd(gg, out, act, alpha)
+    params = not _INPUTS_ONLY[0]
+    if need[0] and need[1] and params and _pair_ok(gpre, dy, w):
+        g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
+        _notify(w)
+        g_w = None
+    else:
+        g_dy = Conv2dFn.apply(gpre, w, None, geom_b, K.ACT_NONE, 0.0, False, dy.dtype) if need[0] else None
+        g_w = _filter_grad(gpre, dy, geom_b, w) if (need[1] and params) else None
+    g_b = None
+    if has_bias and need[2] and params:
+        bsink = _sink_of(bias_ref)
+        if bsink is not None:
+            K.col_reduce(_c(gpre), out=bsink)
+            _notify(bias_ref)
+        else:
+            g_b = ColSumFn.apply(gpre)
+    return g_dy, g_w, g_b
 
 
 class ConvBwdFilterFn(Function):

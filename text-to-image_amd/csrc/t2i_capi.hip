@@ -668,7 +668,7 @@ using namespace t2i;
 
 extern "C" {
 
-int t2i_version(void) { return 8; }
+int t2i_version(void) { return 9; }
 
 const char* t2i_last_error(void) { return g_err; }
 
@@ -1083,6 +1083,10 @@ static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const 
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
   const float* vhave = (opts && opts->xform_mode == T2I_XFORM_HAVE && opts->xform && aligned16(opts->xform) && xform_bytes(*d) &&
                         opts->xform_bytes >= xform_bytes(*d)) ? reinterpret_cast<const float*>(opts->xform) : nullptr;
+  // xform_valid_rows (ABI v9): the kept transform is current for that many leading images of the batch only; the rest is regenerated
+  // from x INTO the caller's buffer (0 or >= B: all of it is current)
+  const int vrows = (vhave && opts->xform_valid_rows > 0 && opts->xform_valid_rows < d->B) ? opts->xform_valid_rows : 0x7fffffff;
+  if (vhave && opts->xform_valid_rows < 0) { set_error("t2i_conv2d_bwd_filter: xform_valid_rows < 0"); return T2I_ERR_INVALID; }
   if (!tuning().no_thin) {
     if (head_conv_eligible(*d))
       return check(head_bwd_filter_launch(*d, x, dy, dw, accumulate ? 1 : 0, (hipStream_t)stream), "t2i_conv2d_bwd_filter(head)");
@@ -1098,9 +1102,9 @@ static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const 
     }
   }
   if (winograd_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
+    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave, vrows);
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave);
+    return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave, vrows);
   if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
     return conv_h_filter(d, x, dy, opts ? opts->a_image : nullptr, opts ? opts->b_image : nullptr, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream);
   IgemmParams p;

@@ -180,8 +180,9 @@ __device__ __forceinline__ int wino_slot(int r, int c, int flip) {
 }
 
 // V[xi][t][c]: one thread = one tile x 4 channels
+// plane_T: tiles per plane of V (>= T; > T when this call fills only a range of a larger batch's planes: x and V then point at that range)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw,
-                                                         size_t T, float* __restrict__ V, int flip) {
+                                                         size_t T, float* __restrict__ V, int flip, size_t plane_T) {
   const int C4 = C >> 2;
   const size_t total = T * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       tt[3][c] = f4sub(d[1][c], d[3][c]);
     }
     float4* o = reinterpret_cast<float4*>(V) + t * C4 + c4;
-    const size_t plane = T * C4;
+    const size_t plane = plane_T * C4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       wst(&o[(size_t)wino_slot(r, 0, flip) * plane], f4sub(tt[r][0], tt[r][2]));
@@ -314,7 +315,7 @@ int winograd_conv(const t2i_conv_desc& d, bool bwd, const float* in, const float
   if (float* Uc = filter_cache_get(w, 0, d.Cin, d.Cout, (size_t)16 * K * N * 4, stream, &fill)) U = Uc;
   if (fill)
     hipLaunchKernelGGL(wino_filter_kernel, dim3(wino_blocks((size_t)K * N)), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V, bwd ? 1 : 0);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (K / 4))), dim3(256), 0, stream, in, d.H, d.W, K, Th, Tw, T, V, bwd ? 1 : 0, T);
   t2i_conv_desc gd = d;                // the 16 GEMMs as a batch of 1x1 convolutions over T "pixels" (fwd) / their input gradient (bwd)
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;   // Cin, Cout as in d
   const int rc = run_batched_gemm(gd, bwd ? MODE_BWD_DATA : MODE_FWD, 16, V, U, Mx, (int64_t)T * K, (int64_t)d.Cin * d.Cout, (int64_t)T * N, stream, "winograd gemm");
@@ -397,8 +398,10 @@ size_t winograd_filter_grad_ws(const t2i_conv_desc& d) {
   return al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4) + al256((size_t)16 * d.Cin * d.Cout * 4);
 }
 
+// Vhave / valid_rows: the caller's kept input transform of x (planes of T tiles) and how many leading images of the batch it is current
+// for (>= d.B: all): the tiles of the images behind are regenerated from x here, into the caller's planes
 int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream, const float* Vhave) {
+                         hipStream_t stream, const float* Vhave, int valid_rows) {
   const size_t T = (size_t)d.B * (d.H / 2) * (d.W / 2);
   if (!ws || ws_bytes < winograd_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_filter_grad_ws(d));
@@ -409,8 +412,14 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
   float* Z = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4));
   float* P = reinterpret_cast<float*>(base + al256(16 * T * d.Cin * 4) + al256(16 * T * d.Cout * 4));
   const int Th = d.H / 2, Tw = d.W / 2;
-  if (Vhave) V = const_cast<float*>(Vhave);          // the forward conv's input transform of this x, kept by the caller
-  else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, 0);
+  if (Vhave) {
+    V = const_cast<float*>(Vhave);          // the forward conv's input transform of this x, kept by the caller
+    if (valid_rows < d.B) {
+      const size_t t0 = (size_t)valid_rows * Th * Tw, Tr = T - t0;
+      hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(Tr * (d.Cin / 4))), dim3(256), 0, stream, x + (size_t)valid_rows * d.H * d.W * d.Cin, d.H,
+                         d.W, d.Cin, Th, Tw, Tr, V + t0 * d.Cin, 0, T);
+    }
+  } else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, 0, T);
   hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.H, d.W, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
@@ -465,10 +474,10 @@ __global__ __launch_bounds__(256) void wino2_filter_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void wino2_input_kernel(const float* __restrict__ x, int H, int W, int C, int Th, int Tw, size_t T,
-                                                          float* __restrict__ V) {
+                                                          float* __restrict__ V, size_t plane_T) {
   const int C4 = C >> 2;
   const size_t total = T * 4 * C4;                        // (tile, phase, ci4)
-  const size_t plane = T * 4 * C4;
+  const size_t plane = plane_T * 4 * C4;                  // (plane_T: see wino_input_kernel)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
     const int ph = (int)((i / C4) & 3);
@@ -622,7 +631,7 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
   if (float* Uc = filter_cache_get(w, 2, d.Cin, d.Cout, (size_t)9 * 4 * d.Cin * d.Cout * 4, stream, &fill)) U = Uc;
   if (fill)
     hipLaunchKernelGGL(wino2_filter_kernel, dim3(wino_blocks((size_t)4 * d.Cin * (d.Cout / 4))), dim3(256), 0, stream, w, d.Cin, d.Cout, U);
-  hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, T);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.Cin = (int32_t)K; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
   {   // all nine positions + the output transform in one work item where that still fills the chip
@@ -856,7 +865,7 @@ size_t winograd_k4s2_filter_grad_ws(const t2i_conv_desc& d) {
 }
 
 int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                              hipStream_t stream, const float* Vhave) {
+                              hipStream_t stream, const float* Vhave, int valid_rows) {
   const size_t T = (size_t)d.B * (d.Ho / 2) * (d.Wo / 2), K = (size_t)4 * d.Cin;
   if (!ws || ws_bytes < winograd_k4s2_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd k4s2 filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_k4s2_filter_grad_ws(d));
@@ -868,8 +877,14 @@ int winograd_k4s2_filter_grad(const t2i_conv_desc& d, const float* x, const floa
   float* Z = reinterpret_cast<float*>(base + al256(9 * T * K * 4));
   float* P = reinterpret_cast<float*>(base + al256(9 * T * K * 4) + al256(9 * T * d.Cout * 4));
   const int Th = d.Ho / 2, Tw = d.Wo / 2;
-  if (Vhave) V = const_cast<float*>(Vhave);
-  else hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V);
+  if (Vhave) {
+    V = const_cast<float*>(Vhave);
+    if (valid_rows < d.B) {                 // (see winograd_filter_grad)
+      const size_t t0 = (size_t)valid_rows * Th * Tw, Tr = T - t0;
+      hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(Tr * d.Cin)), dim3(256), 0, stream, x + (size_t)valid_rows * d.H * d.W * d.Cin, d.H, d.W,
+                         d.Cin, Th, Tw, Tr, V + t0 * K, T);
+    }
+  } else hipLaunchKernelGGL(wino2_input_kernel, dim3(wino_blocks(T * d.Cin)), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, T);
   hipLaunchKernelGGL(wino2_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.Ho, d.Wo, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)(T / S); gd.Cin = (int32_t)K; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;

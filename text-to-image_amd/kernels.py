@@ -296,6 +296,20 @@ def conv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding, math=None):
     return d, ws
 
 
+def rebatch(geom, B):
+    """(descriptor, workspace bytes) of the same convolution on another batch size: a slice of a stacked pass (stacked.py) is an
+    ordinary pass of its own.  Geometry, padding and arithmetic are copied from `geom`'s descriptor."""
+    d = geom[0]
+    if d.B == B:
+        return geom
+    key = ('rebatch', B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.SH, d.SW, d.pad_t, d.pad_l, d.math)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        d2 = ConvDesc(B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.SH, d.SW, d.pad_t, d.pad_l, d.math)
+        hit = _DESC_CACHE[key] = (d2, int(lib.t2i_conv2d_workspace_bytes(ctypes.byref(d2))))
+    return hit
+
+
 def deconv_desc(B, H, W, Cin, Cout, KH, KW, SH, SW, padding, math=None):
     """Descriptor of the ADJOINT conv of a TF conv2d_transpose x[B,H,W,Cin] -> [B,Hout,Wout,Cout]: that conv maps
     [B,Hout,Wout,Cout] -> [B,H,W,Cin] with HWIO filter [KH,KW,Cout,Cin] (the TF deconv layout)."""
@@ -476,9 +490,38 @@ def _storage_flags(opts, a, b, out):
     opts.out_dtype = DT_BF16 if (out is not None and out.dtype == torch.bfloat16) else DT_F32
 
 
+# Where the NEXT conv_fwd whose output has exactly this shape and dtype writes (one shot): the critic step lets the generator's last
+# kernel put G straight into its slot of the stacked critic input [G | x | x_mismatch | x_hat] instead of concatenating afterwards.
+_OUT_INTO = [None]
+
+
+class output_into(object):
+    def __init__(self, t):
+        self.t = t
+
+    def __enter__(self):
+        self.prev, _OUT_INTO[0] = _OUT_INTO[0], self.t
+
+    def __exit__(self, *a):
+        self.taken = _OUT_INTO[0] is None
+        _OUT_INTO[0] = self.prev
+
+
+def _take_out(shape, dtype, device):
+    t = _OUT_INTO[0]
+    if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_contiguous() and t.device == device:
+        _OUT_INTO[0] = None
+        _drop_image(t)
+        return t
+    return None
+
+
 def conv_fwd(x, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, keep_xform=False, out_dtype=None):
     _chk(x, 'x'); _chk(w, 'w', f32=True)
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=_act_dtype((d.B, d.Ho, d.Wo, d.Cout), out_dtype), device=x.device)
+    oshape, odt = (d.B, d.Ho, d.Wo, d.Cout), _act_dtype((d.B, d.Ho, d.Wo, d.Cout), out_dtype)
+    y = _take_out(oshape, odt, x.device) if _OUT_INTO[0] is not None else None
+    if y is None:
+        y = torch.empty(oshape, dtype=odt, device=x.device)
     if _live(x):
         wsp, wsn = _ws_args(x, ws_bytes)
         ev = _TIMER[0].begin(conv_flops(d), conv_algo(d, 'fwd')) if _TIMER[0] is not None else None
@@ -628,9 +671,10 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, out_dtype=N
     return dx
 
 
-def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
+def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0):
     """dw = x (*) dy.  out: an existing [KH,KW,Cin,Cout]-sized buffer to ACCUMULATE into (dw += ...), e.g. the
-    optimizer's gradient arena; returns it."""
+    optimizer's gradient arena; returns it.  xform_valid_rows (with xform): the kept transform is current for that many leading images
+    only — the library regenerates the rest from x, in place in `xform` (t2i_conv_opts.xform_valid_rows)."""
     _chk(x, 'x'); _chk(dy, 'dy')
     if out is not None:
         _chk(out, 'out', f32=True)
@@ -645,6 +689,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None):
         keep = _operand_images(opts, x, dy) if _h_path(d, 'bwd_filter') else None
         if xform is not None and conv_xform_bytes(d):
             opts.xform, opts.xform_bytes, opts.xform_mode = xform.data_ptr(), xform.numel() * 4, XFORM_HAVE
+            opts.xform_valid_rows = int(xform_valid_rows)
         check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, ctypes.byref(opts),
                                         wsp, wsn, _stream()), 't2i_conv2d_bwd_filter')
         if ev is not None:
@@ -899,12 +944,18 @@ def axpby(a, alpha, b=None, beta=0.0, out=None):
     return y
 
 
-def interp(eps, g, x):
+def interp(eps, g, x, out=None):
+    """out: an existing contiguous tensor of g's shape to write into (the x_hat slot of the stacked critic input)."""
     _chk(g, 'g', f32=True); _chk(x, 'x', f32=True)           # the 3-channel image side is float32 in every storage mode
     eps = _chk(eps.reshape(-1), 'eps', f32=True)
     B = g.shape[0]
     assert eps.numel() == B and g.shape == x.shape
-    out = torch.empty_like(g)
+    if out is not None:
+        _chk(out, 'out', f32=True)
+        assert out.shape == g.shape
+        _drop_image(out)
+    else:
+        out = torch.empty_like(g)
     if _live(g):
         check(lib.t2i_interp(_ptr(eps), _ptr(g), _ptr(x), B, g.numel() // B, _ptr(out), _stream()), 't2i_interp')
     return out
@@ -1081,14 +1132,20 @@ D_HEAD_KEYS = ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist
                'balance_loss', 'kt_grad', 'kt')
 
 
-def wgan_d_head(logits, slopes1, slopes2, kt, gp_coeff):
+def wgan_d_head(logits, slopes1, slopes2, kt, gp_coeff, seed_l_into=None):
     """logits [3B] (fake | real | mismatch), slopes [B], kt: device scalar tensor or None (= 1).
-    -> (scalars [12] in D_HEAD_KEYS order, dD/dlogits [3B], dD/dslopes1 [B], dD/dslopes2 [B])"""
+    -> (scalars [12] in D_HEAD_KEYS order, dD/dlogits [3B], dD/dslopes1 [B], dD/dslopes2 [B]).  dD/dlogits depends on kt and B only
+    (1/B | -(1+kt)/B | kt/B): the stacked critic step calls the head once BEFORE the slopes exist, for these seeds alone
+    (seed_l_into: a contiguous float32 [3B] buffer that receives them), and once after, for the scalars and the slope seeds."""
     _chk(logits, 'logits'); _chk(slopes1, 'slopes1'); _chk(slopes2, 'slopes2')
     B = slopes1.numel()
     assert logits.numel() == 3 * B and slopes2.numel() == B
     scal = torch.empty(12, dtype=torch.float32, device=logits.device)
-    sl, s1, s2 = torch.empty_like(logits), torch.empty_like(slopes1), torch.empty_like(slopes2)
+    if seed_l_into is not None:
+        _chk(seed_l_into, 'seed_l_into', f32=True)
+        assert seed_l_into.numel() == 3 * B
+    sl = seed_l_into if seed_l_into is not None else torch.empty_like(logits)
+    s1, s2 = torch.empty_like(slopes1), torch.empty_like(slopes2)
     if _live(logits):
         check(lib.t2i_wgan_d_head(_ptr(logits), _ptr(slopes1), _ptr(slopes2), _ptr(kt), B, gp_coeff, _ptr(sl), _ptr(s1), _ptr(s2),
                                   _ptr(scal), _stream()), 't2i_wgan_d_head')

@@ -19,6 +19,7 @@ from ... import autograd as A
 from ... import kernels as K
 from ... import optim
 from ... import scope as S
+from ... import stacked as ST
 from ...utils import roctx
 from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
                           reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
@@ -32,6 +33,8 @@ _OVERLAP_G_FORWARD = os.environ.get('T2I_OVERLAP_G_FORWARD', '1') != '0'
 # the one-graph iteration trusts the critic's filter images its previous replay regenerated behind the critic's Adam step instead
 # of regenerating them again at its head (dg_step keeps them current across outside writers): T2I_TRUST_IMAGES=0 restores the refresh
 _TRUST_IMAGES = os.environ.get('T2I_TRUST_IMAGES', '1') != '0'
+# single GPU: the critic's four passes of a step as ONE stacked pass of 4B images (stacked.py); T2I_STACK_XHAT=0: the 3B + B form
+_STACK_XHAT = os.environ.get('T2I_STACK_XHAT', '1') != '0'
 
 
 class WGanCls(object):
@@ -63,6 +66,8 @@ class WGanCls(object):
         self._consts = {}
         self._kl = None
         # per-network arithmetic: {'g_net': (math, storage)} — layers of that network are created under kernels.math_scope
+        # the critic's four passes of a step as one stacked pass of 4B images (stacked.py); False: the 3B + B form of rounds 1-5
+        self.stack_xhat = _STACK_XHAT
         self.net_math = {}
         K.forget_scopes()          # a scoped model that lived in this process before leaves no twin policy behind for this one
         if os.environ.get('T2I_G_MATH'):
@@ -162,6 +167,12 @@ class WGanCls(object):
         o = arena.offsets[first_var][0]
         return [(o, arena.numel)], [(0, o)]
 
+    def _d_cut_ranges(self):
+        """The critic arena's two exchange ranges of the cut schedule; the stacked step finishes the whole arena at once."""
+        if self.stack_xhat and self.device.type == 'cuda':
+            return [(0, self.d_arena.numel)], []
+        return self._cut_ranges(self.d_arena, self._CUT_D)
+
     @staticmethod
     def _split_vars(variables, first_var):
         names = list(variables)
@@ -170,11 +181,81 @@ class WGanCls(object):
         i = names.index(first_var)
         return [variables[n] for n in names[i:]], [variables[n] for n in names[:i]]
 
+    def _stack_buffers(self, B, like):
+        """The stacked critic step's persistent inputs for batch B: [G | x | x_mismatch | x_hat] images, the text embedding four
+        times, the upstream gradient of the stacked first-order pass ([dD_loss/dlogits (3B) | ones (B)]) and a dummy slope vector."""
+        bufs = getattr(self, '_stk', None)
+        if bufs is None or bufs['B'] != B:
+            if like.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the stacked critic step allocates its input buffers on its first eager iteration; run one before capturing')
+            dev = like.device
+            seed4 = torch.zeros(4 * B, dtype=torch.float32, device=dev)
+            seed4[3 * B:] = 1.0                  # d sum(D(x_hat)) / d logits: set once, the head rewrites only the first 3B entries
+            bufs = self._stk = {'B': B, 'inp4': torch.zeros((4 * B,) + tuple(self.image_dims), dtype=torch.float32, device=dev),
+                                'cond4': torch.zeros((4 * B, self.embed_dim), dtype=torch.float32, device=dev), 'seed4': seed4,
+                                'zeros': torch.zeros(B, dtype=torch.float32, device=dev)}
+        return bufs
+
+    def _d_losses_stacked(self, feed, cut=False):
+        """d_losses with the critic's four passes as one stacked pass (stacked.py): forward and first-order input-gradient chain on
+        4B images; per layer ONE filter-gradient launch over all 4B rows inside the gradient penalty's double backward (the scored
+        rows' activations x the loss gradient + the penalty's tangent x its chain), the double backward itself on the x_hat rows.
+        Same mathematics as the two-pass form — per-sample arithmetic is unchanged, the sums over the batch are grouped differently
+        (so results agree to rounding, not bit for bit, with T2I_STACK_XHAT=0).
+        cut (data-parallel graph schedule): the stacked step does not cut the critic's backward — the large filter gradients are the
+        LAST things its double backward produces, whichever way it is cut — so the first "part" is the whole step, d_backward_rest()
+        is empty and the whole arena leaves in one exchange, which the generator's forward hides (_d_cut_ranges, dg_step)."""
+        x, xm, cond, z, eps = feed['x'], feed['x_mismatch'], feed['cond'], feed['z'], feed['epsilon']
+        B = x.shape[0]
+        R = 3 * B
+        bufs = self._stack_buffers(B, x)
+        inp4, cond4, seed4 = bufs['inp4'], bufs['cond4'], bufs['seed4']
+        del ST._DEFERRED[:]                       # (records of a step that was abandoned half-way)
+        with torch.no_grad():
+            self._noise = self._ca_noise(feed, 'ca_noise_d', cond[:, :self.compressed_embed_dim])
+            with K.output_into(inp4[:B]):               # the generator's last kernel writes G into its slot
+                G, _, _ = self.generator(z, cond, reuse=True)
+            if G.data_ptr() != inp4.data_ptr():
+                inp4[:B].copy_(G)
+                G = inp4[:B]
+            for src, slot in ((x, inp4[B:2 * B]), (xm, inp4[2 * B:R])):
+                if src.data_ptr() != slot.data_ptr():   # (the captured graphs' static inputs ARE these slots: nothing to copy on replay)
+                    slot.copy_(src)
+            K.interp(eps, inp4[:B], inp4[B:2 * B], out=inp4[R:])
+            cond4.view(4, B, -1).copy_(cond.unsqueeze(0).expand(4, B, cond.shape[1]))
+        x_hat = inp4[R:].detach().requires_grad_(True)
+        cond_hat = cond4[R:].detach().requires_grad_(True)
+        logits = self.discriminator(ST.Stacked(inp4[:R], x_hat), ST.Stacked(cond4[:R], cond_hat), reuse=True)
+        lm, lh = logits.main, logits.hat                         # [3B,1,1,1] (fake | real | mismatch), [B,1,1,1]
+        # dD_loss/dlogits depends on kt alone: the head is asked for it before the slopes exist, so that the loss gradient of the scored
+        # rows and the penalty's first-order chain can run down the layers together
+        K.wgan_d_head(lm.detach().reshape(-1), bufs['zeros'], bufs['zeros'], self.kt, self.gp_coeff, seed_l_into=seed4[:R])
+        self.d_arena.zero_grad()
+        if self.dp is not None and not self._capturing:
+            self.dp.arm(self.d_arena)          # bucketed all-reduce overlaps the rest of this step (bias sinks are written from here on)
+        with ST.first_order_pass(R):
+            gx, gc = torch.autograd.grad([lm, lh], [x_hat, cond_hat], grad_outputs=[seed4[:R].view_as(lm), seed4[R:].view_as(lh)],
+                                         create_graph=True)
+        slopes1, slopes2 = A.GpSlopesFn.apply(gx), A.GpSlopesFn.apply(gc)
+        scal, _, seed_s1, seed_s2 = K.wgan_d_head(lm.detach().reshape(-1), slopes1.detach(), slopes2.detach(), self.kt, self.gp_coeff)
+        torch.autograd.backward([slopes1, slopes2], [seed_s1, seed_s2], inputs=list(self.d_vars.values()))
+        ST.flush_deferred()                       # (filter gradients the double backward did not reach: none on this model)
+        A.side_join()
+        out = {k: scal[i] for i, k in enumerate(K.D_HEAD_KEYS)}
+        i0 = K.D_HEAD_KEYS.index('wdist')
+        out['wd_sums'] = scal[i0:i0 + 2].clone() if self.dp is not None else scal[i0:i0 + 2]      # (see d_losses)
+        out.update(G=G, Dx_hat_logit=lh.detach(), grad_x_hat=gx.detach(), grad_cond=gc.detach())
+        if cut:
+            self._d_rest = None
+        return out
+
     def d_losses(self, feed, cut=False):
         """Everything `sess.run([D_optim, kt_optim, D_loss])` evaluates before the updates.  Returns a dict of scalar
         tensors; leaves the critic gradients in the arena (self.d_arena.grad).
         cut=True (data-parallel graph schedule): only the FIRST part of the backward is run (down to the input of Conv_3); the
         caller starts the exchange of that part's gradients and then runs d_backward_rest()."""
+        if self.stack_xhat and feed['x'].is_cuda:
+            return self._d_losses_stacked(feed, cut)
         x, xm, cond, z, eps = feed['x'], feed['x_mismatch'], feed['cond'], feed['z'], feed['epsilon']
         B = x.shape[0]
         with torch.no_grad():
@@ -223,6 +304,8 @@ class WGanCls(object):
 
     def d_backward_rest(self):
         """Second part of a cut critic backward: from the gradient at the input of Conv_3 through Conv_2, Conv_1, Conv."""
+        if self._d_rest is None:               # the stacked step: nothing was left behind the "cut"
+            return
         d_cut, rest = self._d_rest
         self._d_rest = None
         g, d_cut.grad = d_cut.grad, None
@@ -391,7 +474,7 @@ class WGanCls(object):
         else:
             # five graph launches, four collectives; each backward is cut once so that the bulk of its gradients is on the wire
             # while the rest of the backward (and, for the critic, the generator's forward) still runs — see enable_graphs
-            dA, dB = self._cut_ranges(self.d_arena, self._CUT_D)
+            dA, dB = self._d_cut_ranges()
             gA, gB = self._cut_ranges(self.g_arena, self._CUT_G)
             with roctx.range('d_step segment A: critic losses + backward to Conv_3'):
                 g['d_a'].replay()                  # critic losses + backward down to the input of Conv_3
@@ -421,7 +504,7 @@ class WGanCls(object):
         self.D_optim.prepare(float(feed['learning_rate_d']))
         self.G_optim.prepare(float(feed['learning_rate_g']))
         scale = 1.0 / self.dp.world
-        dA, dB = self._cut_ranges(self.d_arena, self._CUT_D)
+        dA, dB = self._d_cut_ranges()
         gA, gB = self._cut_ranges(self.g_arena, self._CUT_G)
         self._capturing = True                      # the exchanges are issued here, not by armed hooks
         try:
@@ -475,6 +558,14 @@ class WGanCls(object):
         arena, issued eagerly | [Adam (+ kt)] — four graph launches and two collectives per iteration, no collective is
         ever captured."""
         static = {k: feed[k].clone() for k in self._STATIC_KEYS if feed.get(k) is not None}
+        if self.stack_xhat and getattr(self, '_stk', None) is not None and self._stk['B'] == feed['x'].shape[0]:
+            # the stacked critic step reads x and x_mismatch from their slots of [G | x | x_mismatch | x_hat]: the graphs' static inputs
+            # ARE those slots, so that a feed written into static_inputs() is never copied again
+            B_ = feed['x'].shape[0]
+            for k, sl in (('x', slice(B_, 2 * B_)), ('x_mismatch', slice(2 * B_, 3 * B_))):
+                slot = self._stk['inp4'][sl]
+                slot.copy_(feed[k])
+                static[k] = slot
         for k in ('ca_noise_d', 'ca_noise_g'):
             if k not in static:   # re-drawn in place before every replay (_load_static); nothing is drawn here, so the
                 static[k] = torch.zeros(feed['cond'].shape[0], self.compressed_embed_dim, device=self.device)   # RNG stream stays the eager one
@@ -549,9 +640,14 @@ class WGanCls(object):
             self._capturing = False
         self._graphs = {'d': gd, 'g': gg, 'd_upd': gdu, 'g_upd': ggu, 'd_a': gda, 'gf_d_b': ggfdb, 'dupd_g_a': gduga, 'g_b': ggb,
                         'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2), 'static': static, 'loaded': False}
-        self.dp_schedule = ('5 graphs + 4 eager exchanges/iteration: both backward passes cut once (critic at the input of Conv_3: '
-                            '105 of 116 MB leave while the generator forward and the rest of the backward run; generator at the '
-                            '4x4->8x8 boundary: 57 of 91 MB leave before the 4x4 layers)')
+        if self.stack_xhat:
+            self.dp_schedule = ('5 graphs + 3 eager exchanges/iteration: the stacked critic step (4B rows, one filter-gradient launch per layer '
+                                'inside the double backward) finishes its 116 MB arena at once, which leaves while the generator forward '
+                                'runs; the generator\'s backward is cut at the 4x4->8x8 boundary: 57 of 91 MB leave before the 4x4 layers')
+        else:
+            self.dp_schedule = ('5 graphs + 4 eager exchanges/iteration: both backward passes cut once (critic at the input of Conv_3: '
+                                '105 of 116 MB leave while the generator forward and the rest of the backward run; generator at the '
+                                '4x4->8x8 boundary: 57 of 91 MB leave before the 4x4 layers)')
 
     def sampler(self, z_sample, cond_sample):
         """eval-mode generator on fixed samples (reference model.py:57)"""

@@ -16,6 +16,7 @@ import torch
 from .. import autograd as A
 from .. import kernels as K
 from .. import scope as S
+from .. import stacked as ST
 
 NHWC = 'NHWC'
 NCHW = 'NCHW'
@@ -89,7 +90,10 @@ def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=
         w = st.get_variable('weights', (kh, kw, Cin, f), init or S.he_init(kh * kw * Cin))
         b = st.get_variable('biases', (f,), S.constant_init(0.0))
     geom = K.conv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
-    y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha, bool(stats) and kind == K.ACT_NONE and post is None)
+    if isinstance(xp, ST.Stacked):        # the critic's stacked pass (stacked.py): one launch for both parts
+        y = ST.conv2d(xp, w, b, geom, kind, alpha)
+    else:
+        y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha, bool(stats) and kind == K.ACT_NONE and post is None)
     y = _logical(y, df)
     return post(y) if post else y
 
@@ -123,7 +127,12 @@ def fc(x, units, act=None, init=None, bias=True, name=None):
         w = st.get_variable('kernel', (I, units), init or S.he_init(I))
         b = st.get_variable('bias', (units,), S.constant_init(0.0)) if bias else None
     geom = K.conv_desc(B, 1, 1, I, units, 1, 1, 1, 1, 'VALID')
-    y = A.Conv2dFn.apply(x.reshape(B, 1, 1, I), w.view(1, 1, I, units), b, geom, kind, alpha).view(B, units)
+    if isinstance(x, ST.Stacked):
+        Bm, Bh = x.main.shape[0], x.hat.shape[0]
+        y = ST.conv2d(ST.Stacked(x.main.reshape(Bm, 1, 1, I), x.hat.reshape(Bh, 1, 1, I)), w.view(1, 1, I, units), b, geom, kind, alpha)
+        y = ST.Stacked(y.main.view(Bm, units), y.hat.view(Bh, units))
+    else:
+        y = A.Conv2dFn.apply(x.reshape(B, 1, 1, I), w.view(1, 1, I, units), b, geom, kind, alpha).view(B, units)
     return post(y) if post else y
 
 
@@ -258,7 +267,9 @@ def reshape_to_map(x, C, H, W, df=NHWC):
 def add(a, b, act=None, df=NHWC):
     """tf.add followed by an activation (the residual joins, reference models/wgancls/model.py:145-146,190-191)."""
     kind, alpha, post = _split_act(act)
-    if a.dim() == 4:
+    if isinstance(a, ST.Stacked):
+        y = _logical(ST.add_act(_phys(a, df), _phys(b, df), kind, alpha), df)
+    elif a.dim() == 4:
         y = _logical(A.AddActFn.apply(_phys(a, df), _phys(b, df), kind, alpha), df)
     else:
         y = A.AddActFn.apply(a, b, kind, alpha)
@@ -267,6 +278,8 @@ def add(a, b, act=None, df=NHWC):
 
 def concat_tile(feat, emb, df=NHWC):
     """expand_dims x2 -> tile over the spatial map -> concat on channels (reference models/wgancls/model.py:153-155)."""
+    if isinstance(feat, ST.Stacked):
+        return _logical(ST.concat_tile(_phys(feat, df), emb), df)
     return _logical(A.ConcatTileFn.apply(_phys(feat, df), emb), df)
 
 

@@ -44,8 +44,10 @@ def main():
     from branches import record_branches
     from oracle import torch_step as T
     from t2i_amd import kernels as K
+    from t2i_amd.models.wgancls import model as _wm
     from t2i_amd.models.wgancls.model import WGanCls
     from test_step_b64_gpu import N_D, N_G, _split_d_masks, _to_oracle_layout
+    _wm._STACK_XHAT = False          # the per-layer value tables below index the two-pass launch order ([G | x | x_mis], then x_hat)
     B = 64
     dev = torch.device('cuda')
     ocfg = T.Cfg(batch=B)
