@@ -603,6 +603,11 @@ static int wino2_fused_gemm(int lay, int phases, size_t T, int N, int K, const f
     // 128 -> 256 input gradient, 768 items (1.5 rounds) lose 10 % on 256 -> 512 even with the loader transform (profiles/r05_winograd_fused.txt)
     const int64_t rounds = (items + 511) / 512;
     if (items < (int64_t)tuning().wino_fuse_items * (lay == 0 ? 4 : 1) || items * 100 < rounds * 512 * 85) return -1;
+    // ... and with K = 1024 (32 K-tiles x 9 positions per item) the unfused position GEMMs are efficient on their own while a single
+    // round of fused items has nothing to overlap its epilogue with: the 512 -> 1024 input gradient of the stacked critic pass
+    // (256 images, 512 items) 405.7 us fused / 358.9 us unfused; 128 -> 256 (2048 items) 461.6 / 583.2, 256 -> 512 (1024) 428.2 / 425.8
+    // (profiles/r06_stacked_pass.txt)
+    if (K >= 1024 && rounds < 3) return -1;
   }
   q.g.items = (int32_t)items;
   q.g.sa = sa; q.g.sb = sb; q.g.sc = 0;

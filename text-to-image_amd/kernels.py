@@ -880,24 +880,31 @@ def act_fwd(x, act, alpha=0.2):
     return y
 
 
-def act_bwd(dy, y, act, alpha=0.2):
+def act_bwd(dy, y, act, alpha=0.2, out=None):
+    """out: an existing contiguous tensor (a slice of a stacked buffer) to write into; no bf16 twin then."""
     _chk(dy, 'dy'); _chk(y, 'y')
-    dx = torch.empty_like(dy)
+    if out is not None:
+        assert out.shape == dy.shape and out.dtype == dy.dtype and out.is_contiguous()
+        _drop_image(out)
+    dx = out if out is not None else torch.empty_like(dy)
     if _live(dy):
-        twin = _twin_for(dx, dy, y)
+        twin = _twin_for(dx, dy, y) if out is None else None
         check(lib.t2i_act_bwd(_ptr(dy), _ptr(y), dy.numel(), act, alpha, _ptr(dx), _ptr(twin), _same_dt(dy, y), _stream()), 't2i_act_bwd')
         _twin_keep(dx, twin)
     return dx
 
 
-def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
+def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None, dx_out=None):
     """-> (dx = dy*act'(y), colsum(dx)[, colsum(dx*(x2 - center))]) in one pass: a conv layer's activation backward + bias
     gradient, or (with x2 = layer input, center = its batch mean) the masked gradient and both reductions of the batch-norm backward.
     out: gradient-arena slot to ACCUMULATE colsum(dx) into (then the second return value is `out`)."""
     _chk(dy, 'dy'); _chk(y, 'y')
     C = dy.shape[-1]
     rows = dy.numel() // C
-    dx = torch.empty_like(dy)
+    if dx_out is not None:              # a slice of a stacked buffer to write dx into (no bf16 twin then)
+        assert dx_out.shape == dy.shape and dx_out.dtype == dy.dtype and dx_out.is_contiguous()
+        _drop_image(dx_out)
+    dx = dx_out if dx_out is not None else torch.empty_like(dy)
     s = out if out is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
     s2 = torch.empty(C, dtype=torch.float32, device=dy.device) if x2 is not None else None
     if x2 is not None:
@@ -906,7 +913,7 @@ def act_bwd_colsum(dy, y, act, alpha=0.2, x2=None, out=None, center=None):
     if _live(dy):
         need = int(lib.t2i_col_reduce_workspace_bytes(rows, C))
         wsp, wsn = _ws_args(dy, need)
-        twin = _twin_for(dx) if x2 is None else None        # conv bias path: dx is the next input / filter gradient's operand
+        twin = _twin_for(dx) if (x2 is None and dx_out is None) else None        # conv bias path: dx is the next input / filter gradient's operand
         check(lib.t2i_act_bwd_colsum(_ptr(dy), _ptr(y), _ptr(x2), _ptr(_chk(center, 'center') if center is not None else None), rows, C,
                                      act, alpha, _ptr(dx), _ptr(twin), _ptr(s), _ptr(s2),
                                      1 if out is not None else 0, wsp, wsn, _same_dt(dy, y, x2), _stream()), 't2i_act_bwd_colsum')

@@ -21,7 +21,7 @@ from ... import optim
 from ... import scope as S
 from ... import stacked as ST
 from ...utils import roctx
-from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, lrelu_act, relu,
+from ...utils.ops import (NCHW, add, batch_norm, concat_tile, conv2d, conv2d_transpose, fc, fork, lrelu_act, relu,
                           reshape_to_map, tanh, to_nchw, to_nhwc, update_ops)
 
 
@@ -691,7 +691,8 @@ class WGanCls(object):
             if self._keep_cut:                                                 # where the data-parallel schedule cuts the backward (_CUT_D)
                 self._d_cut = h
             trunk = conv2d(h, nf * 8, ks=(4, 4), s=(2, 2), df=fmt)             # Conv_3, linear
-            r = conv2d(trunk, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_4
+            trunk, trunk_ = fork(trunk, df=fmt)                                # (two consumers; a stacked pass sums their gradients in one launch)
+            r = conv2d(trunk_, nf * 2, ks=(1, 1), s=(1, 1), padding='valid', act=act, df=fmt)   # Conv_4
             r = conv2d(r, nf * 4, ks=(3, 3), s=(1, 1), act=act, df=fmt)        # Conv_5
             r = conv2d(r, nf * 8, ks=(3, 3), s=(1, 1), df=fmt)                 # Conv_6
             joined = add(trunk, r, act=act, df=fmt)

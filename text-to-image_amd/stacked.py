@@ -91,12 +91,21 @@ def _both(gm, gh):
 
 
 class SActBwdFn(Function):
-    """(gy * act'(y)) on a stacked pair in one launch.  Differentiated again on the hat rows only (autograd.ActBwdFn there)."""
+    """(gy * act'(y)) on a stacked pair.  Differentiated again on the hat rows only (autograd.ActBwdFn there).
+    colsum_into (a bias slot of the gradient arena, or None): also ACCUMULATE the column sums of the MAIN rows' result into it — the
+    bias gradient of a conv layer, formed in the pass that writes those rows (t2i_act_bwd_colsum) while the hat rows take the plain
+    kernel; without it the whole 4B buffer is one launch."""
 
     @staticmethod
-    def forward(ctx, gym, gyh, y4, act, alpha):
+    def forward(ctx, gym, gyh, y4, act, alpha, colsum_into=None):
         R = gym.shape[0]
-        out4 = K.act_bwd(full(gym, gyh), y4, act, alpha)
+        gy4 = full(gym, gyh)
+        if colsum_into is not None:
+            out4 = torch.empty_like(gy4)
+            K.act_bwd_colsum(gy4[:R], y4[:R], act, alpha, out=colsum_into, dx_out=out4[:R])
+            K.act_bwd(gy4[R:], y4[R:], act, alpha, out=out4[R:])
+        else:
+            out4 = K.act_bwd(gy4, y4, act, alpha)
         ctx.save_for_backward(y4)
         ctx.R, ctx.act, ctx.alpha = R, act, alpha
         ctx.set_materialize_grads(False)
@@ -108,11 +117,11 @@ class SActBwdFn(Function):
         R = ctx.R
         gm = A.ActBwdFn.apply(ggm, y4[:R], ctx.act, ctx.alpha) if ggm is not None else None
         gh = A.ActBwdFn.apply(ggh, y4[R:], ctx.act, ctx.alpha) if ggh is not None else None
-        return gm, gh, None, None, None
+        return gm, gh, None, None, None, None
 
 
-def _sact_bwd(gym, gyh, y4, act, alpha):
-    return SActBwdFn.apply(gym, gyh, y4, act, alpha) if act != K.ACT_NONE else (gym, gyh)
+def _sact_bwd(gym, gyh, y4, act, alpha, colsum_into=None):
+    return SActBwdFn.apply(gym, gyh, y4, act, alpha, colsum_into) if act != K.ACT_NONE else (gym, gyh)
 
 
 # Filter gradients of the stacked step that wait for the double backward (SBwdDataFn): [x4, gp4, w, geometry, kept transform, done].
@@ -232,7 +241,11 @@ class SConv2dFn(Function):
                 gb = gb1 if gb is None else (gb if gb1 is None else gb + gb1)
             return gxm, gxh, gw, gb, None, None, None
         # ---- the stacked first-order pass: one activation backward, one input-gradient launch for all 4B rows
-        gpm, gph = _sact_bwd(gym, gyh, y4, ctx.act, ctx.alpha)
+        bsink = A.sink_at(ctx.bias_ref.data_ptr()) if (ctx.has_bias and need_b) else None
+        fuse_b = bsink is not None and ctx.act != K.ACT_NONE and gym.shape[-1] % 4 == 0      # bias gradient in the activation backward's pass
+        gpm, gph = _sact_bwd(gym, gyh, y4, ctx.act, ctx.alpha, bsink if fuse_b else None)
+        if fuse_b:
+            A._notify(ctx.bias_ref)
         gxm = gxh = None
         rec = None
         if need_xm:
@@ -249,8 +262,7 @@ class SConv2dFn(Function):
         gw = gb = None
         with torch.no_grad():
             gpm_d = _c(gpm.detach())
-            if ctx.has_bias and need_b:
-                bsink = A.sink_at(ctx.bias_ref.data_ptr())
+            if ctx.has_bias and need_b and not fuse_b:
                 if bsink is not None:
                     K.col_reduce(gpm_d, out=bsink)
                     A._notify(ctx.bias_ref)
@@ -324,6 +336,29 @@ class SConcatTileBwdFn(Function):
         if ggfh is None and ggeh is None:
             return None, None, None, None
         return None, A.ConcatTileFn.apply(ggfh, ggeh), None, None
+
+
+class SForkFn(Function):
+    """A stacked tensor that feeds two consumers (the critic's trunk: the bottleneck branch and the residual join).  Forward: the same
+    memory twice.  Backward: the two incoming stacked gradients summed by ONE launch on the whole buffer (autograd's own accumulation
+    would add the main and the hat parts separately into unrelated allocations, which the layer below then has to concatenate)."""
+
+    @staticmethod
+    def forward(ctx, xm, xh):
+        ctx.set_materialize_grads(False)
+        return xm.view_as(xm), xh.view_as(xh), xm.view_as(xm), xh.view_as(xh)
+
+    @staticmethod
+    def backward(ctx, am, ah, bm, bh):
+        if am is not None and ah is not None and bm is not None and bh is not None:
+            return SAddActFn.apply(am, ah, bm, bh, K.ACT_NONE, 0.0)
+        pick = lambda a, b: a if b is None else (b if a is None else a + b)
+        return pick(am, bm), pick(ah, bh)
+
+
+def fork(x):
+    am, ah, bm, bh = SForkFn.apply(x.main, x.hat)
+    return Stacked(am, ah), Stacked(bm, bh)
 
 
 # ---- what utils/ops.py calls when it is handed a Stacked ----------------------------------------------------------------------

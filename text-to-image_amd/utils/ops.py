@@ -276,6 +276,15 @@ def add(a, b, act=None, df=NHWC):
     return post(y) if post else y
 
 
+def fork(x, df=NHWC):
+    """-> (x, x) for a tensor with two consumers.  Plain tensors: the tensor itself twice (autograd sums the two gradients).  A stacked
+    pass (stacked.py): two aliases whose incoming stacked gradients are summed by one launch on the whole buffer."""
+    if not isinstance(x, ST.Stacked):
+        return x, x
+    a, b = ST.fork(_phys(x, df))
+    return _logical(a, df), _logical(b, df)
+
+
 def concat_tile(feat, emb, df=NHWC):
     """expand_dims x2 -> tile over the spatial map -> concat on channels (reference models/wgancls/model.py:153-155)."""
     if isinstance(feat, ST.Stacked):
