@@ -211,6 +211,8 @@ class WGanCls(object):
         bufs = self._stack_buffers(B, x)
         inp4, cond4, seed4 = bufs['inp4'], bufs['cond4'], bufs['seed4']
         del ST._DEFERRED[:]                       # (records of a step that was abandoned half-way)
+        if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            ST.prepare_side(self.device)
         with torch.no_grad():
             self._noise = self._ca_noise(feed, 'ca_noise_d', cond[:, :self.compressed_embed_dim])
             with K.output_into(inp4[:B]):               # the generator's last kernel writes G into its slot
@@ -240,6 +242,7 @@ class WGanCls(object):
         scal, _, seed_s1, seed_s2 = K.wgan_d_head(lm.detach().reshape(-1), slopes1.detach(), slopes2.detach(), self.kt, self.gp_coeff)
         torch.autograd.backward([slopes1, slopes2], [seed_s1, seed_s2], inputs=list(self.d_vars.values()))
         ST.flush_deferred()                       # (filter gradients the double backward did not reach: none on this model)
+        ST.join()                                 # ... and the ones issued on the second stream (T2I_STACK_SIDE)
         A.side_join()
         out = {k: scal[i] for i, k in enumerate(K.D_HEAD_KEYS)}
         i0 = K.D_HEAD_KEYS.index('wdist')

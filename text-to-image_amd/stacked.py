@@ -130,6 +130,33 @@ def _sact_bwd(gym, gyh, y4, act, alpha, colsum_into=None):
 _DEFERRED = []
 _DEFER = [True]
 
+# The deferred filter gradients on a stream of their own (T2I_STACK_SIDE=1): inside the double backward the critical path is the
+# tangent chain — per layer a B-row conv, an activation backward and a copy, kernels that leave most of the chip idle — while the 4B-row
+# filter gradients feed nothing but the optimizer.  Issued on a second stream they fill the chip beside the chain instead of
+# alternating with it.  join() makes the calling stream wait for them (before Adam reads the arena).
+import os as _os
+_SIDE = {'on': _os.environ.get('T2I_STACK_SIDE', '0') == '1', 'stream': None, 'keep': []}
+
+
+def side_filter_gradients(on):
+    prev, _SIDE['on'] = _SIDE['on'], bool(on)
+    return prev
+
+
+def prepare_side(device):
+    """Create the stream and its workspace lane (outside any capture; the lane is sized like the main lane is NOW)."""
+    if _SIDE['on']:
+        if _SIDE['stream'] is None:
+            _SIDE['stream'] = torch.cuda.Stream(device=device)
+        K.stream_lane(_SIDE['stream'], device)
+
+
+def join():
+    s = _SIDE['stream']
+    if s is not None and _SIDE['keep']:
+        torch.cuda.current_stream().wait_stream(s)
+        del _SIDE['keep'][:]
+
 
 def defer_filter_gradients(on):
     prev, _DEFER[0] = _DEFER[0], bool(on)
@@ -190,7 +217,15 @@ class SBwdDataFn(Function):
         K.axpby(tang, 1.0, out=x4[R:])                        # the tangent over the (dead) x_hat rows of the layer's input
         K._drop_image(x4)
         xf, sink, ws4 = rec['xform'], rec['sink'], ctx.geom4[1]
-        A.sunk_launch(lambda: K.conv_bwd_filter(x4, gp4, d4, ws4, out=sink, xform=xf, xform_valid_rows=R if xf is not None else 0), (x4, gp4, xf))
+        launch = lambda: K.conv_bwd_filter(x4, gp4, d4, ws4, out=sink, xform=xf, xform_valid_rows=R if xf is not None else 0)
+        side = _SIDE['stream'] if (_SIDE['on'] and A.SIDE.stream is None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())       # the tangent is in place; everything else it reads was final long ago
+            with torch.cuda.stream(side):
+                launch()
+            _SIDE['keep'].append((x4, gp4, xf, tang))
+        else:
+            A.sunk_launch(launch, (x4, gp4, xf))
         A._notify(w)
         rec['done'] = True
         rec['x4'] = rec['gp4'] = rec['xform'] = None
