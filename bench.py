@@ -165,6 +165,7 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
     for dp in ((LocalRounding() if grad_dtype == 'bf16' else None), make_dp()):
         model = WGanCls(cfg, device=device, seed=0, dp=dp)
         model.net_math = dict(net_math or {})
+        model.pair_g = False          # the data-parallel schedules evaluate the generator twice per iteration: so does their single-replica reference
         real = dp is not None and not isinstance(dp, LocalRounding)
         if real:
             dp.broadcast_variables(model.store)

@@ -129,6 +129,10 @@ typedef struct t2i_conv_opts {
   int32_t xform_valid_rows;  /* v9, T2I_XFORM_HAVE: `xform` is current for the first xform_valid_rows images of the batch only (the caller
                               * changed the images behind them since the forward conv); t2i_conv2d_bwd_filter regenerates the transform of
                               * the remaining images from x, in place in `xform`.  0 (or >= B): all of it is current.  (v8: `reserved`, 0) */
+  int32_t xform_plane_rows;  /* v9, T2I_XFORM_HAVE: `xform` was kept by the forward conv of a LARGER batch of that many images whose leading B
+                              * images are this call's x (a stacked pass of which only the leading part is differentiated).  0: the batch is d->B.
+                              * Honoured by the 3x3 Winograd form; other forms transform x anew. */
+  int32_t reserved;
 } t2i_conv_opts;
 size_t t2i_conv2d_input_transform_bytes(const t2i_conv_desc* d);   /* > 0: fwd and bwd_filter of `d` both take a Winograd path */
 
@@ -244,6 +248,8 @@ int t2i_bn_bwd_fused(const void* dy, const void* y, const void* x, const float* 
  * tile_sum / tile_m2 (optional): the per-tile partials the producing conv's epilogue left (t2i_conv2d_fwd_stats: tile_chunks tiles of tile_rows rows
  * per group) — the statistics' first pass over x is then skipped.  With at most 64 partial rows per column and group the second stage runs in the
  * prologue of the normalisation / dx kernel (two launches, one with tile partials; T2I_BN_FUSE=0: always three).
+ * moving_groups (v9; 0 = all): only the first moving_groups groups move the moving averages — a stacked pass whose later groups are evaluations
+ * outside UPDATE_OPS (the generator's critic-step evaluation stacked behind its generator-step evaluation).
  * moving_updates (>= 1): how many sequential exponential-average steps the moving statistics take with this batch's statistics per group — 2 when
  * ONE evaluation of a network stands for two identical evaluations of the reference graph (gancls: the generator in the D run and in the G run of
  * one iteration, models/gancls/trainer.py:115-134: same feed, no noise, weights unchanged in between; both runs sit under UPDATE_OPS). */
@@ -251,7 +257,7 @@ size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t
 int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
                              float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
                              float alpha, void* y, void* y_h, const float* tile_sum, const float* tile_m2, int32_t tile_chunks, int32_t tile_rows,
-                             int32_t moving_updates, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream);
+                             int32_t moving_updates, int32_t moving_groups, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream);
 int t2i_bn_bwd_grouped(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, int64_t rows_per_group,
                        int32_t C, int32_t groups, int act, float alpha, void* gmask, void* dx, void* dx_h, float* dgamma, float* dbeta, int accumulate,
                        void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream);

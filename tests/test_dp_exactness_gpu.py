@@ -39,8 +39,10 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
     import torch
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
+    # (T2I_PAIR_G=0: a single GPU stacks the generator's two evaluations of an iteration into one pass; the data-parallel schedules keep
+    # two passes — the generator step's forward is what hides the critic's exchange — so their reference does too)
     single = _signature([sys.executable, 'bench.py', '--no-graphs', '--instrument', 'off', '--no-cpu-baseline', '--repeats', '1',
-                         '--min-busy-s', '0', '--no-config3', '--warmup', '3', '--steps', '1'], {})
+                         '--min-busy-s', '0', '--no-config3', '--warmup', '3', '--steps', '1'], {'T2I_PAIR_G': '0'})
     assert single[0] == 4
     # eager schedule: buckets leave while the backward is still running (first step learns the contribution counts)
     eager = _two_ranks(29811, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0'})

@@ -70,7 +70,7 @@ def test_grouped_batch_norm_refuses_bad_tile_partials_and_counts(t2i):
 
     def fwd(rows=256, C=64, groups=2, tile_chunks=4, tile_rows=64, moving_updates=1, tiles=True):
         return L.t2i_bn_train_fwd_grouped(P(1), rows, C, groups, P(2), P(3), 1e-5, 0.9, P(4), P(5), P(6), P(7), P(8), P(9), 0, 0.2, P(10), None,
-                                          P(11) if tiles else None, P(12) if tiles else None, tile_chunks, tile_rows, moving_updates, P(13), ws_n, 0, None)
+                                          P(11) if tiles else None, P(12) if tiles else None, tile_chunks, tile_rows, moving_updates, 0, P(13), ws_n, 0, None)
     assert fwd(tile_chunks=5) == -1 and b'tile partials' in L.t2i_last_error()       # 5 tiles of 64 rows for 256 rows
     assert fwd(tile_chunks=3) == -1                                                  # too few
     assert fwd(moving_updates=0) == -1 and b'moving_updates' in L.t2i_last_error()

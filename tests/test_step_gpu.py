@@ -290,6 +290,7 @@ def test_side_stream_and_dp_single_rank_match_plain(gpu, golden_step, n_critic):
         A.enable_side_stream(side)
         try:
             m = WGanCls(cfg, device=gpu, dp=dp)
+            m.pair_g = False        # (the data-parallel schedules run the generator's two evaluations as two passes: compare like with like)
             m.store.load(params)
             tr = WGanClsTrainer(None, m, None, cfg)
             outs = []
@@ -428,6 +429,53 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
                 assert torch.equal(got[0][n], base[0][n]), (variant, n)
     finally:
         K.set_math('f32')
+
+
+def test_paired_generator_iteration_matches_two_passes(gpu):
+    """Round 6: a single-GPU D + G iteration evaluates the generator ONCE on 2B rows (WGanCls._g_forward_pair, stacked.py) — the
+    generator step's evaluation (gradient, UPDATE_OPS) in front, the critic step's (no gradient, its own conditioning noise) behind,
+    per-evaluation batch-norm statistics — instead of twice on B.  Against the two-pass iteration (pair_g = False) at the benchmark's
+    width, B = 8, same weights and feed: both generated images, every logged scalar, the moving averages (they must have moved ONCE,
+    by the generator step's statistics only) to fp32 rounding; the weight gradients by the kink-tolerant criterion of
+    _check_grad_kinks (a 2B-row GEMM rounds differently from a B-row one: a handful of relu units at their kink take the other
+    branch — see tests/test_step_b64_gpu.py — so a per-element 1e-6 is not owed; a wrong row, statistic or noise is an O(1) error)."""
+    from t2i_amd.models.wgancls.model import WGanCls
+    B = 8
+    cfg = _cfg(128, 1024, 128, 128, 128, B)
+    g = torch.Generator(device=gpu).manual_seed(11)
+    feed = {'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1, 'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+            'cond': torch.randn(B, 1024, generator=g, device=gpu), 'z': torch.randn(B, 128, generator=g, device=gpu),
+            'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4,
+            'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
+            'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)}
+    res = {}
+    for pair in (False, True):
+        m = WGanCls(cfg, device=gpu, seed=3)
+        m.pair_g = pair
+        assert m._pairing(feed) == pair
+        d, gout = m.dg_step(feed)
+        torch.cuda.synchronize()
+        res[pair] = dict(Gd=d['G'].clone(), Gg=gout['G'].clone(), d={k: float(d[k]) for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2')},
+                         g={k: float(gout[k]) for k in ('G_loss', 'G_kl_loss', 'D_loss_fake')}, dgrad={n: m.d_arena.grad_of(n).clone() for n in m.d_vars},
+                         ggrad={n: m.g_arena.grad_of(n).clone() for n in m.g_vars},
+                         moving={n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n})
+    a, b = res[False], res[True]
+    # tanh of logits of magnitude ~20 behind ten batch norms over 8 samples: the yardstick of tests/test_step_b64_gpu.py is 1e-5 x max|logits|
+    assert float((a['Gd'] - b['Gd']).abs().max()) <= 2e-4 and float((a['Gg'] - b['Gg']).abs().max()) <= 2e-4
+    assert float((a['Gd'] - a['Gg']).abs().max()) > 1e-3                                                            # (the two evaluations do differ: their noise)
+    for grp in ('d', 'g'):
+        for k, v in a[grp].items():
+            assert abs(b[grp][k] - v) <= 2e-4 * max(abs(v), 1.0), (k, v, b[grp][k])
+    for n, v in a['moving'].items():
+        w = b['moving'][n]
+        assert float((v - w).abs().max()) <= 1e-5 * max(float(v.abs().max()), 0.1), n      # (some batch means are zero to rounding: absolute floor)
+    for key in ('ggrad', 'dgrad'):
+        top = max(float(v.abs().max()) for v in a[key].values())
+        for n, v in a[key].items():
+            if float(v.abs().max()) < 1e-5 * top:        # a bias in front of a batch norm: its gradient is zero up to fp32 residue on both sides
+                assert float(b[key][n].abs().max()) < 1e-4 * top, n
+                continue
+            _check_grad_kinks(b[key][n], v.double().cpu().numpy(), n, 1e-5)
 
 
 def test_shared_winograd_input_transform_bit_identical(gpu):

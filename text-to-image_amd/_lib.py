@@ -23,7 +23,7 @@ class ConvOpts(ctypes.Structure):
     """t2i_conv_opts: optional side inputs / outputs of one conv call (include/t2i_hip.h)"""
     _fields_ = [('a_image', ctypes.c_void_p), ('b_image', ctypes.c_void_p), ('out_image', ctypes.c_void_p), ('xform', ctypes.c_void_p),
                 ('xform_bytes', ctypes.c_size_t), ('xform_mode', ctypes.c_int32), ('out_image_written', ctypes.c_int32),
-                ('xform_kept', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('xform_valid_rows', ctypes.c_int32)]
+                ('xform_kept', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('xform_valid_rows', ctypes.c_int32), ('xform_plane_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 XFORM_NONE, XFORM_KEEP, XFORM_HAVE = 0, 1, 2
@@ -69,7 +69,7 @@ SIGNATURES = {
     't2i_adam_tf': (ctypes.c_int, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _p]),
     't2i_wgan_d_head': (ctypes.c_int, [_p, _p, _p, _p, _i32, _f, _p, _p, _p, _p, _p]),
     't2i_bn_grouped_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    't2i_bn_train_fwd_grouped': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, ctypes.c_int, _f, _p, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _i32, _p]),
+    't2i_bn_train_fwd_grouped': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, ctypes.c_int, _f, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _i32, _p]),
     't2i_bn_bwd_grouped': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, ctypes.c_int, _f, _p, _p, _p, _p, _p, ctypes.c_int, _p, _sz, _i32, _p]),
     't2i_sigmoid_ce_head': (ctypes.c_int, [_p, _p, _p, _f, _f, _f, _f, _f, _f, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     't2i_ca_kl_fwd': (ctypes.c_int, [_p, _p, _p, _i64, _p, _p, _p]),

@@ -101,9 +101,10 @@ def sunk_launch(launch, keep):
         launch()
 
 
-def _filter_grad(x, gpre, geom, w, xform=None):
+def _filter_grad(x, gpre, geom, w, xform=None, xform_plane_rows=0):
     """dw for weight `w`: into its sink if it has one and this is the final backward, else as a differentiable Function.
-    xform: the Winograd input transform of `x` the forward conv left behind (kernels.LAST_XFORM), or None."""
+    xform: the Winograd input transform of `x` the forward conv left behind (kernels.LAST_XFORM), or None; xform_plane_rows: that
+    transform belongs to a larger, stacked batch of this many images whose leading images are `x` (stacked.py)."""
     if not torch.is_grad_enabled():
         sink = sink_at(w.data_ptr())
         if sink is not None:
@@ -115,12 +116,12 @@ def _filter_grad(x, gpre, geom, w, xform=None):
                 K.WS_LANE[0] = 1                                          # its own split-K workspace
                 try:
                     with torch.cuda.stream(SIDE.stream):
-                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform)
+                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows)
                 finally:
                     K.WS_LANE[0] = 0
                 SIDE.keep.append((xs, gs, xform))
             else:
-                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform)
+                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows)
             _notify(w)
             return None
     if os.environ.get('T2I_DP_DEBUG') == '1' and NOTIFY[0] is not None:
@@ -220,7 +221,7 @@ class Conv2dFn(Function):
         return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d_backward(x, w, y, gy, geom_b, act, alpha, has_bias, bias_ref, need, xform=None):
+def conv2d_backward(x, w, y, gy, geom_b, act, alpha, has_bias, bias_ref, need, xform=None, xform_plane_rows=0):
     """Backward of y = act(conv(x, w) + b) for upstream gradient gy -> (gx, gw, gb); need = (x, w, b) wanted.  Shared by Conv2dFn and
     the per-part cases of stacked.SConv2dFn (a slice of a stacked pass is an ordinary pass of its own)."""
     params = not _INPUTS_ONLY[0]
@@ -246,7 +247,7 @@ def conv2d_backward(x, w, y, gy, geom_b, act, alpha, has_bias, bias_ref, need, x
         _notify(w)
         return gx, None, gb
     gx = ConvBwdDataFn.apply(gpre, w, None, geom_b, K.ACT_NONE, 0.0, x.dtype) if need[0] else None
-    gw = _filter_grad(x, gpre, geom_b, w, xform) if (need[1] and params) else None
+    gw = _filter_grad(x, gpre, geom_b, w, xform, xform_plane_rows) if (need[1] and params) else None
     return gx, gw, gb
 
 

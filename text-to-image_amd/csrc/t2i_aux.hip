@@ -348,6 +348,7 @@ struct BnFin {
   const float* gamma; const float* beta; float eps, decay;
   float* mean; float* rstd; float* scale; float* shift; float* mmean; float* mvar;
   int updates;       // how many times the moving averages take this batch's statistics (1; 2 when one evaluation stands for two identical runs)
+  size_t upd_limit;  // stacked batches: only groups whose offset group * C lies below this move the moving averages (default: all)
 };
 
 __device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float mu, float m2, size_t goff = 0) {
@@ -360,7 +361,7 @@ __device__ __forceinline__ void bn_fin_col(const BnFin& f, int c, float n, float
   const float sc = f.gamma[c] * rs;
   f.scale[goff + c] = sc;
   f.shift[goff + c] = f.beta[c] - mu * sc;
-  if (f.mmean) {                                             // TF fused BN: the moving variance takes the UNBIASED estimate
+  if (f.mmean && goff < f.upd_limit) {                       // TF fused BN: the moving variance takes the UNBIASED estimate
     const float unb = var * (n / fmaxf(n - 1.f, 1.f));
     float mm = f.mmean[c], mv = f.mvar[c];
     for (int u = 0; u < f.updates; ++u) {                    // sequential exponential-average steps, as that many runs of the update op would take
@@ -532,6 +533,7 @@ static BnFin make_fin(const float* gamma, const float* beta, float eps, float de
   f.gamma = gamma; f.beta = beta; f.eps = eps; f.decay = decay;
   f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift; f.mmean = mm; f.mvar = mv;
   f.updates = updates < 1 ? 1 : updates;
+  f.upd_limit = ~(size_t)0;
   return f;
 }
 
@@ -1181,8 +1183,9 @@ size_t bn_grouped_ws(int64_t rows_g, int C, int groups) {
 hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int groups, const float* gamma, const float* beta, float eps, float decay,
                                  float* mean, float* rstd, float* scale, float* shift, float* mm, float* mv, int act, float alpha, float* y,
                                  void* y_h, void* ws, hipStream_t stream, bool x_bf16, const float* tile_sum, const float* tile_m2, int tile_chunks,
-                                 int tile_rows, int moving_updates) {
+                                 int tile_rows, int moving_updates, int moving_groups) {
   // tile_sum != NULL: the producing conv's epilogue left per-tile partials (tile_chunks tiles of tile_rows rows per group): no first stage
+  // moving_groups > 0: only the first moving_groups groups move the moving averages (a stacked pass whose later groups run outside UPDATE_OPS)
   int ct, ncg; int64_t rpc;
   bn_group_plan(rows_g, C, groups, &ct, &ncg, &rpc);
   const float* part0 = tile_sum;
@@ -1201,7 +1204,8 @@ hipError_t bn_fwd_grouped_launch(const void* x, int64_t rows_g, int C, int group
       hipLaunchKernelGGL((col_reduce_stage1_v4<true, false, false>), dim3(ct, groups * ncg), dim3(256), 0, stream, x, (const void*)nullptr, rows, C, rpc,
                          p0, p1, 1, (const float*)nullptr, rows_g, ncg);
   }
-  const BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv, moving_updates);
+  BnFin fin = make_fin(gamma, beta, eps, decay, mean, rstd, scale, shift, mm, mv, moving_updates);
+  if (moving_groups > 0 && moving_groups < groups) fin.upd_limit = (size_t)moving_groups * C;
   uint2* yh = reinterpret_cast<uint2*>(y_h);
   if (tuning().bn_fuse && ncg <= BN_FUSE_MAX_CHUNKS) {          // second stage in the normalisation's prologue: one launch less
     int64_t rpb; int nb_g;

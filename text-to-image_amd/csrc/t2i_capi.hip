@@ -37,7 +37,7 @@ hipError_t bn_finalize_launch(const float*, const float*, int64_t, int, const fl
 hipError_t bn_apply_launch(const void*, const float*, const float*, int64_t, int, int, float, float*, hipStream_t, void* y_h, bool x_bf16);
 size_t bn_grouped_ws(int64_t rows_g, int C, int groups);
 hipError_t bn_fwd_grouped_launch(const void*, int64_t, int, int, const float*, const float*, float, float, float*, float*, float*, float*, float*, float*,
-                                 int, float, float*, void*, void*, hipStream_t, bool, const float*, const float*, int, int, int);
+                                 int, float, float*, void*, void*, hipStream_t, bool, const float*, const float*, int, int, int, int);
 hipError_t bn_bwd_grouped_launch(const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, int, int, float, void*,
                                  float*, float*, float*, int, void*, hipStream_t, void*, bool);
 hipError_t bn_bwd_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
@@ -1083,6 +1083,17 @@ static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const 
   if (!x || !dy || !dw) { set_error("t2i_conv2d_bwd_filter: null tensor"); return T2I_ERR_INVALID; }
   const float* vhave = (opts && opts->xform_mode == T2I_XFORM_HAVE && opts->xform && aligned16(opts->xform) && xform_bytes(*d) &&
                         opts->xform_bytes >= xform_bytes(*d)) ? reinterpret_cast<const float*>(opts->xform) : nullptr;
+  // xform_plane_rows (ABI v9): `xform` is the transform of a LARGER batch (that many images) whose leading B images are this x
+  int prows = 0;
+  if (vhave && opts->xform_plane_rows != 0) {
+    if (opts->xform_plane_rows < d->B) { set_error("t2i_conv2d_bwd_filter: xform_plane_rows < B"); return T2I_ERR_INVALID; }
+    prows = opts->xform_plane_rows;
+    if (prows > d->B) {
+      t2i_conv_desc big = *d; big.B = prows;
+      // only the 3x3 Winograd form strides plane by plane; the 4x4 stride-2 form cuts its planes into slabs: it transforms x anew
+      if (!winograd_filter_eligible(*d) || validate_desc(&big) != T2I_OK || opts->xform_bytes < xform_bytes(big)) { vhave = nullptr; prows = 0; }
+    }
+  }
   // xform_valid_rows (ABI v9): the kept transform is current for that many leading images of the batch only; the rest is regenerated
   // from x INTO the caller's buffer (0 or >= B: all of it is current)
   const int vrows = (vhave && opts->xform_valid_rows > 0 && opts->xform_valid_rows < d->B) ? opts->xform_valid_rows : 0x7fffffff;
@@ -1102,7 +1113,7 @@ static int conv2d_bwd_filter_impl(const t2i_conv_desc* d, const float* x, const 
     }
   }
   if (winograd_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
-    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave, vrows);
+    return winograd_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave, vrows, prows);
   if (winograd_k4s2_eligible(*d, false) && tuning().winograd_k4s2_bwdf && aligned16(x) && aligned16(dy) && aligned16(dw))
     return winograd_k4s2_filter_grad(*d, x, dy, dw, accumulate ? 1 : 0, ws, ws_bytes, (hipStream_t)stream, vhave, vrows);
   if (h_filter_eligible(*d) && aligned16(x) && aligned16(dy) && aligned16(dw))
@@ -1248,7 +1259,7 @@ size_t t2i_bn_grouped_workspace_bytes(int64_t rows_per_group, int32_t C, int32_t
 int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
                              float decay, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, int act,
                              float alpha, void* y, void* y_h, const float* tile_sum, const float* tile_m2, int32_t tile_chunks, int32_t tile_rows,
-                             int32_t moving_updates, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
+                             int32_t moving_updates, int32_t moving_groups, void* ws, size_t ws_bytes, int32_t dtype, t2i_stream_t stream) {
   // the partials of a group are tile_chunks tiles of tile_rows rows, the last one possibly short: every tile must START inside the group
   // (an over-long tile_chunks would give the merge a tile of <= 0 rows: 1/n = inf, NaN statistics written into the moving averages)
   if (tile_sum && (!tile_m2 || tile_chunks <= 0 || tile_rows <= 0 || (int64_t)tile_chunks * tile_rows < rows_per_group ||
@@ -1261,6 +1272,7 @@ int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, i
     set_error("t2i_bn_train_fwd_grouped: moving_updates must be in [1, 8]");
     return T2I_ERR_INVALID;
   }
+  if (moving_groups < 0 || moving_groups > groups) { set_error("t2i_bn_train_fwd_grouped: moving_groups must be in [0, groups]"); return T2I_ERR_INVALID; }
   if (rows_per_group > 0 && C > 0 && groups > 0) {       // element count against the 2^30 limit the conv descriptors enforce (32-bit offsets in the kernels)
     const int64_t lim = ((int64_t)1 << 30) - 16;
     if (rows_per_group > lim / C || rows_per_group * C > lim / groups) {
@@ -1281,7 +1293,7 @@ int t2i_bn_train_fwd_grouped(const void* x, int64_t rows_per_group, int32_t C, i
   if (int rc = h_contract(dtype, true, C, y_h, "t2i_bn_train_fwd_grouped")) return rc;
   const bool h = dtype == T2I_DT_BF16;
   return check(bn_fwd_grouped_launch(x, rows_per_group, C, groups, gamma, beta, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, act, alpha,
-                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h, tile_sum, tile_m2, tile_chunks, tile_rows, moving_updates),
+                                     h ? nullptr : reinterpret_cast<float*>(y), h ? y : y_h, ws, (hipStream_t)stream, h, tile_sum, tile_m2, tile_chunks, tile_rows, moving_updates, moving_groups),
                "t2i_bn_train_fwd_grouped");
 }
 

@@ -105,7 +105,7 @@ int winograd_k4s2_fwd(const t2i_conv_desc& d, const float* x, const float* w, co
                       size_t ws_bytes, hipStream_t stream, float* Vkeep = nullptr);
 size_t winograd_filter_grad_ws(const t2i_conv_desc& d);
 int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream, const float* Vhave = nullptr, int valid_rows = 0x7fffffff);
+                         hipStream_t stream, const float* Vhave = nullptr, int valid_rows = 0x7fffffff, int plane_rows = 0);
 int run_batched_gemm(const t2i_conv_desc& gd, int gmode, int nbatch, const float* a, const float* b, float* c, int64_t sa, int64_t sb, int64_t sc,
                      hipStream_t stream, const char* what);
 

@@ -400,9 +400,12 @@ size_t winograd_filter_grad_ws(const t2i_conv_desc& d) {
 
 // Vhave / valid_rows: the caller's kept input transform of x (planes of T tiles) and how many leading images of the batch it is current
 // for (>= d.B: all): the tiles of the images behind are regenerated from x here, into the caller's planes
+// plane_rows > d.B: Vhave's planes hold the tiles of plane_rows images (the transform of a larger, stacked batch whose LEADING d.B
+// images are this call's x): the batched GEMM strides from plane to plane by that many tiles
 int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t stream, const float* Vhave, int valid_rows) {
+                         hipStream_t stream, const float* Vhave, int valid_rows, int plane_rows) {
   const size_t T = (size_t)d.B * (d.H / 2) * (d.W / 2);
+  const size_t Tp = (Vhave && plane_rows > d.B) ? (size_t)plane_rows * (d.H / 2) * (d.W / 2) : T;
   if (!ws || ws_bytes < winograd_filter_grad_ws(d) || (reinterpret_cast<uintptr_t>(ws) & 15)) {
     set_error("winograd filter gradient: workspace %zu B < %zu B required (or misaligned)", ws_bytes, winograd_filter_grad_ws(d));
     return T2I_ERR_WORKSPACE;
@@ -417,13 +420,13 @@ int winograd_filter_grad(const t2i_conv_desc& d, const float* x, const float* dy
     if (valid_rows < d.B) {
       const size_t t0 = (size_t)valid_rows * Th * Tw, Tr = T - t0;
       hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(Tr * (d.Cin / 4))), dim3(256), 0, stream, x + (size_t)valid_rows * d.H * d.W * d.Cin, d.H,
-                         d.W, d.Cin, Th, Tw, Tr, V + t0 * d.Cin, 0, T);
+                         d.W, d.Cin, Th, Tw, Tr, V + t0 * d.Cin, 0, Tp);
     }
   } else hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks(T * (d.Cin / 4))), dim3(256), 0, stream, x, d.H, d.W, d.Cin, Th, Tw, T, V, 0, T);
   hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks(T * (d.Cout / 4))), dim3(256), 0, stream, dy, d.H, d.W, d.Cout, Th, Tw, T, Z);
   t2i_conv_desc gd = d;
   gd.B = (int32_t)T; gd.H = gd.W = gd.Ho = gd.Wo = 1; gd.KH = gd.KW = gd.SH = gd.SW = 1; gd.pad_t = gd.pad_l = 0;
-  const int rc = run_batched_gemm(gd, MODE_BWD_FILTER, 16, V, Z, P, (int64_t)T * d.Cin, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, stream,
+  const int rc = run_batched_gemm(gd, MODE_BWD_FILTER, 16, V, Z, P, (int64_t)Tp * d.Cin, (int64_t)T * d.Cout, (int64_t)d.Cin * d.Cout, stream,
                                   "winograd filter-gradient gemm");
   if (rc != T2I_OK) return rc;
   hipLaunchKernelGGL(wino_dw_kernel, dim3(wino_blocks((size_t)d.Cin * (d.Cout / 4))), dim3(256), 0, stream, P, d.Cin, d.Cout, accumulate, dw);

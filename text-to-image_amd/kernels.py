@@ -671,7 +671,7 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, out_dtype=N
     return dx
 
 
-def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0):
+def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0, xform_plane_rows=0):
     """dw = x (*) dy.  out: an existing [KH,KW,Cin,Cout]-sized buffer to ACCUMULATE into (dw += ...), e.g. the
     optimizer's gradient arena; returns it.  xform_valid_rows (with xform): the kept transform is current for that many leading images
     only — the library regenerates the rest from x, in place in `xform` (t2i_conv_opts.xform_valid_rows)."""
@@ -690,6 +690,7 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0
         if xform is not None and conv_xform_bytes(d):
             opts.xform, opts.xform_bytes, opts.xform_mode = xform.data_ptr(), xform.numel() * 4, XFORM_HAVE
             opts.xform_valid_rows = int(xform_valid_rows)
+            opts.xform_plane_rows = int(xform_plane_rows)       # the transform of a larger, stacked batch whose leading images are x
         check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, ctypes.byref(opts),
                                         wsp, wsn, _stream()), 't2i_conv2d_bwd_filter')
         if ev is not None:
@@ -800,7 +801,8 @@ def bn_apply_groups(x, scales, shifts, act=ACT_NONE, alpha=0.2):
     return y
 
 
-def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None, moving_updates=1):
+def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha=0.2, moving_mean=None, moving_var=None, moving_updates=1,
+                         moving_groups=0):
     """Training-mode batch norm in at most three launches (t2i_bn_train_fwd_grouped): x [groups * b, ..., C] with per-group statistics
     (groups = 1: the ordinary batch norm).  Uses the producing conv's epilogue partials when it left any (conv_fwd_stats).
     -> (y, mean [groups, C], rstd [groups, C]); moving averages updated in place once per group, in group order."""
@@ -822,7 +824,7 @@ def bn_train_fwd_grouped(x, gamma, beta, eps, decay, groups, act=ACT_NONE, alpha
         twin = _twin_for(y, x)
         check(lib.t2i_bn_train_fwd_grouped(_ptr(x), rows_g, C, groups, _ptr(_chk(gamma)), _ptr(_chk(beta)), eps, decay, _ptr(stat[0]), _ptr(stat[1]),
                                            _ptr(stat[2]), _ptr(stat[3]), _ptr(moving_mean), _ptr(moving_var), act, alpha, _ptr(y), _ptr(twin),
-                                           tsum, tm2, tchunks, trows, int(moving_updates), wsp, wsn, _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
+                                           tsum, tm2, tchunks, trows, int(moving_updates), int(moving_groups), wsp, wsn, _dt(x), _stream()), 't2i_bn_train_fwd_grouped')
         _twin_keep(y, twin)
     return y, stat[0], stat[1]
 

@@ -35,6 +35,9 @@ _OVERLAP_G_FORWARD = os.environ.get('T2I_OVERLAP_G_FORWARD', '1') != '0'
 _TRUST_IMAGES = os.environ.get('T2I_TRUST_IMAGES', '1') != '0'
 # single GPU: the critic's four passes of a step as ONE stacked pass of 4B images (stacked.py); T2I_STACK_XHAT=0: the 3B + B form
 _STACK_XHAT = os.environ.get('T2I_STACK_XHAT', '1') != '0'
+# single GPU, D + G iteration: the generator's two evaluations (critic step: no gradient, its own noise; generator step: under UPDATE_OPS)
+# as ONE stacked pass of 2B rows with per-evaluation batch-norm statistics (stacked.py); T2I_PAIR_G=0: two passes of B
+_PAIR_G = os.environ.get('T2I_PAIR_G', '1') != '0'
 
 
 class WGanCls(object):
@@ -68,6 +71,7 @@ class WGanCls(object):
         # per-network arithmetic: {'g_net': (math, storage)} — layers of that network are created under kernels.math_scope
         # the critic's four passes of a step as one stacked pass of 4B images (stacked.py); False: the 3B + B form of rounds 1-5
         self.stack_xhat = _STACK_XHAT
+        self.pair_g = _PAIR_G                 # (needs stack_xhat: the pair writes both images into the stacked critic input's buffer)
         self.net_math = {}
         K.forget_scopes()          # a scoped model that lived in this process before leaves no twin policy behind for this one
         if os.environ.get('T2I_G_MATH'):
@@ -191,12 +195,14 @@ class WGanCls(object):
             dev = like.device
             seed4 = torch.zeros(4 * B, dtype=torch.float32, device=dev)
             seed4[3 * B:] = 1.0                  # d sum(D(x_hat)) / d logits: set once, the head rewrites only the first 3B entries
-            bufs = self._stk = {'B': B, 'inp4': torch.zeros((4 * B,) + tuple(self.image_dims), dtype=torch.float32, device=dev),
+            # images: [G of the generator step | G of the critic step | x | x_mismatch | x_hat]; the critic's stacked input is the last 4B rows
+            img5 = torch.zeros((5 * B,) + tuple(self.image_dims), dtype=torch.float32, device=dev)
+            bufs = self._stk = {'B': B, 'img5': img5, 'inp4': img5[B:],
                                 'cond4': torch.zeros((4 * B, self.embed_dim), dtype=torch.float32, device=dev), 'seed4': seed4,
                                 'zeros': torch.zeros(B, dtype=torch.float32, device=dev)}
         return bufs
 
-    def _d_losses_stacked(self, feed, cut=False):
+    def _d_losses_stacked(self, feed, cut=False, have_g=False):
         """d_losses with the critic's four passes as one stacked pass (stacked.py): forward and first-order input-gradient chain on
         4B images; per layer ONE filter-gradient launch over all 4B rows inside the gradient penalty's double backward (the scored
         rows' activations x the loss gradient + the penalty's tangent x its chain), the double backward itself on the x_hat rows.
@@ -214,15 +220,20 @@ class WGanCls(object):
         if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
             ST.prepare_side(self.device)
         with torch.no_grad():
-            self._noise = self._ca_noise(feed, 'ca_noise_d', cond[:, :self.compressed_embed_dim])
-            with K.output_into(inp4[:B]):               # the generator's last kernel writes G into its slot
-                G, _, _ = self.generator(z, cond, reuse=True)
-            if G.data_ptr() != inp4.data_ptr():
-                inp4[:B].copy_(G)
+            if have_g:                                      # _g_forward_pair has already put this step's G into its slot
                 G = inp4[:B]
+            else:
+                self._noise = self._ca_noise(feed, 'ca_noise_d', cond[:, :self.compressed_embed_dim])
+                with K.output_into(inp4[:B]):               # the generator's last kernel writes G into its slot
+                    G, _, _ = self.generator(z, cond, reuse=True)
+                if G.data_ptr() != inp4.data_ptr():
+                    K.axpby(G.contiguous(), 1.0, out=inp4[:B])
+                    G = inp4[:B]
+            # (copies into the image buffer go through t2i_axpby, not Tensor.copy_: the paired generator's outputs are views of this
+            # buffer, and a tensor-library in-place op on any other view of it would invalidate them for autograd)
             for src, slot in ((x, inp4[B:2 * B]), (xm, inp4[2 * B:R])):
                 if src.data_ptr() != slot.data_ptr():   # (the captured graphs' static inputs ARE these slots: nothing to copy on replay)
-                    slot.copy_(src)
+                    K.axpby(src.contiguous(), 1.0, out=slot)
             K.interp(eps, inp4[:B], inp4[B:2 * B], out=inp4[R:])
             cond4.view(4, B, -1).copy_(cond.unsqueeze(0).expand(4, B, cond.shape[1]))
         x_hat = inp4[R:].detach().requires_grad_(True)
@@ -252,13 +263,13 @@ class WGanCls(object):
             self._d_rest = None
         return out
 
-    def d_losses(self, feed, cut=False):
+    def d_losses(self, feed, cut=False, have_g=False):
         """Everything `sess.run([D_optim, kt_optim, D_loss])` evaluates before the updates.  Returns a dict of scalar
         tensors; leaves the critic gradients in the arena (self.d_arena.grad).
         cut=True (data-parallel graph schedule): only the FIRST part of the backward is run (down to the input of Conv_3); the
         caller starts the exchange of that part's gradients and then runs d_backward_rest()."""
         if self.stack_xhat and feed['x'].is_cuda:
-            return self._d_losses_stacked(feed, cut)
+            return self._d_losses_stacked(feed, cut, have_g)
         x, xm, cond, z, eps = feed['x'], feed['x_mismatch'], feed['cond'], feed['z'], feed['epsilon']
         B = x.shape[0]
         with torch.no_grad():
@@ -320,9 +331,9 @@ class WGanCls(object):
         self.D_optim.apply(grad_scale=scale, refresh=True if self.dp is None else None)   # the generator half reads these filters next
         K.kt_sgd(self.kt, out['wd_sums'], scale, self.kt_lr)          # GradientDescentOptimizer(0.001) on balance_loss (model.py:100)
 
-    def _d_body(self, feed):
+    def _d_body(self, feed, have_g=False):
         """Device work of the critic step (graph-capturable): losses, backward, [all-reduce], Adam, kt."""
-        out = self.d_losses(feed)
+        out = self.d_losses(feed, have_g=have_g)
         scale = 1.0
         if self.dp is not None:
             scale = self.dp.allreduce_arena(self.d_arena, extra=out['wd_sums'])
@@ -360,6 +371,30 @@ class WGanCls(object):
         self._keep_cut = False
         G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
         return G, G_kl
+
+    def _pairing(self, feed):
+        return self.pair_g and self.stack_xhat and self.dp is None and feed['z'].is_cuda
+
+    def _g_forward_pair(self, feed):
+        """Both generator evaluations of a D + G iteration as ONE stacked pass of 2B rows (stacked.py): the generator step's (leading
+        rows: autograd graph, UPDATE_OPS, noise `ca_noise_g`) and the critic step's (rows behind: no gradient, noise `ca_noise_d`,
+        moving averages untouched).  Same weights, z and text embedding; the conditioning heads are evaluated once (they do not depend
+        on the noise), every batch norm keeps per-evaluation statistics, and the last kernel writes both images into the stacked
+        critic input's buffer.  -> ((G, G_kl) for g_losses(fwd=...), and the critic step's G is in its slot: d_losses(have_g=True))."""
+        cond, z = feed['cond'], feed['z']
+        B = z.shape[0]
+        bufs = self._stack_buffers(B, feed['x'])
+        like = cond[:, :self.compressed_embed_dim]
+        noise_d = self._ca_noise(feed, 'ca_noise_d', like)      # (the order an unpaired iteration draws them in)
+        noise_g = self._ca_noise(feed, 'ca_noise_g', like)
+        img5 = bufs['img5']
+        with update_ops(), K.output_into(img5[:2 * B]):
+            Gs, mean, log_sigma = self.generator(z, cond, reuse=True, pair=(noise_g, noise_d))
+        if Gs.hat.data_ptr() != img5[B:].data_ptr():             # (the last kernel did not take the buffer: copy the critic step's image)
+            with torch.no_grad():
+                K.axpby(Gs.hat.contiguous(), 1.0, out=img5[B:2 * B])
+        G_kl = self._kl if self._kl is not None else self.kl_std_normal_loss(mean, log_sigma).reshape(1)
+        return Gs.main, G_kl
 
     def g_losses(self, feed, fwd=None, cut=False):
         """cut=True: only the first part of the backward (the critic's input gradient and the generator back to the 4x4 -> 8x8
@@ -420,8 +455,8 @@ class WGanCls(object):
             fwd = self._g_forward(feed)
         return fwd
 
-    def _g_body(self, feed, fwd=None):
-        if fwd is not None:                                  # issued ahead on the second stream: join, and tell the allocator
+    def _g_body(self, feed, fwd=None, ahead=True):
+        if fwd is not None and ahead:                        # issued ahead on the second stream: join, and tell the allocator
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._ahead)
             for t in fwd:
@@ -461,6 +496,8 @@ class WGanCls(object):
         if g is None:
             if self.dp is not None and self.dp_cut_eager:
                 return self._dg_cut_eager(feed)
+            if self._pairing(feed):
+                return self._dg_pair_eager(feed)
             return self.d_step(feed), self.g_step(feed)
         self.D_optim.prepare(float(feed['learning_rate_d']))
         self.G_optim.prepare(float(feed['learning_rate_g']))
@@ -498,6 +535,18 @@ class WGanCls(object):
         K.filter_cache_invalidate(external=False)
         self.global_step += 1
         return g['dg_out']
+
+    def _dg_pair_eager(self, feed):
+        """d_step then g_step with the generator's two evaluations as one stacked pass (_g_forward_pair), launched eagerly: the order
+        of the one-graph iteration (enable_graphs)."""
+        self.D_optim.prepare(float(feed['learning_rate_d']))
+        self.G_optim.prepare(float(feed['learning_rate_g']))
+        with roctx.range('wgancls.iteration: paired generator forward, d_step, g_step'):
+            fwd = self._g_forward_pair(feed)
+            d_out = self._d_body(feed, have_g=True)
+            g_out = self._g_body(feed, fwd, ahead=False)
+        self.global_step += 1
+        return d_out, g_out
 
     def _dg_cut_eager(self, feed):
         """The segment sequence of the data-parallel graph schedule (enable_graphs), launched eagerly: the same calls in the same
@@ -544,7 +593,10 @@ class WGanCls(object):
                 if k in noise:
                     torch.nn.init.trunc_normal_(buf, mean=0.0, std=1.0, a=-2.0, b=2.0)
             elif src.data_ptr() != buf.data_ptr():
-                buf.copy_(src.reshape(buf.shape))
+                if k in ('x', 'x_mismatch') and buf._base is not None and src.dtype == buf.dtype and src.is_cuda:
+                    K.axpby(src.reshape(buf.shape).contiguous(), 1.0, out=buf)     # a slot of the stacked image buffer (see _d_losses_stacked)
+                else:
+                    buf.copy_(src.reshape(buf.shape))
         self._graphs['loaded'] = True
 
     def static_inputs(self):
@@ -603,9 +655,14 @@ class WGanCls(object):
                     K.filter_cache_refresh(self.g_arena.flat)
                 else:
                     self._refresh_filters()
-                ahead = self._g_forward_ahead(static) if _OVERLAP_G_FORWARD else None   # beside the critic step, not after it
-                d_out2 = self._d_body(static)
-                g_out2 = self._g_body(static, ahead)
+                if self._pairing(static):
+                    fwd = self._g_forward_pair(static)       # both generator evaluations as one stacked pass of 2B rows
+                    d_out2 = self._d_body(static, have_g=True)
+                    g_out2 = self._g_body(static, fwd, ahead=False)
+                else:
+                    ahead = self._g_forward_ahead(static) if _OVERLAP_G_FORWARD else None   # beside the critic step, not after it
+                    d_out2 = self._d_body(static)
+                    g_out2 = self._g_body(static, ahead)
             self._graphs = {'d': gd, 'g': gg, 'dg': gdg, 'd_out': d_out, 'g_out': g_out, 'dg_out': (d_out2, g_out2),
                             'static': static, 'loaded': False, 'trust': trust, 'epoch': None, 'dref': gref}
             return
@@ -719,16 +776,30 @@ class WGanCls(object):
         u = conv2d(conv2d_transpose(x, nf, ks=(4, 4), s=(2, 2), df=fmt), nf, ks=(3, 3), s=(1, 1), df=fmt, stats=train)
         return batch_norm(u, train=train, act=act, df=fmt)
 
-    def generator(self, z, embed, reuse=False, is_training=True, df=NCHW, cond_noise=True):
+    def generator(self, z, embed, reuse=False, is_training=True, df=NCHW, cond_noise=True, pair=None):
+        """pair = (noise of the leading evaluation, noise of the second): both evaluations of a D + G iteration as one stacked pass
+        (_g_forward_pair); the returned image is then a stacked.Stacked."""
         # config 3's compliant mode (DESIGN 4.16): the generator's layers in their own arithmetic / storage (self.net_math['g_net'])
         with K.math_scope(*self.net_math.get('g_net', (None, None))):
-            return self._generator(z, embed, reuse, is_training, df, cond_noise)
+            return self._generator(z, embed, reuse, is_training, df, cond_noise, pair)
 
-    def _generator(self, z, embed, reuse, is_training, df, cond_noise):
+    def _pair_code(self, z, mean, log_sigma, noise_a, noise_b):
+        """The generator's input code for two evaluations that differ in their conditioning noise only: [z | c_a] with the autograd
+        graph (and the KL term), [z | c_b] without."""
+        code_a, self._kl = A.CaSampleKlFn.apply(mean, log_sigma, noise_a)
+        with torch.no_grad():
+            code_b, _ = K.ca_kl_fwd(mean.detach(), log_sigma.detach(), noise_b)
+            hat = torch.cat([z, code_b], 1)
+        return ST.Stacked(torch.cat([z, code_a], 1), hat)
+
+    def _generator(self, z, embed, reuse, is_training, df, cond_noise, pair=None):
         nf, grid = self.gf_dim, self.output_size // 16
         with S.variable_scope('g_net', reuse=reuse):
             mean, log_sigma = self.generate_conditionals(embed)
-            code = torch.cat([z, self.sample_normal_conditional(mean, log_sigma, cond_noise)], 1)
+            if pair is not None:
+                code = self._pair_code(z, mean, log_sigma, *pair)
+            else:
+                code = torch.cat([z, self.sample_normal_conditional(mean, log_sigma, cond_noise)], 1)
             h = batch_norm(fc(code, nf * 8 * grid * grid), train=is_training, df=df)      # dense_2 + rank-2 BatchNorm
             h = reshape_to_map(h, nf * 8, grid, grid, df)                                 # [B,4,4,8nf]
             h = self._g_bottleneck(h, nf * 2, nf * 8, is_training, df)

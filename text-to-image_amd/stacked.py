@@ -72,6 +72,10 @@ class Stacked(object):
     def detach(self):
         return Stacked(self.main.detach(), self.hat.detach())
 
+    def reshape_parts(self, *tail):
+        """each part reshaped to (its rows,) + tail"""
+        return Stacked(self.main.reshape((self.main.shape[0],) + tuple(tail)), self.hat.reshape((self.hat.shape[0],) + tuple(tail)))
+
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -236,16 +240,18 @@ class SConv2dFn(Function):
     """y = act(conv(x, w) + b) on a stacked pair in one launch (also the dense layers: 1x1 on [B,1,1,C])."""
 
     @staticmethod
-    def forward(ctx, xm, xh, w, b, geom4, act, alpha):
+    def forward(ctx, xm, xh, w, b, geom4, act, alpha, want_stats=False):
         R = xm.shape[0]
         x4 = full(xm, xh)
         d, ws = geom4
         assert d.B == x4.shape[0], (d.B, tuple(x4.shape))
         ctx.set_materialize_grads(False)
         ctx.geom_b4 = K.bwd_geom(geom4)        # the backward GEMMs' descriptor, decided inside the network's math scope (as Conv2dFn does)
-        # the layer's filter gradient transforms the same x (fp32 Winograd): keep the transform if the stacked step will defer it
-        keep = bool(ctx.needs_input_grad[2]) and bool(ctx.needs_input_grad[0]) and _DEFER[0] and ctx.geom_b4 is geom4
-        y4 = K.conv_fwd(x4, w, b, d, ws, act, alpha, keep_xform=keep)
+        # the layer's filter gradient transforms the same x (fp32 Winograd): keep the transform — for the stacked critic step's deferred
+        # launch over all rows, or for the leading part's own filter gradient (the generator pair: xform_plane_rows)
+        keep = bool(ctx.needs_input_grad[2]) and not A._INPUTS_ONLY[0] and ctx.geom_b4 is geom4 and (
+            (bool(ctx.needs_input_grad[0]) and _DEFER[0]) or not ctx.needs_input_grad[1])
+        y4 = (K.conv_fwd_stats if want_stats else K.conv_fwd)(x4, w, b, d, ws, act, alpha, keep_xform=keep)
         ctx.xform = K.LAST_XFORM[0] if keep else None
         K.LAST_XFORM[0] = None
         ctx.save_for_backward(x4, w, y4 if act != K.ACT_NONE else None)
@@ -255,7 +261,7 @@ class SConv2dFn(Function):
     @staticmethod
     def backward(ctx, gym, gyh):
         if gym is None and gyh is None:
-            return (None,) * 7
+            return (None,) * 8
         x4, w, y4 = ctx.saved_tensors
         R, B4 = ctx.R, x4.shape[0]
         need_xm, need_xh, need_w, need_b = ctx.needs_input_grad[:4]
@@ -266,15 +272,18 @@ class SConv2dFn(Function):
             for g, sl, geom, nx in ((gym, slice(0, R), geo_m, need_xm), (gyh, slice(R, B4), geo_h, need_xh)):
                 if g is None:
                     continue
+                # the leading part may read the kept transform of the whole stacked batch (its tiles lead every plane)
+                xf = ctx.xform if sl.start == 0 else None
                 gx, gw1, gb1 = A.conv2d_backward(x4[sl], w, y4[sl] if y4 is not None else None, g, geom, ctx.act, ctx.alpha,
-                                                 ctx.has_bias, ctx.bias_ref, (nx, need_w, need_b))
+                                                 ctx.has_bias, ctx.bias_ref, (nx, need_w, need_b), xf, B4 if xf is not None else 0)
                 if sl.start == 0:
                     gxm = gx
                 else:
                     gxh = gx
                 gw = gw1 if gw is None else (gw if gw1 is None else gw + gw1)
                 gb = gb1 if gb is None else (gb if gb1 is None else gb + gb1)
-            return gxm, gxh, gw, gb, None, None, None
+            ctx.xform = None
+            return gxm, gxh, gw, gb, None, None, None, None
         # ---- the stacked first-order pass: one activation backward, one input-gradient launch for all 4B rows
         bsink = A.sink_at(ctx.bias_ref.data_ptr()) if (ctx.has_bias and need_b) else None
         fuse_b = bsink is not None and ctx.act != K.ACT_NONE and gym.shape[-1] % 4 == 0      # bias gradient in the activation backward's pass
@@ -306,7 +315,7 @@ class SConv2dFn(Function):
             if need_w and rec is None:
                 gw = A._filter_grad(x4[:R], gpm_d, geo_m, w, None)
         ctx.xform = None
-        return gxm, gxh, gw, gb, None, None, None
+        return gxm, gxh, gw, gb, None, None, None, None
 
 
 class SAddActFn(Function):
@@ -373,6 +382,114 @@ class SConcatTileBwdFn(Function):
         return None, A.ConcatTileFn.apply(ggfh, ggeh), None, None
 
 
+class SDeconvFn(Function):
+    """act(conv^T(x, w) + b) on a stacked pair in one launch: tf conv2d_transpose as a forward op (the generator's upsampling layers).
+    Backward per part: autograd.ConvBwdDataFn's, on that part's batch."""
+
+    @staticmethod
+    def forward(ctx, xm, xh, w, b, geom4, act, alpha):
+        R = xm.shape[0]
+        x4 = full(xm, xh)
+        d, ws = geom4
+        ctx.set_materialize_grads(False)
+        out4 = K.conv_bwd_data(x4, w, b, d, ws, act, alpha)
+        ctx.save_for_backward(x4, w, out4 if act != K.ACT_NONE else None)
+        ctx.R, ctx.act, ctx.alpha, ctx.has_bias, ctx.bias_ref = R, act, alpha, b is not None, b
+        ctx.geom_b4 = K.bwd_geom(geom4)
+        return out4[:R], out4[R:]
+
+    @staticmethod
+    def backward(ctx, ggm, ggh):
+        if ggm is None and ggh is None:
+            return (None,) * 7
+        x4, w, out4 = ctx.saved_tensors
+        R, B4 = ctx.R, x4.shape[0]
+        need_xm, need_xh, need_w, need_b = ctx.needs_input_grad[:4]
+        gxm = gxh = gw = gb = None
+        for g, sl, nx in ((ggm, slice(0, R), need_xm), (ggh, slice(R, B4), need_xh)):
+            if g is None:
+                continue
+            geom = K.rebatch(ctx.geom_b4, sl.stop - sl.start)
+            gx, gw1, gb1 = A.bwd_data_backward(x4[sl], w, out4[sl] if out4 is not None else None, g, geom, ctx.act, ctx.alpha, ctx.has_bias,
+                                               ctx.bias_ref, (nx, need_w, need_b))
+            if sl.start == 0:
+                gxm = gx
+            else:
+                gxh = gx
+            gw = gw1 if gw is None else (gw if gw1 is None else gw + gw1)
+            gb = gb1 if gb is None else (gb if gb1 is None else gb + gb1)
+        return gxm, gxh, gw, gb, None, None, None
+
+
+class SBatchNormFn(Function):
+    """Training-mode batch norm + activation of a stacked pair whose two parts are two evaluations of the reference graph (equal
+    sizes): each part is normalised with ITS OWN batch statistics — one grouped launch chain for both (t2i_bn_train_fwd_grouped,
+    groups = 2).  moving_groups = 1: only the leading part moves the moving averages (the generator-step evaluation runs under
+    UPDATE_OPS, the critic step's does not: reference models/wgancls/model.py:98,102).  First order; backward per part."""
+
+    @staticmethod
+    def forward(ctx, xm, xh, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, moving_groups):
+        R = xm.shape[0]
+        assert xh.shape[0] == R, 'the two parts of a stacked batch norm are two evaluations of the same batch size'
+        x4 = full(xm, xh)
+        y4, mean, rstd = K.bn_train_fwd_grouped(x4, gamma, beta, eps, decay, 2, act, alpha, mm, mv, moving_updates, moving_groups)
+        ctx.save_for_backward(x4, gamma, mean, rstd, y4 if act != K.ACT_NONE else None)
+        ctx.R, ctx.act, ctx.alpha = R, act, alpha
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        ctx.set_materialize_grads(False)
+        return y4[:R], y4[R:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gym, gyh):
+        if gym is None and gyh is None:
+            return (None,) * 12
+        x4, gamma, mean, rstd, y4 = ctx.saved_tensors
+        R = ctx.R
+        want_g, want_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gsink = A._sink_of(ctx.gamma_ref) if want_g else None
+        bsink = A._sink_of(ctx.beta_ref) if want_b else None
+        sunk = gsink is not None and bsink is not None
+        outs = [None, None]
+        dgamma = dbeta = None
+        for i, (g, sl) in enumerate(((gym, slice(0, R)), (gyh, slice(R, 2 * R)))):
+            if g is None:
+                continue
+            dx, dg, db = K.bn_bwd_grouped(_c(g), y4[sl] if y4 is not None else None, x4[sl], mean[i:i + 1], rstd[i:i + 1], gamma, 1, ctx.act,
+                                          ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
+            outs[i] = dx
+            if not sunk:
+                dgamma = dg if dgamma is None else dgamma + dg
+                dbeta = db if dbeta is None else dbeta + db
+        if sunk:
+            A._notify(ctx.gamma_ref); A._notify(ctx.beta_ref)
+            dgamma = dbeta = None
+        return (outs[0], outs[1], dgamma if want_g else None, dbeta if want_b else None) + (None,) * 8
+
+
+def batch_norm_ok(x):
+    """the grouped batch-norm kernels take this stacked tensor (C % 4 == 0, 16-byte aligned equal parts)"""
+    m, h = x.main, x.hat
+    return (m.shape[0] == h.shape[0] and m.shape[-1] % 4 == 0 and m.is_contiguous() and h.is_contiguous() and m.data_ptr() % 16 == 0 and
+            (m.numel() * m.element_size()) % 16 == 0)
+
+
+class STransposeFn(Function):
+    """physical [B,C,H,W] -> physical [B,H,W,C] on a stacked pair (autograd.NchwToNhwcFn; ops.reshape_to_map)."""
+
+    @staticmethod
+    def forward(ctx, xm, xh):
+        R = xm.shape[0]
+        ctx.R = R
+        ctx.set_materialize_grads(False)
+        y4 = K.nchw_to_nhwc(full(xm, xh))
+        return y4[:R], y4[R:]
+
+    @staticmethod
+    def backward(ctx, gm, gh):
+        return (A.NhwcToNchwFn.apply(gm) if gm is not None else None), (A.NhwcToNchwFn.apply(gh) if gh is not None else None)
+
+
 class SForkFn(Function):
     """A stacked tensor that feeds two consumers (the critic's trunk: the bottleneck branch and the residual join).  Forward: the same
     memory twice.  Backward: the two incoming stacked gradients summed by ONE launch on the whole buffer (autograd's own accumulation
@@ -397,8 +514,23 @@ def fork(x):
 
 
 # ---- what utils/ops.py calls when it is handed a Stacked ----------------------------------------------------------------------
-def conv2d(xp, w, b, geom4, act, alpha):
-    ym, yh = SConv2dFn.apply(xp.main, xp.hat, w, b, geom4, act, alpha)
+def conv2d(xp, w, b, geom4, act, alpha, want_stats=False):
+    ym, yh = SConv2dFn.apply(xp.main, xp.hat, w, b, geom4, act, alpha, want_stats)
+    return Stacked(ym, yh)
+
+
+def conv2d_transpose(xp, w, b, geom4, act, alpha):
+    ym, yh = SDeconvFn.apply(xp.main, xp.hat, w, b, geom4, act, alpha)
+    return Stacked(ym, yh)
+
+
+def batch_norm(xp, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates=1, moving_groups=1):
+    ym, yh = SBatchNormFn.apply(xp.main, xp.hat, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, moving_groups)
+    return Stacked(ym, yh)
+
+
+def nchw_to_nhwc(x):
+    ym, yh = STransposeFn.apply(x.main, x.hat)
     return Stacked(ym, yh)
 
 

@@ -90,8 +90,8 @@ def conv2d(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=None, name=
         w = st.get_variable('weights', (kh, kw, Cin, f), init or S.he_init(kh * kw * Cin))
         b = st.get_variable('biases', (f,), S.constant_init(0.0))
     geom = K.conv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
-    if isinstance(xp, ST.Stacked):        # the critic's stacked pass (stacked.py): one launch for both parts
-        y = ST.conv2d(xp, w, b, geom, kind, alpha)
+    if isinstance(xp, ST.Stacked):        # a stacked pass (stacked.py): one launch for both parts
+        y = ST.conv2d(xp, w, b, geom, kind, alpha, bool(stats) and kind == K.ACT_NONE and post is None)
     else:
         y = A.Conv2dFn.apply(xp, w, b, geom, kind, alpha, bool(stats) and kind == K.ACT_NONE and post is None)
     y = _logical(y, df)
@@ -110,7 +110,10 @@ def conv2d_transpose(x, f, ks=(4, 4), s=(2, 2), padding='SAME', act=None, init=N
         w = st.get_variable('weights', (kh, kw, f, Cin), init or S.he_init(kh * kw * f))
         b = st.get_variable('biases', (f,), S.constant_init(0.0))
     geom = K.deconv_desc(B, H, W, Cin, f, kh, kw, sh, sw, padding)
-    y = A.ConvBwdDataFn.apply(xp, w, b, geom, kind, alpha)
+    if isinstance(xp, ST.Stacked):
+        y = ST.conv2d_transpose(xp, w, b, geom, kind, alpha)
+    else:
+        y = A.ConvBwdDataFn.apply(xp, w, b, geom, kind, alpha)
     y = _logical(y, df)
     return post(y) if post else y
 
@@ -178,7 +181,16 @@ def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df
         gamma = st.get_variable('gamma', (C,), init.get('gamma', S.constant_init(1.0)))
         mm = st.get_variable('moving_mean', (C,), S.constant_init(0.0), trainable=False)
         mv = st.get_variable('moving_variance', (C,), S.constant_init(1.0), trainable=False)
-    if train and groups > 1:
+    if train and isinstance(xp, ST.Stacked):
+        # two evaluations of the reference graph stacked along the batch axis (the generator pair): per-part statistics; only the leading
+        # part — the evaluation that runs under UPDATE_OPS — moves the moving averages
+        if groups != 1:
+            raise NotImplementedError('batch_norm(groups > 1) on a stacked pair')
+        upd = _UPDATE_OPS[0]
+        if not ST.batch_norm_ok(xp):
+            raise NotImplementedError('stacked batch norm needs C % 4 == 0 and 16-byte aligned equal parts')
+        y = ST.batch_norm(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, max(int(upd), 1), 1)
+    elif train and groups > 1:
         upd = _UPDATE_OPS[0]
         if int(upd) > 1:
             raise NotImplementedError('update_ops(times > 1) with a stacked batch')
@@ -259,6 +271,10 @@ def reshape_to_map(x, C, H, W, df=NHWC):
     logical-NCHW view; with df=NHWC the reshape is free."""
     _check_df(df)
     B = x.shape[0]
+    if isinstance(x, ST.Stacked):
+        if df == NHWC:
+            return x.reshape_parts(H, W, C)
+        return ST.nchw_to_nhwc(x.reshape_parts(C, H, W)).permute(0, 3, 1, 2)
     if df == NHWC:
         return x.reshape(B, H, W, C)
     return A.NchwToNhwcFn.apply(x.reshape(B, C, H, W)).permute(0, 3, 1, 2)
