@@ -72,7 +72,7 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 9 (v9: t2i_conv_opts.reserved became xform_valid_rows — same layout, 0 keeps the v8 meaning; v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 9 (v9: t2i_conv_opts gained xform_valid_rows / xform_plane_rows, t2i_bn_train_fwd_grouped gained moving_groups, t2i_trunc_normal added; v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
@@ -340,6 +340,11 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
  * scale = 1/ranks, so that wd, wd2 are the global-batch means (the loss is quadratic in them: averaging per-rank
  * gradients would not be its gradient).  Single rank: the two means and scale = 1. */
 int t2i_kt_sgd(float* kt, const float* wdist_sums, float scale, float lr, t2i_stream_t stream);
+/* v9.  out[i] = mean + std * t_i, t_i ~ N(0, 1) truncated to [lo, hi] (tf.truncated_normal: reference models/wgancls/model.py:119, the
+ * conditioning-augmentation noise redrawn on every run), by CDF inversion of Philox4x32-10 uniforms keyed by (seed, offset + i / 4): the
+ * draw is a pure function of (seed, offset, i).  The caller advances offset by (n + 3) / 4 per call.  One launch (the tensor library's
+ * trunc_normal_ is eight). */
+int t2i_trunc_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float mean, float std, float lo, float hi, t2i_stream_t stream);
 
 /* ---- PGGAN operators: reference utils/ops.py:74-81 (layer_norm), :100-101 (pool), :109-111 (upscale) ------------ */
 /* y[b,h,w,:] = scale * sum of the 2x2 window of x [B,H,W,C] (H, W even) -> [B,H/2,W/2,C].  scale = 1/4 is

@@ -954,6 +954,29 @@ def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
     assert close(mean, mu.float(), 2e-6) and close(rstd, (1.0 / torch.sqrt(var + 1e-5)).float(), 5e-6)
 
 
+def test_trunc_normal_kernel_distribution_and_reproducibility(K):
+    """t2i_trunc_normal (tf.truncated_normal, reference models/wgancls/model.py:119): N(0,1) cut at +-2 by CDF inversion of Philox
+    uniforms.  Distribution against scipy's truncnorm (bounds, mean, variance 0.7737, Kolmogorov-Smirnov on 2^20 draws), a pure function
+    of the device generator's (seed, offset) — torch.manual_seed reproduces it, consecutive draws differ and do not overlap — and odd
+    lengths (the last quad is partial)."""
+    import scipy.stats as st
+    torch.manual_seed(1234)
+    a = K.trunc_normal_(torch.empty(1 << 20, device='cuda'))
+    b = K.trunc_normal_(torch.empty(1 << 20, device='cuda'))
+    torch.manual_seed(1234)
+    a2 = K.trunc_normal_(torch.empty(1 << 20, device='cuda'))
+    c = K.trunc_normal_(torch.empty((1 << 20) + 3, device='cuda'))
+    assert torch.equal(a, a2) and not torch.equal(a, b) and torch.equal(c[:1 << 20], b)
+    x = a.double().cpu().numpy()
+    assert x.min() >= -2.0 and x.max() <= 2.0 and x.min() < -1.99 and x.max() > 1.99
+    assert abs(x.mean()) < 4e-3 and abs(x.var() - 0.77374) < 4e-3
+    ks = st.kstest(x, st.truncnorm(-2.0, 2.0).cdf)
+    assert ks.statistic < 3e-3, ks            # 1.36 / sqrt(2^20) = 1.3e-3 is the 5 % critical value; 24-bit uniforms add < 1e-6
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 4e-3 and abs(np.corrcoef(x, b.double().cpu().numpy())[0, 1]) < 4e-3
+    y = K.trunc_normal_(torch.empty(7, device='cuda'), mean=3.0, std=0.5)
+    assert float(y.min()) >= 2.0 and float(y.max()) <= 4.0
+
+
 @pytest.mark.parametrize('shape,groups,act', [((3 * 6, 4, 4, 6), 3, 'lrelu'), ((2 * 5, 8, 8, 18), 2, 'none'), ((3 * 4, 4, 4, 10), 3, 'relu')])
 def test_grouped_batch_norm_odd_channels(K, shape, groups, act):
     """autograd.BatchNormTrainGroupedFn where the grouped entry points do not apply (C % 4 != 0: a critic with an odd DF_DIM):

@@ -1519,6 +1519,55 @@ __global__ void kt_sgd_kernel(float* __restrict__ kt, const float* __restrict__ 
   *kt = k - lr * grad;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Truncated normal (tf.truncated_normal, reference models/wgancls/model.py:119: the conditioning-augmentation noise the graph redraws on
+// every run): out = mean + std * t with t ~ N(0,1) restricted to [lo, hi] — by inverting the normal CDF on a uniform draw in
+// (Phi(lo), Phi(hi)), the same construction torch.nn.init.trunc_normal_ uses (8 tensor-library launches per draw: uniform, two scalings,
+// erfinv, two more scalings, clamp).  Uniforms come from Philox4x32-10 keyed by (seed, offset + element / 4): counter-based, so the draw
+// is a pure function of (seed, offset, index) — reproducible whatever the launch geometry.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void trunc_normal_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long offset,
+                                                           float mean, float std, float lo, float hi, float cdf_lo, float cdf_span) {
+  const size_t quads = (n + 3) >> 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long ctr = offset + q;
+    unsigned r[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t i = q * 4 + e;
+      if (i >= n) break;
+      const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1), 24 bits
+      const float p = cdf_lo + u * cdf_span;                                       // in (Phi(lo), Phi(hi))
+      float t = 1.41421356237f * erfinvf(2.f * p - 1.f);
+      t = fminf(fmaxf(t, lo), hi);
+      out[i] = mean + std * t;
+    }
+  }
+}
+
+hipError_t trunc_normal_launch(float* out, size_t n, unsigned long long seed, unsigned long long offset, float mean, float std, float lo, float hi,
+                               hipStream_t stream) {
+  const double cl = 0.5 * (1.0 + erf((double)lo / 1.4142135623730951)), ch = 0.5 * (1.0 + erf((double)hi / 1.4142135623730951));
+  const size_t quads = (n + 3) >> 2;
+  size_t blocks = (quads + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(trunc_normal_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, out, n, seed, offset, mean, std, lo, hi, (float)cl,
+                     (float)(ch - cl));
+  return hipGetLastError();
+}
+
 hipError_t kt_sgd_launch(float* kt, const float* sums, float scale, float lr, hipStream_t stream) {
   hipLaunchKernelGGL(kt_sgd_kernel, dim3(1), dim3(1), 0, stream, kt, sums, scale, lr);
   return hipGetLastError();

@@ -1266,6 +1266,21 @@ def tuning_set(key, value):
     _XFORM_BYTES.clear()
 
 
+def trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    """In place: t = mean + std * n with n ~ N(0,1) truncated to [a, b] (a, b in units of the standard normal: the reference's
+    tf.truncated_normal cuts at +-2 standard deviations; with mean 0, std 1 these are torch.nn.init.trunc_normal_'s arguments).
+    One launch (t2i_trunc_normal) instead of the tensor library's eight.  The Philox (seed, offset) come from — and advance — the
+    device's torch generator, so torch.manual_seed / torch.cuda.manual_seed make the draws reproducible like any other."""
+    _chk(t, 't', f32=True)
+    if _live(t):
+        gen = torch.cuda.default_generators[t.device.index if t.device.index is not None else torch.cuda.current_device()]
+        seed, off = int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, int(gen.get_offset())
+        quads = (t.numel() + 3) // 4
+        gen.set_offset(off + 4 * ((quads + 3) // 4))              # (torch wants multiples of 4)
+        check(lib.t2i_trunc_normal(_ptr(t), t.numel(), seed, off, float(mean), float(std), float(a), float(b), _stream()), 't2i_trunc_normal')
+    return t
+
+
 def kt_sgd(kt, wdist_sums, scale, lr):
     """kt -= lr * d balance_loss / d kt from the (rank-summed) batch means wdist, wdist2; in place on the device scalar."""
     _chk(wdist_sums, 'wdist_sums')

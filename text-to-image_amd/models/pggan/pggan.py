@@ -94,7 +94,7 @@ class PGGAN(object):
     def _noise(self, feed, key, like):
         n = feed.get(key)
         if n is None:
-            n = torch.nn.init.trunc_normal_(torch.empty_like(like), 0.0, 1.0, -2.0, 2.0)
+            n = K.trunc_normal_(torch.empty_like(like))
         return n
 
     def d_losses(self, feed):
@@ -196,7 +196,7 @@ class PGGAN(object):
             st['eps_graph'].uniform_(0.0, 1.0)
         for k in ('ca_noise_d', 'ca_noise_g'):
             if feed.get(k) is None or feed[k] is st[k]:
-                torch.nn.init.trunc_normal_(st[k], 0.0, 1.0, -2.0, 2.0)
+                K.trunc_normal_(st[k])
 
     def iteration(self, idx, feed):
         """One D update then one G update (pggan.py:196-197)."""
@@ -315,7 +315,7 @@ class PGGAN(object):
             return mean
         eps = getattr(self, '_ca', None)
         if eps is None or eps.shape != mean.shape:
-            eps = torch.nn.init.trunc_normal_(torch.empty_like(mean), 0.0, 1.0, -2.0, 2.0)
+            eps = K.trunc_normal_(torch.empty_like(mean))
         return mean + torch.exp(log_sigma) * eps
 
     def kl_std_normal_loss(self, mean, log_sigma):

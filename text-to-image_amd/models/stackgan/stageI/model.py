@@ -67,7 +67,7 @@ class ConditionalGan(object):
         """noise: the truncated-normal draw (a feed key here so that runs are reproducible); None -> drawn on the device."""
         if cond_noise:
             if noise is None:
-                noise = torch.nn.init.trunc_normal_(torch.empty_like(mean), 0.0, 1.0, -2.0, 2.0)
+                noise = K.trunc_normal_(torch.empty_like(mean))
             return mean + torch.exp(log_sigma) * noise
         return mean
 

@@ -149,7 +149,7 @@ class ConditionalGanTrainer(object):
     def _draw_noise(self, feed):
         for k in self.NOISE_KEYS:
             if feed.get(k) is None or feed[k] is self._graphs.static.get(k):
-                torch.nn.init.trunc_normal_(self._graphs.static[k], 0.0, 1.0, -2.0, 2.0)
+                K.trunc_normal_(self._graphs.static[k])
 
     def iteration(self, feed, epoch=0):
         lr = self.lr * (0.5 ** (epoch // 100))                       # trainer.py:119,127

@@ -75,7 +75,7 @@ class ConditionalGan(object):
     def sample_normal_conditional(self, mean, log_sigma, cond_noise, noise=None):
         if cond_noise:
             if noise is None:
-                noise = torch.nn.init.trunc_normal_(torch.empty_like(mean), 0.0, 1.0, -2.0, 2.0)
+                noise = K.trunc_normal_(torch.empty_like(mean))
             return mean + torch.exp(log_sigma) * noise
         return mean
 

@@ -145,7 +145,7 @@ class WGanCls(object):
         n = feed.get(key)
         if n is None:    # tf.truncated_normal(tf.shape(mean)) resampled per run (model.py:119)
             n = torch.empty_like(like)
-            torch.nn.init.trunc_normal_(n, mean=0.0, std=1.0, a=-2.0, b=2.0)
+            K.trunc_normal_(n)
         return n
 
     # Where the data-parallel graph schedule cuts the two backward passes so that the exchange of the gradients that are final
@@ -478,7 +478,7 @@ class WGanCls(object):
             if not self._graphs['loaded']:
                 self._load_static(feed, noise=('ca_noise_g',))
             elif feed.get('ca_noise_g') is None:       # inputs were loaded by d_step on this feed: only the G step's own draw is due
-                torch.nn.init.trunc_normal_(self._graphs['static']['ca_noise_g'], mean=0.0, std=1.0, a=-2.0, b=2.0)
+                K.trunc_normal_(self._graphs['static']['ca_noise_g'])
             self._graphs['loaded'] = False
             self._graphs['g'].replay()
             if self.dp is not None:
@@ -591,7 +591,7 @@ class WGanCls(object):
                 if k not in ('ca_noise_d', 'ca_noise_g'):
                     raise KeyError('feed lacks %r, which the captured graphs read' % k)
                 if k in noise:
-                    torch.nn.init.trunc_normal_(buf, mean=0.0, std=1.0, a=-2.0, b=2.0)
+                    K.trunc_normal_(buf)
             elif src.data_ptr() != buf.data_ptr():
                 if k in ('x', 'x_mismatch') and buf._base is not None and src.dtype == buf.dtype and src.is_cuda:
                     K.axpby(src.reshape(buf.shape).contiguous(), 1.0, out=buf)     # a slot of the stacked image buffer (see _d_losses_stacked)
@@ -733,7 +733,7 @@ class WGanCls(object):
         eps = getattr(self, '_noise', None)
         if eps is None or eps.shape != mean.shape:
             eps = torch.empty_like(mean)
-            torch.nn.init.trunc_normal_(eps, mean=0.0, std=1.0, a=-2.0, b=2.0)
+            K.trunc_normal_(eps)
         code, self._kl = A.CaSampleKlFn.apply(mean, log_sigma, eps)     # one launch; the KL term rides along
         return code
 
