@@ -954,6 +954,48 @@ def test_grouped_batch_norm_equals_one_pass_per_group(K, shape, groups, act):
     assert close(mean, mu.float(), 2e-6) and close(rstd, (1.0 / torch.sqrt(var + 1e-5)).float(), 5e-6)
 
 
+@pytest.mark.parametrize('case', [(24, 4, 4, 512, 1024, 3, 1), (64, 8, 8, 512, 512, 3, 1), (128, 16, 16, 256, 256, 3, 1), (16, 32, 32, 128, 256, 4, 2), (8, 16, 16, 256, 512, 4, 2)])
+def test_kept_input_transform_of_a_stacked_pass_is_bit_identical(K, case):
+    """The forward conv's kept Winograd input transform (t2i_conv_opts.xform, T2I_XFORM_KEEP / _HAVE) as the stacked passes use it
+    (ABI v9, text-to-image_amd/stacked.py) — both against the filter gradient that transforms x itself, bit for bit:
+      xform_valid_rows = R: the rows behind the first R images were overwritten after the forward conv (the stacked critic step puts the
+        gradient penalty's tangent there); the library regenerates their tiles in place and runs ONE launch over all rows;
+      xform_plane_rows = n: the filter gradient of the LEADING B images of a stacked batch of n reads their tiles out of the n-image
+        planes (the paired generator's generator-step half); honoured by the 3x3 form, the 4x4 stride-2 form transforms x anew."""
+    B, H, W, Cin, Cout, k, s = case
+    g = torch.Generator(device='cpu').manual_seed(31)
+    d, ws = K.conv_desc(B, H, W, Cin, Cout, k, k, s, s, 'SAME')
+    if not K.conv_xform_bytes(d):
+        pytest.skip('forward conv and filter gradient of this shape do not share a Winograd transform')
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(k, k, Cin, Cout, generator=g) * 0.05).cuda()
+    dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).cuda()
+    K.conv_fwd(x, w, None, d, ws, keep_xform=True)
+    V = K.LAST_XFORM[0]
+    K.LAST_XFORM[0] = None
+    assert V is not None
+    # ---- valid rows: overwrite the last quarter of the batch, as the stacked critic step does
+    R = B - B // 4
+    x2 = x.clone()
+    x2[R:] = torch.randn(B - R, H, W, Cin, generator=g).cuda()
+    ref = K.conv_bwd_filter(x2, dy, d, ws)
+    got = K.conv_bwd_filter(x2, dy, d, ws, xform=V.clone(), xform_valid_rows=R)
+    assert torch.equal(got, ref)
+    stale = K.conv_bwd_filter(x2, dy, d, ws, xform=V.clone())              # (without the hint the stale tiles are used: the hint matters)
+    assert not torch.equal(stale, ref)
+    # ---- plane rows: the leading half of the batch against the whole batch's planes
+    Bh = B // 2
+    dh, wsh = K.rebatch((d, ws), Bh)
+    if k == 3 and B >= 64:                  # (the cases that are there for this path: the half batch is on the 3x3 Winograd form itself)
+        assert K.conv_xform_bytes(dh) > 0 and K.conv_algo(dh, 'bwd_filter') == 'winograd_f2x2_3x3'
+    ref_h = K.conv_bwd_filter(x[:Bh], dy[:Bh], dh, wsh)
+    got_h = K.conv_bwd_filter(x[:Bh], dy[:Bh], dh, wsh, xform=V, xform_plane_rows=B)
+    assert torch.equal(got_h, ref_h)
+    acc = torch.full_like(ref_h, 0.25)
+    K.conv_bwd_filter(x[:Bh], dy[:Bh], dh, wsh, out=acc.view(-1), xform=V, xform_plane_rows=B)
+    assert float((acc - (ref_h + 0.25)).abs().max()) <= 1e-6 * max(float(ref_h.abs().max()), 1.0)
+
+
 def test_trunc_normal_kernel_distribution_and_reproducibility(K):
     """t2i_trunc_normal (tf.truncated_normal, reference models/wgancls/model.py:119): N(0,1) cut at +-2 by CDF inversion of Philox
     uniforms.  Distribution against scipy's truncnorm (bounds, mean, variance 0.7737, Kolmogorov-Smirnov on 2^20 draws), a pure function

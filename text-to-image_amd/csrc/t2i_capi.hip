@@ -147,8 +147,10 @@ static Tuning& tuning_mut() {
     v.hft_boost = env_int("T2I_HFT_BOOST", 130);           // x0.01: planner efficiency of igemm_hft_kernel's 128x128 tile against igemm_h_filter_kernel's
     v.hft_ovh = env_int("T2I_HFT_OVH", 80);                // x0.1 K-tile steps: its fixed cost per workgroup
     v.bgemm = env_int("T2I_BGEMM", 1);                     // batched (Winograd) fp32 GEMMs: persistent workgroups (t2i_bgemm.hip); 0: one workgroup per tile (igemm_kernel)
-    v.bgemm_tile = env_int("T2I_BGEMM_TILE", 11);          // persistent batched GEMM tile: 11 / 21 / 12 / 22 = 64 a x 64 b; 0 = by item count (measured: the larger tiles lose at every batch size, profiles/r04_bgemm_tiles.txt)
-    v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 1024);   // ... a larger tile is taken when it still leaves at least this many work items (2 resident per CU = 512)
+    v.bgemm_tile = env_int("T2I_BGEMM_TILE", 0);           // persistent batched GEMM tile: 11 / 21 / 12 / 22 = 64 a x 64 b; 0 = by item count.  Rounds 4-5: the larger tiles lost at every
+                                                           // batch size (profiles/r04_bgemm_tiles.txt) and 11 was the default; round 6: the stacked critic pass (4B rows) has launches with
+                                                           // >= 8192 64x64 items, where the 128x128 tile (half the operand bytes per multiply-add) wins: 12.73 -> 12.64 ms on the step
+    v.bgemm_big_items = env_int("T2I_BGEMM_BIG_ITEMS", 2048);   // ... a larger tile is taken when it still leaves at least this many work items (sweep 1024 .. 6144: profiles/r06_stacked_pass.txt, section 6)
     v.dma_ovh = env_int("T2I_DMA_OVH", 120);               // x0.1 K-tile steps: prologue + epilogue of an igemm_hd_kernel workgroup in the planner's model
     v.dma_split_us = env_int("T2I_DMA_SPLIT_US", 29);      // x0.1 us: fixed cost of its split-K reduction launch
     v.tile8_eff = env_int("T2I_TILE8_EFF", 0);             // x0.01: planner efficiency of the 8-wave 256x128 bf16 tile relative to 128x128 (0: only when forced with force_tile = 42)
