@@ -72,7 +72,7 @@ typedef struct t2i_conv_desc {
 enum { T2I_MATH_F32 = 0, T2I_MATH_BF16 = 1 };
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int t2i_version(void);            /* ABI version, currently 9 (v9: t2i_conv_opts gained xform_valid_rows / xform_plane_rows, t2i_bn_train_fwd_grouped gained moving_groups, t2i_trunc_normal added; v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
+int t2i_version(void);            /* ABI version, currently 9 (v9: t2i_conv_opts gained xform_valid_rows / xform_plane_rows, t2i_bn_train_fwd_grouped gained moving_groups, t2i_trunc_normal and t2i_zero_ranges added; v8: t2i_sigmoid_ce_head, t2i_bn_train_fwd_grouped, t2i_bn_bwd_grouped, t2i_bn_grouped_workspace_bytes added — no existing signature changed; v7: v7: t2i_conv2d_bwd_pair, t2i_row_scale_div, t2i_stat, t2i_filter_cache_assume added, t2i_adam_tf takes m == NULL at beta1 == 0 — no existing signature changed; v2: t2i_conv_desc.math; v3: caller-owned filter-cache arena,
                                    * t2i_tuning_set, t2i_kt_sgd; v4: t2i_filter_cache_refresh, bf16 operand images; v5: t2i_conv_opts
                                    * and explicit image arguments instead of thread-local one-shot hand-overs; v6: bf16 STORAGE —
                                    * activation tensors may be bf16 at this interface: t2i_dtype arguments, t2i_conv_opts.in_dtype /
@@ -340,6 +340,9 @@ int t2i_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float l
  * scale = 1/ranks, so that wd, wd2 are the global-batch means (the loss is quadratic in them: averaging per-rank
  * gradients would not be its gradient).  Single rank: the two means and scale = 1. */
 int t2i_kt_sgd(float* kt, const float* wdist_sums, float scale, float lr, t2i_stream_t stream);
+/* v9.  base[start_r + i] = 0 for every range r < n of the DEVICE table ranges[n][2] = (start, length) in elements: the small slots of a gradient arena
+ * whose large filter slots take their first contribution of a step as a plain store (accumulate = 0) and therefore need no zero-fill. */
+int t2i_zero_ranges(float* base, const int64_t* ranges, int32_t n, t2i_stream_t stream);
 /* v9.  out[i] = mean + std * t_i, t_i ~ N(0, 1) truncated to [lo, hi] (tf.truncated_normal: reference models/wgancls/model.py:119, the
  * conditioning-augmentation noise redrawn on every run), by CDF inversion of Philox4x32-10 uniforms keyed by (seed, offset + i / 4): the
  * draw is a pure function of (seed, offset, i).  The caller advances offset by (n + 3) / 4 per call.  One launch (the tensor library's

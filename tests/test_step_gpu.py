@@ -431,6 +431,43 @@ def test_bf16_operand_images_and_batched_refresh_bit_identical(gpu):
         K.set_math('f32')
 
 
+def test_store_first_gradient_slots_equal_zero_filled_ones(gpu):
+    """optim.Arena(store_first): the large filter slots of the gradient arenas are not zero-filled — the first contribution of a step is
+    written as a plain store (accumulate = 0 in the filter-gradient epilogue), later ones add.  0 + x == x in fp32, so both steps' arenas
+    must equal the zero-filled ones bit for bit (full width, B = 8; the critic's first layer and text projection take two contributions,
+    every other filter one).  And a slot that gets NO contribution is zeroed by finish_step() before the optimizer reads it."""
+    from t2i_amd.models.wgancls.model import WGanCls
+    B = 8
+    cfg = _cfg(128, 1024, 128, 128, 128, B)
+    g = torch.Generator(device=gpu).manual_seed(13)
+    feed = {'x': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1, 'x_mismatch': torch.rand(B, 64, 64, 3, generator=g, device=gpu) * 2 - 1,
+            'cond': torch.randn(B, 1024, generator=g, device=gpu), 'z': torch.randn(B, 128, generator=g, device=gpu),
+            'epsilon': torch.rand(B, 1, 1, 1, generator=g, device=gpu), 'learning_rate_d': 1e-4, 'learning_rate_g': 1e-4,
+            'ca_noise_d': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2),
+            'ca_noise_g': torch.randn(B, 128, generator=g, device=gpu).clamp_(-2, 2)}
+    res = {}
+    for store in (False, True):
+        m = WGanCls(cfg, device=gpu, seed=3)
+        m.d_arena.enable_sinks(store_first=store)
+        m.g_arena.enable_sinks(store_first=store)
+        assert (m.d_arena._store_first is not None) == store
+        m.d_arena.grad.fill_(7.0); m.g_arena.grad.fill_(-3.0)          # stale values: the step must not depend on what the arenas held
+        m.d_losses(feed)
+        m.g_losses(feed)
+        torch.cuda.synchronize()
+        res[store] = (m.d_arena.grad.clone(), m.g_arena.grad.clone())
+        if store:
+            assert len(m.d_arena._store_first) >= 8 and m.d_arena._touched >= m.d_arena._store_first
+            # a step that skips a filter: its slot is zeroed before the optimizer reads the arena
+            m.d_arena.zero_grad()
+            name = 'd_net/Conv_7/weights'
+            assert float(m.d_arena.grad_of(name).abs().max()) > 0          # (not zero-filled: last step's gradient is still there)
+            m.d_arena._touched = set(m.d_arena._store_first) - {name}
+            m.d_arena.finish_step()
+            assert float(m.d_arena.grad_of(name).abs().max()) == 0.0
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
 def test_paired_generator_iteration_matches_two_passes(gpu):
     """Round 6: a single-GPU D + G iteration evaluates the generator ONCE on 2B rows (WGanCls._g_forward_pair, stacked.py) — the
     generator step's evaluation (gradient, UPDATE_OPS) in front, the critic step's (no gradient, its own conditioning noise) behind,

@@ -82,6 +82,7 @@ SIGNATURES = {
     't2i_filter_cache_enable': (ctypes.c_int, [ctypes.c_int]),
     't2i_tuning_set': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_double]),
     't2i_kt_sgd': (ctypes.c_int, [_p, _p, _f, _f, _p]),
+    't2i_zero_ranges': (ctypes.c_int, [_p, _p, _i32, _p]),
     't2i_trunc_normal': (ctypes.c_int, [_p, _i64, ctypes.c_uint64, ctypes.c_uint64, _f, _f, _f, _f, _p]),
     't2i_filter_cache_invalidate': (None, [_p, ctypes.c_size_t]),
     't2i_filter_cache_bytes': (ctypes.c_size_t, []),

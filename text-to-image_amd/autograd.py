@@ -30,8 +30,18 @@ SINKS = {}          # address -> (weakref to the parameter leaf, its slot of the
 NOTIFY = [None]
 
 
-def register_sink(param, slot):
-    SINKS[param.data_ptr()] = (weakref.ref(param), slot)
+def register_sink(param, slot, first_touch=None):
+    """first_touch: callable() -> bool (optim.Arena): True exactly once per step for a slot whose first contribution may be a plain store."""
+    SINKS[param.data_ptr()] = (weakref.ref(param), slot, first_touch)
+
+
+def sink_accumulate(ptr):
+    """Must the contribution about to be written into the sink of the parameter at `ptr` be ADDED to what the slot holds?  False exactly for
+    the first contribution of a step into a slot the arena does not zero (optim.Arena.zero_grad): that one is written as a plain store."""
+    e = SINKS.get(ptr)
+    if e is None or e[2] is None:
+        return True
+    return not e[2]()
 
 
 def sink_at(ptr):
@@ -109,6 +119,7 @@ def _filter_grad(x, gpre, geom, w, xform=None, xform_plane_rows=0):
         sink = sink_at(w.data_ptr())
         if sink is not None:
             xs, gs = _c(x), _c(gpre)
+            acc = sink_accumulate(w.data_ptr())
             if xs is not x:
                 xform = None
             if SIDE.stream is not None:
@@ -116,12 +127,12 @@ def _filter_grad(x, gpre, geom, w, xform=None, xform_plane_rows=0):
                 K.WS_LANE[0] = 1                                          # its own split-K workspace
                 try:
                     with torch.cuda.stream(SIDE.stream):
-                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows)
+                        K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows, accumulate=acc)
                 finally:
                     K.WS_LANE[0] = 0
                 SIDE.keep.append((xs, gs, xform))
             else:
-                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows)
+                K.conv_bwd_filter(xs, gs, geom[0], geom[1], out=sink, xform=xform, xform_plane_rows=xform_plane_rows, accumulate=acc)
             _notify(w)
             return None
     if os.environ.get('T2I_DP_DEBUG') == '1' and NOTIFY[0] is not None:
@@ -243,7 +254,8 @@ def conv2d_backward(x, w, y, gy, geom_b, act, alpha, has_bias, bias_ref, need, x
             gb = ColSumFn.apply(gpre)
     if need[0] and need[1] and params and _pair_ok(gpre, x, w):
         # final backward on bf16 tensors: the input gradient and the (sunk) filter gradient in one launch
-        gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=x.dtype)
+        gx = K.conv_bwd_pair(K.PAIR_BWD_DATA, _c(gpre), w, _c(x), _c(gpre), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=x.dtype,
+                             accumulate=sink_accumulate(w.data_ptr()))
         _notify(w)
         return gx, None, gb
     gx = ConvBwdDataFn.apply(gpre, w, None, geom_b, K.ACT_NONE, 0.0, x.dtype) if need[0] else None
@@ -282,7 +294,8 @@ def bwd_data_backward(dy, w, out, gg, geom_b, act, alpha, has_bias, bias_ref, ne
     gpre = _act_bwd(gg, out, act, alpha)
     params = not _INPUTS_ONLY[0]
     if need[0] and need[1] and params and _pair_ok(gpre, dy, w):
-        g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=dy.dtype)
+        g_dy = K.conv_bwd_pair(K.PAIR_FWD, _c(gpre), w, _c(gpre), _c(dy), geom_b[0], geom_b[1], sink_at(w.data_ptr()), out_dtype=dy.dtype,
+                               accumulate=sink_accumulate(w.data_ptr()))
         _notify(w)
         g_w = None
     else:

@@ -1568,6 +1568,20 @@ hipError_t trunc_normal_launch(float* out, size_t n, unsigned long long seed, un
   return hipGetLastError();
 }
 
+// Zero a table of element ranges of one buffer in one launch (the small slots of a gradient arena — biases, batch-norm gamma / beta — between
+// the large filter slots, whose first contribution of a step is a plain store: optim.Arena.zero_grad).  ranges: device int64 [n][2] = (start, length).
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long long* __restrict__ ranges, int n) {
+  for (int r = blockIdx.x; r < n; r += gridDim.x) {
+    const long long s = ranges[2 * r], len = ranges[2 * r + 1];
+    for (long long i = threadIdx.x; i < len; i += 256) base[s + i] = 0.f;
+  }
+}
+
+hipError_t zero_ranges_launch(float* base, const long long* ranges, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(n < 1024 ? n : 1024), dim3(256), 0, stream, base, ranges, n);
+  return hipGetLastError();
+}
+
 hipError_t kt_sgd_launch(float* kt, const float* sums, float scale, float lr, hipStream_t stream) {
   hipLaunchKernelGGL(kt_sgd_kernel, dim3(1), dim3(1), 0, stream, kt, sums, scale, lr);
   return hipGetLastError();

@@ -64,6 +64,7 @@ hipError_t col_reduce_partials_launch(const float*, const float*, int, int, floa
 hipError_t adam_tf_launch(float*, const float*, float*, float*, int64_t, float, const float*, float, float, float, float,
                           hipStream_t);
 hipError_t kt_sgd_launch(float*, const float*, float, float, hipStream_t);
+hipError_t zero_ranges_launch(float*, const long long*, int, hipStream_t);
 hipError_t trunc_normal_launch(float*, size_t, unsigned long long, unsigned long long, float, float, float, float, hipStream_t);
 hipError_t act_bwd_colsum_launch(const void*, const void*, const void*, const float*, int64_t, int, int, float, float*, float*,
                                  float*, int, void*, hipStream_t, void* dx_h, bool in_bf16);
@@ -1550,6 +1551,11 @@ int t2i_tuning_set(const char* key, double value) {
 int t2i_kt_sgd(float* kt, const float* wdist_sums, float scale, float lr, t2i_stream_t stream) {
   if (!kt || !wdist_sums) { set_error("t2i_kt_sgd: bad argument"); return T2I_ERR_INVALID; }
   return check(kt_sgd_launch(kt, wdist_sums, scale, lr, (hipStream_t)stream), "t2i_kt_sgd");
+}
+
+int t2i_zero_ranges(float* base, const int64_t* ranges, int32_t n, t2i_stream_t stream) {
+  if (!base || !ranges || n <= 0) { set_error("t2i_zero_ranges: bad argument"); return T2I_ERR_INVALID; }
+  return check(zero_ranges_launch(base, reinterpret_cast<const long long*>(ranges), n, (hipStream_t)stream), "t2i_zero_ranges");
 }
 
 int t2i_trunc_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float mean, float std, float lo, float hi, t2i_stream_t stream) {

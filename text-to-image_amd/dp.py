@@ -356,6 +356,8 @@ class DataParallel(object):
         of the arena whose gradients are final NOW — the part of a backward that has been cut in two; the caller issues the
         remaining ranges with another call before finish_allreduce."""
         st = self.attach(arena)
+        if hasattr(arena, 'finish_step'):
+            arena.finish_step()                    # (filter slots no contribution was stored into this step: zeroed before anything reads them)
         if ranges is not None and st['armed']:
             raise RuntimeError('start_allreduce(ranges=...) belongs to the cut (un-armed) schedule: this arena is armed for the '
                                'bucket-overlap schedule, which would exchange every bucket now — including the ones the cut says '
@@ -447,6 +449,8 @@ class LocalRounding(object):
         pass
 
     def start_allreduce(self, arena, extra=None, ranges=None):
+        if hasattr(arena, 'finish_step'):
+            arena.finish_step()
         for a, b in (ranges if ranges is not None else [(0, arena.numel)]):
             if b > a:
                 g = arena.grad[a:b]

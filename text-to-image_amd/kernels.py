@@ -671,7 +671,7 @@ def conv_bwd_data(dy, w, bias, d, ws_bytes, act=ACT_NONE, alpha=0.2, out_dtype=N
     return dx
 
 
-def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0, xform_plane_rows=0):
+def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0, xform_plane_rows=0, accumulate=True):
     """dw = x (*) dy.  out: an existing [KH,KW,Cin,Cout]-sized buffer to ACCUMULATE into (dw += ...), e.g. the
     optimizer's gradient arena; returns it.  xform_valid_rows (with xform): the kept transform is current for that many leading images
     only — the library regenerates the rest from x, in place in `xform` (t2i_conv_opts.xform_valid_rows)."""
@@ -691,7 +691,8 @@ def conv_bwd_filter(x, dy, d, ws_bytes, out=None, xform=None, xform_valid_rows=0
             opts.xform, opts.xform_bytes, opts.xform_mode = xform.data_ptr(), xform.numel() * 4, XFORM_HAVE
             opts.xform_valid_rows = int(xform_valid_rows)
             opts.xform_plane_rows = int(xform_plane_rows)       # the transform of a larger, stacked batch whose leading images are x
-        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if out is not None else 0, ctypes.byref(opts),
+        # accumulate=False with out=: the slot's FIRST contribution of a step is a plain store (optim.Arena: no zero-fill, no read)
+        check(lib.t2i_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), 1 if (out is not None and accumulate) else 0, ctypes.byref(opts),
                                         wsp, wsn, _stream()), 't2i_conv2d_bwd_filter')
         if ev is not None:
             ev.record()
@@ -709,7 +710,7 @@ def pair_calls(on=None):
     return _PAIR[0]
 
 
-def conv_bwd_pair(first, g, w, fx, fdy, d, ws_bytes, dw_out, out_dtype=None):
+def conv_bwd_pair(first, g, w, fx, fdy, d, ws_bytes, dw_out, out_dtype=None, accumulate=True):
     """One layer's backward pair: out1 = conv^T(g, w) (first = PAIR_BWD_DATA) or conv(g, w) (PAIR_FWD), and dw_out += fx (*) fdy
     (the gradient sink).  Same results as conv_bwd_data / conv_fwd followed by conv_bwd_filter(out=dw_out); on bf16 tensors the
     two GEMMs share one launch (t2i_conv2d_bwd_pair).  Returns out1."""
@@ -733,7 +734,7 @@ def conv_bwd_pair(first, g, w, fx, fdy, d, ws_bytes, dw_out, out_dtype=None):
         keep1 = _operand_images(o1, g) if _h_path(d, which) else None
         _storage_flags(o2, fx, fdy, None)
         keep2 = _operand_images(o2, fx, fdy) if _h_path(d, 'bwd_filter') else None
-        check(lib.t2i_conv2d_bwd_pair(ctypes.byref(d), first, _ptr(g), _ptr(w), _ptr(out1), ctypes.byref(o1), _ptr(fx), _ptr(fdy), _ptr(dw_out), 1,
+        check(lib.t2i_conv2d_bwd_pair(ctypes.byref(d), first, _ptr(g), _ptr(w), _ptr(out1), ctypes.byref(o1), _ptr(fx), _ptr(fdy), _ptr(dw_out), 1 if accumulate else 0,
                                       ctypes.byref(o2), ws1p, ws1n, ws2p, ws2n, _stream()), 't2i_conv2d_bwd_pair')
         del keep1, keep2
         if ev is not None:
@@ -1264,6 +1265,14 @@ def tuning_set(key, value):
     _DESC_CACHE.clear()
     _H_ALGO.clear()
     _XFORM_BYTES.clear()
+
+
+def zero_ranges(base, table):
+    """base[start:start + length] = 0 for every (start, length) row of the device int64 table [n, 2], one launch (t2i_zero_ranges)."""
+    _chk(base, 'base', f32=True)
+    assert table.dtype == torch.int64 and table.dim() == 2 and table.shape[1] == 2 and table.is_contiguous() and table.device == base.device
+    if _live(base) and table.shape[0]:
+        check(lib.t2i_zero_ranges(_ptr(base), _ptr(table), int(table.shape[0]), _stream()), 't2i_zero_ranges')
 
 
 def trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):

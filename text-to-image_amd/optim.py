@@ -49,15 +49,67 @@ class Arena(object):
                     opt._materialize_m()
             if dead:
                 self.before_zero = tuple(r for r in self.before_zero if r() is not None)
-        self.grad.zero_()
+        if self._store_first is not None:
+            # the large filter slots are not zeroed: their first contribution of the step is a plain store (first_touch); one launch zeroes
+            # the small slots between them
+            K.zero_ranges(self.grad, self._small_ranges)
+            self._touched = set()
+            self._pending_check = True
+        else:
+            self.grad.zero_()
 
     before_zero = ()
+    _store_first = None
+    _pending_check = False
 
-    def enable_sinks(self):
-        """Let the filter-gradient GEMMs accumulate directly into this arena (autograd.SINKS)."""
+    def enable_sinks(self, store_first=None):
+        """Let the filter-gradient GEMMs accumulate directly into this arena (autograd.SINKS).
+        store_first (default: T2I_STORE_FIRST != 0): the slots of the large filters (>= 2^16 elements; conv / deconv / dense kernels) are
+        never zero-filled — the first contribution a step writes into such a slot is a plain store (accumulate = 0 in the filter-gradient
+        epilogue), later ones add.  Saves the fill (116 + 91 MB per wgancls iteration) and the epilogues' read of the slot.  A slot that
+        receives NO contribution in a step would keep the previous step's gradient: finish_step() — called by the optimizer before it
+        reads the arena — zeroes exactly those."""
         from . import autograd as A
+        if store_first is None:
+            store_first = os.environ.get('T2I_STORE_FIRST', '1') != '0'
+        big = set()
+        self._store_first, self._pending_check = None, False          # (a repeated call re-decides)
+        if store_first and self.grad.is_cuda:
+            big = {n for n, v in self.vars.items() if v.numel() >= (1 << 16) and v.dim() >= 2}
         for n, v in self.vars.items():     # kernels, biases, BN gamma/beta: every gradient is summed in place by its kernel
-            A.register_sink(v, self.grad_of(n).view(-1))
+            A.register_sink(v, self.grad_of(n).view(-1), (lambda name=n: self._first_touch(name)) if n in big else None)
+        if big:
+            self._store_first = big
+            self._touched = set(big)           # until the first zero_grad every slot holds zeros already: accumulate
+            runs, start = [], None
+            for n in self.names:               # maximal runs of small slots (padding included), in arena order
+                o, k = self.offsets[n]
+                end = o + (k + 3) // 4 * 4
+                if n in big:
+                    if start is not None:
+                        runs.append((start, o - start)); start = None
+                else:
+                    if start is None:
+                        start = o
+                    last_end = end
+            if start is not None:
+                runs.append((start, self.numel - start))
+            self._small_ranges = torch.tensor(runs if runs else [[0, 0]], dtype=torch.int64, device=self.grad.device).reshape(-1, 2)
+
+    def _first_touch(self, name):
+        if name in self._touched:
+            return False
+        self._touched.add(name)
+        return True
+
+    def finish_step(self):
+        """Before the optimizer (or a gradient exchange) reads the arena: large slots that received no contribution since zero_grad still
+        hold the previous step's gradient — zero them (none on the models here: every filter gets its gradient every step)."""
+        if self._store_first is not None and self._pending_check:
+            for n in self._store_first - self._touched:
+                self.grad_of(n).zero_()
+                self._touched.add(n)
+            self._pending_check = False
 
     def grad_of(self, name):
         o, k = self.offsets[name]
@@ -129,6 +181,7 @@ class AdamTF(object):
         (kernels.filter_cache_refresh).  Default: yes for eager launches; not inside a capture, whose successor graph starts
         with a refresh of everything — pass True where the same capture goes on to use these filters (the critic's update in
         a one-graph iteration)."""
+        self.arena.finish_step()
         K.adam_tf(self.arena.flat, self.arena.grad, None if self.skip_m else self._m, self.v, 0.0, self.beta1, self.beta2, self.eps, grad_scale,
                   lr_t_dev=self.lr_t_dev)
         if self.skip_m:

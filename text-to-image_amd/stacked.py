@@ -221,7 +221,8 @@ class SBwdDataFn(Function):
         K.axpby(tang, 1.0, out=x4[R:])                        # the tangent over the (dead) x_hat rows of the layer's input
         K._drop_image(x4)
         xf, sink, ws4 = rec['xform'], rec['sink'], ctx.geom4[1]
-        launch = lambda: K.conv_bwd_filter(x4, gp4, d4, ws4, out=sink, xform=xf, xform_valid_rows=R if xf is not None else 0)
+        acc = A.sink_accumulate(w.data_ptr())
+        launch = lambda: K.conv_bwd_filter(x4, gp4, d4, ws4, out=sink, xform=xf, xform_valid_rows=R if xf is not None else 0, accumulate=acc)
         side = _SIDE['stream'] if (_SIDE['on'] and A.SIDE.stream is None) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())       # the tangent is in place; everything else it reads was final long ago
