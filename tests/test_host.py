@@ -261,10 +261,15 @@ def test_bf16_image_cache_is_keyed_on_base_version_and_capture(monkeypatch):
     assert len(made) == 1 and K.bf16_image(y) is img and len(made) == 1
     view = y.permute(0, 3, 1, 2).permute(0, 2, 3, 1)                 # NHWC -> "NCHW" -> NHWC: another object, same memory, same order
     assert view is not y and K.bf16_image(view) is img and len(made) == 1
-    assert K.bf16_image(y[1:]) is not img and len(made) == 2        # a slice is another tensor (different address)
+    part = K.bf16_image(y[1:])                                       # round 6: a contiguous run of rows of a tensor that has an image reads
+    assert part is not img and len(made) == 1 and part.data_ptr() == img[1:].data_ptr() and part.shape == y[1:].shape   # the same rows of that image
+    z = torch.randn(2, 4, 4, 8)
+    assert K.bf16_image(z[1:]).shape == z[1:].shape and len(made) == 2     # (no image on the base: the slice gets its own)
     y.add_(1.0)                                                       # version bump: the image is stale
+    assert len(made) == 2
     img2 = K.bf16_image(view)
     assert img2 is not img and len(made) == 3 and K.bf16_image(y) is img2
+    assert K.bf16_image(y[:1]).data_ptr() == img2.data_ptr() and len(made) == 3
     shim.cap = 7                                                      # inside a capture: the eager image is not reused ...
     img3 = K.bf16_image(y)
     assert img3 is not img2 and len(made) == 4 and K.bf16_image(view) is img3

@@ -399,6 +399,20 @@ def bf16_image(t):
     cap = int(lib.t2i_capture_id(_stream()))      # an image made outside the current capture (eager, or an earlier capture) is
     if c is not None and c[0] == t._version and c[2] == t.data_ptr() and c[3] == cap:      # not part of this graph: never reused
         return c[1]
+    if c is None and h is t:
+        # a contiguous run of rows of a tensor that HAS an image (a part of a stacked pass, stacked.py: the producer wrote the twin of the
+        # whole stacked tensor): the same rows of that image
+        b = t._base
+        cb = getattr(b, '_t2i_h', None) if b is not None else None
+        if (cb is not None and cb[0] == t._version and cb[3] == cap and cb[2] == b.data_ptr() and t.is_contiguous() and b.is_contiguous() and
+                t.dim() == b.dim() and t.shape[1:] == b.shape[1:] and t.dtype == b.dtype):
+            row = t[0].numel() * t.element_size() if t.shape[0] else 0
+            off = t.data_ptr() - b.data_ptr()
+            if row and off % row == 0 and 0 <= off // row and off // row + t.shape[0] <= b.shape[0]:
+                r0 = off // row
+                part = cb[1][r0:r0 + t.shape[0]]
+                if part.data_ptr() % 16 == 0:
+                    return part
     img = cast_bf16(t)
     h._t2i_h = (t._version, img, t.data_ptr(), cap)
     return img
