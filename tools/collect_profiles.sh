@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box: gpurun -- tools/collect_profiles.sh [round]).
 # Kernel trace and each PMC group are separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
-# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r05);
+# pass; counters are never combined with sys/runtime tracing).  Everything lands in gpurun_out/<round>/ (default r06);
 # copy what should be judged into profiles/ with the round prefix.
 set -u
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-ROUND="${1:-r05}"
+ROUND="${1:-r06}"
 OUT="$REPO/gpurun_out/$ROUND"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --instrument off --repeats 1 --min-busy-s 0 --no-config3 --no-side-rows"
