@@ -76,8 +76,14 @@ class Arena(object):
         self._store_first, self._pending_check = None, False          # (a repeated call re-decides)
         if store_first and self.grad.is_cuda:
             big = {n for n, v in self.vars.items() if v.numel() >= (1 << 16) and v.dim() >= 2}
+        import weakref
+        me = weakref.ref(self)             # (the sink registry must not keep the arena — and through it the parameters — alive)
+
+        def first_touch(name):
+            a = me()
+            return a._first_touch(name) if a is not None else False
         for n, v in self.vars.items():     # kernels, biases, BN gamma/beta: every gradient is summed in place by its kernel
-            A.register_sink(v, self.grad_of(n).view(-1), (lambda name=n: self._first_touch(name)) if n in big else None)
+            A.register_sink(v, self.grad_of(n).view(-1), (lambda name=n: first_touch(name)) if n in big else None)
         if big:
             self._store_first = big
             self._touched = set(big)           # until the first zero_grad every slot holds zeros already: accumulate
