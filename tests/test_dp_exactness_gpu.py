@@ -45,21 +45,23 @@ def test_two_rank_exchange_reproduces_the_single_process_weights():
                          '--min-busy-s', '0', '--no-config3', '--warmup', '3', '--steps', '1'], {'T2I_PAIR_G': '0'})
     assert single[0] == 4
     # eager schedule: buckets leave while the backward is still running (first step learns the contribution counts)
-    eager = _two_ranks(29811, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0'})
-    # graph segments (the default): 2 eager set-up iterations, capture, then replays — both backward passes cut once, the first
-    # part's gradients on the wire while the rest (and the generator forward) runs
-    graphs = _two_ranks(29812, ['--warmup', '1', '--steps', '1'], {})
+    # (T2I_PREFLIGHT=0 on the three fp32 runs: the comparison with `single` below IS that check — the bf16 run and
+    # test_bench_gpus_2_launches_itself_and_describes_the_exchange keep bench.py's own preflight)
+    eager = _two_ranks(29811, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_PREFLIGHT': '0'})
+    # graph segments (the default): 2 eager set-up iterations, capture, then replays — the stacked critic step's arena on the wire while
+    # the generator forward runs, the generator's backward cut once
+    graphs = _two_ranks(29812, ['--warmup', '1', '--steps', '1'], {'T2I_PREFLIGHT': '0'})
     # the same segment sequence launched eagerly (WGanCls._dg_cut_eager)
     # ... with the fp32 buckets through the reduce-scatter + all-gather form (T2I_DP_F32_EXCHANGE=rs_ag; on gloo: its gather-and-sum
     # stand-in): two ranks, so bit for bit the all-reduce's result
-    cut_eager = _two_ranks(29813, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_DP_CUT_EAGER': '1', 'T2I_DP_F32_EXCHANGE': 'rs_ag'})
+    cut_eager = _two_ranks(29813, ['--warmup', '3', '--steps', '1'], {'T2I_DP_GRAPHS': '0', 'T2I_DP_CUT_EAGER': '1', 'T2I_DP_F32_EXCHANGE': 'rs_ag', 'T2I_PREFLIGHT': '0'})
     assert eager == single, (eager, single)
     assert graphs == single, (graphs, single)
     assert cut_eager == single, (cut_eager, single)
     # config 3: bf16 gradient buckets summed in fp32.  bench.py's preflight demands that the two-rank run on identical data equals,
     # bit for bit, a single replica whose gradient arena is rounded to bf16 once (dp.LocalRounding) and aborts otherwise
     _two_ranks(29814, ['--math', 'bf16', '--warmup', '1', '--steps', '1'], {})
-    # (both two-rank runs also went through bench.py's own data-parallel preflight, which aborts the run on a mismatch)
+    # (that run went through bench.py's own data-parallel preflight, which aborts the run on a mismatch)
 
 
 def test_bench_gpus_2_launches_itself_and_describes_the_exchange():
