@@ -117,7 +117,9 @@ def _stage2_full_size(gpu, bf16):
     moving0 = {n: v.detach().clone() for n, v in m.store.vars.items() if 'moving' in n}
     tr = ConditionalGanTrainer(None, m, None, c2)
     if tr.batched:          # the critic passes of one sess.run stacked along the batch axis (see _cgan_steps)
-        plan, plan_g = [('G',), ('Dfake', 'Dmatch', 'Dmis')], [('G',), ('Dfake',), ('Dmatch', 'Dmis')]
+        plan = [('G',), ('Dfake', 'Dmatch', 'Dmis')]
+        # the generator step: round 6 stacks its three critic evaluations too (fake with the gradient | match | mismatch); T2I_CGAN_STACK_G=0: two passes
+        plan_g = plan if os.environ.get('T2I_CGAN_STACK_G', '1') != '0' else [('G',), ('Dfake',), ('Dmatch', 'Dmis')]
     else:
         plan = plan_g = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
     chk = Checker()
@@ -262,7 +264,9 @@ def _cgan_steps(tag, tr, m, hf, d_oracle, g_oracle, loss_keys_d, loss_keys_g, ch
     # the HIP passes in launch order (tests/branches.split_sections): gancls stacks the critic passes of one sess.run along the batch axis
     # (GanClsTrainer.batched: fake | match | mismatch in the critic step; fake, then match | mismatch, in the generator step)
     if getattr(tr, 'batched', False):
-        plan, plan_g = [('G',), ('Dfake', 'Dmatch', 'Dmis')], [('G',), ('Dfake',), ('Dmatch', 'Dmis')]
+        plan = [('G',), ('Dfake', 'Dmatch', 'Dmis')]
+        # the generator step: round 6 stacks its three critic evaluations too (fake with the gradient | match | mismatch); T2I_CGAN_STACK_G=0: two passes
+        plan_g = plan if os.environ.get('T2I_CGAN_STACK_G', '1') != '0' else [('G',), ('Dfake',), ('Dmatch', 'Dmis')]
     else:
         plan = plan_g = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
     rec = []

@@ -7,9 +7,13 @@ import time
 import torch
 
 from ... import autograd as A
+from ... import stacked as ST
 from ... import kernels as K
 from ... import optim
 from ...utils.ops import update_ops
+
+# the generator step's three critic evaluations as one stacked pass (stacked.py); T2I_CGAN_STACK_G=0: fake pass + [match | mismatch] pass
+_STACK_G = os.environ.get('T2I_CGAN_STACK_G', '1') != '0'
 
 
 class GanClsTrainer(object):
@@ -79,16 +83,25 @@ class GanClsTrainer(object):
         with update_ops():
             if G is None:
                 G = m.generator(z, phi, reuse=True)
-            with m.store.frozen('d_net'):
-                _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
             # G_optim also sits under ALL update ops of the graph: the match / mismatch critic passes run in this
             # sess.run too, only to move their batch-norm moving averages (trainer.py:46-51)
-            with torch.no_grad():
-                if self.batched:
-                    m.discriminator(torch.cat([x, xw], 0), torch.cat([phi, phi], 0), reuse=True, _prob=False, groups=2)
-                else:
-                    m.discriminator(x, phi, reuse=True, _prob=False)
-                    m.discriminator(xw, phi, reuse=True, _prob=False)
+            if self.batched and _STACK_G and x.is_cuda:
+                # round 6: fake | match | mismatch as ONE stacked pass of three evaluations (stacked.py): every conv once on 3B rows, per-evaluation
+                # batch-norm statistics, the moving averages move once per evaluation in this order (as the three calls did); only the fake rows
+                # carry a gradient, so the backward runs on B rows as before
+                with m.store.frozen('d_net'):
+                    _, ls = m.discriminator(ST.Stacked(G, torch.cat([x, xw], 0)), ST.Stacked(phi, torch.cat([phi, phi], 0)), reuse=True, _prob=False,
+                                            groups=3)
+                l_fake = ls.main
+            else:
+                with m.store.frozen('d_net'):
+                    _, l_fake = m.discriminator(G, phi, reuse=True, _prob=False)
+                with torch.no_grad():
+                    if self.batched:
+                        m.discriminator(torch.cat([x, xw], 0), torch.cat([phi, phi], 0), reuse=True, _prob=False, groups=2)
+                    else:
+                        m.discriminator(x, phi, reuse=True, _prob=False)
+                        m.discriminator(xw, phi, reuse=True, _prob=False)
         losses, seeds, _ = K.sigmoid_ce_head([l_fake.detach().reshape(-1)], [1.0], [1.0], want_prob=False)      # G_loss: label 1 (trainer.py:36)
         m.g_arena.zero_grad()
         if m.dp is not None and not getattr(self, '_capturing', False):

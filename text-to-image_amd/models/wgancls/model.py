@@ -388,7 +388,7 @@ class WGanCls(object):
         noise_d = self._ca_noise(feed, 'ca_noise_d', like)      # (the order an unpaired iteration draws them in)
         noise_g = self._ca_noise(feed, 'ca_noise_g', like)
         img5 = bufs['img5']
-        with update_ops(), K.output_into(img5[:2 * B]):
+        with update_ops(), ST.moving_groups(1), K.output_into(img5[:2 * B]):       # only the generator step's evaluation moves the moving averages
             Gs, mean, log_sigma = self.generator(z, cond, reuse=True, pair=(noise_g, noise_d))
         if Gs.hat.data_ptr() != img5[B:].data_ptr():             # (the last kernel did not take the buffer: copy the critic step's image)
             with torch.no_grad():

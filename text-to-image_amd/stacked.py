@@ -422,20 +422,39 @@ class SDeconvFn(Function):
         return gxm, gxh, gw, gb, None, None, None
 
 
+_MOVING = [0]      # how many leading groups of a stacked batch norm move the moving averages (0 = all): see moving_groups()
+
+
+class moving_groups(object):
+    """with moving_groups(1): the stacked batch norms inside let only their first group move the moving averages (the paired generator:
+    only the generator step's evaluation runs under UPDATE_OPS).  Default 0: every group does, in stacking order."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev, _MOVING[0] = _MOVING[0], self.n
+
+    def __exit__(self, *a):
+        _MOVING[0] = self.prev
+
+
 class SBatchNormFn(Function):
-    """Training-mode batch norm + activation of a stacked pair whose two parts are two evaluations of the reference graph (equal
-    sizes): each part is normalised with ITS OWN batch statistics — one grouped launch chain for both (t2i_bn_train_fwd_grouped,
-    groups = 2).  moving_groups = 1: only the leading part moves the moving averages (the generator-step evaluation runs under
-    UPDATE_OPS, the critic step's does not: reference models/wgancls/model.py:98,102).  First order; backward per part."""
+    """Training-mode batch norm + activation of a stacked pair that consists of `groups` evaluations of the reference graph of equal size
+    (main = the leading ones): each evaluation is normalised with ITS OWN batch statistics — one grouped launch chain for all
+    (t2i_bn_train_fwd_grouped).  moving_groups = k > 0: only the first k evaluations move the moving averages (the paired generator:
+    the generator-step evaluation runs under UPDATE_OPS, the critic step's does not: reference models/wgancls/model.py:98,102).
+    First order; backward per part, on that part's groups."""
 
     @staticmethod
-    def forward(ctx, xm, xh, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, moving_groups):
+    def forward(ctx, xm, xh, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, moving_grp, groups):
         R = xm.shape[0]
-        assert xh.shape[0] == R, 'the two parts of a stacked batch norm are two evaluations of the same batch size'
         x4 = full(xm, xh)
-        y4, mean, rstd = K.bn_train_fwd_grouped(x4, gamma, beta, eps, decay, 2, act, alpha, mm, mv, moving_updates, moving_groups)
+        assert x4.shape[0] % groups == 0 and R % (x4.shape[0] // groups) == 0, (tuple(x4.shape), R, groups)
+        y4, mean, rstd = K.bn_train_fwd_grouped(x4, gamma, beta, eps, decay, groups, act, alpha, mm, mv, moving_updates, moving_grp)
         ctx.save_for_backward(x4, gamma, mean, rstd, y4 if act != K.ACT_NONE else None)
-        ctx.R, ctx.act, ctx.alpha = R, act, alpha
+        ctx.R, ctx.act, ctx.alpha, ctx.gm = R, act, alpha, R // (x4.shape[0] // groups)
+        ctx.groups = groups
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.set_materialize_grads(False)
         return y4[:R], y4[R:]
@@ -444,19 +463,19 @@ class SBatchNormFn(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gym, gyh):
         if gym is None and gyh is None:
-            return (None,) * 12
+            return (None,) * 13
         x4, gamma, mean, rstd, y4 = ctx.saved_tensors
-        R = ctx.R
+        R, gm = ctx.R, ctx.gm
         want_g, want_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gsink = A._sink_of(ctx.gamma_ref) if want_g else None
         bsink = A._sink_of(ctx.beta_ref) if want_b else None
         sunk = gsink is not None and bsink is not None
         outs = [None, None]
         dgamma = dbeta = None
-        for i, (g, sl) in enumerate(((gym, slice(0, R)), (gyh, slice(R, 2 * R)))):
+        for i, (g, sl, gs) in enumerate(((gym, slice(0, R), slice(0, gm)), (gyh, slice(R, x4.shape[0]), slice(gm, ctx.groups)))):
             if g is None:
                 continue
-            dx, dg, db = K.bn_bwd_grouped(_c(g), y4[sl] if y4 is not None else None, x4[sl], mean[i:i + 1], rstd[i:i + 1], gamma, 1, ctx.act,
+            dx, dg, db = K.bn_bwd_grouped(_c(g), y4[sl] if y4 is not None else None, x4[sl], mean[gs], rstd[gs], gamma, gs.stop - gs.start, ctx.act,
                                           ctx.alpha, dgamma_out=gsink if sunk else None, dbeta_out=bsink if sunk else None)
             outs[i] = dx
             if not sunk:
@@ -465,14 +484,17 @@ class SBatchNormFn(Function):
         if sunk:
             A._notify(ctx.gamma_ref); A._notify(ctx.beta_ref)
             dgamma = dbeta = None
-        return (outs[0], outs[1], dgamma if want_g else None, dbeta if want_b else None) + (None,) * 8
+        return (outs[0], outs[1], dgamma if want_g else None, dbeta if want_b else None) + (None,) * 9
 
 
-def batch_norm_ok(x):
-    """the grouped batch-norm kernels take this stacked tensor (C % 4 == 0, 16-byte aligned equal parts)"""
+def batch_norm_ok(x, groups=2):
+    """the grouped batch-norm kernels take this stacked tensor (C % 4 == 0, whole groups per part, 16-byte aligned groups)"""
     m, h = x.main, x.hat
-    return (m.shape[0] == h.shape[0] and m.shape[-1] % 4 == 0 and m.is_contiguous() and h.is_contiguous() and m.data_ptr() % 16 == 0 and
-            (m.numel() * m.element_size()) % 16 == 0)
+    rows = m.shape[0] + h.shape[0]
+    if rows % groups or m.shape[0] % (rows // groups) or not (m.is_contiguous() and h.is_contiguous()):
+        return False
+    per = (rows // groups) * (m[0].numel() if m.shape[0] else 0) * m.element_size()
+    return m.shape[-1] % 4 == 0 and m.data_ptr() % 16 == 0 and per % 16 == 0
 
 
 class STransposeFn(Function):
@@ -525,8 +547,8 @@ def conv2d_transpose(xp, w, b, geom4, act, alpha):
     return Stacked(ym, yh)
 
 
-def batch_norm(xp, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates=1, moving_groups=1):
-    ym, yh = SBatchNormFn.apply(xp.main, xp.hat, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, moving_groups)
+def batch_norm(xp, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates=1, groups=2):
+    ym, yh = SBatchNormFn.apply(xp.main, xp.hat, gamma, beta, mm, mv, eps, decay, act, alpha, moving_updates, _MOVING[0], groups)
     return Stacked(ym, yh)
 
 

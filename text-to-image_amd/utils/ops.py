@@ -184,12 +184,11 @@ def batch_norm(x, train, init=None, act=None, name=None, eps=1e-5, decay=0.9, df
     if train and isinstance(xp, ST.Stacked):
         # two evaluations of the reference graph stacked along the batch axis (the generator pair): per-part statistics; only the leading
         # part — the evaluation that runs under UPDATE_OPS — moves the moving averages
-        if groups != 1:
-            raise NotImplementedError('batch_norm(groups > 1) on a stacked pair')
+        total = int(groups) if groups > 1 else 2          # groups = 1: each part is one evaluation (the paired generator)
         upd = _UPDATE_OPS[0]
-        if not ST.batch_norm_ok(xp):
-            raise NotImplementedError('stacked batch norm needs C % 4 == 0 and 16-byte aligned equal parts')
-        y = ST.batch_norm(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, max(int(upd), 1), 1)
+        if not ST.batch_norm_ok(xp, total):
+            raise NotImplementedError('stacked batch norm needs C % 4 == 0, whole evaluations per part and 16-byte aligned evaluations')
+        y = ST.batch_norm(xp, gamma, beta, mm if upd else None, mv if upd else None, eps, decay, kind, alpha, max(int(upd), 1), total)
     elif train and groups > 1:
         upd = _UPDATE_OPS[0]
         if int(upd) > 1:

@@ -10,6 +10,7 @@ import torch
 from .. import autograd as A
 from .. import kernels as K
 from .. import scope as S
+from .. import stacked as ST
 from .ops import _split_act
 
 
@@ -35,7 +36,8 @@ def conv2d(inputs, filters, kernel_size, strides=(1, 1), padding='valid', activa
         w = st.get_variable('kernel', (kh, kw, Cin, filters),
                             kernel_initializer or glorot_uniform_init(kh * kw * Cin, kh * kw * filters))
         b = st.get_variable('bias', (filters,), S.constant_init(0.0))
-    y = A.Conv2dFn.apply(inputs, w, b, K.conv_desc(B, H, W, Cin, filters, kh, kw, sh, sw, padding), kind, alpha)
+    geom = K.conv_desc(B, H, W, Cin, filters, kh, kw, sh, sw, padding)
+    y = ST.conv2d(inputs, w, b, geom, kind, alpha) if isinstance(inputs, ST.Stacked) else A.Conv2dFn.apply(inputs, w, b, geom, kind, alpha)
     return post(y) if post else y
 
 
@@ -60,6 +62,9 @@ def dense(inputs, units, activation=None, kernel_initializer=None, name=None):
     with st.variable_scope(name or st.unique_op_name('dense'), reuse=st.reuse()):
         w = st.get_variable('kernel', (I, units), kernel_initializer or glorot_uniform_init(I, units))
         b = st.get_variable('bias', (units,), S.constant_init(0.0))
-    y = A.Conv2dFn.apply(inputs.reshape(B, 1, 1, I), w.view(1, 1, I, units), b, K.conv_desc(B, 1, 1, I, units, 1, 1, 1, 1, 'VALID'),
-                         kind, alpha).view(B, units)
+    geom = K.conv_desc(B, 1, 1, I, units, 1, 1, 1, 1, 'VALID')
+    if isinstance(inputs, ST.Stacked):        # a stacked pass (stacked.py)
+        y = ST.conv2d(inputs.reshape_parts(1, 1, I), w.view(1, 1, I, units), b, geom, kind, alpha).reshape_parts(units)
+    else:
+        y = A.Conv2dFn.apply(inputs.reshape(B, 1, 1, I), w.view(1, 1, I, units), b, geom, kind, alpha).view(B, units)
     return post(y) if post else y
