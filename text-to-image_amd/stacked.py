@@ -18,7 +18,11 @@ the Functions below take and return both, launch on the whole buffer, and give a
 backward walks is the x_hat slice's alone and nothing is ever zero-padded to 4B.  If the two parts of an argument are not
 adjacent in memory (never the case on the path above) they are concatenated: correct, one copy slower.
 
-The data-parallel schedules keep the two-pass form (their cut points are defined on it: dp.py, WGanCls._CUT_D)."""
+The data-parallel schedules run the same stacked critic step, uncut (WGanCls._d_cut_ranges).
+
+The same machinery stacks other evaluations that share weights: the generator's two evaluations of a wgancls
+iteration (SBatchNormFn: per-evaluation statistics, moving_groups), and the three critic evaluations of the generator step of the
+sigmoid-CE trainers (gancls, StackGAN: fake with the gradient | match | mismatch)."""
 import torch
 from torch.autograd import Function
 
