@@ -996,6 +996,18 @@ def test_kept_input_transform_of_a_stacked_pass_is_bit_identical(K, case):
     assert float((acc - (ref_h + 0.25)).abs().max()) <= 1e-6 * max(float(ref_h.abs().max()), 1.0)
 
 
+def test_zero_ranges_touches_exactly_its_ranges(K):
+    """t2i_zero_ranges (the small slots of a gradient arena whose large slots are store-first, optim.Arena.zero_grad): a device table of
+    (start, length) element ranges, one launch; everything outside the ranges keeps its bits."""
+    buf = torch.arange(1, 5001, dtype=torch.float32, device='cuda')
+    ref = buf.clone()
+    table = torch.tensor([[0, 3], [17, 1], [100, 1000], [4096, 904]], dtype=torch.int64, device='cuda')
+    K.zero_ranges(buf, table)
+    for s0, n in table.tolist():
+        ref[s0:s0 + n] = 0
+    assert torch.equal(buf, ref)
+
+
 def test_trunc_normal_kernel_distribution_and_reproducibility(K):
     """t2i_trunc_normal (tf.truncated_normal, reference models/wgancls/model.py:119): N(0,1) cut at +-2 by CDF inversion of Philox
     uniforms.  Distribution against scipy's truncnorm (bounds, mean, variance 0.7737, Kolmogorov-Smirnov on 2^20 draws), a pure function

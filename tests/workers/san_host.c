@@ -87,7 +87,21 @@ int main(void) {
     rejected += t2i_conv2d_fwd(&d, dummy, dummy, NULL, dummy, T2I_ACT_NONE, 0.f, NULL, NULL, 0, NULL) != T2I_OK;
     rejected += t2i_conv2d_bwd_data(&d, dummy, dummy, NULL, dummy, T2I_ACT_NONE, 0.f, NULL, NULL, 0, NULL) != T2I_OK;
     rejected += t2i_conv2d_bwd_filter(&d, dummy, dummy, dummy, 0, NULL, NULL, 0, NULL) != T2I_OK;
-    if (rejected != 6) { fprintf(stderr, "only %d of 6 invalid calls were rejected\n", rejected); return 3; }
+    /* ABI v9: xform_valid_rows / xform_plane_rows outside their range, the new small entry points with bad arguments */
+    d = desc(64, 8, 8, 512, 512, 3, 1, 0);                     /* forward conv and filter gradient share a Winograd transform here */
+    t2i_conv_opts o;
+    memset(&o, 0, sizeof(o));
+    _Alignas(16) static float big[64];
+    o.xform = big; o.xform_bytes = (size_t)1 << 40; o.xform_mode = T2I_XFORM_HAVE; o.xform_valid_rows = -1;
+    rejected += t2i_conv2d_bwd_filter(&d, dummy, dummy, dummy, 0, &o, NULL, 0, NULL) != T2I_OK && strstr(t2i_last_error(), "xform_valid_rows") != NULL;
+    o.xform_valid_rows = 0; o.xform_plane_rows = 4;            /* fewer images than the batch */
+    rejected += t2i_conv2d_bwd_filter(&d, dummy, dummy, dummy, 0, &o, NULL, 0, NULL) != T2I_OK && strstr(t2i_last_error(), "xform_plane_rows") != NULL;
+    rejected += t2i_trunc_normal(NULL, 16, 1, 0, 0.f, 1.f, -2.f, 2.f, NULL) != T2I_OK;
+    rejected += t2i_trunc_normal(dummy, 4, 1, 0, 0.f, 0.f, -2.f, 2.f, NULL) != T2I_OK;
+    rejected += t2i_trunc_normal(dummy, 4, 1, 0, 0.f, 1.f, 2.f, -2.f, NULL) != T2I_OK;
+    rejected += t2i_zero_ranges(dummy, NULL, 3, NULL) != T2I_OK;
+    rejected += t2i_zero_ranges(dummy, (const int64_t*)big, 0, NULL) != T2I_OK;
+    if (rejected != 13) { fprintf(stderr, "only %d of 13 invalid calls were rejected\n", rejected); return 3; }
     if (!t2i_last_error()[0]) { fprintf(stderr, "no error message after a rejected call\n"); return 3; }
   }
   printf("san_host: %d host-side queries, %d invalid compute calls rejected, no sanitizer report (checksum %llu)\n", calls, rejected, acc);
