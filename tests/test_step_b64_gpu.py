@@ -114,6 +114,18 @@ def _cached(setup, key, fn):
     return c[key]
 
 
+
+def _critic_alone(T, ocfg, P, feed, G_hip, mask_hat, got):
+    """D(x_hat)'s error with the generator's taken out: the float64 critic evaluated on the x_hat the HIP path's OWN generator image makes
+    (same pinned branches) is the reference, so what remains is the twelve critic layers' arithmetic alone.  Yardstick (round 6, CPU run of
+    the oracle in float32 pinned to the float64 branches, B = 64 / 16 / 8): chain G -> x_hat -> D 5.6e-6 / 3.8e-6 / 8.9e-6 from float64, of
+    which the critic alone 1.9e-6 / 1.2e-6 / 1.3e-6 — the chain's error is mostly G's (5e-5 absolute per pixel in any fp32 arithmetic,
+    behind ten batch norms) pushed through the critic."""
+    with torch.no_grad():
+        xh = feed['eps'] * G_hip.detach().double().cpu() + (1.0 - feed['eps']) * feed['x']
+        ref = T.discriminator(P, ocfg, xh, feed['cond'], T.MaskTape(mask_hat))
+    return relerr(got, ref)
+
 def test_b64_critic_step_mask_pinned(setup):
     T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
     rec = []
@@ -141,6 +153,7 @@ def test_b64_critic_step_mask_pinned(setup):
     # the same difference against max|G| (= 1): printed — bench.py's parity block quotes both yardsticks
     print('  G against max|G| instead: %.2e (the yardstick above is max|logits|)' % relerr(d['G'], ref['G']))
     chk('D(x_hat)', relerr(d['Dx_hat_logit'], ref['Dx_hat']), 1e-5)      # SURVEY 8(c)'s forward bound (12 layers in series; measured 0.7e-5)
+    chk('D(x_hat), the critic alone', _critic_alone(T, ocfg, P, feed, d['G'], masks['Dxh'], d['Dx_hat_logit']), 1e-5)
     # ---- losses: 1e-5 relative
     for k in ('D_loss', 'D_loss_real', 'D_loss_fake', 'D_loss_mismatch', 'wdist', 'wdist2', 'real_gp', 'real_gp2', 'reg_loss'):
         e = abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0)
@@ -221,6 +234,66 @@ def test_b64_generator_step_mask_pinned(setup):
     for n in m.g_vars:
         if float(free['grads'][n].abs().max()) >= 1e-9:
             _check_grad_kinks(m.g_arena.grad_of(n), free['grads'][n].numpy(), n, 0.0)
+
+
+def test_paired_stacked_iteration_mask_pinned(setup):
+    """The path the benchmark replays on one GPU (round 6), end to end against the float64 oracle: ONE generator evaluation of 2B rows for both
+    steps (WGanCls._g_forward_pair: the generator step's half in front, the critic step's behind, per-evaluation batch-norm statistics, the
+    conditioning heads shared), the stacked critic step on the image it left in its slot (d_losses(have_g=True)) and the generator step on the
+    leading half (g_losses(fwd=...)).  Mask-pinned like the tests above, same bounds: forward 1e-5, loss scalars 1e-5, every gradient tensor of
+    both networks 1e-4 — at B = 64 (the metric's batch), 16 and 8."""
+    T, ocfg, P, feed, m, f, B = (setup[k] for k in ('T', 'ocfg', 'P', 'feed', 'm', 'f', 'B'))
+    assert m._pairing(f)
+    rec = []
+    with record_branches(rec):
+        fwd = m._g_forward_pair(f)
+        d = m.d_losses(f, have_g=True)
+        g = m.g_losses(f, fwd=fwd)
+        torch.cuda.synchronize()
+    assert len(rec) == N_G + 2 * N_D, len(rec)
+    rec = [_to_oracle_layout(x) for x in rec]
+    gen, d4, dg = rec[:N_G], rec[N_G:N_G + N_D], rec[N_G + N_D:]
+    assert [x.shape[0] for x in gen[:2]] == [B, B] and all(x.shape[0] == 2 * B for x in gen[2:])      # the two conditioning heads are evaluated once
+    assert all(x.shape[0] == 4 * B for x in d4) and all(x.shape[0] == B for x in dg)
+    half = lambda x, i: x if x.shape[0] == B else x[i * B:(i + 1) * B]
+    masks_d = {'G': [half(x, 1) for x in gen], 'Dg': [x[:B] for x in d4], 'Dx': [x[B:2 * B] for x in d4], 'Dxmi': [x[2 * B:3 * B] for x in d4],
+               'Dxh': [x[3 * B:] for x in d4]}
+    masks_g = {'G': [half(x, 0) for x in gen], 'Dg': dg}
+    rd = T.d_step(P, ocfg, feed, 0.7, masks=masks_d)
+    rg = T.g_step(P, ocfg, feed, masks=masks_g)
+    bad = []
+
+    def chk(name, err, tol):
+        print('  %-34s %.2e  (tol %.0e)%s' % (name, err, tol, '' if err <= tol else '   <-- FAIL'))
+        if not err <= tol:
+            bad.append((name, err, tol))
+    chk('G of the critic step (vs max|logits|)', relerr(d['G'], rd['G'], scale=rd['G_logits_absmax']), 1e-5)
+    chk('G of the generator step', relerr(g['G'], rg['G'], scale=rg['G_logits_absmax']), 1e-5)
+    # D(x_hat) per network at SURVEY 8(c)'s 1e-5: the generator above (against max|logits|), the critic on the x_hat the HIP generator's image
+    # makes here.  The CHAIN generator -> x_hat -> critic against float64 compounds the two (G's 5e-5 absolute per-pixel error pushed through
+    # twelve more layers): measured 1.16e-5 at B = 64 in this form, 0.95e-5 in the unpaired form of the test above, 0.6e-5 at B = 16 / 8 — on
+    # either side of 1e-5 by the summation order alone (Winograd off: 1.21e-5), with torch-CPU fp32 at 0.56e-5 (_critic_alone's docstring).
+    # Bounded at 2e-5 so that a real defect in the hand-off (the image slot, the x_hat rows of the stacked pass) still fails.
+    chk('D(x_hat), the critic alone', _critic_alone(T, ocfg, P, feed, d['G'], masks_d['Dxh'], d['Dx_hat_logit']), 1e-5)
+    chk('D(x_hat), chain G -> x_hat -> D', relerr(d['Dx_hat_logit'], rd['Dx_hat']), 2e-5)
+    for k in ('D_loss', 'wdist', 'wdist2', 'real_gp', 'real_gp2'):
+        chk(k, abs(float(d[k]) - rd[k]) / max(abs(rd[k]), 1.0), 1e-5)
+    for k in ('G_loss', 'G_kl_loss', 'D_loss_fake'):
+        chk(k, abs(float(g[k]) - rg[k]) / max(abs(rg[k]), 1.0), 1e-5)
+    scales = _cached(setup, 'scales', lambda: T.d_step_term_scales(P, ocfg, feed, 0.7))
+    for n in m.d_vars:
+        r = rd['grads'][n]
+        if float(r.abs().max()) < 1e-9 * scales[n]:
+            chk('grad ' + n + ' (exact zero: vs uncancelled scale)', relerr(m.d_arena.grad_of(n), r, scale=scales[n]), 1e-4)
+        else:
+            chk('grad ' + n, relerr(m.d_arena.grad_of(n), r), 1e-4)
+    for n in m.g_vars:
+        r = rg['grads'][n]
+        if float(r.abs().max()) < 1e-9:
+            chk('grad ' + n + ' (exact zero: absolute)', float(m.g_arena.grad_of(n).abs().max()), 1e-4)
+        else:
+            chk('grad ' + n, relerr(m.g_arena.grad_of(n), r), 1e-4)
+    assert not bad, bad
 
 
 CONFIG3 = 'config3'          # BASELINE configs[2] as benchmarked: the compliant per-network arithmetic (kernels.CONFIG3_NET_MATH)

@@ -274,6 +274,11 @@ bool winograd_eligible(const t2i_conv_desc& d, bool bwd_data) {
   // critic layer the x_hat pass runs at B=64, and with it on the Winograd path D(x_hat) of the full-width step moves from 7e-6 to
   // 1.1e-5 of the float64 oracle, past SURVEY 8(c)'s 1e-5: parity first, the threshold stays.  4x4x256->256 and 8x8x128->128
   // (1.7e7) gain 5 % / lose 18 % forward and lose in the filter gradient.
+  // Round 6: the stacked critic pass runs that layer on 4B = 256 images (T*K*N = 1.3e8), so it IS on the Winograd form there.  Re-measured
+  // with the error split per network (tests/test_step_b64_gpu.py::_critic_alone, B = 64): D(x_hat) of the critic alone 4.7e-6 with it on
+  // Winograd / 3.8e-6 with a per-image threshold keeping it direct (paired form 5.1e-6 / 5.7e-6), the chain G -> x_hat -> D 8.7e-6 / 9.0e-6
+  // — the 7e-6 -> 1.1e-5 of round 4 was G's error pushed through the critic landing on either side of 1e-5 by the summation order, not this
+  // layer's form.  The per-image threshold cost 0.85 % of the iteration and bought no parity margin: not kept.
   const int64_t T = (int64_t)d.B * (d.H / 2) * (d.W / 2);
   return T * d.Cin * d.Cout >= (int64_t)tuning().winograd_minwork;
 }
