@@ -30,7 +30,7 @@ python "$REPO/tools/pmc_summary.py" "$OUT/pmcb_FETCH_SIZE" "$OUT/pmcb_WRITE_SIZE
 rm -rf "$OUT/ktrace_bf16" "$OUT/pmcb_FETCH_SIZE" "$OUT/pmcb_WRITE_SIZE" "$OUT/pmcb_SQ_VALU_MFMA_BUSY_CYCLES"
 cd "$REPO"
 timeout 300 python tools/bench_conv.py --batch 64 > "$OUT/conv_microbench_B64.txt" 2>&1
-timeout 300 python tools/bench_conv.py --batch 192 --filter D > "$OUT/conv_microbench_B192.txt" 2>&1
+timeout 300 python tools/bench_conv.py --batch 256 --filter D > "$OUT/conv_microbench_B256.txt" 2>&1     # the stacked critic pass: 4B rows
 timeout 300 python tools/bench_conv.py --batch 64 --math bf16 > "$OUT/conv_microbench_bf16_B64.txt" 2>&1
 timeout 300 python tools/bench_conv.py --batch 512 --math bf16 --reps 10 > "$OUT/conv_microbench_bf16_B512.txt" 2>&1
 { echo "== bf16 tensors in and out (config 3 as it runs: no cast launches inside the timed calls), B = 64"; timeout 300 python tools/bench_conv.py --batch 64 --math bf16 --storage bf16 --reps 10 2>&1 | grep -v amdgpu
