@@ -124,7 +124,19 @@ class SActBwdFn(Function):
         (y4,) = ctx.saved_tensors
         R = ctx.R
         gm = A.ActBwdFn.apply(ggm, y4[:R], ctx.act, ctx.alpha) if ggm is not None else None
-        gh = A.ActBwdFn.apply(ggh, y4[R:], ctx.act, ctx.alpha) if ggh is not None else None
+        gh = None
+        if ggh is not None:
+            yh = y4[R:]
+            if _TANGENT_IN_PLACE[0] and _DEFER[0] and not torch.is_grad_enabled() and ctx.act in (K.ACT_LRELU, K.ACT_RELU) and \
+                    ggh.dtype == yh.dtype and K._twin_for(yh, ggh) is None:
+                # The double backward of the gradient penalty (no third order): the result is the tangent that the layer ABOVE writes over
+                # the x_hat rows of its input for its one filter-gradient launch (SBwdDataFn.backward) — and its input IS this y4.  The
+                # mask read here was those rows' last use as activations, and the kernel is elementwise, so it writes the tangent where it
+                # is wanted: one copy launch less per layer, same bits.
+                gh = K.act_bwd(_c(ggh), yh, ctx.act, ctx.alpha, out=yh)
+                K._drop_image(y4)
+            else:
+                gh = A.ActBwdFn.apply(ggh, yh, ctx.act, ctx.alpha)
         return gm, gh, None, None, None, None
 
 
@@ -144,6 +156,9 @@ _DEFER = [True]
 # alternating with it.  join() makes the calling stream wait for them (before Adam reads the arena).
 import os as _os
 _SIDE = {'on': _os.environ.get('T2I_STACK_SIDE', '0') == '1', 'stream': None, 'keep': []}
+# SActBwdFn.backward writes the penalty's tangent straight over the x_hat rows of the activation it masks with (= the next layer's input,
+# where SBwdDataFn.backward wants it); 0: a fresh tensor + the copy, as before — same bits, nine launches more
+_TANGENT_IN_PLACE = [_os.environ.get('T2I_TANGENT_IN_PLACE', '1') != '0']
 
 
 def side_filter_gradients(on):
@@ -222,7 +237,8 @@ class SBwdDataFn(Function):
         g_dy = A.Conv2dFn.apply(ggh, w, None, gh, K.ACT_NONE, 0.0, False, gp4.dtype) if ctx.needs_input_grad[1] else None
         x4, d4 = rec['x4'], ctx.geom4[0]
         tang = _c(ggh)
-        K.axpby(tang, 1.0, out=x4[R:])                        # the tangent over the (dead) x_hat rows of the layer's input
+        if tang.data_ptr() != x4[R:].data_ptr():              # (already there: SActBwdFn.backward of the layer below wrote it in place)
+            K.axpby(tang, 1.0, out=x4[R:])                    # the tangent over the (dead) x_hat rows of the layer's input
         K._drop_image(x4)
         xf, sink, ws4 = rec['xform'], rec['sink'], ctx.geom4[1]
         acc = A.sink_accumulate(w.data_ptr())
