@@ -186,6 +186,9 @@ def f32_outputs():
 # the latter when they are constructed outside any scope, so a later, unscoped model in the same process starts from the plain rules.
 _MIXED = [False]
 _BWD_MATH = [None]
+_SCOPE_TWINS = [os.environ.get('T2I_SCOPE_TWINS', '1') != '0']      # 0: the rule of rounds 4-5 (A/B; it never made a twin, see _twin_for)
+_SCOPE_GRAD = [True]     # torch.is_grad_enabled() when the innermost math_scope was entered — by model code, outside any autograd Function (inside a
+                         # Function.forward grad mode is always off): "will this forward be differentiated?", for _twin_for
 
 
 def forget_scopes():
@@ -203,7 +206,8 @@ def math_scope(math=None, storage=None, bwd_math=None):
     if math is None and storage is None and bwd_math is None:
         yield
         return
-    pm, ps, pb = _MATH[0], _STORE[0], _BWD_MATH[0]
+    pm, ps, pb, pg = _MATH[0], _STORE[0], _BWD_MATH[0], _SCOPE_GRAD[0]
+    _SCOPE_GRAD[0] = torch.is_grad_enabled()
     _MIXED[0] = 'bwd_bf16' if (bwd_math is not None and _MATH_CODES[str(bwd_math).lower()] == MATH_BF16) or _MIXED[0] == 'bwd_bf16' else 'fwd'
     try:
         if math is not None:
@@ -213,7 +217,7 @@ def math_scope(math=None, storage=None, bwd_math=None):
         _BWD_MATH[0] = _MATH_CODES[str(bwd_math).lower()] if bwd_math is not None else None
         yield
     finally:
-        _MATH[0], _STORE[0], _BWD_MATH[0] = pm, ps, pb
+        _MATH[0], _STORE[0], _BWD_MATH[0], _SCOPE_GRAD[0] = pm, ps, pb, pg
 
 
 # BASELINE configs[2] ("bf16 MFMA") as benchmarked and as its parity test asserts (<= 2e-2 on every tensor, tests/test_step_b64_gpu.py):
@@ -445,7 +449,9 @@ def _twin_for(out, *inputs):
     want = _MATH[0] == MATH_BF16
     if _MIXED[0]:
         if _BWD_MATH[0] == MATH_BF16:            # inside a scope whose backward GEMMs read bf16 images: the saved activations get theirs here
-            want = torch.is_grad_enabled()
+            # (round 6: the grad mode of the scope's entry — the producers run inside autograd Functions, where torch.is_grad_enabled() is
+            # always False, so this rule never made a twin and every saved activation of the scoped network was cast in a launch of its own)
+            want = _SCOPE_GRAD[0] if _SCOPE_TWINS[0] else torch.is_grad_enabled()
         elif _STORE[0] is torch.bfloat16:        # outside the scope, bf16 storage: a float32 tensor here belongs to the scoped network's backward
             want = _MIXED[0] == 'bwd_bf16'
     if out.dtype != torch.float32 or not want or not (_TWINS[0] and _BF16_IMAGES[0]) or out.shape[-1] % 64 or out.numel() % 8:

@@ -87,6 +87,11 @@ def _c(t):
 
 def full(a, b):
     """The whole buffer behind the parts (a detached view; no copy) — or their concatenation if they are not adjacent."""
+    ba = a._base
+    if (ba is not None and ba is b._base and not ba.requires_grad and ba.is_contiguous() and a.is_contiguous() and b.is_contiguous() and
+            ba.dtype == a.dtype == b.dtype and ba.dim() == a.dim() and ba.shape[1:] == a.shape[1:] == b.shape[1:] and
+            ba.shape[0] == a.shape[0] + b.shape[0] and ba.data_ptr() == a.data_ptr() and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()):
+        return ba            # the producing Function's own output tensor: the object that carries the bf16 twin its kernel wrote (kernels._twin_keep)
     a, b = _c(a.detach()), _c(b.detach())
     if (a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
             b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()):
