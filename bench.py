@@ -615,7 +615,8 @@ def main():
                                             'parity': 'NOT within BASELINE.md\'s 2e-2 (tests/test_step_b64_gpu.py[all_bf16] states its measured envelope: G 2.15e-2, '
                                                       'D(x_hat) 3.8e-2, generator-step gradients <= 1.07e-1): reported for the kernels\' sake, not as config 3'}
             blk['parity'] = {
-                'test': 'tests/test_step_b64_gpu.py::test_config3_bf16_steps_mask_pinned[B64] (also [B16], [B8]; full width, mask-pinned vs the float64 oracle, '
+                'test': 'tests/test_step_b64_gpu.py::test_config3_bf16_steps_mask_pinned[B64] (also [B16], [B8]; full width, in the form replayed here — one 2B-row '
+                        'generator evaluation, the stacked critic step, the generator step on the leading half —, mask-pinned vs the float64 oracle, '
                         'plus G, D(x_hat) and every loss scalar against the UN-pinned oracle)',
                 'stated_in_BASELINE_md': 'bf16-MFMA configuration: rel <= 2e-2 vs the fp32 oracle',
                 'bounds_relative_l2': {'G': 2e-2, 'D(x_hat)': 2e-2, 'grad_x_hat': 2e-2, 'loss_scalars': 2e-2, 'critic_step_gradients': 2e-2,
