@@ -85,14 +85,13 @@ def _rel_l2(got, ref):
     return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
 
 
-# Measured envelope of the ALL-bf16 arithmetic on Stage-II at full width, batch 2 (relative L2 per tensor against the mask-pinned float64
-# oracle; MI355X, round 6) — what bench.py's `next_rows[stackgan_stage2, bf16]` row runs.  NOT a 2e-2 claim: ~60 conv + batch-norm
-# layers in series with statistics over two samples amplify the 2^-8 operand rounding far beyond it; the bounds below are ~1.5x the
-# measured values and exist so that the row's arithmetic cannot get worse silently.  Measured (profiles/r06_bf16_side_row_parity.txt):
-# 2.3e-2 / 2.1e-2 of the branches differ from the float64 oracle's own (fp32: 2.6e-6); mask-pinned: loss scalars <= 9.4e-2 (critic
-# step) / 2.6e-1 (G_gan_loss), the 256x256 image 1.46e-1, critic gradients median 2.4e-1 / worst 3.8e-1, generator gradients median
-# 4.2e-1 / worst 4.8e-1 (relative L2 per tensor).
-STAGE2_BF16_ENVELOPE = dict(loss=0.4, image=0.25, d_grad=0.6, g_grad=0.75, flips=4e-2)
+# Stage-II in reduced precision (round 6): what bench.py's `next_rows[stackgan_stage2, bf16]` row runs is kernels.FWD_F32_BWD_BF16 on all three
+# networks — every forward GEMM in fp32 math, every input- / filter-gradient GEMM in bf16 math — and that arithmetic is held to BASELINE.md's 2e-2
+# on every loss and every gradient tensor below.  (The all-bf16 arithmetic the row ran before sits far outside it on this model — ~60 conv +
+# batch-norm layers in series with statistics over two samples amplify the 2^-8 operand rounding: 2.3e-2 of the branches differ from the
+# float64 oracle's own, the 256x256 image is 1.46e-1 off, critic gradients median 2.4e-1, generator gradients median 4.2e-1,
+# profiles/r06_bf16_side_row_parity.txt — and CONFIG3_NET_MATH on the generators alone leaves the generator-step gradients at a median of 2.0e-2.)
+STAGE2_COMPLIANT = dict(loss=2e-2, image=2e-2, d_grad=2e-2, g_grad=2e-2, flips=1e-4)       # kernels.FWD_F32_BWD_BF16 on all three networks
 
 
 def _stage2_full_size(gpu, bf16):
@@ -108,7 +107,14 @@ def _stage2_full_size(gpu, bf16):
     o1, o2 = SG.Cfg(batch=B), SG.Cfg(out_size=256, real_label=0.95, batch=B)
     P = OrderedDict((n, v.float().double()) for n, v in SG.init_variables(o2, 2, o1, seed=0).items())      # fp32-representable
     feed = {k: v.float().double() for k, v in SG.synthetic_feed(o2, 2, o1, seed=1).items()}
-    m = StageII(StageI(c1, build_model=False, device=gpu), c2)
+    compliant = bf16 == 'compliant'
+    s1 = StageI(c1, build_model=False, device=gpu)
+    m = StageII(s1, c2, build_model=False)
+    if compliant:       # every forward GEMM of the three networks in fp32 math, every backward GEMM in bf16 math (kernels.FWD_F32_BWD_BF16)
+        from t2i_amd import kernels as K
+        s1.net_math = {'g_net': K.FWD_F32_BWD_BF16, 'd_net': K.FWD_F32_BWD_BF16}
+        m.net_math = {'g_net': K.FWD_F32_BWD_BF16, 'd_net': K.FWD_F32_BWD_BF16}
+    m.build_model()
     m.store.load({n: v.numpy() for n, v in P.items()})
     assert m.output_size == 256 and [n for n in m.store.vars] == list(P)
     f = {k: v.float().to(gpu) for k, v in feed.items()}
@@ -123,19 +129,31 @@ def _stage2_full_size(gpu, bf16):
     else:
         plan = plan_g = [('G',), ('Dfake',), ('Dmatch',), ('Dmis',)]
     chk = Checker()
-    env = STAGE2_BF16_ENVELOPE
+    env = STAGE2_COMPLIANT
     flip_tol = env['flips'] if bf16 else 1e-4
 
-    def grads(arena, names, ref, tol):
+    def grads(arena, names, ref, tol, l1=None):
         if not bf16:
             return chk.grads(arena, names, ref, tol)
-        worst = []
-        for n in names:                         # relative L2 per tensor (the yardstick of the config-3 test), exact-zero tensors skipped
-            if float(ref[n].abs().max()) >= 1e-9:
+        worst, unc = [], []
+        for n in names:                         # relative L2 per tensor (the yardstick of the config-3 test)
+            got, r = arena.grad_of(n).detach().double().cpu().reshape(-1), ref[n].reshape(-1)
+            s1_ = float(l1[n].norm()) if (l1 is not None and n in l1) else 0.0
+            if s1_ > 4.0 * float(r.norm()):
+                # a bias whose gradient is a small difference of large terms (zero in front of a batch norm, a border effect behind a zero-padded
+                # convolution): the rounding error of sum g scales with sum |g| (oracle/torch_stackgan._BIAS_L1) — that is the yardstick, and the
+                # exactly-zero ones are held to it too instead of being skipped
+                unc.append((float((got - r).norm()) / s1_, n))
+            elif float(r.abs().max()) >= 1e-9:
                 worst.append((_rel_l2(arena.grad_of(n), ref[n]), n))
         worst.sort()
-        print('  bf16 gradients, relative L2: median %.3e, worst %.3e (%s)' % (worst[len(worst) // 2][0], worst[-1][0], worst[-1][1]))
+        print('  bf16 gradients, relative L2: median %.3e, worst %.3e (%s), then %s' % (
+            worst[len(worst) // 2][0], worst[-1][0], worst[-1][1], ', '.join('%.2e %s' % w for w in worst[-4:-1][::-1])))
         chk('worst gradient (relative L2)', worst[-1][0], tol)
+        if unc:
+            unc.sort()
+            print('  %d cancelling bias gradients against sum |g|: worst %.3e (%s)' % (len(unc), unc[-1][0], unc[-1][1]))
+            chk('worst cancelling bias gradient (vs sum |g|)', unc[-1][0], tol)
     # ---- critic step
     rec = []
     with record_branches(rec):
@@ -149,15 +167,19 @@ def _stage2_full_size(gpu, bf16):
     print('Stage-II critic step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
     assert fl <= flip_tol * units
     with T.use_tape(T.SectionTape(masks)):
-        ref = SG.d_step(P, o2, feed, 2, o1)
+        ref = SG.d_step(P, o2, feed, 2, o1, bias_l1=compliant)
     for k in ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'):
         chk(k, abs(float(d[k]) - ref[k]) / max(abs(ref[k]), 1.0), env['loss'] if bf16 else 1e-4)
     if bf16:
-        assert _rel_l2(d['G'], ref['G']) > 1e-4, 'reduced precision is not in use'
+        assert compliant and _rel_l2(d['G'], ref['G']) < 1e-4, 'the forward passes are meant to be fp32 here'
         chk('G (256x256 image, relative L2)', _rel_l2(d['G'], ref['G']), env['image'])
     else:
         chk('G (256x256 image, tanh output)', relerr(d['G'], ref['G'], scale=1.0), 2e-4)
-    grads(m.d_arena, m.d_vars, ref['grads'], env['d_grad'] if bf16 else 2e-4)
+    grads(m.d_arena, m.d_vars, ref['grads'], env['d_grad'] if bf16 else 2e-4, ref.get('bias_l1'))
+    if compliant:
+        worst = max(_rel_l2(m.d_arena.grad_of(n), ref['grads'][n]) for n in m.d_vars if n.endswith('weights'))
+        assert worst > 1e-4, 'reduced precision is not in use in the backward GEMMs'
+
     with torch.no_grad():                      # undo the moving-average side effect of the probe pass
         for n, v in moving0.items():
             m.store.vars[n].copy_(v)
@@ -174,29 +196,15 @@ def _stage2_full_size(gpu, bf16):
     print('Stage-II generator step: %d of %d branches differ (%.2e)' % (fl, units, fl / units))
     assert fl <= flip_tol * units
     with T.use_tape(T.SectionTape(masks)):
-        gref = SG.g_step(P, o2, feed, 2, o1)
+        gref = SG.g_step(P, o2, feed, 2, o1, bias_l1=compliant)
     for k in ('G_loss', 'G_gan_loss', 'G_kl_loss'):
         chk(k, abs(float(g[k]) - gref[k]) / max(abs(gref[k]), 1.0), env['loss'] if bf16 else 1e-4)
-    grads(m.g_arena, m.g_vars, gref['grads'], env['g_grad'] if bf16 else 2e-4)
+    grads(m.g_arena, m.g_vars, gref['grads'], env['g_grad'] if bf16 else 2e-4, gref.get('bias_l1'))
     assert not chk.bad, chk.bad
 
 
 def test_stackgan_stage2_full_size(gpu):
     _stage2_full_size(gpu, bf16=False)
-
-
-def test_stackgan_stage2_all_bf16_envelope(gpu):
-    """The arithmetic of bench.py's `next_rows[stackgan_stage2, bf16]` row — set_math('bf16') with float32 activation tensors (bf16 operand
-    images), every GEMM of all three networks — on the same full-width Stage-II step, mask-pinned.  NOT a 2e-2 claim (the row says so):
-    the measured envelope, asserted (STAGE2_BF16_ENVELOPE)."""
-    from t2i_amd import kernels as K
-    K.set_math('bf16')
-    try:
-        _stage2_full_size(gpu, bf16=True)
-    finally:
-        K.set_storage('f32')
-        K.set_math('f32')
-        K.filter_cache_reset()
 
 
 # The default sweep keeps every stage's shapes once (stages 1-4 in both forms where cheap, 6 stable, 7 in transition); the two middle cases
@@ -369,3 +377,18 @@ def test_stackgan_stage1_full_width(gpu):
                 ('D_loss', 'D_real_match_loss', 'D_real_mismatch_loss', 'D_synthetic_loss'), ('G_loss', 'G_gan_loss', 'G_kl_loss'), chk, T,
                 may_cancel=(logit_bias,))
     assert not chk.bad, chk.bad
+
+
+def test_stackgan_stage2_fwd_f32_bwd_bf16_within_2e2(gpu):
+    """Stage-II with every forward GEMM of its three networks in fp32 math and every input- / filter-gradient GEMM in bf16 math
+    (kernels.FWD_F32_BWD_BF16: bf16 operand images, fp32 accumulate): the same full-width step, mask-pinned, every loss and every gradient
+    tensor of both steps within BASELINE.md's 2e-2 (relative L2 per tensor; biases whose gradient is a small difference of large terms against
+    sum |g|, the exactly-zero ones included).  The forward being fp32, the image is exact and the pinning touches the fp32 tests' handful of units."""
+    from t2i_amd import kernels as K
+    K.set_math('bf16')
+    try:
+        _stage2_full_size(gpu, bf16='compliant')
+    finally:
+        K.set_storage('f32')
+        K.set_math('f32')
+        K.filter_cache_reset()

@@ -224,6 +224,9 @@ def math_scope(math=None, storage=None, bwd_math=None):
 # per-network arithmetic (math, storage, backward math) handed to math_scope by the models.  Networks not named run in the
 # process-wide setting (set_math('bf16') + set_storage('bf16')): the critic.  DESIGN.md 4.16.
 CONFIG3_NET_MATH = {'g_net': ('f32', 'f32', 'bf16')}
+# Every forward GEMM in fp32 math on fp32 tensors, every input- and filter-gradient GEMM in bf16 math (bf16 operand images, fp32 accumulate): the
+# arithmetic under which the batch-normalised StackGAN Stage-II step stays inside 2e-2 (tests/test_fullsize_gpu.py)
+FWD_F32_BWD_BF16 = ('f32', 'f32', 'bf16')
 
 
 def bwd_geom(geom):

@@ -32,6 +32,9 @@ class ConditionalGan(object):
         self.store = S.set_default_store(store or S.VariableStore(device=device, seed=seed))
         self.device = self.store.device
         self.dp = dp
+        # per-network arithmetic (kernels.math_scope): {'g_net' | 'd_net': (math, storage, backward math)} — that network's layers are created under it
+        # (kernels.FWD_F32_BWD_BF16: forward GEMMs in fp32, input- and filter-gradient GEMMs in bf16); {} = the process-wide setting
+        self.net_math = {}
         if build_model:
             self.build_model()
 
@@ -75,7 +78,7 @@ class ConditionalGan(object):
     def discriminator(self, inputs, embed, is_training=True, reuse=False, _prob=True, groups=1):
         """-> (sigmoid(logits), logits), logits [B,1,1,1]  (model.py:77-121)"""
         nf, act, bn_init, s16 = self.df_dim, lrelu_act(0.2), self.batch_norm_init, self.output_size // 16
-        with S.variable_scope('d_net', reuse=reuse):
+        with K.math_scope(*self.net_math.get('d_net', (None, None))), S.variable_scope('d_net', reuse=reuse):
             h = conv2d(inputs, nf, ks=(4, 4), s=(2, 2), act=act, init=self.w_init)
             for mult, a in ((2, act), (4, act), (8, None)):
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), init=self.w_init)
@@ -111,7 +114,7 @@ class ConditionalGan(object):
     def generator(self, z, embed, is_training=True, reuse=False, cond_noise=True, noise=None):
         """-> (image NHWC in [-1,1], mean, log_sigma)  (model.py:123-171)"""
         nf, s16 = self.gf_dim, self.output_size // 16
-        with S.variable_scope('g_net', reuse=reuse):
+        with K.math_scope(*self.net_math.get('g_net', (None, None))), S.variable_scope('g_net', reuse=reuse):
             mean, log_sigma = self.generate_conditionals(embed)
             code = self.sample_normal_conditional(mean, log_sigma, cond_noise, noise)
             h = dense(torch.cat([z, code], 1), nf * 8 * s16 * s16, kernel_initializer=self.w_init)

@@ -37,6 +37,9 @@ class ConditionalGan(object):
         self.store = S.set_default_store(stagei.store)               # one variable store, like one TF graph
         self.device = self.store.device
         self.dp = dp
+        # per-network arithmetic (kernels.math_scope): {'g_net' | 'd_net': (math, storage, backward math)} — that network's layers are created under it
+        # (kernels.FWD_F32_BWD_BF16: forward GEMMs in fp32, input- and filter-gradient GEMMs in bf16); {} = the process-wide setting
+        self.net_math = {}
         if build_model:
             self.build_model()
 
@@ -82,7 +85,7 @@ class ConditionalGan(object):
     # ---- discriminator (stageII/model.py:78-133) --------------------------------------------------------------------------
     def discriminator(self, inputs, embed, is_training=True, reuse=False, _prob=True, groups=1):
         nf, act, bn_init, s16 = self.df_dim, lrelu_act(0.2), self.batch_norm_init, self.output_size // 64
-        with S.variable_scope('stageII_d_net', reuse=reuse):
+        with K.math_scope(*self.net_math.get('d_net', (None, None))), S.variable_scope('stageII_d_net', reuse=reuse):
             h = conv2d(inputs, nf, ks=(4, 4), s=(2, 2), act=act, init=self.w_init)
             for mult in (2, 4, 8, 16, 32):
                 h = conv2d(h, nf * mult, ks=(4, 4), s=(2, 2), init=self.w_init)
@@ -129,7 +132,7 @@ class ConditionalGan(object):
 
     def generator(self, image, embed, is_training=True, reuse=False, cond_noise=True, noise=None):
         """image: the Stage-I output [B,64,64,3] -> (image [B,256,256,3], mean, log_sigma)"""
-        with S.variable_scope('stageII_g_net', reuse=reuse):
+        with K.math_scope(*self.net_math.get('g_net', (None, None))), S.variable_scope('stageII_g_net', reuse=reuse):
             encoded = self.generator_encode_image(image, is_training=is_training)          # [B,16,16,4*gf]
             mean, log_sigma = self.generate_conditionals(embed)
             code = self.sample_normal_conditional(mean, log_sigma, cond_noise, noise)

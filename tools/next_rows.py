@@ -121,6 +121,13 @@ def _stackgan(K, dev, math, stage, batch, budget_s):
     cfg = config_from_yaml(os.path.join(PKG, 'stackgan', 'stageI' if stage == 1 else 'stageII', 'cfg', 'flowers.yml'))
     cfg.TRAIN.BATCH_SIZE = cfg1.TRAIN.BATCH_SIZE = batch
     model, tr = build(stage, cfg, cfg1, device=dev)
+    compliant = math == 'bf16' and stage == 2
+    if compliant:
+        # every forward GEMM of the critic, the Stage-II generator and the frozen Stage-I generator in fp32 math, every input- / filter-gradient GEMM in
+        # bf16 math (kernels.FWD_F32_BWD_BF16): the arithmetic tests/test_fullsize_gpu.py::test_stackgan_stage2_fwd_f32_bwd_bf16_within_2e2 holds to 2e-2
+        nm = {'g_net': K.FWD_F32_BWD_BF16, 'd_net': K.FWD_F32_BWD_BF16}
+        model.net_math = dict(nm)
+        model.stagei.net_math = dict(nm)
     feed = tr.make_feed()
     tr.iteration(feed)
     flop, calls = _count_eager(K, lambda: tr.iteration(feed))
@@ -130,12 +137,17 @@ def _stackgan(K, dev, math, stage, batch, budget_s):
     tr._graphs = None
     what = ('StackGAN Stage-I 64x64' if stage == 1 else 'StackGAN Stage-II 256x256 (frozen Stage-I generator in training mode inside)')
     extra = None
-    if math == 'bf16':
-        # every GEMM of every network in bf16 math: NOT a 2e-2 claim (no tolerance is stated for this row anywhere in BASELINE.md); the
-        # measured envelope of exactly this arithmetic is asserted by tests/test_fullsize_gpu.py::test_stackgan_stage2_all_bf16_envelope
-        extra = {'arithmetic': {'mode': 'all_bf16', 'note': 'every GEMM of the critic, the Stage-II generator and the frozen Stage-I generator in bf16 '
-                                'math (bf16 MFMA operands, fp32 accumulate), %s activation tensors: OUTSIDE 2e-2, kernel throughput only — '
-                                'envelope in tests/test_fullsize_gpu.py::test_stackgan_stage2_all_bf16_envelope' % K.get_storage()}}
+    if compliant:
+        extra = {'arithmetic': {'mode': 'fwd_f32_bwd_bf16', 'net_math': {k: list(v) for k, v in model.net_math.items()},
+                                'note': 'every forward GEMM of the three networks in fp32 math, every input- and filter-gradient GEMM in bf16 math (bf16 operand '
+                                        'images, fp32 accumulate), fp32 tensors',
+                                'parity': 'tests/test_fullsize_gpu.py::test_stackgan_stage2_fwd_f32_bwd_bf16_within_2e2: every loss and every gradient tensor of both '
+                                          'steps <= 2e-2 (relative L2, mask-pinned; measured <= 1.27e-2), the image exact'}}
+    elif math == 'bf16':
+        # every GEMM of every network in bf16 math: NOT a 2e-2 claim, and no parity test runs Stage-I in this arithmetic (the batch-normalised StackGAN step
+        # at batch 2 sits 1.5e-1 .. 4.8e-1 from the oracle in it: DESIGN.md section 8): kernel throughput only
+        extra = {'arithmetic': {'mode': 'all_bf16', 'note': 'every GEMM of both networks in bf16 math (bf16 MFMA operands, fp32 accumulate), %s activation '
+                                'tensors: OUTSIDE 2e-2, kernel throughput only, no parity test in this arithmetic' % K.get_storage()}}
     return _row('stackgan_stage%d' % stage, what + ', D + G update', batch, math, dt, n, flop, calls, extra)
 
 
