@@ -37,7 +37,7 @@ timeout 300 python tools/bench_conv.py --batch 512 --math bf16 --reps 10 > "$OUT
   echo "== B = 512"; timeout 300 python tools/bench_conv.py --batch 512 --math bf16 --storage bf16 --reps 10 2>&1 | grep -v amdgpu; } > "$OUT/conv_microbench_bf16_tensors.txt"
 timeout 300 python tools/bench_aux.py 2>&1 | grep -v amdgpu > "$OUT/hbm_kernels.txt"
 { timeout 900 python tools/next_rows.py --math f32 --budget-s 2.0 2>&1 | grep -v amdgpu
-  timeout 600 python tools/next_rows.py --math bf16 --budget-s 2.0 --rows gancls wgancls_b8 2>&1 | grep -v amdgpu
+  timeout 600 python tools/next_rows.py --math bf16 --budget-s 2.0 --rows wgancls_b8 2>&1 | grep -v amdgpu     # (the compliant config-3 arithmetic; every bf16 row prints its arithmetic and parity test)
   timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu
 import sys; sys.path.insert(0, '.')
 import t2i_amd
@@ -45,7 +45,7 @@ from t2i_amd import kernels as K
 K.filter_cache(True)
 from tools.next_rows import measure_rows
 for r in measure_rows(['stage2'], 'bf16', 2.0, storage='f32'):
-    print('%-16s bf16 (fp32 tensors) B=%-3d %8.2f ms/iteration %9.1f img/s | %.2f GFLOP/img | %.3f of the bf16 matrix peak' % (r['row'], r['batch'], r['ms_per_iteration'], r['images_per_sec'], r['algorithmic_gflop_per_image'], r['frac_vs_driver_ms']) if 'error' not in r else r)
+    print('%-16s bf16 (fp32 tensors) B=%-3d %8.2f ms/iteration %9.1f img/s | %.2f GFLOP/img | %.3f of the bf16 matrix peak\n                      arithmetic: %s — %s' % (r['row'], r['batch'], r['ms_per_iteration'], r['images_per_sec'], r['algorithmic_gflop_per_image'], r['frac_vs_driver_ms'], r['arithmetic']['mode'], r['arithmetic'].get('parity')) if 'error' not in r else r)
 PY
 } > "$OUT/next_rows_throughput.txt"
 # per-kernel statistics of the next rows (StackGAN Stage-II, PGGAN stage 7): one kernel-trace pass each

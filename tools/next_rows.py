@@ -111,6 +111,9 @@ def _gancls(K, dev, math, batch, budget_s):
              'frac_vs_reference_graph_flops': ref_flop / dt / 1e12 / PEAK[math],
              'note': 'algorithmic_gflop_per_image / frac_vs_driver_ms count the LAUNCHED convolutions (one generator forward per iteration); '
                      'reference_graph_* count the two identical generator forwards the reference\'s D run and G run evaluate'}
+    if math == 'bf16':
+        extra['arithmetic'] = {'mode': 'all_bf16', 'note': 'every GEMM of both networks in bf16 math: no tolerance is claimed and NO parity test runs gancls in this arithmetic '
+                                                           '(its batch-normalised critic is the case DESIGN.md section 8 measures far outside 2e-2 on Stage-II): kernel throughput only'}
     return _row('gancls', 'gancls 64x64 (reference dims: z 100, GF 128, DF 64), D + G update, both under UPDATE_OPS', batch, math, dt, n, flop, calls, extra)
 
 
@@ -272,6 +275,9 @@ def main():
             print('%-16s %-4s B=%-3d %8.2f ms/iteration %9.1f img/s | %7.2f GFLOP/img algorithmic (%d conv calls) | %7.1f TFLOP/s = %.3f of the %s matrix peak '
                   '(frac_vs_driver_ms) | %s' % (r['row'], r['dtype'], r['batch'], r['ms_per_iteration'], r['images_per_sec'], r['algorithmic_gflop_per_image'],
                                                 r['conv_calls_per_iteration'], r['achieved_tflops'], r['frac_vs_driver_ms'], r['dtype'], r['workload']))
+            if r.get('arithmetic'):
+                ar = r['arithmetic']
+                print('%-16s      arithmetic: %s — %s' % ('', ar.get('mode'), ar.get('parity') or ar.get('note')))
             if 'frac_vs_reference_graph_flops' in r:
                 print('%-16s      (the reference graph\'s %.2f GFLOP/img incl. its second, identical generator forward: %.3f of the peak)' % (
                     '', r['reference_graph_gflop_per_image'], r['frac_vs_reference_graph_flops']))
