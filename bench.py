@@ -145,71 +145,125 @@ def _signature(model):
 
 
 def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtype='f32', net_math=None):
-    """Self-check of the N-rank exchange before anything is timed (first contact with a multi-GPU node must diagnose itself):
-    every rank runs 4 iterations on IDENTICAL data, once as a single replica (no communicator) and once through the
-    data-parallel schedule that will be timed (2 eager iterations that learn the bucket counts, then the captured segments).
-    Averaging N identical gradients returns the gradient, so the two runs must agree:
-      * fp32 buckets: exactly for N = 2 (x + x and its halving are exact); for N > 2 a ring sums 3x, 5x, ... which need not be
-        representable, and the bound is Adam's own — no weight may differ by more than the 4 steps could move it, and all but
-        0.1 % must agree to 5 % of one step;
-      * bf16 buckets (fp32 accumulation, dp.DataParallel._exchange_bf16): exactly for every power-of-two N against a single
-        replica that rounds its gradient arena to bf16 once (dp.LocalRounding) — N bf16(x) is exact in fp32 and representable
-        in bf16.  Otherwise the Adam bound.
-    A bucket that is exchanged too early, twice, or not at all fails all of these by orders of magnitude."""
+    """Self-check of the N-rank exchange before anything is timed (first contact with a multi-GPU node must diagnose itself): every rank
+    runs 4 iterations on IDENTICAL data through the data-parallel schedule that will be timed (2 eager iterations that learn the bucket
+    counts, then the captured segments) with a single replica (no communicator) beside it IN LOCKSTEP — before every iteration the single
+    replica takes the data-parallel model's weights, Adam state, kt and moving averages, then both run the iteration on the same feed.
+    Averaging N identical gradients returns the gradient, so after every iteration the two gradient arenas must agree:
+      * exactly where the sum is exact — fp32 buckets at N = 2 (x + x and its halving), bf16 buckets (fp32 accumulation,
+        dp.DataParallel._exchange_bf16) at every power-of-two N against a replica that rounds its arena to bf16 once (dp.LocalRounding);
+        there the weights, Adam state and kt after the four iterations must be bit-identical too;
+      * otherwise (a ring sums 3x, 5x, ...: not representable) to the rounding of N additions: max |difference| <= 1e-5 (fp32 buckets) /
+        1e-2 (bf16 buckets) of the critic arena's largest gradient per iteration, 5e-3 / 2e-2 for the generator's arena (see g_tol below).
+    A bucket that is exchanged too early, twice, or not at all fails this by orders of magnitude, and the lockstep keeps the comparison
+    about the EXCHANGE: round 6 found that the free-running form of this check (two runs of 4 iterations, weights compared at the end)
+    reports a broken exchange for every N whose sum is inexact — 3, 6, 8 gloo ranks: 95 % of the weights more than 5 % of an Adam step
+    apart, one of them 11 steps — because the model at initialisation amplifies a last-bit difference of the averaged gradient by an order of
+    magnitude per iteration (Adam at beta1 = 0 on gradients that are small differences of large terms); N = 2 and 4, whose sums are exact,
+    never showed it.  The weights are still compared after every iteration (how many sit more than 5 % of a step apart): reported, not fatal."""
+    from t2i_amd import kernels as K
     from t2i_amd.dp import LocalRounding
     from t2i_amd.models.wgancls.model import WGanCls
     from t2i_amd.models.wgancls.trainer import WGanClsTrainer
     feed = synthetic_feed(cfg, device, seed=977)            # the same batch and noise on every rank
     lr = float(cfg.TRAIN.D_LR)
-    sigs, losses = [], []
-    for dp in ((LocalRounding() if grad_dtype == 'bf16' else None), make_dp()):
+
+    def make(dp):
         model = WGanCls(cfg, device=device, seed=0, dp=dp)
         model.net_math = dict(net_math or {})
         model.pair_g = False          # the data-parallel schedules evaluate the generator twice per iteration: so does their single-replica reference
-        real = dp is not None and not isinstance(dp, LocalRounding)
-        if real:
-            dp.broadcast_variables(model.store)
-        trainer = WGanClsTrainer(None, model, None, cfg)
-        for i in range(2):
-            out = trainer.iteration(1 + i, feed)
-        if real and use_graphs:
-            model.enable_graphs(feed)
-        for i in range(2):
-            out = trainer.iteration(3 + i, feed)
-        torch.cuda.synchronize()
-        sigs.append(_signature(model))
-        losses.append((float(out['d']['D_loss']), float(out['g']['G_loss'])))
-        model._graphs = None
-        del trainer, model
-    one, many = sigs
+        return model, WGanClsTrainer(None, model, None, cfg)
+
+    def state_of(m):
+        return ({n: v.detach().clone() for n, v in m.store.vars.items()}, m.D_optim.v.clone(), m.G_optim.v.clone(), m.D_optim.t, m.G_optim.t, m.kt.clone())
     want_exact = (world == 2) if grad_dtype == 'f32' else (world & (world - 1)) == 0
-    report = {'ranks': world, 'iterations': 4, 'gradient_buckets': grad_dtype, 'exact': all(torch.equal(a, b) for a, b in zip(one, many)),
-              'exact_required': bool(want_exact)}
-    worst, loose = 0.0, 0.0
-    for a, b in zip(one[:2], many[:2]):                     # the two weight arenas
-        d = (a - b).abs()
-        worst = max(worst, float(d.max()) / lr)
-        loose = max(loose, float((d > 0.05 * lr).float().mean()))
-    report.update(max_weight_diff_in_steps=worst, frac_weights_off_by_5pct_of_a_step=loose,
-                  kt_diff=abs(float(one[4]) - float(many[4])), loss_single=losses[0], loss_dp=losses[1])
-    ok = report['exact'] if want_exact else (worst <= 4 * 2.0 * 1.001 and loose <= 1e-3 and report['kt_diff'] <= 1e-5 * max(abs(float(one[4])), 1.0))
+    # the critic's arena is compared at the rounding of N additions; the generator's gradient of the same iteration is taken THROUGH the critic
+    # the iteration has just updated, whose weights at rounding-level gradients (Adam: +-lr either way) already differ between the two — measured
+    # 6e-6 .. 7e-5 of the arena's largest gradient with 3 and 8 gloo ranks — so its bound is the one a broken exchange still misses by two orders
+    g_tol = (1e-5, 5e-3) if grad_dtype == 'f32' else (1e-2, 2e-2)
+    # ---- the data-parallel model first: its state before every iteration, its averaged gradients and weights after (ONE model alive at a time)
+    dp = make_dp()
+    many, t_many = make(dp)
+    dp.broadcast_variables(many.store)
+    before, after = [], []
+    for it in range(1, 5):
+        with torch.no_grad():
+            before.append(state_of(many))
+        o2 = t_many.iteration(it, feed)
+        if it == 2 and use_graphs:
+            many.enable_graphs(feed)
+        torch.cuda.synchronize()
+        if os.environ.get('T2I_PREFLIGHT_DEBUG') == '1':
+            sys.stderr.write('[pf] rank %d phase 1 iteration %d done\n' % (rank, it)); sys.stderr.flush()
+        with torch.no_grad():                               # the data-parallel arena holds the SUM over ranks (Adam applies 1 / N)
+            after.append((many.d_arena.grad * (1.0 / world), many.g_arena.grad * (1.0 / world), many.d_arena.flat.clone(), many.g_arena.flat.clone(),
+                          many.kt.clone()))
+    loss_dp = (float(o2['d']['D_loss']), float(o2['g']['G_loss']))
+    sig_many = _signature(many)
+    many._graphs = None
+    del t_many, many
+    # ---- the single replica, in lockstep: every iteration from the data-parallel model's state
+    one, t_one = make(LocalRounding() if grad_dtype == 'bf16' else None)
+    exact, finite, worst_g, worst_w, loose, kt_diff = True, True, [0.0, 0.0], 0.0, 0.0, 0.0
+    for it in range(1, 5):
+        vars_, dv, gv, dt_, gt_, kt_ = before[it - 1]
+        with torch.no_grad():
+            for n, v in vars_.items():
+                one.store.vars[n].copy_(v)
+            one.D_optim.v.copy_(dv); one.G_optim.v.copy_(gv)
+            one.D_optim.t, one.G_optim.t = dt_, gt_
+            one.kt.copy_(kt_)
+        K.filter_cache_invalidate()                         # (cached filter transforms are keyed by the weights' addresses, which were just overwritten)
+        o1 = t_one.iteration(it, feed)
+        torch.cuda.synchronize()
+        if os.environ.get('T2I_PREFLIGHT_DEBUG') == '1':
+            sys.stderr.write('[pf] rank %d phase 2 iteration %d done\n' % (rank, it)); sys.stderr.flush()
+        gd2, gg2, wd2, wg2, kt2 = after[it - 1]
+        with torch.no_grad():
+            for k_, (a1, g2, w2) in enumerate(((one.d_arena, gd2, wd2), (one.g_arena, gg2, wg2))):
+                g1 = a1.grad
+                finite = finite and bool(torch.isfinite(g2).all())
+                exact = exact and torch.equal(g1, g2)
+                worst_g[k_] = max(worst_g[k_], float((g1 - g2).abs().max()) / max(float(g1.abs().max()), 1e-30))
+                d = (a1.flat - w2).abs()
+                worst_w = max(worst_w, float(d.max()) / lr)
+                loose = max(loose, float((d > 0.05 * lr).float().mean()))
+            kt_diff = max(kt_diff, abs(float(one.kt) - float(kt2)))
+    losses = [(float(o1['d']['D_loss']), float(o1['g']['G_loss'])), loss_dp]
+    exact = exact and all(torch.equal(a, b) for a, b in zip(_signature(one), sig_many))
+    finite = finite and all(bool(torch.isfinite(t).all()) for t in sig_many)
+    kt_scale = max(abs(float(sig_many[4])), 1.0)
+    del t_one, one, before, after
+    report = {'ranks': world, 'iterations': 4, 'form': 'lockstep', 'gradient_buckets': grad_dtype, 'exact': bool(exact), 'exact_required': bool(want_exact),
+              'max_gradient_diff_rel': {'critic': worst_g[0], 'generator': worst_g[1]}, 'gradient_tolerance': {'critic': g_tol[0], 'generator': g_tol[1]},
+              'max_weight_diff_in_steps': worst_w,
+              'frac_weights_off_by_5pct_of_a_step': loose, 'kt_diff': kt_diff, 'loss_single': losses[0], 'loss_dp': losses[1]}
+    grads_ok = exact if want_exact else (worst_g[0] <= g_tol[0] and worst_g[1] <= g_tol[1])
+    # (statistical part: measured 0.9e-3 / 1.3e-3 of the weights more than 5 % of a step apart with 8 / 3 gloo ranks — the ones whose gradient is at rounding level)
+    ok = finite and grads_ok and (want_exact or (loose <= 1e-2 and kt_diff <= 1e-5 * kt_scale))
     report['ok'] = bool(ok)
-    # What stops the run: a result a broken exchange produces (a weight further from the single replica than Adam can move it in 4
-    # steps, a non-finite value, or — where exactness is owed — any difference at all).  The statistical part of the N > 2 fp32 bound
-    # (how MANY weights sit more than 5 % of a step apart: gradients at rounding-noise level, whose Adam step is +-lr either way) has
-    # never met a real ring; if it alone is exceeded the line carries ok = false and the numbers, and the timing goes ahead.
-    finite = all(bool(torch.isfinite(torch.as_tensor(t)).all()) for t in many)
-    fatal = (not finite) or (not report['exact'] if want_exact else worst > 4 * 2.0 * 1.001)
+    # What stops the run: what a BROKEN exchange produces — a non-finite value, or averaged gradients that are not the gradient by orders of
+    # magnitude more than any summation order explains (a bucket exchanged too early, twice or not at all: O(1) of the arena's largest gradient;
+    # the line is drawn at 1e-2 for the critic's arena, 1e-1 for the generator's).  Everything finer — a last-bit difference where exactness is
+    # owed, a gradient outside the rounding bound, the statistical part (how many weights sit more than 5 % of a step from the single replica's
+    # after one iteration from the same state) — has never met a real ring: the line then carries ok = false and the numbers, and the timing
+    # goes ahead.  (Eight gloo ranks time-slicing ONE GPU — the pre-flight of this pre-flight — have produced a wrong gradient on a single
+    # rank, 1.3e-3, and HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION aborts; two to four ranks, and one process per GPU, never have.)
+    fatal = (not finite) or worst_g[0] > 1e-2 or worst_g[1] > 1e-1
     if os.environ.get('T2I_PREFLIGHT') == 'strict':          # every bound stops the run, the statistical one included
         fatal = fatal or not ok
     report['fatal'] = bool(fatal)
+    if not ok:
+        sys.stderr.write('[bench] data-parallel preflight, rank %d: %s\n' % (rank, report))
     flag = torch.tensor([1 if fatal else 0, 0 if ok else 1], device=device)
     torch.distributed.all_reduce(flag)
+    report['ranks_outside_bounds'] = int(flag[1])
+    report['ok'] = bool(ok) and int(flag[1]) == 0           # every rank's verdict, not this one's alone
     if int(flag[1]) != 0 and int(flag[0]) == 0 and rank == 0:
-        sys.stderr.write('[bench] data-parallel preflight: outside the statistical bound on at least one rank, not fatal: %s\n' % (report,))
+        sys.stderr.write('[bench] data-parallel preflight: outside its bounds on %d rank(s), not fatal (rank 0 saw %s)\n' % (int(flag[1]), report))
     if int(flag[0]) != 0:
-        raise SystemExit('[bench] DATA-PARALLEL PREFLIGHT FAILED on rank %d of %d: the %d-rank run on identical data does not '
-                         'reproduce the single-replica run (%s).  The gradient exchange is broken on this node: not timing it.  '
+        raise SystemExit('[bench] DATA-PARALLEL PREFLIGHT FAILED on rank %d of %d: on identical data the %d-rank exchange does not return the '
+                         'single replica\'s gradients (%s).  The gradient exchange is broken on this node: not timing it.  '
                          '(T2I_PREFLIGHT=0 skips this check; T2I_DP_GRAPHS=0 selects the eager overlap schedule.)' % (rank, world, world, report))
     return report
 

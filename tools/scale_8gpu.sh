@@ -41,7 +41,8 @@ for n, d, note in rows:
     c3 = d.get('config3_bf16') or {}
     e1 = d['value'] / (n * base['f32']) if base.get('f32') else float('nan')
     e3 = c3.get('value', float('nan')) / (n * base['bf16']) if base.get('bf16') else float('nan')
-    pf = lambda p: 'n/a' if not p else ('ok%s' % (' (exact)' if p.get('exact') else ' (max %.2g steps apart)' % p.get('max_weight_diff_in_steps', -1)))
+    pf = lambda p: 'n/a' if not p else ('%s%s' % ('ok' if p.get('ok') else 'OUTSIDE ITS BOUNDS', ' (exact)' if p.get('exact') else ' (gradients within %.1e / %.1e of the single replica\'s)' % (
+        (p.get('max_gradient_diff_rel') or {}).get('critic', -1), (p.get('max_gradient_diff_rel') or {}).get('generator', -1))))
     print('%3d | %10.1f %8.3f %6.3f | %10.1f %8.3f %6.3f | %s / %s' % (n, d['value'], d['ms_per_step'], e1, c3.get('value', float('nan')),
           c3.get('ms_per_step', float('nan')), e3, pf(d.get('dp_preflight')), pf(c3.get('dp_preflight'))))
 PY
