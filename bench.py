@@ -193,8 +193,6 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
         if it == 2 and use_graphs:
             many.enable_graphs(feed)
         torch.cuda.synchronize()
-        if os.environ.get('T2I_PREFLIGHT_DEBUG') == '1':
-            sys.stderr.write('[pf] rank %d phase 1 iteration %d done\n' % (rank, it)); sys.stderr.flush()
         with torch.no_grad():                               # the data-parallel arena holds the SUM over ranks (Adam applies 1 / N)
             after.append((many.d_arena.grad * (1.0 / world), many.g_arena.grad * (1.0 / world), many.d_arena.flat.clone(), many.g_arena.flat.clone(),
                           many.kt.clone()))
@@ -216,8 +214,6 @@ def dp_preflight(cfg, device, make_dp, use_graphs, rank, world, batch, grad_dtyp
         K.filter_cache_invalidate()                         # (cached filter transforms are keyed by the weights' addresses, which were just overwritten)
         o1 = t_one.iteration(it, feed)
         torch.cuda.synchronize()
-        if os.environ.get('T2I_PREFLIGHT_DEBUG') == '1':
-            sys.stderr.write('[pf] rank %d phase 2 iteration %d done\n' % (rank, it)); sys.stderr.flush()
         gd2, gg2, wd2, wg2, kt2 = after[it - 1]
         with torch.no_grad():
             for k_, (a1, g2, w2) in enumerate(((one.d_arena, gd2, wd2), (one.g_arena, gg2, wg2))):
