@@ -105,9 +105,12 @@ def _worker(rank, world, port, mode, q):
             want = sum(g[n] for g in gathered)
             if mode == 'bf16':     # each rank's contribution is rounded to bf16 ONCE, the sum is taken in fp32 and rounded to bf16 once:
                 want = sum(g[n].bfloat16().float() for g in gathered).bfloat16().float()      # bit for bit, on every rank
-                assert torch.equal(arena.grad_of(n), want), (n, (arena.grad_of(n) - want).abs().max())
+                if world == 2:
+                    assert torch.equal(arena.grad_of(n), want), (n, (arena.grad_of(n) - want).abs().max())
+                else:              # three addends: the fp32 sum may round differently by the order the ranks are taken in — one bf16 ulp at most
+                    assert torch.allclose(arena.grad_of(n), want, rtol=2.0 ** -7, atol=1e-6), (n, (arena.grad_of(n) - want).abs().max())
                 assert arena.grad_of(n).dtype == torch.float32
-            elif mode == 'rs_ag':  # two ranks: a + b in either order is the same float — bit for bit what the all-reduce leaves
+            elif mode == 'rs_ag' and world == 2:  # two ranks: a + b in either order is the same float — bit for bit what the all-reduce leaves
                 assert torch.equal(arena.grad_of(n), gathered[0][n] + gathered[1][n]), n
             else:
                 assert torch.allclose(arena.grad_of(n), want, atol=1e-5), n
@@ -236,6 +239,23 @@ def test_dp_allreduce_two_ranks(mode):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in results), results
+
+
+@pytest.mark.parametrize('mode', ['hooks', 'bf16', 'rs_ag'])
+def test_dp_allreduce_three_ranks(mode):
+    """The same exchange with an odd world size (round 6: every data-parallel check had run with two ranks only, and the one thing that then broke
+    at three — bench.dp_preflight's verdict — was outside these tests): bucket plans, overlap hooks, the bf16 and the reduce-scatter + all-gather
+    forms (their gloo stand-ins) and the scale 1 / 3; sums of three addends are compared to rounding, not bit for bit."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, mode, q)) for r in range(3)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
