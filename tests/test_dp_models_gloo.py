@@ -117,12 +117,13 @@ def _worker(rank, world, port, which, q):
         q.put((rank, 'FAILED: %s\n%s' % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize('which', ['wgancls', 'wgancls_cut', 'stackgan1', 'pggan'])
-def test_model_iteration_exchanges_every_gradient_once(which):
+@pytest.mark.parametrize('which,world', [('wgancls', 2), ('wgancls_cut', 2), ('stackgan1', 2), ('pggan', 2), ('wgancls', 3), ('wgancls_cut', 3)])
+def test_model_iteration_exchanges_every_gradient_once(which, world):
+    """(world 3, round 6: an odd number of ranks through both wgancls schedules — every check had run with two)"""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, which, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
