@@ -91,3 +91,32 @@ def test_bench_gpus_2_launches_itself_and_describes_the_exchange():
     assert 4 * (28995329 + 22643287) <= ex['payload_bytes_per_step'] <= 4 * (28995329 + 22643287) + 4096
     assert ex['ms_in_collectives_per_step'] > 0 and ex['ms_compute_stream_stalled_per_step'] >= 0
     assert out['dp_preflight']['ok'] and out['dp_preflight']['exact']
+
+
+def _bench_gpus_3_preflight_holds_an_inexact_sum_to_rounding():
+    """(110 s on one GPU — three processes, eight iterations each behind their imports — so it is part of the suite under T2I_FULL_SWEEP=1 only,
+    like the extra PGGAN cases: the default `-m gpu` run keeps the two-rank tests above.)  Three ranks (gloo on GPU 0): the sum of three identical gradients is not representable in general, so the preflight cannot demand bits
+    — its free-running form of rounds 3-5 declared exactly this exchange broken (95 % of the weights off after 4 iterations, the model amplifying
+    the last bit) and stopped the run.  The lockstep form must pass: gradients of the critic's arena within 1e-5 of the single replica's, the
+    generator's within 5e-3 (measured 8e-8 / 6e-5), nothing fatal, and the line is printed."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(T2I_SAME_DEVICE='1', T2I_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '3', '--steps', '1', '--warmup', '1', '--repeats', '1', '--min-busy-s', '0',
+                        '--no-cpu-baseline', '--no-config3', '--instrument', 'off'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    pf = out['dp_preflight']
+    assert out['n_gpus'] == 3 and out['config']['global_batch'] == 192 and pf['ranks'] == 3 and pf['form'] == 'lockstep'
+    assert pf['ok'] and not pf['fatal'] and not pf['exact_required'] and pf['ranks_outside_bounds'] == 0 and out['dp_preflight_ok'] is True
+    assert pf['max_gradient_diff_rel']['critic'] <= 1e-5 and pf['max_gradient_diff_rel']['generator'] <= 5e-3
+
+
+if os.environ.get('T2I_FULL_SWEEP') == '1':
+    test_bench_gpus_3_preflight_holds_an_inexact_sum_to_rounding = _bench_gpus_3_preflight_holds_an_inexact_sum_to_rounding
